@@ -1,0 +1,31 @@
+"""GPU parity tests proper: every HIP kernel through the C ABI vs the CPU oracle (fp64) on seeded inputs."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fn):
+    from tests import gpu_checks
+    res = fn()
+    bad = gpu_checks.failures(res)
+    assert not bad, 'parity failures (name, rel err, tol): %r' % bad
+
+
+def test_conv_fprop_dgrad_wgrad():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv)
+
+
+def test_conv_views_and_epilogues():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv_views_and_epilogues)
+
+
+def test_instnorm_act():
+    from tests import gpu_checks
+    _run(gpu_checks.check_inorm)
+
+
+def test_convlstm_gates():
+    from tests import gpu_checks
+    _run(gpu_checks.check_lstm)

@@ -1,0 +1,603 @@
+// conv_igemm.hip -- implicit-GEMM convolution for gfx950 on the fp32 MFMA pipe.
+//
+// One kernel family covers every dense contraction of the SAVP hot path (see include/savp_hip.h):
+// ConvLSTM 5x5 gate convs (rnn_ops.py:121), conv_pool2d stride-2 convs (ops.py:844), upsample_conv2d
+// (= conv2d_transpose, ops.py:707 -> DGRAD mode), 3x3 heads (ops.py:528), encoder 4x4 s2 (networks.py:18-25),
+// the discriminators' conv2d/conv3d ladders (networks.py:45-102), dense layers as 1x1 convs (ops.py:12), and
+// the data-/weight-gradients of all of them.
+//
+// Design (MI355X-first, not a port of anything):
+//   * 256-thread workgroups = 4 wave64, 2x2 wave grid, each wave owns WMxWN tiles of 32x32 accumulated by
+//     v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak of the chip).
+//   * the im2col gather happens on the fly while staging global -> registers -> LDS; the next K-tile's global
+//     loads are issued before the MFMA loop of the current tile (register prefetch + double-buffered LDS, one
+//     barrier per K-tile of 32).
+//   * FPROP/DGRAD: LDS rows are [row][k] with k contiguous (+4 pad -> conflict-free ds_read_b128); each lane
+//     reads 4 consecutive k for its row and feeds 4 MFMA k-steps (A and B use the same k permutation).
+//   * DGRAD of strided convs is phase-decomposed (blockIdx.z = output phase) so no MAC is spent on the zeros
+//     of the transposed convolution.
+//   * WGRAD: K = all output pixels (time and batch folded in), split-K over blockIdx.z with fp32 atomics;
+//     LDS is K-major so both operands are staged with float4 along their contiguous channel axis.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define BKP 36          // padded K row (floats) for the row-major-K LDS layout
+#define NTHREADS 256
+
+struct ConvP {
+    int mode;
+    int N, D, H, W, Cx;
+    int Do, Ho, Wo, Cy;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    int beta, act;
+    float alpha;
+    const float* x; long long x_sn, x_sd, x_sh, x_sw;
+    const float* y; long long y_sn, y_sd, y_sh, y_sw;
+    const float* w;
+    float* out;          // destination (y for FPROP, x for DGRAD, dW for WGRAD)
+    const float* bias;
+    const float* aux;
+    int splitk;
+    unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
+};
+
+__device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
+    // floor(p / d) for p < 2^24, d < 2^16 with magic = ceil(2^40 / d)
+    return (unsigned)(((unsigned long long)p * magic) >> 40);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------------------------------------------------
+// FPROP / DGRAD kernel.  GEMM: C[M = grid pixels][N = dst channels] = A[M][K=(taps,Cred)] * B[K][N]
+// ------------------------------------------------------------------------------------------------------------
+struct DimGeom {          // one spatial dimension of the (possibly phase-restricted) problem
+    int Mdim;             // extent of the M-grid along this dim
+    int base, mstep;      // source coord = base + m*mstep + j*jstep
+    int jstep;
+    int nt;               // number of (reduced) taps
+    int t0, tstep;        // full weight tap index = t0 + j*tstep
+    int ob, os;           // destination coord = ob + m*os
+    int srcN;             // source extent (bounds)
+};
+
+__device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out, int k, int s, int p) {
+    DimGeom g;
+    if (!dgrad) {
+        g.Mdim = Out; g.base = -p; g.mstep = s; g.jstep = 1; g.nt = k; g.t0 = 0; g.tstep = 1;
+        g.ob = 0; g.os = 1; g.srcN = In;
+    } else {
+        int u0 = (f + p) % s;
+        g.nt = (k > u0) ? (k - u0 + s - 1) / s : 0;
+        g.base = (f + p - u0) / s; g.mstep = 1; g.jstep = -1;
+        g.t0 = u0; g.tstep = s;
+        g.Mdim = (In > f) ? (In - f + s - 1) / s : 0;
+        g.ob = f; g.os = s; g.srcN = Out;
+    }
+    return g;
+}
+
+template <int WM, int WN, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int RA = BM / 32, RB = BN / 32;        // float4 rows fetched per thread for A / B
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BM][BKP]
+    float* Bs = smem + 2 * BM * BKP;                   // [2][BN][BKP]
+
+    const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
+    // phase decode (DGRAD only): blockIdx.z -> (fd, fh, fw)
+    int fz = blockIdx.z;
+    int fw = dgrad ? fz % p.sw : 0; fz = dgrad ? fz / p.sw : 0;
+    int fh = dgrad ? fz % p.sh : 0; fz = dgrad ? fz / p.sh : 0;
+    int fd = fz;
+    const DimGeom gd = make_geom(dgrad, fd, p.D, p.Do, p.kd, p.sd, p.pd);
+    const DimGeom gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
+    const DimGeom gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
+
+    const int Cred = dgrad ? p.Cy : p.Cx;             // reduction channels
+    const int Nout = dgrad ? p.Cx : p.Cy;             // destination channels
+    const int ntaps = gd.nt * gh.nt * gw.nt;
+    const int K = ntaps * Cred;
+    const int ldb = p.kd * p.kh * p.kw * Cred;        // packed weight row length
+    const int Mtot = p.N * gd.Mdim * gh.Mdim * gw.Mdim;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    if (m0 >= Mtot) return;                            // uniform per workgroup (phase with fewer pixels)
+
+    const float* __restrict__ src = dgrad ? p.y : p.x;
+    const long long s_sn = dgrad ? p.y_sn : p.x_sn;
+    const int s_sd = (int)(dgrad ? p.y_sd : p.x_sd), s_sh = (int)(dgrad ? p.y_sh : p.x_sh),
+              s_sw = (int)(dgrad ? p.y_sw : p.x_sw);
+    const float* __restrict__ wt = p.w;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kv = tid & 7, r0 = tid >> 3;
+
+    // ---- per-thread A rows --------------------------------------------------------------------------------
+    long long a_base[RA];
+    int a_cd[RA], a_ch[RA], a_cw[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        int m = m0 + r0 + 32 * j;
+        a_ok[j] = m < Mtot;
+        int mm = a_ok[j] ? m : 0;
+        int qw = mm % gw.Mdim; mm /= gw.Mdim;
+        int qh = mm % gh.Mdim; mm /= gh.Mdim;
+        int qd = mm % gd.Mdim; int n = mm / gd.Mdim;
+        a_base[j] = (long long)n * s_sn;
+        a_cd[j] = gd.base + qd * gd.mstep;
+        a_ch[j] = gh.base + qh * gh.mstep;
+        a_cw[j] = gw.base + qw * gw.mstep;
+    }
+    // ---- per-thread B rows --------------------------------------------------------------------------------
+    bool b_ok[RB];
+    long long b_base[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        int n = n0 + r0 + 32 * j;
+        b_ok[j] = n < Nout;
+        b_base[j] = (long long)(b_ok[j] ? n : 0) * ldb;
+    }
+    // ---- K state (vector path): this thread's float4 sits at k = kt*32 + kv*4 -------------------------------
+    int kc = 0, jd = 0, jh = 0, jw = 0;     // channel offset, reduced tap indices
+    if (VEC) {
+        int k = kv * 4;
+        kc = k % Cred; int tap = k / Cred;
+        jw = tap % max(gw.nt, 1); tap /= max(gw.nt, 1);
+        jh = tap % max(gh.nt, 1); jd = tap / max(gh.nt, 1);
+    }
+
+    float4 ra[RA], rb[RB];
+
+    auto fetch = [&](int kt) {
+        if (VEC) {
+            const bool kok = (jd < gd.nt) && (ntaps > 0);
+            const int zd0 = jd * gd.jstep, zh0 = jh * gh.jstep, zw0 = jw * gw.jstep;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                int zd = a_cd[j] + zd0, zh = a_ch[j] + zh0, zw = a_cw[j] + zw0;
+                bool ok = a_ok[j] && kok && (unsigned)zd < (unsigned)gd.srcN && (unsigned)zh < (unsigned)gh.srcN &&
+                          (unsigned)zw < (unsigned)gw.srcN;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = ldg4(src + a_base[j] + (long long)zd * s_sd + (long long)zh * s_sh + (long long)zw * s_sw + kc);
+                ra[j] = v;
+            }
+            const int ta = gd.t0 + jd * gd.tstep, tu = gh.t0 + jh * gh.tstep, tv = gw.t0 + jw * gw.tstep;
+            const long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + kc;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_ok[j] && kok) v = ldg4(wt + b_base[j] + woff);
+                rb[j] = v;
+            }
+            // advance by BK
+            kc += BK;
+            while (kc >= Cred) {
+                kc -= Cred;
+                if (++jw >= gw.nt) { jw = 0; if (++jh >= gh.nt) { jh = 0; ++jd; } }
+            }
+        } else {
+            // scalar path: arbitrary Cred (first layers with 3/6/14 channels, the 53-channel mask conv)
+            float av[RA][4], bv[RB][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int k = kt * BK + kv * 4 + e;
+                bool kok = k < K;
+                int kk = kok ? k : 0;
+                int c = kk % Cred; int tap = kk / Cred;
+                int tw_ = tap % max(gw.nt, 1); tap /= max(gw.nt, 1);
+                int th_ = tap % max(gh.nt, 1); int td_ = tap / max(gh.nt, 1);
+#pragma unroll
+                for (int j = 0; j < RA; ++j) {
+                    int zd = a_cd[j] + td_ * gd.jstep, zh = a_ch[j] + th_ * gh.jstep, zw = a_cw[j] + tw_ * gw.jstep;
+                    bool ok = a_ok[j] && kok && (unsigned)zd < (unsigned)gd.srcN && (unsigned)zh < (unsigned)gh.srcN &&
+                              (unsigned)zw < (unsigned)gw.srcN;
+                    av[j][e] = ok ? src[a_base[j] + (long long)zd * s_sd + (long long)zh * s_sh + (long long)zw * s_sw + c] : 0.f;
+                }
+                int ta = gd.t0 + td_ * gd.tstep, tu = gh.t0 + th_ * gh.tstep, tv = gw.t0 + tw_ * gw.tstep;
+                long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + c;
+#pragma unroll
+                for (int j = 0; j < RB; ++j) bv[j][e] = (b_ok[j] && kok) ? wt[b_base[j] + woff] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < RA; ++j) ra[j] = make_float4(av[j][0], av[j][1], av[j][2], av[j][3]);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rb[j] = make_float4(bv[j][0], bv[j][1], bv[j][2], bv[j][3]);
+        }
+    };
+    auto stage = [&](int buf) {
+        float* a = As + buf * BM * BKP;
+        float* b = Bs + buf * BN * BKP;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(a + (r0 + 32 * j) * BKP + kv * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(b + (r0 + 32 * j) * BKP + kv * 4) = rb[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int nk = (K + BK - 1) / BK;
+
+    if (nk > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) fetch(kt + 1);
+        const float* a = As + cur * BM * BKP;
+        const float* b = Bs + cur * BN * BKP;
+#pragma unroll
+        for (int c8 = 0; c8 < BK / 8; ++c8) {
+            float4 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(a + (wm0 + i * 32 + l31) * BKP + c8 * 8 + khalf * 4);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(b + (wn0 + j * 32 + l31) * BKP + c8 * 8 + khalf * 4);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: destination row offsets through LDS -------------------------------------------------------
+    long long* rowoff = reinterpret_cast<long long*>(smem);     // [BM], -1 = invalid
+    float* __restrict__ dst = p.out;
+    const long long d_sn = dgrad ? p.x_sn : p.y_sn;
+    const long long d_sd = dgrad ? p.x_sd : p.y_sd, d_sh = dgrad ? p.x_sh : p.y_sh, d_sw = dgrad ? p.x_sw : p.y_sw;
+    if (tid < BM) {
+        int m = m0 + tid;
+        long long off = -1;
+        if (m < Mtot) {
+            int mm = m;
+            int qw = mm % gw.Mdim; mm /= gw.Mdim;
+            int qh = mm % gh.Mdim; mm /= gh.Mdim;
+            int qd = mm % gd.Mdim; int n = mm / gd.Mdim;
+            off = (long long)n * d_sn + (long long)(gd.ob + qd * gd.os) * d_sd + (long long)(gh.ob + qh * gh.os) * d_sh +
+                  (long long)(gw.ob + qw * gw.os) * d_sw;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= Nout) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const long long off = rowoff[row];
+                if (off < 0) continue;
+                float v = acc[i][j][r] + bias;
+                float* q = dst + off + col;
+                if (p.beta) v += *q;
+                if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
+                else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                else if (p.act == SAVP_ACT_DLRELU_FROM_OUT) v *= (p.aux[off + col] > 0.f ? 1.f : p.alpha);
+                *q = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// WGRAD kernel.  GEMM: dW[M=(tap,cx)][N=cy] += A[M][K=pixels] * B[K][N];  split-K over blockIdx.z.
+// ------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, bool VECA, bool VECB>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(ConvP p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BMP = BM + 4, BNP = BN + 4;
+    constexpr int AV = BM / 4, BV = BN / 4;          // float4 columns per k row
+    constexpr int AK = NTHREADS / AV, BKK = NTHREADS / BV;   // k rows covered per pass
+    constexpr int AP = BK / AK, BP = BK / BKK;       // passes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BK][BMP]
+    float* Bs = smem + 2 * BK * BMP;                   // [2][BK][BNP]
+
+    const int M = p.kd * p.kh * p.kw * p.Cx;
+    const int Nn = p.Cy;
+    const int HWo = p.Ho * p.Wo, DHWo = p.Do * HWo;
+    const int Ktot = p.N * DHWo;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // K range of this split (multiple of BK)
+    const int ktiles = (Ktot + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt_begin = blockIdx.z * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+
+    const float* __restrict__ X = p.x;
+    const float* __restrict__ Y = p.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // A mapping: fixed m-vector per thread
+    const int amv = tid % AV, akk = tid / AV;
+    int a_m = m0 + amv * 4;
+    int a_c[4], a_td[4], a_th[4], a_tw[4]; bool a_mok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int m = a_m + e;
+        a_mok[e] = m < M;
+        int mm = a_mok[e] ? m : 0;
+        a_c[e] = mm % p.Cx; int tap = mm / p.Cx;
+        a_tw[e] = tap % p.kw; tap /= p.kw;
+        a_th[e] = tap % p.kh; a_td[e] = tap / p.kh;
+    }
+    const int bnv = tid % BV, bkk = tid / BV;
+    const int b_n = n0 + bnv * 4;
+
+    float4 ra[AP], rb[BP];
+
+    auto decode = [&](int pix, int& n, int& od, int& oy, int& ox) {
+        unsigned up = (unsigned)pix;
+        n = (int)fastdiv(up, p.magDHW); unsigned r = up - (unsigned)n * DHWo;
+        od = (int)fastdiv(r, p.magHW); r -= (unsigned)od * HWo;
+        oy = (int)fastdiv(r, p.magW); ox = (int)(r - (unsigned)oy * p.Wo);
+    };
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            int pix = kt * BK + akk + j * AK;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < Ktot) {
+                int n, od, oy, ox; decode(pix, n, od, oy, ox);
+                const long long nb = (long long)n * p.x_sn;
+                if (VECA) {
+                    int zd = od * p.sd - p.pd + a_td[0], zh = oy * p.sh - p.ph + a_th[0], zw = ox * p.sw - p.pw + a_tw[0];
+                    if (a_mok[0] && (unsigned)zd < (unsigned)p.D && (unsigned)zh < (unsigned)p.H && (unsigned)zw < (unsigned)p.W)
+                        v = ldg4(X + nb + zd * p.x_sd + zh * p.x_sh + zw * p.x_sw + a_c[0]);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int zd = od * p.sd - p.pd + a_td[e], zh = oy * p.sh - p.ph + a_th[e], zw = ox * p.sw - p.pw + a_tw[e];
+                        bool ok = a_mok[e] && (unsigned)zd < (unsigned)p.D && (unsigned)zh < (unsigned)p.H && (unsigned)zw < (unsigned)p.W;
+                        t[e] = ok ? X[nb + zd * p.x_sd + zh * p.x_sh + zw * p.x_sw + a_c[e]] : 0.f;
+                    }
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            int pix = kt * BK + bkk + j * BKK;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < Ktot) {
+                int n, od, oy, ox; decode(pix, n, od, oy, ox);
+                const float* q = Y + (long long)n * p.y_sn + od * p.y_sd + oy * p.y_sh + ox * p.y_sw;
+                if (VECB) {
+                    if (b_n < Nn) v = ldg4(q + b_n);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (b_n + e < Nn) ? q[b_n + e] : 0.f;
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        float* a = As + buf * BK * BMP;
+        float* b = Bs + buf * BK * BNP;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) *reinterpret_cast<float4*>(a + (akk + j * AK) * BMP + amv * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<float4*>(b + (bkk + j * BKK) * BNP + bnv * 4) = rb[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    fetch(kt_begin);
+    stage(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) fetch(kt + 1);
+        const float* a = As + cur * BK * BMP;
+        const float* b = Bs + cur * BK * BNP;
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            float af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = a[(k2 * 2 + khalf) * BMP + wm0 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = b[(k2 * 2 + khalf) * BNP + wn0 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt_end) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* __restrict__ dW = p.out;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= Nn) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row < M) unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------------------
+static unsigned long long magic40(int d) {
+    if (d <= 0) d = 1;
+    return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
+}
+
+template <int WM, int WN>
+static hipError_t launch_fd(const ConvP& p, bool vec, dim3 grid, hipStream_t st) {
+    size_t lds = (size_t)2 * (64 * WM + 64 * WN) * BKP * sizeof(float);
+    if (vec) {
+        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_fd_kernel<WM, WN, true>), grid, dim3(NTHREADS), lds, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_fd_kernel<WM, WN, false>), grid, dim3(NTHREADS), lds, st, p);
+    }
+    return hipGetLastError();
+}
+
+template <int WM, int WN>
+static hipError_t launch_wg(const ConvP& p, bool va, bool vb, dim3 grid, hipStream_t st) {
+    size_t lds = (size_t)2 * BK * ((64 * WM + 4) + (64 * WN + 4)) * sizeof(float);
+#define WG_CASE(A, B)                                                                                              \
+    {                                                                                                              \
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<WM, WN, A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                             \
+        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, A, B>), grid, dim3(NTHREADS), lds, st, p);                   \
+    }
+    if (va && vb) WG_CASE(true, true)
+    else if (va) WG_CASE(true, false)
+    else if (vb) WG_CASE(false, true)
+    else WG_CASE(false, false)
+#undef WG_CASE
+    return hipGetLastError();
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static void pick_tile(long long M, long long N, int& wm, int& wn) {
+    // cost model: rounds over the 256 CUs x tile area x a re-read penalty for small tiles
+    const int opts[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    double best = 1e300;
+    for (int i = 0; i < 4; ++i) {
+        long long bm = 64 * opts[i][0], bn = 64 * opts[i][1];
+        long long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn;
+        double wgs = (double)tm * tn;
+        double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;
+        double eff = (bm * bn == 128 * 128) ? 1.0 : (bm * bn == 64 * 64 ? 1.3 : 1.12);
+        double cost = rounds * (double)(bm * bn) * eff;
+        if (cost < best) { best = cost; wm = opts[i][0]; wn = opts[i][1]; }
+    }
+}
+
+extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
+    if (!a || !a->x || !a->y || !a->w) return SAVP_EINVAL;
+    if (a->sd < 1 || a->sh < 1 || a->sw < 1 || a->kd < 1 || a->kh < 1 || a->kw < 1) return SAVP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p;
+    p.mode = a->mode;
+    p.N = a->N; p.D = a->D; p.H = a->H; p.W = a->W; p.Cx = a->Cx;
+    p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo; p.Cy = a->Cy;
+    p.kd = a->kd; p.kh = a->kh; p.kw = a->kw; p.sd = a->sd; p.sh = a->sh; p.sw = a->sw;
+    p.pd = a->pd; p.ph = a->ph; p.pw = a->pw;
+    p.beta = a->beta; p.act = a->act; p.alpha = a->alpha;
+    p.x = (const float*)a->x; p.x_sn = a->x_sn; p.x_sd = a->x_sd; p.x_sh = a->x_sh; p.x_sw = a->x_sw;
+    p.y = (const float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
+    p.w = (const float*)a->w;
+    p.bias = a->bias; p.aux = a->aux;
+    p.splitk = 1;
+    p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
+    int wm = 0, wn = 0;
+    if (a->tile) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
+    hipError_t err;
+    const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
+    const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
+    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
+        const bool dg = a->mode == SAVP_CONV_DGRAD;
+        p.out = (float*)(dg ? a->x : a->y);
+        const int Cred = dg ? a->Cy : a->Cx;
+        const int Nout = dg ? a->Cx : a->Cy;
+        const bool vec = (Cred % 4 == 0) && (dg ? ys4 : xs4) && aligned16(a->w);
+        long long Mmax;
+        int phases = 1;
+        if (dg) {
+            phases = a->sd * a->sh * a->sw;
+            Mmax = (long long)a->N * ((a->D + a->sd - 1) / a->sd) * ((a->H + a->sh - 1) / a->sh) * ((a->W + a->sw - 1) / a->sw);
+        } else {
+            Mmax = (long long)a->N * a->Do * a->Ho * a->Wo;
+        }
+        if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
+        if (!wm) pick_tile(Mmax * phases, Nout, wm, wn);
+        const int BM = 64 * wm, BN = 64 * wn;
+        dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((Nout + BN - 1) / BN), (unsigned)phases);
+        if (wm == 2 && wn == 2) err = launch_fd<2, 2>(p, vec, grid, st);
+        else if (wm == 2 && wn == 1) err = launch_fd<2, 1>(p, vec, grid, st);
+        else if (wm == 1 && wn == 2) err = launch_fd<1, 2>(p, vec, grid, st);
+        else err = launch_fd<1, 1>(p, vec, grid, st);
+    } else if (a->mode == SAVP_CONV_WGRAD) {
+        p.out = (float*)a->w;
+        const long long M = (long long)a->kd * a->kh * a->kw * a->Cx;
+        const long long Ktot = (long long)a->N * a->Do * a->Ho * a->Wo;
+        // fastdiv exactness domain: p * d < 2^40 for every (pixel index p, divisor d)
+        if (Ktot <= 0 || (double)Ktot * (double)((long long)a->Do * a->Ho * a->Wo) >= 1099511627776.0) return SAVP_EINVAL;
+        const bool va = (a->Cx % 4 == 0) && xs4;
+        const bool vb = (a->Cy % 4 == 0) && ys4;
+        if (!wm) {
+            wm = (M > 64) ? 2 : 1;
+            wn = (a->Cy > 64) ? 2 : 1;
+        }
+        const int BM = 64 * wm, BN = 64 * wn;
+        const long long tiles = ((M + BM - 1) / BM) * ((a->Cy + BN - 1) / BN);
+        const long long ktiles = (Ktot + BK - 1) / BK;
+        int splitk = a->splitk;
+        if (splitk <= 0) {
+            long long want = (512 + tiles - 1) / tiles;           // ~2 workgroups per CU
+            long long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;     // at least 8 K-tiles per split
+            splitk = (int)(want < maxs ? want : maxs);
+            if (splitk < 1) splitk = 1;
+        }
+        if (splitk > ktiles) splitk = (int)ktiles;
+        if (splitk < 1) splitk = 1;
+        p.splitk = splitk;
+        dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a->Cy + BN - 1) / BN), (unsigned)splitk);
+        if (wm == 2 && wn == 2) err = launch_wg<2, 2>(p, va, vb, grid, st);
+        else if (wm == 2 && wn == 1) err = launch_wg<2, 1>(p, va, vb, grid, st);
+        else if (wm == 1 && wn == 2) err = launch_wg<1, 2>(p, va, vb, grid, st);
+        else err = launch_wg<1, 1>(p, va, vb, grid, st);
+    } else {
+        return SAVP_EINVAL;
+    }
+    return err == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}

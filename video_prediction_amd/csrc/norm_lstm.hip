@@ -1,0 +1,486 @@
+// norm_lstm.hip -- fused instance-norm(+activation) and the fused ConvLSTM gate block, forward and backward.
+//
+// Replaces, per call, what the reference spends 2 transposes + nn.fused_batch_norm + activation on
+// (layers/normalization.py:146-170, savp_model.py:463-464,499-500) and, for the ConvLSTM cell
+// (rnn_ops.py:148-165), IN(4F) + split + sigmoid/tanh + Hadamard + IN(F) + tanh*sigmoid -- about 14 TF ops --
+// with ONE kernel each way.  One workgroup owns (sample n, 4 consecutive channels) over the whole H*W plane,
+// so both per-sample reductions are workgroup-local (no grid sync, no atomics except the per-channel
+// gamma/beta gradients which are summed over samples and timesteps).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+#define NT 256
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// sum NV per-thread values over the 256-thread block; result broadcast to all threads. `sh` >= 4*NV floats.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = wave_sum(v[i]);
+        if (lane == 0) sh[wave * NV + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh via exp; exact enough in fp32 (|err| ~ 1e-7) and saturates correctly
+    float e = __expf(-2.f * fabsf(x));
+    float t = (1.f - e) / (1.f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return fmaxf(v, alpha * v);
+    return v;
+}
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float alpha) {
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? 1.f : alpha;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// instance norm + activation, forward.  grid = N * C/4
+// ------------------------------------------------------------------------------------------------------------
+struct InormP {
+    int N, HW, C;
+    const float* x; long long x_sn, x_sp;
+    const float* gamma; const float* beta;
+    float eps; int act; float alpha;
+    int nout; float* out[4]; long long o_sn[4], o_sp[4];
+    float* mean; float* rstd;       // [N, C]
+    // backward
+    int ndy; const float* dy[4]; long long dy_sn[4], dy_sp[4];
+    const float* yout; long long y_sn, y_sp;    // saved activation output (for the activation mask)
+    float* dx; long long dx_sn, dx_sp; int dx_beta;
+    float* dgamma; float* dbeta;
+};
+
+__global__ __launch_bounds__(NT) void inorm_fwd_kernel(InormP p) {
+    __shared__ float sh[4 * 4];
+    const int cg = p.C / 4;
+    const int n = blockIdx.x / cg, c0 = (blockIdx.x % cg) * 4;
+    const float* x = p.x + (long long)n * p.x_sn + c0;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int px = threadIdx.x; px < p.HW; px += NT) {
+        float4 v = ld4(x + (long long)px * p.x_sp);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+    block_sum<4>(s, sh);
+    const float inv = 1.f / (float)p.HW;
+    const float m0 = s[0] * inv, m1 = s[1] * inv, m2 = s[2] * inv, m3 = s[3] * inv;
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int px = threadIdx.x; px < p.HW; px += NT) {
+        float4 v = ld4(x + (long long)px * p.x_sp);
+        q[0] += (v.x - m0) * (v.x - m0); q[1] += (v.y - m1) * (v.y - m1);
+        q[2] += (v.z - m2) * (v.z - m2); q[3] += (v.w - m3) * (v.w - m3);
+    }
+    block_sum<4>(q, sh);
+    const float r0 = rsqrtf(q[0] * inv + p.eps), r1 = rsqrtf(q[1] * inv + p.eps), r2 = rsqrtf(q[2] * inv + p.eps),
+                r3 = rsqrtf(q[3] * inv + p.eps);
+    if (threadIdx.x == 0) {
+        float* mp = p.mean + (long long)n * p.C + c0; float* rp = p.rstd + (long long)n * p.C + c0;
+        mp[0] = m0; mp[1] = m1; mp[2] = m2; mp[3] = m3;
+        rp[0] = r0; rp[1] = r1; rp[2] = r2; rp[3] = r3;
+    }
+    const float4 g = ld4(p.gamma + c0), b = ld4(p.beta + c0);
+    for (int px = threadIdx.x; px < p.HW; px += NT) {
+        float4 v = ld4(x + (long long)px * p.x_sp);
+        float4 o;
+        o.x = act_fwd((v.x - m0) * r0 * g.x + b.x, p.act, p.alpha);
+        o.y = act_fwd((v.y - m1) * r1 * g.y + b.y, p.act, p.alpha);
+        o.z = act_fwd((v.z - m2) * r2 * g.z + b.z, p.act, p.alpha);
+        o.w = act_fwd((v.w - m3) * r3 * g.w + b.w, p.act, p.alpha);
+        for (int k = 0; k < p.nout; ++k) st4(p.out[k] + (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k] + c0, o);
+    }
+}
+
+__global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
+    __shared__ float sh[4 * 8];
+    const int cg = p.C / 4;
+    const int n = blockIdx.x / cg, c0 = (blockIdx.x % cg) * 4;
+    const float* x = p.x + (long long)n * p.x_sn + c0;
+    const float* yo = p.yout + (long long)n * p.y_sn + c0;
+    const float4 m = ld4(p.mean + (long long)n * p.C + c0), r = ld4(p.rstd + (long long)n * p.C + c0);
+    const float4 g = ld4(p.gamma + c0);
+    auto load_dz = [&](int px, float4& xh) -> float4 {
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < p.ndy; ++k) {
+            float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + c0);
+            d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        }
+        float4 y = ld4(yo + (long long)px * p.y_sp);
+        d.x *= act_grad_from_out(y.x, p.act, p.alpha); d.y *= act_grad_from_out(y.y, p.act, p.alpha);
+        d.z *= act_grad_from_out(y.z, p.act, p.alpha); d.w *= act_grad_from_out(y.w, p.act, p.alpha);
+        float4 v = ld4(x + (long long)px * p.x_sp);
+        xh.x = (v.x - m.x) * r.x; xh.y = (v.y - m.y) * r.y; xh.z = (v.z - m.z) * r.z; xh.w = (v.w - m.w) * r.w;
+        return d;
+    };
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int px = threadIdx.x; px < p.HW; px += NT) {
+        float4 xh; float4 d = load_dz(px, xh);
+        s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
+        s[4] += d.x * xh.x; s[5] += d.y * xh.y; s[6] += d.z * xh.z; s[7] += d.w * xh.w;
+    }
+    block_sum<8>(s, sh);
+    if (threadIdx.x < 4) {
+        unsafeAtomicAdd(p.dbeta + c0 + threadIdx.x, s[threadIdx.x]);
+        unsafeAtomicAdd(p.dgamma + c0 + threadIdx.x, s[4 + threadIdx.x]);
+    }
+    const float inv = 1.f / (float)p.HW;
+    float* dx = p.dx + (long long)n * p.dx_sn + c0;
+    for (int px = threadIdx.x; px < p.HW; px += NT) {
+        float4 xh; float4 d = load_dz(px, xh);
+        float4 o;
+        o.x = g.x * r.x * (d.x - s[0] * inv - xh.x * s[4] * inv);
+        o.y = g.y * r.y * (d.y - s[1] * inv - xh.y * s[5] * inv);
+        o.z = g.z * r.z * (d.z - s[2] * inv - xh.z * s[6] * inv);
+        o.w = g.w * r.w * (d.w - s[3] * inv - xh.w * s[7] * inv);
+        float* q = dx + (long long)px * p.dx_sp;
+        if (p.dx_beta) { float4 t = ld4(q); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        st4(q, o);
+    }
+}
+
+extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
+    if (!a || a->C % 4 || a->nout < 1 || a->nout > 4) return SAVP_EINVAL;
+    InormP p;
+    p.N = a->N; p.HW = a->HW; p.C = a->C;
+    p.x = (const float*)a->x.p; p.x_sn = a->x.sn; p.x_sp = a->x.sp;
+    p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.act = a->act; p.alpha = a->alpha;
+    p.nout = a->nout;
+    for (int i = 0; i < a->nout; ++i) { p.out[i] = (float*)a->out[i].p; p.o_sn[i] = a->out[i].sn; p.o_sp[i] = a->out[i].sp; }
+    p.mean = a->mean; p.rstd = a->rstd;
+    hipLaunchKernelGGL(inorm_fwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}
+
+extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
+    if (!a || a->C % 4 || a->ndy < 1 || a->ndy > 4) return SAVP_EINVAL;
+    InormP p;
+    p.N = a->N; p.HW = a->HW; p.C = a->C;
+    p.x = (const float*)a->x.p; p.x_sn = a->x.sn; p.x_sp = a->x.sp;
+    p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.act = a->act; p.alpha = a->alpha;
+    p.mean = a->mean; p.rstd = a->rstd;
+    p.ndy = a->ndy;
+    for (int i = 0; i < a->ndy; ++i) { p.dy[i] = (const float*)a->dy[i].p; p.dy_sn[i] = a->dy[i].sn; p.dy_sp[i] = a->dy[i].sp; }
+    p.yout = (const float*)a->out[0].p; p.y_sn = a->out[0].sn; p.y_sp = a->out[0].sp;
+    p.dx = (float*)a->dx.p; p.dx_sn = a->dx.sn; p.dx_sp = a->dx.sp; p.dx_beta = a->dx_beta;
+    p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+    hipLaunchKernelGGL(inorm_bwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fused ConvLSTM gate block.  gates_pre [N, HW, 4F] contiguous (order i, j, f, o as in rnn_ops.py:150).
+// One workgroup = (n, 4 channels); HW <= 1024 (every ConvLSTM plane of the reference is <= 32x32).
+// ------------------------------------------------------------------------------------------------------------
+#define MAXPPT 4
+struct LstmP {
+    int N, HW, F;
+    const float* gates;
+    const float* c_prev; long long cp_sn, cp_sp;          // may be null (zero state)
+    const float *g1, *b1, *g2, *b2;
+    float eps, forget_bias;
+    float* c_new;                                         // [N, HW, F] contiguous
+    int nh; float* h[4]; long long h_sn[4], h_sp[4];
+    float *mean1, *rstd1, *mean2, *rstd2;                 // [N,4F], [N,F]
+    // backward
+    int ndh; const float* dh[4]; long long dh_sn[4], dh_sp[4];
+    const float* dc_new;                                  // [N,HW,F] contiguous or null
+    float* dgates;                                        // [N,HW,4F]
+    float* dc_prev;                                       // [N,HW,F] contiguous or null
+    float *dg1, *db1, *dg2, *db2;
+};
+
+__global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmP p) {
+    __shared__ float sh[4 * 16];
+    const int cg = p.F / 4;
+    const int n = blockIdx.x / cg, c0 = (blockIdx.x % cg) * 4;
+    const int F = p.F;
+    const float* gp = p.gates + (long long)n * p.HW * 4 * F + c0;
+    float4 gi[MAXPPT], gj[MAXPPT], gf[MAXPPT], go[MAXPPT];
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            const float* q = gp + (long long)px * 4 * F;
+            gi[t] = ld4(q); gj[t] = ld4(q + F); gf[t] = ld4(q + 2 * F); go[t] = ld4(q + 3 * F);
+            s[0] += gi[t].x; s[1] += gi[t].y; s[2] += gi[t].z; s[3] += gi[t].w;
+            s[4] += gj[t].x; s[5] += gj[t].y; s[6] += gj[t].z; s[7] += gj[t].w;
+            s[8] += gf[t].x; s[9] += gf[t].y; s[10] += gf[t].z; s[11] += gf[t].w;
+            s[12] += go[t].x; s[13] += go[t].y; s[14] += go[t].z; s[15] += go[t].w;
+        }
+    }
+    block_sum<16>(s, sh);
+    const float inv = 1.f / (float)p.HW;
+    float mu[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mu[i] = s[i] * inv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#define SQ(a, m) (((a) - (m)) * ((a) - (m)))
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            s[0] += SQ(gi[t].x, mu[0]); s[1] += SQ(gi[t].y, mu[1]); s[2] += SQ(gi[t].z, mu[2]); s[3] += SQ(gi[t].w, mu[3]);
+            s[4] += SQ(gj[t].x, mu[4]); s[5] += SQ(gj[t].y, mu[5]); s[6] += SQ(gj[t].z, mu[6]); s[7] += SQ(gj[t].w, mu[7]);
+            s[8] += SQ(gf[t].x, mu[8]); s[9] += SQ(gf[t].y, mu[9]); s[10] += SQ(gf[t].z, mu[10]); s[11] += SQ(gf[t].w, mu[11]);
+            s[12] += SQ(go[t].x, mu[12]); s[13] += SQ(go[t].y, mu[13]); s[14] += SQ(go[t].z, mu[14]); s[15] += SQ(go[t].w, mu[15]);
+        }
+    }
+    block_sum<16>(s, sh);
+    float rs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rs[i] = rsqrtf(s[i] * inv + p.eps);
+    if (threadIdx.x < 16) {
+        const int q = threadIdx.x >> 2, c = threadIdx.x & 3;
+        p.mean1[(long long)n * 4 * F + q * F + c0 + c] = mu[threadIdx.x];
+        p.rstd1[(long long)n * 4 * F + q * F + c0 + c] = rs[threadIdx.x];
+    }
+    float ga[16], be[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ga[q * 4 + c] = p.g1[q * F + c0 + c]; be[q * 4 + c] = p.b1[q * F + c0 + c]; }
+
+    // normalised gates -> c_pre ; keep sigmoid(o) and c_pre in registers
+    float cpre[MAXPPT][4], so[MAXPPT][4];
+    float s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)px * p.cp_sp + c0);
+            const float iv[4] = {gi[t].x, gi[t].y, gi[t].z, gi[t].w}, jv[4] = {gj[t].x, gj[t].y, gj[t].z, gj[t].w};
+            const float fv[4] = {gf[t].x, gf[t].y, gf[t].z, gf[t].w}, ov[4] = {go[t].x, go[t].y, go[t].z, go[t].w};
+            const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float in_ = (iv[c] - mu[c]) * rs[c] * ga[c] + be[c];
+                float jn = (jv[c] - mu[4 + c]) * rs[4 + c] * ga[4 + c] + be[4 + c];
+                float fn = (fv[c] - mu[8 + c]) * rs[8 + c] * ga[8 + c] + be[8 + c];
+                float on = (ov[c] - mu[12 + c]) * rs[12 + c] * ga[12 + c] + be[12 + c];
+                float cn = cpv[c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+                cpre[t][c] = cn; so[t][c] = sigmoidf_(on);
+                s2[c] += cn;
+            }
+        }
+    }
+    block_sum<4>(s2, sh);
+    float mu2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { mu2[c] = s2[c] * inv; s2[c] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s2[c] += SQ(cpre[t][c], mu2[c]);
+        }
+    }
+    block_sum<4>(s2, sh);
+    float rs2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rs2[c] = rsqrtf(s2[c] * inv + p.eps);
+    if (threadIdx.x < 4) {
+        p.mean2[(long long)n * F + c0 + threadIdx.x] = mu2[threadIdx.x];
+        p.rstd2[(long long)n * F + c0 + threadIdx.x] = rs2[threadIdx.x];
+    }
+    const float4 g2 = ld4(p.g2 + c0), b2 = ld4(p.b2 + c0);
+    const float g2v[4] = {g2.x, g2.y, g2.z, g2.w}, b2v[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            float cn[4], hv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cn[c] = (cpre[t][c] - mu2[c]) * rs2[c] * g2v[c] + b2v[c];
+                hv[c] = tanhf_(cn[c]) * so[t][c];
+            }
+            st4(p.c_new + ((long long)n * p.HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
+            const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            for (int k = 0; k < p.nh; ++k) st4(p.h[k] + (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmP p) {
+    __shared__ float sh[4 * 32];
+    const int cg = p.F / 4;
+    const int n = blockIdx.x / cg, c0 = (blockIdx.x % cg) * 4;
+    const int F = p.F;
+    const float* gp = p.gates + (long long)n * p.HW * 4 * F + c0;
+    float mu[16], rs[16], ga[16], be[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long o = (long long)n * 4 * F + q * F + c0 + c;
+            mu[q * 4 + c] = p.mean1[o]; rs[q * 4 + c] = p.rstd1[o];
+            ga[q * 4 + c] = p.g1[q * F + c0 + c]; be[q * 4 + c] = p.b1[q * F + c0 + c];
+        }
+    float mu2[4], rs2[4], g2v[4], b2v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mu2[c] = p.mean2[(long long)n * F + c0 + c]; rs2[c] = p.rstd2[(long long)n * F + c0 + c];
+        g2v[c] = p.g2[c0 + c]; b2v[c] = p.b2[c0 + c];
+    }
+    // per-pixel state kept in registers
+    float xh[MAXPPT][16];     // normalised (pre-affine) gates
+    float dz2[MAXPPT][4];     // d c_new (total)
+    float xh2[MAXPPT][4];     // normalised c_pre
+    float don[MAXPPT][4];     // d o_n (post-affine)
+    float cpv[MAXPPT][4];
+    float r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            const float* q = gp + (long long)px * 4 * F;
+            const float4 a0 = ld4(q), a1 = ld4(q + F), a2 = ld4(q + 2 * F), a3 = ld4(q + 3 * F);
+            const float raw[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xh[t][i] = (raw[i] - mu[i]) * rs[i];
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)px * p.cp_sp + c0);
+            cpv[t][0] = cp.x; cpv[t][1] = cp.y; cpv[t][2] = cp.z; cpv[t][3] = cp.w;
+            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < p.ndh; ++k) {
+                float4 tt = ld4(p.dh[k] + (long long)n * p.dh_sn[k] + (long long)px * p.dh_sp[k] + c0);
+                dh.x += tt.x; dh.y += tt.y; dh.z += tt.z; dh.w += tt.w;
+            }
+            float4 dcn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.dc_new) dcn = ld4(p.dc_new + ((long long)n * p.HW + px) * F + c0);
+            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcnv[4] = {dcn.x, dcn.y, dcn.z, dcn.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float in_ = xh[t][c] * ga[c] + be[c];
+                float jn = xh[t][4 + c] * ga[4 + c] + be[4 + c];
+                float fn = xh[t][8 + c] * ga[8 + c] + be[8 + c];
+                float on = xh[t][12 + c] * ga[12 + c] + be[12 + c];
+                float cpre = cpv[t][c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+                float x2 = (cpre - mu2[c]) * rs2[c];
+                float cn = x2 * g2v[c] + b2v[c];
+                float th = tanhf_(cn), so = sigmoidf_(on);
+                xh2[t][c] = x2;
+                dz2[t][c] = dhv[c] * so * (1.f - th * th) + dcnv[c];
+                don[t][c] = dhv[c] * th * so * (1.f - so);
+                r2[c] += dz2[t][c]; r2[4 + c] += dz2[t][c] * x2;
+            }
+        }
+    }
+    block_sum<8>(r2, sh);
+    if (threadIdx.x < 4) {
+        unsafeAtomicAdd(p.db2 + c0 + threadIdx.x, r2[threadIdx.x]);
+        unsafeAtomicAdd(p.dg2 + c0 + threadIdx.x, r2[4 + threadIdx.x]);
+    }
+    const float inv = 1.f / (float)p.HW;
+    float dg[MAXPPT][16];     // d (post-affine normalised gate)
+    float r1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r1[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            float dcp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float dcpre = g2v[c] * rs2[c] * (dz2[t][c] - r2[c] * inv - xh2[t][c] * r2[4 + c] * inv);
+                float in_ = xh[t][c] * ga[c] + be[c];
+                float jn = xh[t][4 + c] * ga[4 + c] + be[4 + c];
+                float fn = xh[t][8 + c] * ga[8 + c] + be[8 + c];
+                float si = sigmoidf_(in_), tj = tanhf_(jn), sf = sigmoidf_(fn + p.forget_bias);
+                dcp[c] = dcpre * sf;
+                dg[t][c] = dcpre * tj * si * (1.f - si);
+                dg[t][4 + c] = dcpre * si * (1.f - tj * tj);
+                dg[t][8 + c] = dcpre * cpv[t][c] * sf * (1.f - sf);
+                dg[t][12 + c] = don[t][c];
+            }
+            if (p.dc_prev) st4(p.dc_prev + ((long long)n * p.HW + px) * F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { r1[i] += dg[t][i]; r1[16 + i] += dg[t][i] * xh[t][i]; }
+        }
+    }
+    block_sum<32>(r1, sh);
+    if (threadIdx.x < 16) {
+        const int q = threadIdx.x >> 2, c = threadIdx.x & 3;
+        unsafeAtomicAdd(p.db1 + q * F + c0 + c, r1[threadIdx.x]);
+        unsafeAtomicAdd(p.dg1 + q * F + c0 + c, r1[16 + threadIdx.x]);
+    }
+    float* dgp = p.dgates + (long long)n * p.HW * 4 * F + c0;
+#pragma unroll
+    for (int t = 0; t < MAXPPT; ++t) {
+        const int px = threadIdx.x + t * NT;
+        if (px < p.HW) {
+            float o[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = ga[i] * rs[i] * (dg[t][i] - r1[i] * inv - xh[t][i] * r1[16 + i] * inv);
+            float* q = dgp + (long long)px * 4 * F;
+            st4(q, make_float4(o[0], o[1], o[2], o[3]));
+            st4(q + F, make_float4(o[4], o[5], o[6], o[7]));
+            st4(q + 2 * F, make_float4(o[8], o[9], o[10], o[11]));
+            st4(q + 3 * F, make_float4(o[12], o[13], o[14], o[15]));
+        }
+    }
+}
+
+static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
+    if (!a || a->F % 4 || a->HW > MAXPPT * NT || a->HW < 1) return SAVP_EINVAL;
+    p.N = a->N; p.HW = a->HW; p.F = a->F;
+    p.gates = a->gates;
+    p.c_prev = (const float*)a->c_prev.p; p.cp_sn = a->c_prev.sn; p.cp_sp = a->c_prev.sp;
+    p.g1 = a->gamma1; p.b1 = a->beta1; p.g2 = a->gamma2; p.b2 = a->beta2;
+    p.eps = a->eps; p.forget_bias = a->forget_bias;
+    p.c_new = a->c_new;
+    p.nh = a->nh;
+    if (a->nh < 0 || a->nh > 4 || a->ndh < 0 || a->ndh > 4) return SAVP_EINVAL;
+    for (int i = 0; i < a->nh; ++i) { p.h[i] = (float*)a->h[i].p; p.h_sn[i] = a->h[i].sn; p.h_sp[i] = a->h[i].sp; }
+    p.mean1 = a->mean1; p.rstd1 = a->rstd1; p.mean2 = a->mean2; p.rstd2 = a->rstd2;
+    p.ndh = a->ndh;
+    for (int i = 0; i < a->ndh; ++i) { p.dh[i] = (const float*)a->dh[i].p; p.dh_sn[i] = a->dh[i].sn; p.dh_sp[i] = a->dh[i].sp; }
+    p.dc_new = a->dc_new; p.dgates = a->dgates; p.dc_prev = a->dc_prev;
+    p.dg1 = a->dgamma1; p.db1 = a->dbeta1; p.dg2 = a->dgamma2; p.db2 = a->dbeta2;
+    return SAVP_OK;
+}
+
+extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
+    LstmP p;
+    int rc = fill_lstm(p, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}
+
+extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
+    LstmP p;
+    int rc = fill_lstm(p, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}

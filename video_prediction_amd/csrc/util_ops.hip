@@ -1,0 +1,269 @@
+// util_ops.hip -- HBM-bound glue kernels of the SAVP path (all fp32, channels-last views).
+//
+//   tile_channels : tile_concat's broadcast of a [R,c] vector over the pixels of a concat-buffer slice
+//                   (ops.py:968-1006, savp_model.py:456-459,467-469,492-494,503-505); also the backward of the
+//                   global average pool.
+//   colsum        : sum over pixels (and optionally rows): bias gradients, gradient of tile_concat, global
+//                   average pool (networks.py:30).
+//   select        : scheduled-sampling tf.where(ground_truth[t], images, gen_image) (savp_model.py:406) and its
+//                   gradient routing.
+//   gather_clips  : the discriminator's random clip gather tf.gather_nd (savp_model.py:97-102) and its adjoint.
+//   axpby / fill  : flat elementwise helpers (z concatenation savp_model.py:725, gradient accumulation).
+//   adam          : tf.train.AdamOptimizer update on a flat parameter arena (base_model.py:486-487).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+#define NT 256
+
+static inline unsigned nblocks(long long n, int per = NT) {
+    long long b = (n + per - 1) / per;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void tile_channels_kernel(const float* __restrict__ z, long long R, int HW, int C, float scale, float* out,
+                                     long long sn, long long sp, int beta) {
+    long long total = R * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long rp = i / C;
+        int p = (int)(rp % HW);
+        long long r = rp / HW;
+        float v = z[r * C + c] * scale;
+        float* q = out + r * sn + (long long)p * sp + c;
+        *q = beta ? *q + v : v;
+    }
+}
+
+extern "C" int savp_tile_channels(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out,
+                                  int32_t beta) {
+    if (!z || !out.p || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
+    long long total = (long long)R * HW * C;
+    unsigned nb = nblocks(total);
+    if (nb > 65535u * 8) nb = 65535u * 8;
+    hipLaunchKernelGGL(tile_channels_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, z, (long long)R, HW, C, scale,
+                       (float*)out.p, (long long)out.sn, (long long)out.sp, beta);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// colsum: in view [R, HW, C]; per_row: out[r*C+c] (=|+=) scale * sum_p ; else out[c] += scale * sum_{r,p} (atomic).
+// grid = (R, pixel chunks, channel blocks of 64)
+__global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ in, long long sn, long long sp, int HW, int C,
+                                                    float scale, float* out, int per_row, int chunk) {
+    __shared__ float sh[NT];
+    const long long r = blockIdx.x;
+    const int cb = blockIdx.z * 64;
+    const int c = cb + (threadIdx.x & 63);
+    const int pl = threadIdx.x >> 6;                 // 4 pixel lanes
+    const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+    float s = 0.f;
+    if (c < C)
+        for (int p = p0 + pl; p < p1; p += 4) s += in[r * sn + (long long)p * sp + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        float t = (sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]) * scale;
+        if (per_row) unsafeAtomicAdd(out + r * C + c, t);
+        else unsafeAtomicAdd(out + c, t);
+    }
+}
+
+extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out,
+                           int32_t per_row) {
+    // NOTE: always accumulates (atomically) into `out`; zero it first for an overwrite.
+    if (!in.p || !out || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
+    int chunk = 256;
+    dim3 grid((unsigned)R, (unsigned)((HW + chunk - 1) / chunk), (unsigned)((C + 63) / 64));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)in.p, (long long)in.sn,
+                       (long long)in.sp, HW, C, scale, out, per_row, chunk);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct SelP {
+    int N, HW, C;
+    const int* mask;                         // [N] nonzero -> take a
+    const float* a; long long a_sn, a_sp;
+    const float* b; long long b_sn, b_sp;    // may be null (treated as zeros)
+    int nout; float* out[4]; long long o_sn[4], o_sp[4];
+};
+
+__global__ void select_kernel(SelP p) {
+    long long total = (long long)p.N * p.HW * p.C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % p.C);
+        long long np = i / p.C;
+        int px = (int)(np % p.HW);
+        int n = (int)(np / p.HW);
+        float v;
+        if (p.mask[n]) v = p.a[n * p.a_sn + px * p.a_sp + c];
+        else v = p.b ? p.b[n * p.b_sn + px * p.b_sp + c] : 0.f;
+        for (int k = 0; k < p.nout; ++k) p.out[k][n * p.o_sn[k] + px * p.o_sp[k] + c] = v;
+    }
+}
+
+extern "C" int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, SavpView a, SavpView b,
+                           int32_t nout, const SavpView* outs) {
+    if (!mask || !a.p || nout < 1 || nout > 4 || !outs) return SAVP_EINVAL;
+    SelP p;
+    p.N = N; p.HW = HW; p.C = C; p.mask = mask;
+    p.a = (const float*)a.p; p.a_sn = a.sn; p.a_sp = a.sp;
+    p.b = (const float*)b.p; p.b_sn = b.sn; p.b_sp = b.sp;
+    p.nout = nout;
+    for (int i = 0; i < nout; ++i) { p.out[i] = (float*)outs[i].p; p.o_sn[i] = outs[i].sn; p.o_sp[i] = outs[i].sp; }
+    hipLaunchKernelGGL(select_kernel, dim3(nblocks((long long)N * HW * C)), dim3(NT), 0, (hipStream_t)stream, p);
+    return LAUNCH_OK();
+}
+
+// db[n] += (mask[n] ? 0 : sum_k din_k[n])   (gradient of the not-ground-truth branch)
+struct SelBP {
+    int N, HW, C;
+    const int* mask;
+    int nin; const float* din[4]; long long i_sn[4], i_sp[4];
+    float* db; long long b_sn, b_sp;
+};
+
+__global__ void select_bwd_kernel(SelBP p) {
+    long long total = (long long)p.N * p.HW * p.C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % p.C);
+        long long np = i / p.C;
+        int px = (int)(np % p.HW);
+        int n = (int)(np / p.HW);
+        if (p.mask[n]) continue;
+        float v = 0.f;
+        for (int k = 0; k < p.nin; ++k) v += p.din[k][n * p.i_sn[k] + px * p.i_sp[k] + c];
+        p.db[n * p.b_sn + px * p.b_sp + c] += v;
+    }
+}
+
+extern "C" int savp_select_bwd(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, int32_t nin,
+                               const SavpView* dins, SavpView db) {
+    if (!mask || !db.p || nin < 1 || nin > 4 || !dins) return SAVP_EINVAL;
+    SelBP p;
+    p.N = N; p.HW = HW; p.C = C; p.mask = mask; p.nin = nin;
+    for (int i = 0; i < nin; ++i) { p.din[i] = (const float*)dins[i].p; p.i_sn[i] = dins[i].sn; p.i_sp[i] = dins[i].sp; }
+    p.db = (float*)db.p; p.b_sn = db.sn; p.b_sp = db.sp;
+    hipLaunchKernelGGL(select_bwd_kernel, dim3(nblocks((long long)N * HW * C)), dim3(NT), 0, (hipStream_t)stream, p);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gather_clips: src time-major [L, B, E] (E = H*W*C contiguous), dst batch-major [B, clip, E]:
+//   dst[b,i,:] = src[t_start[b]+i, b, :]   ; adjoint: src[t_start[b]+i, b, :] += dst[b,i,:]
+__global__ void gather_clips_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ t_start,
+                                    int B, int clip, long long E, int adjoint, float* srcw, const float* dstr) {
+    long long total = (long long)B * clip * (E / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long e4 = i % (E / 4);
+        long long bi = i / (E / 4);
+        int ci = (int)(bi % clip);
+        int b = (int)(bi / clip);
+        long long so = ((long long)(t_start[b] + ci) * B + b) * E + e4 * 4;
+        long long d_o = ((long long)b * clip + ci) * E + e4 * 4;
+        if (!adjoint) {
+            *reinterpret_cast<float4*>(dst + d_o) = *reinterpret_cast<const float4*>(src + so);
+        } else {
+            float4 g = *reinterpret_cast<const float4*>(dstr + d_o);
+            float4 o = *reinterpret_cast<float4*>(srcw + so);
+            o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
+            *reinterpret_cast<float4*>(srcw + so) = o;
+        }
+    }
+}
+
+extern "C" int savp_gather_clips(void* stream, float* src, float* dst, const int32_t* t_start, int32_t B, int32_t clip,
+                                 int64_t E, int32_t adjoint) {
+    if (!src || !dst || !t_start || E % 4) return SAVP_EINVAL;
+    long long total = (long long)B * clip * (E / 4);
+    unsigned nb = nblocks(total);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(gather_clips_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (const float*)src, dst, t_start, B,
+                       clip, (long long)E, adjoint, src, (const float*)dst);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void axpby_kernel(long long n, float a, const float* __restrict__ x, float b, const float* y, float* out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = a * x[i];
+        if (y) v += b * y[i];
+        out[i] = v;
+    }
+}
+
+extern "C" int savp_axpby(void* stream, int64_t n, float a, const float* x, float b, const float* y, float* out) {
+    if (!x || !out || n < 0) return SAVP_EINVAL;
+    if (n == 0) return SAVP_OK;
+    unsigned nb = nblocks(n);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, a, x, b, y, out);
+    return LAUNCH_OK();
+}
+
+__global__ void fill_view_kernel(float* out, long long sn, long long sp, long long R, int HW, int C, float value) {
+    long long total = R * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long rp = i / C;
+        int p = (int)(rp % HW);
+        long long r = rp / HW;
+        out[r * sn + (long long)p * sp + c] = value;
+    }
+}
+
+extern "C" int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW, int32_t C, float value) {
+    if (!out.p) return SAVP_EINVAL;
+    unsigned nb = nblocks((long long)R * HW * C);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(fill_view_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (float*)out.p, (long long)out.sn,
+                       (long long)out.sp, (long long)R, HW, C, value);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed on the host and passed in;
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p -= lr_t * m / (sqrt(v) + eps)       (epsilon outside the sqrt)
+// gscale multiplies the gradient first (1/world_size after a sum all-reduce).
+__global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr_t, float b1, float b2, float eps, float gscale) {
+    long long n4 = n / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(f)                                       \
+    {                                                  \
+        float gr = gg.f * gscale;                      \
+        mm.f = b1 * mm.f + (1.f - b1) * gr;            \
+        vv.f = b2 * vv.f + (1.f - b2) * gr * gr;       \
+        pp.f -= lr_t * mm.f / (sqrtf(vv.f) + eps);     \
+    }
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long long i = n4 * 4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gr = g[i] * gscale;
+        float mi = b1 * m[i] + (1.f - b1) * gr;
+        float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+extern "C" int savp_adam(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1,
+                         float beta2, float eps, float gscale) {
+    if (!p || !g || !m || !v || n < 1) return SAVP_EINVAL;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return SAVP_EINVAL;
+    unsigned nb = nblocks(n / 4 + 1);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, lr_t, beta1, beta2,
+                       eps, gscale);
+    return LAUNCH_OK();
+}

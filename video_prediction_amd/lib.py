@@ -1,0 +1,134 @@
+"""ctypes binding of libsavp_hip.so (C ABI in include/savp_hip.h).
+
+There is no fallback: if the library has not been built (``python __graft_entry__.py build`` or
+``video_prediction_amd.build.build()``) every compute entry raises.  Tensors are torch tensors used purely as HBM
+allocations; kernels receive raw device pointers, element strides and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsavp_hip.so')
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+CONV_FPROP, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_SIGMOID, ACT_DLRELU_FROM_OUT = 0, 1, 2, 3
+
+
+class SavpConvArgs(ctypes.Structure):
+    _fields_ = [
+        ('mode', c_i32),
+        ('N', c_i32), ('D', c_i32), ('H', c_i32), ('W', c_i32), ('Cx', c_i32),
+        ('Do', c_i32), ('Ho', c_i32), ('Wo', c_i32), ('Cy', c_i32),
+        ('kd', c_i32), ('kh', c_i32), ('kw', c_i32),
+        ('sd', c_i32), ('sh', c_i32), ('sw', c_i32),
+        ('pd', c_i32), ('ph', c_i32), ('pw', c_i32),
+        ('beta', c_i32), ('act', c_i32), ('alpha', c_f32), ('splitk', c_i32), ('tile', c_i32),
+        ('x', c_vp), ('x_sn', c_i64), ('x_sd', c_i64), ('x_sh', c_i64), ('x_sw', c_i64),
+        ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
+        ('w', c_vp), ('bias', c_vp), ('aux', c_vp),
+    ]
+
+
+_lib = None
+
+
+def get():
+    """Return the loaded library; raise loudly when it is missing (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libsavp_hip.so not found at %s -- build it first (python -c "import __graft_entry__ as g; g.build()"). '
+                'video_prediction_amd has no non-HIP fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.savp_version.restype = ctypes.c_char_p
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+EXPORTS = {}     # name -> (restype, argtypes); filled by _declare, checked by tests against include/savp_hip.h
+
+
+def _sig(lib, name, argtypes, restype=c_i32):
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    EXPORTS[name] = fn
+    return fn
+
+
+def _declare(lib):
+    P = ctypes.POINTER
+    _sig(lib, 'savp_conv', [c_vp, P(SavpConvArgs)])
+    for name, argtypes in _EXTRA_SIGS.items():
+        _sig(lib, name, argtypes)
+
+
+_EXTRA_SIGS = {}
+
+
+def register(name, argtypes):
+    """Declare one more C-ABI entry point (used by kernels.py so that signatures live next to their wrappers)."""
+    _EXTRA_SIGS[name] = argtypes
+    if _lib is not None:
+        _sig(_lib, name, argtypes)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (what, rc))
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('video_prediction_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError('expected float32, got %s' % t.dtype)
+
+
+class SavpView(ctypes.Structure):
+    _fields_ = [('p', c_vp), ('sn', c_i64), ('sp', c_i64)]
+
+
+class SavpInormArgs(ctypes.Structure):
+    _fields_ = [
+        ('N', c_i32), ('HW', c_i32), ('C', c_i32), ('act', c_i32), ('alpha', c_f32), ('eps', c_f32),
+        ('x', SavpView), ('gamma', c_vp), ('beta', c_vp),
+        ('nout', c_i32), ('out', SavpView * 4), ('mean', c_vp), ('rstd', c_vp),
+        ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
+        ('dgamma', c_vp), ('dbeta', c_vp),
+    ]
+
+
+class SavpLstmArgs(ctypes.Structure):
+    _fields_ = [
+        ('N', c_i32), ('HW', c_i32), ('F', c_i32), ('eps', c_f32), ('forget_bias', c_f32),
+        ('gates', c_vp), ('c_prev', SavpView),
+        ('gamma1', c_vp), ('beta1', c_vp), ('gamma2', c_vp), ('beta2', c_vp),
+        ('c_new', c_vp), ('nh', c_i32), ('h', SavpView * 4),
+        ('mean1', c_vp), ('rstd1', c_vp), ('mean2', c_vp), ('rstd2', c_vp),
+        ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
+        ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
+    ]
+
+
+register('savp_instnorm_act_fwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
+register('savp_instnorm_act_bwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
+register('savp_convlstm_gates_fwd', [c_vp, ctypes.POINTER(SavpLstmArgs)])
+register('savp_convlstm_gates_bwd', [c_vp, ctypes.POINTER(SavpLstmArgs)])
