@@ -115,6 +115,90 @@ typedef struct SavpLstmArgs {
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * HBM-bound glue (util_ops.hip).  See the file header for the reference lines each one replaces.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* out[r,p,c] (=|+=) scale*z[r,c]  : tile_concat broadcast (ops.py:968-1006) / backward of global average pool */
+int savp_tile_channels(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out, int32_t beta);
+/* out[(r,)c] += scale*sum_p in[r,p,c] (atomic accumulate; per_row keeps r) : bias grads, d(tile_concat), avg pool */
+int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out, int32_t per_row);
+/* out_k = mask[n] ? a : b   (scheduled sampling tf.where, savp_model.py:406); b.p may be NULL (zeros) */
+int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, SavpView a, SavpView b, int32_t nout,
+                const SavpView* outs);
+/* db += mask[n] ? 0 : sum_k din_k */
+int savp_select_bwd(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, int32_t nin, const SavpView* dins,
+                    SavpView db);
+/* dst[b,i,:] = src[t_start[b]+i, b, :] (tf.gather_nd, savp_model.py:97-102); adjoint: src[...] += dst[...] */
+int savp_gather_clips(void* stream, float* src, float* dst, const int32_t* t_start, int32_t B, int32_t clip, int64_t E,
+                      int32_t adjoint);
+int savp_axpby(void* stream, int64_t n, float a, const float* x, float b, const float* y, float* out);
+int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW, int32_t C, float value);
+/* tf.train.AdamOptimizer on a flat arena (base_model.py:486-487); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
+int savp_adam(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2,
+              float eps, float gscale);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CDNA head + mask compositing (cdna_composite.hip): savp_model.py:551-559, 893-923, 634-646.
+ * ------------------------------------------------------------------------------------------------------------ */
+int savp_cdna_kernels_fwd(void* stream, const float* raw, float* kern, int32_t N, int32_t kh, int32_t kw, int32_t K);
+int savp_cdna_kernels_bwd(void* stream, const float* raw, const float* dkern, float* draw, int32_t N, int32_t kh, int32_t kw,
+                          int32_t K);
+typedef struct SavpCdnaArgs {
+    int32_t N, H, W, C, K, kh, kw;
+    SavpView img;                  /* [N,H,W,C] */
+    const float* kern;             /* normalised kernels [N, kh*kw, K] */
+    SavpView out;                  /* [N,H,W,K*C], channel k*C+c */
+    SavpView dout;                 /* bwd: gradient of out */
+    SavpView dimg; int32_t dimg_beta;   /* bwd: p may be NULL */
+    float* dkern;                  /* bwd: [N, kh*kw, K], overwritten; may be NULL */
+} SavpCdnaArgs;
+int savp_cdna_apply_fwd(void* stream, const SavpCdnaArgs* a);
+int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a);
+typedef struct SavpCompositeArgs {
+    int32_t N, HW, M, C;
+    const float* logits;           /* [N*HW, M] */
+    SavpView timgs;                /* [N,HW,M*C], channel m*C+c */
+    SavpView gen;                  /* [N,HW,C] */
+    float* masks;                  /* optional [N*HW, M] */
+    SavpView dgen;
+    float* dlogits;
+    SavpView dtimgs; int32_t dt_beta;
+} SavpCompositeArgs;
+int savp_composite_fwd(void* stream, const SavpCompositeArgs* a);
+int savp_composite_bwd(void* stream, const SavpCompositeArgs* a);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * small_ops.hip: z-LSTM over all timesteps (savp_model.py:354-362), reparameterisation + KL
+ * (savp_model.py:45-49,711-712; losses.py:57-60), image / GAN / feature-matching losses (losses.py:6-54).
+ * Loss entries accumulate the (unweighted) loss value into *loss_out and the weighted gradient into d*.
+ * ------------------------------------------------------------------------------------------------------------ */
+int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates, float* cs,
+                    int32_t T, int32_t B, int32_t nz, float forget_bias);
+int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
+                    const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias);
+int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
+                     float* z, float* kl_out);
+int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
+                     const float* dz, float klw, float* dmu, float* dls_raw);
+int savp_lp_loss(void* stream, int64_t n, int32_t p2, const float* pred, const float* target, float weight, float* loss_out,
+                 float* dpred);
+int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out, float* dlogits,
+                    int32_t beta);
+int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,
+                         float* loss_out, float* df0, int32_t beta);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * weight_prep.hip: packing for the conv kernel, conv_pool2d / upsample_conv2d kernel folding (ops.py:838-842,
+ * 697-704) and spectral normalisation with its full gradient (ops.py:1020-1049).
+ * ------------------------------------------------------------------------------------------------------------ */
+int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale, float* wt, float* wd);
+int savp_fold_pool(void* stream, const float* in, float* out, int32_t k, int64_t C, int32_t adjoint);
+int savp_fold_bilinear(void* stream, const float* in, float* out, int32_t k, int32_t Cin, int32_t F, int32_t adjoint);
+/* ws: 8 + 2C + 2K floats; after fwd ws[0]=sigma, ws[1]=1/sigma; u_new receives u_final */
+int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, float* u_new);
+int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, const float* G, float* dW,
+                int32_t beta);
+
 #ifdef __cplusplus
 }
 #endif

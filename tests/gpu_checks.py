@@ -251,8 +251,311 @@ def check_lstm(seed=3):
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# util ops
+# ---------------------------------------------------------------------------------------------------------------
+def check_util(seed=4):
+    out = []
+    rng = np.random.default_rng(seed)
+    R, H, W, C = 6, 8, 8, 8
+    z = rnd(rng, R, C)
+    big = torch.zeros(R, H, W, 24, device=DEV)
+    K.tile_channels(dev(z), big[..., 8:16], scale=0.5)
+    ref = torch.zeros(R, H, W, 24, dtype=torch.float64)
+    ref[..., 8:16] = 0.5 * z[:, None, None, :]
+    out.append(('tile_channels', rel_err(big, ref), 1e-6))
+    x = rnd(rng, R, H, W, 24)
+    o1 = torch.zeros(C, device=DEV)
+    K.colsum(dev(x)[..., 8:16], o1, scale=2.0)
+    out.append(('colsum_all', rel_err(o1, 2.0 * x[..., 8:16].sum(dim=(0, 1, 2))), 1e-5))
+    o2 = torch.zeros(R, C, device=DEV)
+    K.colsum(dev(x)[..., 8:16], o2, per_row=True)
+    out.append(('colsum_rows', rel_err(o2, x[..., 8:16].sum(dim=(1, 2))), 1e-5))
+    x200 = rnd(rng, 3, 5, 7, 200)
+    o3 = torch.zeros(200, device=DEV)
+    K.colsum(dev(x200), o3)
+    out.append(('colsum_c200', rel_err(o3, x200.sum(dim=(0, 1, 2))), 1e-5))
+    # select fwd / bwd
+    N, C3 = 4, 3
+    a, b = rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3)
+    mask = torch.tensor([1, 0, 0, 1], dtype=torch.int32)
+    o_a = torch.zeros(N, H, W, 14, device=DEV)
+    o_b = torch.zeros(N, H, W, C3, device=DEV)
+    K.select(mask.to(DEV), dev(a), dev(b), [o_a[..., :3], o_b])
+    ref = torch.where(mask.bool()[:, None, None, None], a, b)
+    out.append(('select', rel_err(o_a[..., :3], ref) + rel_err(o_b, ref), 1e-7))
+    d1, d2, db0 = rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3)
+    dbd = dev(db0)
+    K.select_bwd(mask.to(DEV), [dev(d1), dev(d2)], dbd)
+    ref = db0 + torch.where(mask.bool()[:, None, None, None], torch.zeros_like(d1), d1 + d2)
+    out.append(('select_bwd', rel_err(dbd, ref), 1e-6))
+    # gather clips + adjoint
+    L, B, clip = 9, 3, 4
+    src = rnd(rng, L, B, 4, 4, 3)
+    ts = torch.tensor([0, 5, 2], dtype=torch.int32)
+    dst = torch.empty(B, clip, 4, 4, 3, device=DEV)
+    K.gather_clips(dev(src), dst, ts.to(DEV))
+    ref = torch.stack([src[ts[b]:ts[b] + clip, b] for b in range(B)], dim=0)
+    out.append(('gather_clips', rel_err(dst, ref), 1e-7))
+    g = rnd(rng, B, clip, 4, 4, 3)
+    acc0 = rnd(rng, L, B, 4, 4, 3)
+    accd = dev(acc0)
+    K.gather_clips(accd, dev(g), ts.to(DEV), adjoint=True)
+    ref = acc0.clone()
+    for b in range(B):
+        ref[ts[b]:ts[b] + clip, b] += g[b]
+    out.append(('gather_clips_adjoint', rel_err(accd, ref), 1e-6))
+    # axpby, fill
+    xx, yy = rnd(rng, 1000), rnd(rng, 1000)
+    od = torch.empty(1000, device=DEV)
+    K.axpby(2.0, dev(xx), -0.5, dev(yy), od)
+    out.append(('axpby', rel_err(od, 2 * xx - 0.5 * yy), 1e-6))
+    fb = dev(rnd(rng, 2, 4, 4, 8))
+    K.fill_view(fb[..., 2:6], 0.0)
+    out.append(('fill_view', float(fb[..., 2:6].abs().max()), 0.0))
+    # adam (two steps) vs oracle
+    n = 1003
+    p0, g1, g2 = rnd(rng, n), rnd(rng, n), rnd(rng, n)
+    pd, md, vd = torch.zeros(1004, device=DEV), torch.zeros(1004, device=DEV), torch.zeros(1004, device=DEV)
+    pd[:n] = dev(p0)
+    pr, mr, vr = p0.clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    import math
+    for t, g in ((1, g1), (2, g2)):
+        gd = torch.zeros(1004, device=DEV)
+        gd[:n] = dev(g) * 4.0
+        lr_t = 2e-4 * math.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+        K.adam(pd[:n], gd[:n], md[:n], vd[:n], lr_t, 0.5, 0.999, gscale=0.25)
+        pr, mr, vr = TF.adam_update(pr, g, mr, vr, 2e-4, 0.5, 0.999, t)
+    out.append(('adam_p', rel_err(pd[:n], pr), 1e-6))
+    # fp32 (1 - beta2) differs from the fp64 oracle's by 4.7e-5 relative -- same as TF's fp32 Adam kernel
+    out.append(('adam_v', rel_err(vd[:n], vr), 1e-4))
+    torch.cuda.synchronize()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cdna + composite
+# ---------------------------------------------------------------------------------------------------------------
+def check_cdna_composite(seed=5):
+    out = []
+    rng = np.random.default_rng(seed)
+    for (N, H, W, C, Kk) in [(3, 16, 16, 3, 4), (2, 8, 12, 1, 4)]:
+        kh = kw = 5
+        raw = (rnd(rng, N, kh, kw, Kk) * 0.3).requires_grad_(True)
+        img = torch.tensor(rng.random((N, H, W, C)), dtype=torch.float64, requires_grad=True)
+        ident = torch.as_tensor(OS.identity_kernel((kh, kw)))
+        kern = raw + ident[None, :, :, None]
+        kern = torch.relu(kern - OS.RELU_SHIFT) + OS.RELU_SHIFT
+        kern = kern / kern.sum(dim=(1, 2), keepdim=True)
+        timgs = OS.apply_cdna_kernels(img, kern)
+        ref_out = torch.cat(timgs, dim=-1)                       # channel k*C + c
+        dout = rnd(rng, *ref_out.shape)
+        (ref_out * dout).sum().backward()
+        tag = 'cdna_%dx%dx%d' % (H, W, C)
+        rawd = dev(raw).reshape(N, kh * kw * Kk)
+        kd = torch.empty(N, kh * kw, Kk, device=DEV)
+        K.cdna_kernels_fwd(rawd, kd, kh, kw, Kk)
+        out.append((tag + '/kernels', rel_err(kd.reshape(N, kh, kw, Kk), kern), TOL_OP))
+        big = torch.zeros(N, H, W, 32 + Kk * C, device=DEV)
+        ov = big[..., 32:]
+        imgd = dev(img)
+        K.cdna_apply_fwd(imgd, kd, ov, kh, kw, Kk)
+        out.append((tag + '/apply', rel_err(ov, ref_out), TOL_OP))
+        dimg = torch.empty(N, H, W, C, device=DEV)
+        dk = torch.empty(N, kh * kw, Kk, device=DEV)
+        K.cdna_apply_bwd(imgd, kd, dev(dout), dimg, dk, kh, kw, Kk)
+        out.append((tag + '/dimg', rel_err(dimg, img.grad), 5e-5))
+        draw = torch.empty(N, kh * kw * Kk, device=DEV)
+        K.cdna_kernels_bwd(rawd, dk, draw, kh, kw, Kk)
+        out.append((tag + '/draw', rel_err(draw.reshape(N, kh, kw, Kk), raw.grad), 5e-5))
+    # identity property: zero dense output => CDNA returns the input image exactly (savp_model.py:551,968-980)
+    N, H, W, C, Kk = 2, 8, 8, 3, 4
+    img = torch.tensor(rng.random((N, H, W, C)))
+    kd = torch.empty(N, 25, Kk, device=DEV)
+    K.cdna_kernels_fwd(torch.zeros(N, 25 * Kk, device=DEV), kd, 5, 5, Kk)
+    ov = torch.empty(N, H, W, Kk * C, device=DEV)
+    K.cdna_apply_fwd(dev(img), kd, ov, 5, 5, Kk)
+    out.append(('cdna_identity', rel_err(ov, torch.cat([img] * Kk, dim=-1)), 1e-6))
+    # composite
+    for (N, H, W, C, M) in [(2, 16, 16, 3, 7), (2, 8, 8, 1, 7)]:
+        logits = (rnd(rng, N, H, W, M) * 2).requires_grad_(True)
+        timgs = torch.tensor(rng.random((N, H, W, M * C)), dtype=torch.float64, requires_grad=True)
+        masks = torch.softmax(logits, dim=-1)
+        gen = sum(masks[..., k:k + 1] * timgs[..., k * C:(k + 1) * C] for k in range(M))
+        dgen = rnd(rng, *gen.shape)
+        (gen * dgen).sum().backward()
+        tag = 'composite_c%d' % C
+        big = dev(torch.cat([torch.zeros(N, H, W, 32, dtype=torch.float64), timgs.detach()], dim=-1))
+        tv = big[..., 32:]
+        ld = dev(logits)
+        gd = torch.empty(N, H, W, C, device=DEV)
+        md = torch.empty(N, H, W, M, device=DEV)
+        K.composite_fwd(ld, tv, gd, md)
+        out.append((tag + '/gen', rel_err(gd, gen), TOL_OP))
+        out.append((tag + '/masks', rel_err(md, masks), TOL_OP))
+        amism = int((md.argmax(dim=-1).cpu() != masks.argmax(dim=-1)).sum())
+        out.append((tag + '/mask_argmax_mismatches', float(amism), 0.0))
+        dl = torch.empty(N, H, W, M, device=DEV)
+        dbig = torch.zeros(N, H, W, 32 + M * C, device=DEV)
+        K.composite_bwd(ld, tv, dev(dgen), dl, dbig[..., 32:])
+        out.append((tag + '/dlogits', rel_err(dl, logits.grad), 5e-5))
+        out.append((tag + '/dtimgs', rel_err(dbig[..., 32:], timgs.grad), 5e-5))
+    torch.cuda.synchronize()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------------------------
+def check_small(seed=6):
+    out = []
+    rng = np.random.default_rng(seed)
+    for (T, B, nz) in [(7, 4, 8), (5, 3, 32)]:
+        zs = rnd(rng, T, B, nz).requires_grad_(True)
+        W = (rnd(rng, 2 * nz, 4 * nz) * 0.3).requires_grad_(True)
+        b = (rnd(rng, 4 * nz) * 0.1).requires_grad_(True)
+        c = torch.zeros(B, nz, dtype=torch.float64)
+        h = torch.zeros(B, nz, dtype=torch.float64)
+        hs = []
+        for t in range(T):
+            ho, (c, h) = TF.lstm_cell(zs[t], c, h, W, b)
+            hs.append(ho)
+        hs = torch.stack(hs)
+        dh = rnd(rng, T, B, nz)
+        (hs * dh).sum().backward()
+        tag = 'lstm_z_nz%d' % nz
+        zd, Wd, bd = dev(zs), dev(W), dev(b)
+        ho = torch.empty(T, B, nz, device=DEV)
+        gates = torch.empty(T, B, 4 * nz, device=DEV)
+        cs = torch.empty(T, B, nz, device=DEV)
+        K.lstm_z_fwd(zd, Wd, bd, ho, gates, cs)
+        out.append((tag + '/h', rel_err(ho, hs), TOL_OP))
+        dz = torch.empty(T, B, nz, device=DEV)
+        dW = torch.zeros(2 * nz, 4 * nz, device=DEV)
+        db = torch.zeros(4 * nz, device=DEV)
+        K.lstm_z_bwd(zd, Wd, ho, gates, cs, dev(dh), dz, dW, db)
+        out.append((tag + '/dz', rel_err(dz, zs.grad), 5e-5))
+        out.append((tag + '/dW', rel_err(dW, W.grad), 5e-5))
+        out.append((tag + '/db', rel_err(db, b.grad), 5e-5))
+    # reparam + KL
+    T, B, nz = 5, 4, 8
+    mu = rnd(rng, T, B, nz).requires_grad_(True)
+    lsr = (rnd(rng, T, B, nz) * 6).requires_grad_(True)       # some values beyond the [-10, 10] clip
+    eps = rnd(rng, T, B, nz)
+    ls = torch.clamp(lsr, -10, 10)
+    z = mu + torch.sqrt(torch.exp(ls)) * eps
+    from oracle import train as OT
+    kl = OT.kl_loss(mu, ls)
+    dz = rnd(rng, T, B, nz)
+    ((z * dz).sum() + 0.7 * kl).backward()
+    lsd, zd_, kld = torch.empty(T, B, nz, device=DEV), torch.empty(T, B, nz, device=DEV), torch.zeros(1, device=DEV)
+    K.reparam_fwd(dev(mu), dev(lsr), dev(eps), lsd, zd_, kld)
+    out.append(('reparam/z', rel_err(zd_, z), TOL_OP))
+    out.append(('reparam/kl', rel_err(kld, kl.reshape(1)), 1e-5))
+    dmu, dls = torch.empty(T, B, nz, device=DEV), torch.empty(T, B, nz, device=DEV)
+    K.reparam_bwd(dev(mu), dev(lsr), dev(eps), dev(dz), 0.7, dmu, dls)
+    out.append(('reparam/dmu', rel_err(dmu, mu.grad), 1e-5))
+    out.append(('reparam/dls', rel_err(dls, lsr.grad), 1e-5))
+    # l1 / l2
+    pred = torch.tensor(rng.random((3, 2, 8, 8, 3)), dtype=torch.float64, requires_grad=True)
+    targ = torch.tensor(rng.random((3, 2, 8, 8, 3)), dtype=torch.float64)
+    for p2, fn, nm in ((False, OT.l1_loss, 'l1'), (True, OT.l2_loss, 'l2')):
+        pred.grad = None
+        l = fn(pred, targ)
+        (100.0 * l).backward()
+        lo = torch.zeros(1, device=DEV)
+        dp = torch.zeros(pred.shape, device=DEV)
+        K.lp_loss(dev(pred), dev(targ), 100.0, lo, dp, p2=p2)
+        out.append((nm + '/loss', rel_err(lo, l.reshape(1)), 1e-5))
+        out.append((nm + '/dpred', rel_err(dp, pred.grad), 1e-5))
+    # lsgan
+    lg = rnd(rng, 16, 1).requires_grad_(True)
+    l = OT.gan_loss(lg, 1.0, 'LSGAN')
+    (0.1 * l).backward()
+    lo = torch.zeros(1, device=DEV)
+    dl = torch.empty(16, 1, device=DEV)
+    K.lsgan_loss(dev(lg), 1.0, 0.1, lo, dl)
+    out.append(('lsgan/loss', rel_err(lo, l.reshape(1)), 1e-5))
+    out.append(('lsgan/dlogits', rel_err(dl, lg.grad), 1e-5))
+    # cosine distance
+    for Cc in (32, 256, 64):
+        f0 = rnd(rng, 4, 2, 5, 5, Cc).requires_grad_(True)
+        f1 = rnd(rng, 4, 2, 5, 5, Cc)
+        l = OT.cosine_distance(f0, f1)
+        (10.0 * l).backward()
+        lo = torch.zeros(1, device=DEV)
+        df = torch.empty(f0.shape, device=DEV)
+        K.cosine_distance(dev(f0), dev(f1), 10.0, lo, df)
+        out.append(('cosine_c%d/loss' % Cc, rel_err(lo, l.reshape(1)), 1e-5))
+        out.append(('cosine_c%d/df0' % Cc, rel_err(df, f0.grad), 5e-5))
+    torch.cuda.synchronize()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight prep: packing, folds (+adjoints), spectral norm fwd/bwd
+# ---------------------------------------------------------------------------------------------------------------
+def check_weight_prep(seed=7):
+    out = []
+    rng = np.random.default_rng(seed)
+    w = rnd(rng, 3, 3, 20, 12)
+    sc = torch.tensor([0.37], dtype=torch.float64)
+    wt = torch.empty(12, 9 * 20, device=DEV)
+    wd = torch.empty(20, 9 * 12, device=DEV)
+    K.pack_weights(dev(w), wt, wd, scale=dev(sc))
+    out.append(('pack/wt', rel_err(wt, pack_wt(w) * 0.37), 1e-6))
+    out.append(('pack/wd', rel_err(wd, pack_wd(w) * 0.37), 1e-6))
+    # fold_pool + adjoint
+    for k in (5, 3):
+        w = rnd(rng, k, k, 6, 8).requires_grad_(True)
+        kp = O.pool_kernel(w, (2, 2))
+        g = rnd(rng, *kp.shape)
+        (kp * g).sum().backward()
+        o = torch.empty(kp.shape, device=DEV)
+        K.fold_pool(dev(w), o, k)
+        out.append(('fold_pool_k%d' % k, rel_err(o, kp), 1e-6))
+        dw = torch.zeros(w.shape, device=DEV)
+        K.fold_pool(dev(g), dw, k, adjoint=True)
+        out.append(('fold_pool_k%d_adj' % k, rel_err(dw, w.grad), 1e-6))
+    # fold_bilinear + adjoint
+    w = rnd(rng, 3, 3, 10, 6).requires_grad_(True)
+    ku = O.upsample_kernel(w, (2, 2))
+    g = rnd(rng, *ku.shape)
+    (ku * g).sum().backward()
+    o = torch.empty(ku.shape, device=DEV)
+    K.fold_bilinear(dev(w), o, 3, 10, 6)
+    out.append(('fold_bilinear', rel_err(o, ku), 1e-6))
+    dw = torch.zeros(w.shape, device=DEV)
+    K.fold_bilinear(dev(g), dw, 3, 10, 6, adjoint=True)
+    out.append(('fold_bilinear_adj', rel_err(dw, w.grad), 1e-6))
+    # spectral norm
+    for shape in [(3, 3, 3, 16, 32), (4, 4, 4, 8, 16), (640, 1)]:
+        W = (rnd(rng, *shape) * 0.05).requires_grad_(True)
+        C = shape[-1]
+        u = rnd(rng, 1, C)
+        Wb, u_fin = O.spectral_normed_weight(W, u)
+        G = rnd(rng, *shape)
+        (Wb * G).sum().backward()
+        Kdim = W.numel() // C
+        ws = torch.zeros(K.sn_ws_size(Kdim, C), device=DEV)
+        Wd, ud = dev(W), dev(u).reshape(C)
+        un = torch.empty(C, device=DEV)
+        K.sn_fwd(Wd, ud, ws, un)
+        tag = 'sn_%s' % 'x'.join(map(str, shape))
+        sigma_ref = (W.detach() / Wb.detach()).flatten()[0]
+        out.append((tag + '/sigma', rel_err(ws[0:1], sigma_ref.reshape(1)), 1e-5))
+        out.append((tag + '/u_final', rel_err(un, u_fin.detach().reshape(C)), 1e-5))
+        dW = torch.empty(shape, device=DEV)
+        K.sn_bwd(Wd, ud, ws, dev(G), dW)
+        out.append((tag + '/dW', rel_err(dW, W.grad), 1e-4))
+    torch.cuda.synchronize()
+    return out
+
+
 ALL_CHECKS = [('conv', check_conv), ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
-              ('lstm', check_lstm)]
+              ('lstm', check_lstm), ('util', check_util), ('cdna_composite', check_cdna_composite),
+              ('small', check_small), ('weight_prep', check_weight_prep)]
 
 
 def failures(results):

@@ -29,3 +29,23 @@ def test_instnorm_act():
 def test_convlstm_gates():
     from tests import gpu_checks
     _run(gpu_checks.check_lstm)
+
+
+def test_util_ops():
+    from tests import gpu_checks
+    _run(gpu_checks.check_util)
+
+
+def test_cdna_and_composite():
+    from tests import gpu_checks
+    _run(gpu_checks.check_cdna_composite)
+
+
+def test_small_ops():
+    from tests import gpu_checks
+    _run(gpu_checks.check_small)
+
+
+def test_weight_prep_and_spectral_norm():
+    from tests import gpu_checks
+    _run(gpu_checks.check_weight_prep)

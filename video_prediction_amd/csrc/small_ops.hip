@@ -1,0 +1,297 @@
+// small_ops.hip -- the tiny-tensor ends of the SAVP graph, each fused to one launch:
+//   lstm_z fwd/bwd   : tf.nn.rnn_cell.LSTMCell on z for ALL timesteps in one kernel (savp_model.py:354-362,426-432);
+//                      the recurrence only involves z, so it is hoisted out of the per-frame loop.
+//   reparam fwd/bwd  : clip(log_sigma_sq,-10,10); z = mu + sqrt(exp(ls))*eps; KL(mu,ls) (savp_model.py:45-49,711-712,
+//                      losses.py:57-60) and their gradients.
+//   l1/l2 loss       : losses.py:6-11 value + gradient in one pass.
+//   lsgan loss       : losses.py:41-44 on the [B,1] logits.
+//   cosine distance  : losses.py:14-22 feature-matching term, value + gradient w.r.t. the first argument.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+#define NT 256
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) {
+    float e = __expf(-2.f * fabsf(x));
+    return copysignf((1.f - e) / (1.f + e), x);
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_sum1(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    float s = wsum(v);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lstm_z.  zs [T,B,nz]; W [2nz,4nz] (rows: z then h; gate order i,j,f,o); b [4nz].  One workgroup per batch row,
+// 4nz threads.  Saves pre-activation gates [T,B,4nz] and cell states c [T,B,nz].
+// ---------------------------------------------------------------------------------------------------------------
+#define MAXNZ 64
+__global__ void lstm_z_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ W, const float* __restrict__ bias,
+                                  float* __restrict__ hout, float* __restrict__ gates, float* __restrict__ cs, int T, int B,
+                                  int nz, float forget_bias) {
+    __shared__ float sh_h[MAXNZ], sh_z[MAXNZ], sh_g[4 * MAXNZ];
+    const int b = blockIdx.x, j = threadIdx.x;
+    float c = 0.f;
+    if (j < nz) sh_h[j] = 0.f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (j < nz) sh_z[j] = zs[((long long)t * B + b) * nz + j];
+        __syncthreads();
+        float g = bias[j];
+        for (int i = 0; i < nz; ++i) g += sh_z[i] * W[i * 4 * nz + j] + sh_h[i] * W[(nz + i) * 4 * nz + j];
+        sh_g[j] = g;
+        gates[((long long)t * B + b) * 4 * nz + j] = g;
+        __syncthreads();
+        if (j < nz) {
+            float gi = sh_g[j], gj = sh_g[nz + j], gf = sh_g[2 * nz + j], go = sh_g[3 * nz + j];
+            c = sigm(gf + forget_bias) * c + sigm(gi) * tanh_(gj);
+            float h = sigm(go) * tanh_(c);
+            cs[((long long)t * B + b) * nz + j] = c;
+            hout[((long long)t * B + b) * nz + j] = h;
+            sh_h[j] = h;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __restrict__ W, const float* __restrict__ hout,
+                                  const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dh_out,
+                                  float* __restrict__ dzs, float* __restrict__ dW, float* __restrict__ db, int T, int B, int nz,
+                                  float forget_bias) {
+    __shared__ float sh_dg[4 * MAXNZ], sh_x[2 * MAXNZ], sh_dh[MAXNZ];
+    const int b = blockIdx.x, j = threadIdx.x;
+    float dWcol[2 * MAXNZ];
+#pragma unroll
+    for (int i = 0; i < 2 * MAXNZ; ++i) dWcol[i] = 0.f;
+    float dbj = 0.f;
+    float dc_next = 0.f;
+    if (j < nz) sh_dh[j] = 0.f;           // dh carried from t+1
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const long long o = (long long)t * B + b;
+        if (j < nz) {
+            float gi = gates[o * 4 * nz + j], gj = gates[o * 4 * nz + nz + j], gf = gates[o * 4 * nz + 2 * nz + j],
+                  go = gates[o * 4 * nz + 3 * nz + j];
+            float c = cs[o * nz + j];
+            float cprev = t > 0 ? cs[(o - B) * nz + j] : 0.f;
+            float dh = dh_out[o * nz + j] + sh_dh[j];
+            float so = sigm(go), tc = tanh_(c);
+            float dc = dh * so * (1.f - tc * tc) + dc_next;
+            float si = sigm(gi), tj = tanh_(gj), sf = sigm(gf + forget_bias);
+            sh_dg[j] = dc * tj * si * (1.f - si);
+            sh_dg[nz + j] = dc * si * (1.f - tj * tj);
+            sh_dg[2 * nz + j] = dc * cprev * sf * (1.f - sf);
+            sh_dg[3 * nz + j] = dh * tc * so * (1.f - so);
+            dc_next = dc * sf;
+            sh_x[j] = zs[o * nz + j];
+            sh_x[nz + j] = t > 0 ? hout[(o - B) * nz + j] : 0.f;
+        }
+        __syncthreads();
+        const float dgj = sh_dg[j];
+        dbj += dgj;
+#pragma unroll
+        for (int i = 0; i < 2 * MAXNZ; ++i)
+            if (i < 2 * nz) dWcol[i] += sh_x[i] * dgj;
+        __syncthreads();
+        // dx = W dgate : thread i < 2nz computes sum_j W[i][j] * dg[j]
+        if (j < 2 * nz) {
+            float s = 0.f;
+            for (int q = 0; q < 4 * nz; ++q) s += W[j * 4 * nz + q] * sh_dg[q];
+            if (j < nz) dzs[o * nz + j] = s;
+            else sh_dh[j - nz] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * MAXNZ; ++i)
+        if (i < 2 * nz) unsafeAtomicAdd(dW + i * 4 * nz + j, dWcol[i]);
+    unsafeAtomicAdd(db + j, dbj);
+}
+
+extern "C" int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates,
+                               float* cs, int32_t T, int32_t B, int32_t nz, float forget_bias) {
+    if (!zs || !W || !bias || !hout || !gates || !cs || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_z_fwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, bias, hout, gates, cs, T, B, nz,
+                       forget_bias);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates,
+                               const float* cs, const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B,
+                               int32_t nz, float forget_bias) {
+    if (!zs || !W || !hout || !gates || !cs || !dh_out || !dzs || !dW || !db || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_z_bwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, hout, gates, cs, dh_out, dzs, dW,
+                       db, T, B, nz, forget_bias);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reparameterisation + KL.  n = T*B*nz elements; rows = T*B (the KL mean is over rows).
+// fwd: ls = clip(ls_raw); z = mu + exp(0.5 ls)*eps; kl_out += -0.5*sum(1+ls-mu^2-exp(ls))/rows
+// bwd: dmu = dz + klw*mu/rows ; dls_raw = [ls_raw in [-10,10]] * (dz*eps*0.5*exp(0.5 ls) - 0.5*klw*(1-exp(ls))/rows)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(long long n, int rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
+                                   float* z, float* kl_out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float l = fminf(fmaxf(ls_raw[i], -10.f), 10.f);
+        float m = mu[i];
+        ls[i] = l;
+        z[i] = m + __expf(0.5f * l) * eps[i];
+        acc += 1.f + l - m * m - __expf(l);
+    }
+    float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0 && kl_out) unsafeAtomicAdd(kl_out, -0.5f * t / (float)rows);
+}
+
+__global__ void reparam_bwd_kernel(long long n, int rows, const float* mu, const float* ls_raw, const float* eps, const float* dz,
+                                   float klw, float* dmu, float* dls_raw) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float lr = ls_raw[i];
+        float l = fminf(fmaxf(lr, -10.f), 10.f);
+        float g = dz ? dz[i] : 0.f;
+        dmu[i] = g + klw * mu[i] / (float)rows;
+        float d = g * eps[i] * 0.5f * __expf(0.5f * l) - 0.5f * klw * (1.f - __expf(l)) / (float)rows;
+        dls_raw[i] = (lr >= -10.f && lr <= 10.f) ? d : 0.f;
+    }
+}
+
+extern "C" int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
+                                float* ls, float* z, float* kl_out) {
+    if (!mu || !ls_raw || !eps || !ls || !z) return SAVP_EINVAL;
+    unsigned nb = (unsigned)((n + NT - 1) / NT);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, rows, mu, ls_raw, eps, ls, z,
+                       kl_out);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
+                                const float* dz, float klw, float* dmu, float* dls_raw) {
+    if (!mu || !ls_raw || !eps || !dmu || !dls_raw) return SAVP_EINVAL;
+    unsigned nb = (unsigned)((n + NT - 1) / NT);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, rows, mu, ls_raw, eps, dz,
+                       klw, dmu, dls_raw);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// l1 / l2 image loss: loss_out += mean(|t-p|) or mean((t-p)^2); dpred += weight * dloss/dpred  (dpred may be null)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void lp_loss_kernel(long long n, int p2, const float* pred, const float* target, float weight, float* loss_out,
+                               float* dpred) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const float invn = 1.f / (float)n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float d = pred[i] - target[i];
+        if (p2) {
+            acc += d * d;
+            if (dpred) dpred[i] += weight * 2.f * d * invn;
+        } else {
+            acc += fabsf(d);
+            // tf.abs gradient is sign(x) (0 at 0)
+            if (dpred) dpred[i] += weight * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invn;
+        }
+    }
+    float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t * invn);
+}
+
+extern "C" int savp_lp_loss(void* stream, int64_t n, int32_t p2, const float* pred, const float* target, float weight,
+                            float* loss_out, float* dpred) {
+    if (!pred || !target || n < 1) return SAVP_EINVAL;
+    unsigned nb = (unsigned)((n + NT - 1) / NT);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(lp_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, p2, pred, target, weight,
+                       loss_out, dpred);
+    return LAUNCH_OK();
+}
+
+// LSGAN on logits [n]: loss_out += mean((l-label)^2); dlogits (=|+=) weight*2*(l-label)/n
+__global__ void lsgan_kernel(int n, const float* logits, float label, float weight, float* loss_out, float* dlogits, int beta) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float d = logits[i] - label;
+        acc += d * d;
+        if (dlogits) {
+            float g = weight * 2.f * d / (float)n;
+            dlogits[i] = beta ? dlogits[i] + g : g;
+        }
+    }
+    float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t / (float)n);
+}
+
+extern "C" int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out,
+                               float* dlogits, int32_t beta) {
+    if (!logits || n < 1) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, n, logits, label, weight, loss_out, dlogits, beta);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cosine feature distance over the channel axis: f0,f1 [P,C] contiguous.
+// loss_out += mean_P( 0.5*|a-b|^2 ), a = f0/(|f0|+eps), b = f1/(|f1|+eps);  df0 (=|+=) weight * dloss/df0
+// one wave per position.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void cosine_kernel(long long P, int C, const float* __restrict__ f0, const float* __restrict__ f1,
+                                                    float weight, float eps, float* loss_out, float* df0, int beta) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lacc = 0.f;
+    for (long long pos = blockIdx.x * 4LL + wave; pos < P; pos += (long long)gridDim.x * 4) {
+        const float* a = f0 + pos * C;
+        const float* b = f1 + pos * C;
+        float n0 = 0.f, n1 = 0.f;
+        for (int c = lane; c < C; c += 64) { n0 += a[c] * a[c]; n1 += b[c] * b[c]; }
+        n0 = sqrtf(wsum(n0)); n1 = sqrtf(wsum(n1));
+        const float s0 = n0 + eps, s1 = n1 + eps;
+        float dist = 0.f, dotag = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float d = a[c] / s0 - b[c] / s1;
+            dist += d * d;
+            dotag += a[c] * d;
+        }
+        dist = wsum(dist); dotag = wsum(dotag);
+        if (lane == 0) lacc += 0.5f * dist;
+        if (df0) {
+            // g = (a_n - b_n) * weight / P ; df0 = g/s0 - f0 * (f0.g) / (n0 * s0^2)
+            const float wp = weight / (float)P;
+            const float coef = n0 > 0.f ? dotag / (n0 * s0 * s0) : 0.f;
+            for (int c = lane; c < C; c += 64) {
+                float d = a[c] / s0 - b[c] / s1;
+                float g = wp * (d / s0 - a[c] * coef);
+                df0[pos * C + c] = beta ? df0[pos * C + c] + g : g;
+            }
+        }
+    }
+    float t = block_sum1(lacc, sh);
+    if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t / (float)P);
+}
+
+extern "C" int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,
+                                    float* loss_out, float* df0, int32_t beta) {
+    if (!f0 || !f1 || P < 1 || C < 1) return SAVP_EINVAL;
+    unsigned nb = (unsigned)((P + 3) / 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(cosine_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)P, C, f0, f1, weight, eps, loss_out,
+                       df0, beta);
+    return LAUNCH_OK();
+}

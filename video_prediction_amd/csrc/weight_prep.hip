@@ -1,0 +1,272 @@
+// weight_prep.hip -- per-step weight preparation (the reference does these as TF graph algebra on every run):
+//   pack_weights     : HWIO master weights -> the k-contiguous layouts the implicit-GEMM kernel streams
+//                      (WT[Cy][taps*Cx] for FPROP, WD[Cx][taps*Cy] for DGRAD), optionally scaled by a device scalar
+//                      (1/sigma of spectral normalisation).
+//   fold_pool        : conv_pool2d's avg-pool folding of the kernel (ops.py:838-842) and its adjoint.
+//   fold_bilinear    : upsample_conv2d's bilinear folding (ops.py:697-704) and its adjoint.
+//   sn_*             : spectral_normed_weight (ops.py:1020-1049), one power iteration, forward and the full
+//                      backward (gradients flow through sigma, u', v -- the reference has no stop_gradient).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+#define NT 256
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_sum1(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    float s = wsum(v);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+// src [T, Cx, Cy]
+__global__ void pack_weights_kernel(const float* __restrict__ src, long long T, int Cx, int Cy, const float* scale, float* wt,
+                                    float* wd) {
+    const long long total = T * Cx * Cy;
+    const float s = scale ? *scale : 1.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cy = (int)(i % Cy);
+        long long r = i / Cy;
+        int cx = (int)(r % Cx);
+        long long t = r / Cx;
+        float v = src[i] * s;
+        if (wt) wt[(long long)cy * (T * Cx) + t * Cx + cx] = v;
+        if (wd) wd[(long long)cx * (T * Cy) + t * Cy + cy] = v;
+    }
+}
+
+extern "C" int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale,
+                                 float* wt, float* wd) {
+    if (!src || (!wt && !wd)) return SAVP_EINVAL;
+    long long total = (long long)T * Cx * Cy;
+    unsigned nb = (unsigned)((total + NT - 1) / NT);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, src, (long long)T, Cx, Cy, scale, wt, wd);
+    return LAUNCH_OK();
+}
+
+// fold_pool: src [k,k,C] -> dst [k+1,k+1,C];  adjoint: dsrc[k,k,C] += from ddst
+__global__ void fold_pool_kernel(const float* __restrict__ in, float* __restrict__ out, int k, long long C, int adjoint) {
+    const int ko = k + 1;
+    const long long total = adjoint ? (long long)k * k * C : (long long)ko * ko * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long c = i % C;
+        long long r = i / C;
+        float s = 0.f;
+        if (!adjoint) {
+            int b = (int)(r % ko), a = (int)(r / ko);
+            for (int di = 0; di < 2; ++di)
+                for (int dj = 0; dj < 2; ++dj) {
+                    int u = a - di, v = b - dj;
+                    if (u >= 0 && u < k && v >= 0 && v < k) s += in[((long long)u * k + v) * C + c];
+                }
+            out[i] = 0.25f * s;
+        } else {
+            int v = (int)(r % k), u = (int)(r / k);
+            for (int di = 0; di < 2; ++di)
+                for (int dj = 0; dj < 2; ++dj) s += in[((long long)(u + di) * ko + (v + dj)) * C + c];
+            out[i] += 0.25f * s;
+        }
+    }
+}
+
+extern "C" int savp_fold_pool(void* stream, const float* in, float* out, int32_t k, int64_t C, int32_t adjoint) {
+    if (!in || !out || k < 1) return SAVP_EINVAL;
+    long long total = (long long)(k + 1) * (k + 1) * C;
+    unsigned nb = (unsigned)((total + NT - 1) / NT);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(fold_pool_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, in, out, k, (long long)C, adjoint);
+    return LAUNCH_OK();
+}
+
+// fold_bilinear (stride 2): W [k,k,Cin,F] -> Kup [k+3,k+3,F,Cin];  adjoint: dW += from dKup
+__device__ __forceinline__ float bil1(int i) { return (i == 0 || i == 3) ? 0.25f : ((i == 1 || i == 2) ? 0.75f : 0.f); }
+
+__global__ void fold_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int k, int Cin, int F, int adjoint) {
+    const int ko = k + 3;
+    const long long total = adjoint ? (long long)k * k * Cin * F : (long long)ko * ko * Cin * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (!adjoint) {
+            // out index: ((a*ko + b)*F + f)*Cin + ci
+            int ci = (int)(i % Cin); long long r = i / Cin;
+            int f = (int)(r % F); r /= F;
+            int b = (int)(r % ko), a = (int)(r / ko);
+            float s = 0.f;
+            for (int u = 0; u < k; ++u) {
+                float wu = bil1(a + u - (k - 1));
+                if (wu == 0.f) continue;
+                for (int v = 0; v < k; ++v) {
+                    float wv = bil1(b + v - (k - 1));
+                    if (wv == 0.f) continue;
+                    s += wu * wv * in[(((long long)u * k + v) * Cin + ci) * F + f];
+                }
+            }
+            out[i] = s;
+        } else {
+            // out (dW) index: ((u*k + v)*Cin + ci)*F + f ; in = dKup
+            int f = (int)(i % F); long long r = i / F;
+            int ci = (int)(r % Cin); r /= Cin;
+            int v = (int)(r % k), u = (int)(r / k);
+            float s = 0.f;
+            for (int a = 0; a < ko; ++a) {
+                float wu = bil1(a + u - (k - 1));
+                if (wu == 0.f) continue;
+                for (int b = 0; b < ko; ++b) {
+                    float wv = bil1(b + v - (k - 1));
+                    if (wv == 0.f) continue;
+                    s += wu * wv * in[(((long long)a * ko + b) * F + f) * Cin + ci];
+                }
+            }
+            out[i] += s;
+        }
+    }
+}
+
+extern "C" int savp_fold_bilinear(void* stream, const float* in, float* out, int32_t k, int32_t Cin, int32_t F, int32_t adjoint) {
+    if (!in || !out || k < 1) return SAVP_EINVAL;
+    long long total = (long long)(k + 3) * (k + 3) * Cin * F;
+    unsigned nb = (unsigned)((total + NT - 1) / NT);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(fold_bilinear_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, in, out, k, Cin, F, adjoint);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// spectral norm.  W [K, C] (K = prod(kernel dims, Cin), C = Cout), u [C].
+//   a = W u ; v = a/(|a|+eps) ; b = W^T v ; u' = b/(|b|+eps) ; sigma = v^T W u' = |b|^2/(|b|+eps)
+// workspace ws (floats): [0]=sigma [1]=1/sigma [2]=|a| [3]=|b| [4]=kappa [5]=<G,W> [6]=a.gv [7]=|a|^2 acc
+//                        [8 .. 8+C) = b ; [8+C .. 8+2C) = u' ; [8+2C .. 8+2C+K) = a ; [.. +K) = gv/ga
+// ---------------------------------------------------------------------------------------------------------------
+#define SN_EPS 1e-12f
+
+// y[k] = sum_c W[k,c] x[c]; one wave per row; optionally accumulates sum_k y[k]^2 into *sq and sum_k y[k]*z[k] into *dotz
+__global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                          float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                          float* dotz) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sqacc = 0.f, dzacc = 0.f;
+    for (long long k = blockIdx.x * 4LL + wave; k < K; k += (long long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += W[k * C + c] * x[c];
+        s = wsum(s) * xscale;
+        if (lane == 0) {
+            y[k] = s;
+            sqacc += s * s;
+            if (z) dzacc += s * z[k];
+        }
+    }
+    if (lane == 0) {
+        if (sq) unsafeAtomicAdd(sq, sqacc);
+        if (dotz) unsafeAtomicAdd(dotz, dzacc);
+    }
+}
+
+// y[c] += sum_k W[k,c] x[k]   (atomic; y zeroed by the caller)
+__global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                          float* __restrict__ y, int rows_per_block) {
+    const long long k0 = (long long)blockIdx.x * rows_per_block;
+    const long long k1 = min(K, k0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float s = 0.f;
+        for (long long k = k0; k < k1; ++k) s += W[k * C + c] * x[k];
+        unsafeAtomicAdd(y + c, s);
+    }
+}
+
+// single workgroup: finish the forward scalars. bt = W^T a (unnormalised)
+__global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, int C, float* u_new) {
+    __shared__ float sh[4];
+    const float na = sqrtf(ws[7]);
+    const float s = na + SN_EPS;
+    float* b = ws + 8;
+    float* up = ws + 8 + C;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += NT) { float v = b[c] / s; b[c] = v; acc += v * v; }
+    const float nb2 = block_sum1(acc, sh);
+    const float nb = sqrtf(nb2);
+    for (int c = threadIdx.x; c < C; c += NT) { float v = b[c] / (nb + SN_EPS); up[c] = v; if (u_new) u_new[c] = v; }
+    if (threadIdx.x == 0) {
+        const float sigma = nb2 / (nb + SN_EPS);
+        ws[0] = sigma; ws[1] = 1.f / sigma; ws[2] = na; ws[3] = nb;
+        ws[4] = (nb + 2.f * SN_EPS) / ((nb + SN_EPS) * (nb + SN_EPS));   // kappa: dsigma/db = kappa*b
+    }
+}
+
+extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, float* u_new) {
+    // ws must hold 8 + 2C + 2K floats.  On return ws[1] = 1/sigma (device scalar for pack_weights), u_new = u_final.
+    if (!W || !u || !ws || K < 1 || C < 1) return SAVP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws, 0, (size_t)(8 + C) * sizeof(float), st);
+    float* a = ws + 8 + 2 * C;
+    unsigned nb = (unsigned)((K + 3) / 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7, (const float*)nullptr,
+                       (float*)nullptr);
+    int rpb = 64;
+    hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
+                       (const float*)a, ws + 8, rpb);
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(NT), 0, st, ws, C, u_new);
+    return LAUNCH_OK();
+}
+
+// <G, W> -> ws[5]
+__global__ __launch_bounds__(NT) void sn_dot_kernel(const float* __restrict__ G, const float* __restrict__ W, long long n, float* out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += G[i] * W[i];
+    float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, t);
+}
+
+// dW[k,c] (=|+=) G/sigma + alpha*(kappa * v_k * b_c + ga_k * u_c)
+//   v = a/s ; ga = gv/s - a*(a.gv)/(na*s^2) with gv = kappa * (W b) stored in ws (unscaled W b; kappa applied here)
+__global__ __launch_bounds__(NT) void sn_bwd_apply_kernel(const float* __restrict__ G, long long K, int C, const float* __restrict__ u,
+                                                          const float* __restrict__ ws, float* __restrict__ dW, int beta) {
+    const float sigma = ws[0], na = ws[2], kappa = ws[4];
+    const float s = na + SN_EPS;
+    const float alpha = -ws[5] / (sigma * sigma);               // dL/dsigma = -<G,W>/sigma^2
+    const float adotgv = ws[6] * kappa;                          // a . gv
+    const float* b = ws + 8;
+    const float* a = ws + 8 + 2 * C;
+    const float* wb = a + K;                                     // W b
+    const long long total = K * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = i / C;
+        const int c = (int)(i % C);
+        const float ak = a[k];
+        const float gvk = kappa * wb[k];
+        const float gak = gvk / s - (na > 0.f ? ak * adotgv / (na * s * s) : 0.f);
+        float v = G[i] / sigma + alpha * (kappa * (ak / s) * b[c] + gak * u[c]);
+        dW[i] = beta ? dW[i] + v : v;
+    }
+}
+
+extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, const float* G, float* dW,
+                           int32_t beta) {
+    // ws as left by savp_sn_fwd for the same (W, u).  G = dL/dW_bar [K,C]; dW = dL/dW.
+    if (!W || !u || !ws || !G || !dW) return SAVP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws + 5, 0, 2 * sizeof(float), st);
+    long long n = (long long)K * C;
+    unsigned nb = (unsigned)((n + NT - 1) / NT);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(nb), dim3(NT), 0, st, G, W, n, ws + 5);
+    float* a = ws + 8 + 2 * C;
+    unsigned nr = (unsigned)((K + 3) / 4);
+    if (nr > 2048) nr = 2048;
+    // wb = W b ; ws[6] = a . wb
+    hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
+                       (float*)nullptr, (const float*)a, ws + 6);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nb), dim3(NT), 0, st, G, (long long)K, C, u, (const float*)ws, dW, beta);
+    return LAUNCH_OK();
+}

@@ -168,3 +168,219 @@ def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates
     a.dc_prev = dc_prev.data_ptr() if dc_prev is not None else None
     a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = [d.data_ptr() for d in dparams]
     lib.check(lib.get().savp_convlstm_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_bwd')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# util ops
+# ---------------------------------------------------------------------------------------------------------------
+def _L():
+    return lib.get()
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _rows(t):
+    """Leading rows R for a view [R..., HW..., C] treated as [R, HW, C]: callers pass 3-D+ tensors [R, spatial.., C]."""
+    return t.shape[0]
+
+
+def tile_channels(z, out, scale=1.0, beta=0):
+    """out[r, p, c] (=|+=) scale * z[r, c]; z [R, C] contiguous; out view [R, spatial..., C]."""
+    lib.require_device(z, out)
+    R, C = z.shape
+    lib.check(_L().savp_tile_channels(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out), int(beta)),
+              'savp_tile_channels')
+
+
+def colsum(x, out, scale=1.0, per_row=False):
+    """out += scale * sum over pixels (and rows unless per_row) of x [R, spatial..., C]."""
+    lib.require_device(x, out)
+    lib.check(_L().savp_colsum(lib.stream(), view(x), x.shape[0], _hw(x), x.shape[-1], float(scale), _p(out), int(per_row)),
+              'savp_colsum')
+
+
+def _view_array(tensors):
+    arr = (lib.SavpView * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = view(t)
+    return arr
+
+
+def select(mask, a, b, outs):
+    lib.require_device(a, b, *outs)
+    bv = view(b) if b is not None else lib.SavpView()
+    lib.check(_L().savp_select(lib.stream(), a.shape[0], _hw(a), a.shape[-1], _p(mask), view(a), bv, len(outs),
+                               _view_array(outs)), 'savp_select')
+
+
+def select_bwd(mask, dins, db):
+    lib.check(_L().savp_select_bwd(lib.stream(), db.shape[0], _hw(db), db.shape[-1], _p(mask), len(dins), _view_array(dins),
+                                   view(db)), 'savp_select_bwd')
+
+
+def gather_clips(src, dst, t_start, adjoint=False):
+    """src [L,B,H,W,C] contiguous time-major, dst [B,clip,H,W,C] contiguous."""
+    lib.require_device(src, dst)
+    L, B = src.shape[:2]
+    clip = dst.shape[1]
+    E = src[0, 0].numel()
+    assert src.is_contiguous() and dst.is_contiguous() and dst.shape[0] == B
+    lib.check(_L().savp_gather_clips(lib.stream(), _p(src), _p(dst), _p(t_start), B, clip, E, int(adjoint)), 'savp_gather_clips')
+
+
+def axpby(a, x, b, y, out):
+    assert x.is_contiguous() and out.is_contiguous() and (y is None or y.is_contiguous())
+    lib.check(_L().savp_axpby(lib.stream(), x.numel(), float(a), _p(x), float(b), _p(y), _p(out)), 'savp_axpby')
+
+
+def fill_view(out, value=0.0):
+    lib.check(_L().savp_fill_view(lib.stream(), view(out), out.shape[0], _hw(out), out.shape[-1], float(value)), 'savp_fill_view')
+
+
+def adam(p, g, m, v, lr_t, beta1, beta2, eps=1e-8, gscale=1.0):
+    lib.check(_L().savp_adam(lib.stream(), p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr_t), float(beta1), float(beta2),
+                             float(eps), float(gscale)), 'savp_adam')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cdna / composite
+# ---------------------------------------------------------------------------------------------------------------
+def cdna_kernels_fwd(raw, kern, kh, kw, K):
+    lib.check(_L().savp_cdna_kernels_fwd(lib.stream(), _p(raw), _p(kern), raw.shape[0], kh, kw, K), 'savp_cdna_kernels_fwd')
+
+
+def cdna_kernels_bwd(raw, dkern, draw, kh, kw, K):
+    lib.check(_L().savp_cdna_kernels_bwd(lib.stream(), _p(raw), _p(dkern), _p(draw), raw.shape[0], kh, kw, K),
+              'savp_cdna_kernels_bwd')
+
+
+def _cdna_args(img, kern, kh, kw, K):
+    a = lib.SavpCdnaArgs()
+    a.N, a.H, a.W, a.C = img.shape
+    a.K, a.kh, a.kw = K, kh, kw
+    a.img = view(img)
+    a.kern = _p(kern)
+    return a
+
+
+def cdna_apply_fwd(img, kern, out, kh, kw, K):
+    a = _cdna_args(img, kern, kh, kw, K)
+    a.out = view(out)
+    lib.check(_L().savp_cdna_apply_fwd(lib.stream(), ctypes.byref(a)), 'savp_cdna_apply_fwd')
+
+
+def cdna_apply_bwd(img, kern, dout, dimg, dkern, kh, kw, K, dimg_beta=0):
+    a = _cdna_args(img, kern, kh, kw, K)
+    a.dout = view(dout)
+    if dimg is not None:
+        a.dimg = view(dimg)
+    a.dimg_beta = int(dimg_beta)
+    a.dkern = _p(dkern)
+    lib.check(_L().savp_cdna_apply_bwd(lib.stream(), ctypes.byref(a)), 'savp_cdna_apply_bwd')
+
+
+def _comp_args(logits, timgs, C):
+    a = lib.SavpCompositeArgs()
+    a.N, a.HW, a.M, a.C = logits.shape[0], _hw(logits), logits.shape[-1], C
+    assert logits.is_contiguous()
+    a.logits = _p(logits)
+    a.timgs = view(timgs)
+    return a
+
+
+def composite_fwd(logits, timgs, gen, masks=None):
+    a = _comp_args(logits, timgs, gen.shape[-1])
+    a.gen = view(gen)
+    a.masks = _p(masks)
+    lib.check(_L().savp_composite_fwd(lib.stream(), ctypes.byref(a)), 'savp_composite_fwd')
+
+
+def composite_bwd(logits, timgs, dgen, dlogits, dtimgs, dt_beta=0):
+    a = _comp_args(logits, timgs, dgen.shape[-1])
+    a.dgen = view(dgen)
+    a.dlogits = _p(dlogits)
+    a.dtimgs = view(dtimgs)
+    a.dt_beta = int(dt_beta)
+    lib.check(_L().savp_composite_bwd(lib.stream(), ctypes.byref(a)), 'savp_composite_bwd')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------------------------
+def lstm_z_fwd(zs, W, b, hout, gates, cs, forget_bias=1.0):
+    T, B, nz = zs.shape
+    lib.check(_L().savp_lstm_z_fwd(lib.stream(), _p(zs), _p(W), _p(b), _p(hout), _p(gates), _p(cs), T, B, nz, float(forget_bias)),
+              'savp_lstm_z_fwd')
+
+
+def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0):
+    T, B, nz = zs.shape
+    lib.check(_L().savp_lstm_z_bwd(lib.stream(), _p(zs), _p(W), _p(hout), _p(gates), _p(cs), _p(dh_out), _p(dzs), _p(dW), _p(db),
+                                   T, B, nz, float(forget_bias)), 'savp_lstm_z_bwd')
+
+
+def reparam_fwd(mu, ls_raw, eps, ls, z, kl_out=None):
+    rows = mu.numel() // mu.shape[-1]
+    lib.check(_L().savp_reparam_fwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(ls), _p(z), _p(kl_out)),
+              'savp_reparam_fwd')
+
+
+def reparam_bwd(mu, ls_raw, eps, dz, klw, dmu, dls_raw):
+    rows = mu.numel() // mu.shape[-1]
+    lib.check(_L().savp_reparam_bwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(dz), float(klw), _p(dmu),
+                                    _p(dls_raw)), 'savp_reparam_bwd')
+
+
+def lp_loss(pred, target, weight, loss_out=None, dpred=None, p2=False):
+    assert pred.is_contiguous() and target.is_contiguous()
+    lib.check(_L().savp_lp_loss(lib.stream(), pred.numel(), int(p2), _p(pred), _p(target), float(weight), _p(loss_out), _p(dpred)),
+              'savp_lp_loss')
+
+
+def lsgan_loss(logits, label, weight, loss_out=None, dlogits=None, beta=0):
+    lib.check(_L().savp_lsgan_loss(lib.stream(), logits.numel(), _p(logits), float(label), float(weight), _p(loss_out), _p(dlogits),
+                                   int(beta)), 'savp_lsgan_loss')
+
+
+def cosine_distance(f0, f1, weight, loss_out=None, df0=None, beta=0, eps=1e-10):
+    assert f0.is_contiguous() and f1.is_contiguous()
+    C = f0.shape[-1]
+    lib.check(_L().savp_cosine_distance(lib.stream(), f0.numel() // C, C, _p(f0), _p(f1), float(weight), float(eps), _p(loss_out),
+                                        _p(df0), int(beta)), 'savp_cosine_distance')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight prep
+# ---------------------------------------------------------------------------------------------------------------
+def pack_weights(src, wt=None, wd=None, scale=None):
+    """src HWIO [..., Cx, Cy] contiguous -> wt [Cy, taps*Cx] and/or wd [Cx, taps*Cy]; scale = device scalar tensor."""
+    Cx, Cy = src.shape[-2], src.shape[-1]
+    T = src.numel() // (Cx * Cy)
+    lib.check(_L().savp_pack_weights(lib.stream(), _p(src), T, Cx, Cy, _p(scale), _p(wt), _p(wd)), 'savp_pack_weights')
+
+
+def fold_pool(inp, out, k, adjoint=False):
+    C = (out.numel() if adjoint else inp.numel()) // (k * k)
+    lib.check(_L().savp_fold_pool(lib.stream(), _p(inp), _p(out), k, C, int(adjoint)), 'savp_fold_pool')
+
+
+def fold_bilinear(inp, out, k, Cin, F, adjoint=False):
+    lib.check(_L().savp_fold_bilinear(lib.stream(), _p(inp), _p(out), k, Cin, F, int(adjoint)), 'savp_fold_bilinear')
+
+
+def sn_ws_size(K, C):
+    return 8 + 2 * C + 2 * K
+
+
+def sn_fwd(W, u, ws, u_new=None):
+    C = W.shape[-1]
+    K = W.numel() // C
+    lib.check(_L().savp_sn_fwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(u_new)), 'savp_sn_fwd')
+
+
+def sn_bwd(W, u, ws, G, dW, beta=0):
+    C = W.shape[-1]
+    K = W.numel() // C
+    lib.check(_L().savp_sn_bwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(G), _p(dW), int(beta)), 'savp_sn_bwd')

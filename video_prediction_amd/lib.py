@@ -132,3 +132,48 @@ register('savp_instnorm_act_fwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
 register('savp_instnorm_act_bwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
 register('savp_convlstm_gates_fwd', [c_vp, ctypes.POINTER(SavpLstmArgs)])
 register('savp_convlstm_gates_bwd', [c_vp, ctypes.POINTER(SavpLstmArgs)])
+
+
+class SavpCdnaArgs(ctypes.Structure):
+    _fields_ = [
+        ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('K', c_i32), ('kh', c_i32), ('kw', c_i32),
+        ('img', SavpView), ('kern', c_vp), ('out', SavpView), ('dout', SavpView),
+        ('dimg', SavpView), ('dimg_beta', c_i32), ('dkern', c_vp),
+    ]
+
+
+class SavpCompositeArgs(ctypes.Structure):
+    _fields_ = [
+        ('N', c_i32), ('HW', c_i32), ('M', c_i32), ('C', c_i32),
+        ('logits', c_vp), ('timgs', SavpView), ('gen', SavpView), ('masks', c_vp),
+        ('dgen', SavpView), ('dlogits', c_vp), ('dtimgs', SavpView), ('dt_beta', c_i32),
+    ]
+
+
+_PV = ctypes.POINTER(SavpView)
+register('savp_tile_channels', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView, c_i32])
+register('savp_colsum', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32, c_vp, c_i32])
+register('savp_select', [c_vp, c_i32, c_i32, c_i32, c_vp, SavpView, SavpView, c_i32, _PV])
+register('savp_select_bwd', [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, _PV, SavpView])
+register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32])
+register('savp_axpby', [c_vp, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp])
+register('savp_fill_view', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32])
+register('savp_adam', [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32])
+register('savp_cdna_kernels_fwd', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
+register('savp_cdna_kernels_bwd', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
+register('savp_cdna_apply_fwd', [c_vp, ctypes.POINTER(SavpCdnaArgs)])
+register('savp_cdna_apply_bwd', [c_vp, ctypes.POINTER(SavpCdnaArgs)])
+register('savp_composite_fwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
+register('savp_composite_bwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
+register('savp_lstm_z_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
+register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
+register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
+register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp])
+register('savp_lp_loss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])
+register('savp_lsgan_loss', [c_vp, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
+register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
+register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp])
+register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
+register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
+register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
+register('savp_sn_bwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32])
