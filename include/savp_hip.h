@@ -128,9 +128,14 @@ int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* m
 /* db += mask[n] ? 0 : sum_k din_k */
 int savp_select_bwd(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, int32_t nin, const SavpView* dins,
                     SavpView db);
-/* dst[b,i,:] = src[t_start[b]+i, b, :] (tf.gather_nd, savp_model.py:97-102); adjoint: src[...] += dst[...] */
+/* dst[b,i,:] = src[(t_start[b]+i)*src_t_stride + b*E + :] (tf.gather_nd, savp_model.py:97-102); adjoint: src += dst */
 int savp_gather_clips(void* stream, float* src, float* dst, const int32_t* t_start, int32_t B, int32_t clip, int64_t E,
-                      int32_t adjoint);
+                      int64_t src_t_stride, int32_t adjoint);
+/* out = dy * y * (1-y) (contiguous out): backward of the sigmoid fused into a conv epilogue (savp_model.py:572) */
+int savp_sigmoid_bwd(void* stream, SavpView dy, SavpView y, float* out, int64_t N, int32_t HW, int32_t C);
+/* ops.dense for few rows (M <= 64), split over K: out[M,C] = scale*x[M,K] W[K,C] + bias (out contiguous) */
+int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,
+                   const float* bias, const float* scale, float* out);
 int savp_axpby(void* stream, int64_t n, float a, const float* x, float b, const float* y, float* out);
 int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW, int32_t C, float value);
 /* tf.train.AdamOptimizer on a flat arena (base_model.py:486-487); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
@@ -180,8 +185,8 @@ int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, con
                      float* z, float* kl_out);
 int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
                      const float* dz, float klw, float* dmu, float* dls_raw);
-int savp_lp_loss(void* stream, int64_t n, int32_t p2, const float* pred, const float* target, float weight, float* loss_out,
-                 float* dpred);
+int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride, int32_t p2,
+                 const float* pred, const float* target, float weight, float* loss_out, float* dpred);
 int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out, float* dlogits,
                     int32_t beta);
 int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,

@@ -1,0 +1,174 @@
+"""Model-level GPU parity: the HIP engine (generator unroll, encoder, discriminators, losses, Adam) vs the fp64 oracle
+on identical variables, inputs and injected noise."""
+import numpy as np
+import torch
+
+from oracle import savp as OS
+from oracle import train as OT
+from video_prediction_amd import variables as V
+from video_prediction_amd.hparams import HParams
+from video_prediction_amd.models.hparam_defaults import savp_defaults
+from video_prediction_amd.models.savp_model import SAVPEngine
+
+DEV = 'cuda:0'
+
+
+def make_hparams(**over):
+    hp = HParams(**savp_defaults())
+    hp.override_from_dict(over)
+    return hp
+
+
+def rel(got, ref):
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
+    ref = torch.as_tensor(np.asarray(ref.detach().cpu() if torch.is_tensor(ref) else ref)).double()
+    return float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+
+
+def synth(hp, B, H, W, C, seed=0, smooth=True):
+    """Seeded synthetic video in [0,1] (temporally smooth so that CDNA / masks are exercised off-saturation)."""
+    T = hp.sequence_length
+    rng = np.random.default_rng(seed)
+    x = rng.random((1, B, H, W, C))
+    frames = [x]
+    for _ in range(T - 1):
+        x = np.clip(x + rng.normal(0, 0.05, x.shape), 0, 1) if smooth else rng.random((1, B, H, W, C))
+        frames.append(x)
+    return torch.tensor(np.concatenate(frames, axis=0))            # [T,B,H,W,C] fp64
+
+
+def make_noise(hp, B, seed=1, sampling=True):
+    T1 = hp.sequence_length - 1
+    rng = np.random.default_rng(seed)
+    noise = {}
+    if hp.nz:
+        noise['eps'] = torch.tensor(rng.standard_normal((T1, B, hp.nz)))
+        noise['prior'] = torch.tensor(rng.standard_normal((hp.sequence_length - hp.context_frames, B, hp.nz)))
+    ns = T1 - hp.context_frames
+    if sampling:
+        noise['ground_truth_sampling'] = torch.tensor(rng.random((ns, B)) < 0.5)
+        noise['ground_truth_sampling_enc'] = torch.tensor(rng.random((ns, B)) < 0.5)
+    if T1 - hp.clip_length + 1 > 0:
+        for phase in ('pre', 'post'):
+            noise['d_indices_' + phase] = {k: (rng.integers(0, T1, B), rng.integers(0, T1 - hp.clip_length + 1, B))
+                                           for k in ('enc_real', 'enc_fake', 'real', 'fake')}
+    return noise
+
+
+def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None):
+    hp = make_hparams(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid')
+    specs = V.variable_specs(hp, (H, W, C), mode='test')
+    vals = V.init_variables(specs, seed=4)
+    # perturb norm params / biases so that they matter
+    rng = np.random.default_rng(9)
+    for k in vals:
+        if k.endswith('gamma'):
+            vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('bias'):
+            vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('kernel'):
+            vals[k] = (vals[k] * 3).astype(np.float32)
+    images = synth(hp, B, H, W, C, seed)
+    noise = make_noise(hp, B, sampling=True)
+    P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
+    with torch.no_grad():
+        ref = OS.generator_fn(OS.Scope(P).sub('generator'), {'images': images}, 'train', hp, noise)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, device=DEV)
+    eng.mode = 'train'          # honour the injected scheduled-sampling mask like mode='train' does
+    eng.set_images(images.float().to(DEV), time_major=True)
+    eng.prep_generator_weights()
+    gen = eng.forward_generator(noise, collect_masks=True)
+    torch.cuda.synchronize()
+    tag = tag or ('gen_fwd_nz%d_%dx%d' % (nz, H, W))
+    out = []
+    lo = B if nz else 0
+    out.append((tag + '/gen_images', rel(gen[:, lo:], ref['gen_images']), 1e-3))
+    g = eng.gen
+    masks = g.masks.reshape(g.T1, g.N, H, W, 1, g.M)
+    out.append((tag + '/masks', rel(masks[:, lo:], ref['masks']), 1e-3))
+    # bit-exact argmax of the compositing masks except where the oracle's top-2 margin is < 1e-5
+    m_ref = ref['masks'].squeeze(-2)
+    top2 = m_ref.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-5
+    mism = (masks[:, lo:].squeeze(-2).argmax(-1).cpu() != m_ref.argmax(-1)) & safe
+    out.append((tag + '/mask_argmax_mismatch_frac', float(mism.sum()) / float(safe.sum()), 0.0))
+    kern_ref = ref['_kernels']                                   # [T1,B,5,5,4]
+    kern = g.cdna_kern.v.reshape(g.T1, g.N, 5, 5, 4)[:, lo:]
+    out.append((tag + '/cdna_kernels', rel(kern, kern_ref), 1e-3))
+    kr = kern_ref.reshape(g.T1, B, 25, 4)
+    t2 = kr.topk(2, dim=2).values
+    safe = (t2[:, :, 0] - t2[:, :, 1]) > 1e-5
+    mism = (kern.reshape(g.T1, B, 25, 4).argmax(2).cpu() != kr.argmax(2)) & safe
+    out.append((tag + '/cdna_tap_argmax_mismatch', float(mism.sum()), 0.0))
+    if nz:
+        out.append((tag + '/gen_images_enc', rel(gen[:, :B], ref['gen_images_enc']), 1e-3))
+        out.append((tag + '/zs_mu', rel(eng.enc.mu, ref['zs_mu_enc']), 1e-4))
+        out.append((tag + '/zs_log_sigma_sq', rel(eng.enc.ls, ref['zs_log_sigma_sq_enc']), 1e-4))
+    return out
+
+
+def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='train', **over):
+    hpd = dict(context_frames=2, sequence_length=T, clip_length=4, nz=nz, lr=2e-4, beta1=0.5, beta2=0.999,
+               l1_weight=100.0, l2_weight=0.0, kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1,
+               video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
+    hpd.update(over)
+    hp = make_hparams(**hpd)
+    specs = V.variable_specs(hp, (H, W, C), mode='train')
+    vals = V.init_variables(specs, seed=4)
+    rng = np.random.default_rng(9)
+    for k in vals:
+        if k.endswith('gamma'):
+            vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('bias'):
+            vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('kernel') and k.startswith('generator'):
+            vals[k] = (vals[k] * 3).astype(np.float32)
+    images = synth(hp, B, H, W, C, seed)
+    P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
+    st = OT.init_opt_state(P)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='train', values=vals, device=DEV)
+    eng.set_images(images.float().to(DEV), time_major=True)
+    out = []
+    for it in range(steps):
+        noise = make_noise(hp, B, seed=100 + it, sampling=True)
+        P, st, info_ref = OT.train_step(P, st, {'images': images}, hp, noise, noise['d_indices_pre'], noise['d_indices_post'],
+                                        step=it)
+        info = eng.train_step(noise, return_grads=True)
+        torch.cuda.synchronize()
+        t = '%s/step%d' % (tag, it)
+        if 'd_loss' in info_ref:
+            out.append((t + '/d_loss', rel(info['d_loss'], torch.tensor(info_ref['d_loss'])), 1e-3))
+        out.append((t + '/g_loss', rel(info['g_loss'], torch.tensor(info_ref['g_loss'])), 1e-3))
+        for nm, (l, w) in info['g_losses'].items():
+            out.append((t + '/' + nm, rel(l, torch.tensor(info_ref['g_losses'][nm])), 2e-3))
+        for grp, key in (('d', 'd_grads'), ('g', 'g_grads')):
+            worst, worst_name = 0.0, ''
+            for name, gref in info_ref.get(key, {}).items():
+                e = rel(info[key][name], gref)
+                if e > worst:
+                    worst, worst_name = e, name
+            if key in info_ref:
+                out.append((t + '/%s_grad_worst[%s]' % (grp, worst_name.split('/', 1)[-1][-40:]), worst, 5e-3))
+        worst, worst_name = 0.0, ''
+        for name, pref in P.items():
+            e = rel(eng.store[name], pref)
+            if e > worst:
+                worst, worst_name = e, name
+        out.append((t + '/param_worst[%s]' % worst_name[-40:], worst, 2e-3))
+    return out
+
+
+def check_model_small():
+    res = []
+    res += check_generator_forward(nz=0, B=2, T=5)
+    res += check_generator_forward(nz=8, B=2, T=4)
+    res += check_generator_forward(nz=0, B=1, T=3, H=64, W=64, C=1, tag='gen_fwd_gray')
+    return res
+
+
+def check_train_small():
+    res = []
+    res += check_train_step(B=2, T=6, nz=8, steps=2, tag='train_savp')
+    res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                            vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)
+    return res

@@ -16,7 +16,9 @@ def main():
     only = set(sys.argv[1:])
     results = {}
     nbad = 0
-    for name, fn in gpu_checks.ALL_CHECKS:
+    from tests import gpu_model_checks
+    checks = list(gpu_checks.ALL_CHECKS) + [('model_fwd', gpu_model_checks.check_model_small), ('model_train', gpu_model_checks.check_train_small)]
+    for name, fn in checks:
         if only and name not in only:
             continue
         t0 = time.time()

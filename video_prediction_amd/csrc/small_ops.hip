@@ -193,33 +193,37 @@ extern "C" int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const flo
 // ---------------------------------------------------------------------------------------------------------------
 // l1 / l2 image loss: loss_out += mean(|t-p|) or mean((t-p)^2); dpred += weight * dloss/dpred  (dpred may be null)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void lp_loss_kernel(long long n, int p2, const float* pred, const float* target, float weight, float* loss_out,
-                               float* dpred) {
+__global__ void lp_loss_kernel(long long rows, long long row_len, long long p_rs, long long t_rs, int p2, const float* pred,
+                               const float* target, float weight, float* loss_out, float* dpred) {
     __shared__ float sh[4];
     float acc = 0.f;
+    const long long n = rows * row_len;
     const float invn = 1.f / (float)n;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float d = pred[i] - target[i];
+        const long long r = i / row_len, e = i - r * row_len;
+        float d = pred[r * p_rs + e] - target[r * t_rs + e];
         if (p2) {
             acc += d * d;
-            if (dpred) dpred[i] += weight * 2.f * d * invn;
+            if (dpred) dpred[r * p_rs + e] += weight * 2.f * d * invn;
         } else {
             acc += fabsf(d);
             // tf.abs gradient is sign(x) (0 at 0)
-            if (dpred) dpred[i] += weight * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invn;
+            if (dpred) dpred[r * p_rs + e] += weight * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invn;
         }
     }
     float t = block_sum1(acc, sh);
     if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t * invn);
 }
 
-extern "C" int savp_lp_loss(void* stream, int64_t n, int32_t p2, const float* pred, const float* target, float weight,
-                            float* loss_out, float* dpred) {
-    if (!pred || !target || n < 1) return SAVP_EINVAL;
+extern "C" int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride,
+                            int32_t p2, const float* pred, const float* target, float weight, float* loss_out, float* dpred) {
+    // pred/dpred addressed as [rows][row_len] with row stride pred_row_stride (a half of a [T,2B,...] buffer)
+    if (!pred || !target || rows < 1 || row_len < 1) return SAVP_EINVAL;
+    long long n = (long long)rows * row_len;
     unsigned nb = (unsigned)((n + NT - 1) / NT);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(lp_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, p2, pred, target, weight,
-                       loss_out, dpred);
+    hipLaunchKernelGGL(lp_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)rows, (long long)row_len,
+                       (long long)pred_row_stride, (long long)target_row_stride, p2, pred, target, weight, loss_out, dpred);
     return LAUNCH_OK();
 }
 

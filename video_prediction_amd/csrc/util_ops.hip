@@ -154,16 +154,17 @@ extern "C" int savp_select_bwd(void* stream, int32_t N, int32_t HW, int32_t C, c
 
 // ---------------------------------------------------------------------------------------------------------------
 // gather_clips: src time-major [L, B, E] (E = H*W*C contiguous), dst batch-major [B, clip, E]:
-//   dst[b,i,:] = src[t_start[b]+i, b, :]   ; adjoint: src[t_start[b]+i, b, :] += dst[b,i,:]
+//   dst[b,i,:] = src[(t_start[b]+i)*src_ts + b*E + :]   ; adjoint: src[...] += dst[b,i,:]
+//   (src_ts = element stride between timesteps, so one half of a [T,2B,...] buffer can be addressed)
 __global__ void gather_clips_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ t_start,
-                                    int B, int clip, long long E, int adjoint, float* srcw, const float* dstr) {
+                                    int B, int clip, long long E, long long src_ts, int adjoint, float* srcw, const float* dstr) {
     long long total = (long long)B * clip * (E / 4);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         long long e4 = i % (E / 4);
         long long bi = i / (E / 4);
         int ci = (int)(bi % clip);
         int b = (int)(bi / clip);
-        long long so = ((long long)(t_start[b] + ci) * B + b) * E + e4 * 4;
+        long long so = (long long)(t_start[b] + ci) * src_ts + (long long)b * E + e4 * 4;
         long long d_o = ((long long)b * clip + ci) * E + e4 * 4;
         if (!adjoint) {
             *reinterpret_cast<float4*>(dst + d_o) = *reinterpret_cast<const float4*>(src + so);
@@ -177,13 +178,13 @@ __global__ void gather_clips_kernel(const float* __restrict__ src, float* __rest
 }
 
 extern "C" int savp_gather_clips(void* stream, float* src, float* dst, const int32_t* t_start, int32_t B, int32_t clip,
-                                 int64_t E, int32_t adjoint) {
-    if (!src || !dst || !t_start || E % 4) return SAVP_EINVAL;
+                                 int64_t E, int64_t src_ts, int32_t adjoint) {
+    if (!src || !dst || !t_start || E % 4 || src_ts % 4) return SAVP_EINVAL;
     long long total = (long long)B * clip * (E / 4);
     unsigned nb = nblocks(total);
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(gather_clips_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (const float*)src, dst, t_start, B,
-                       clip, (long long)E, adjoint, src, (const float*)dst);
+                       clip, (long long)E, (long long)src_ts, adjoint, src, (const float*)dst);
     return LAUNCH_OK();
 }
 
@@ -265,5 +266,61 @@ extern "C" int savp_adam(void* stream, int64_t n, float* p, const float* g, floa
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, lr_t, beta1, beta2,
                        eps, gscale);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dpre = dy * y * (1 - y) : backward of the sigmoid fused into the scratch-image conv epilogue (savp_model.py:572)
+__global__ void sigmoid_bwd_kernel(const float* dy, long long dy_sn, long long dy_sp, const float* y, long long y_sn, long long y_sp,
+                                   float* out, long long N, int HW, int C) {
+    long long total = N * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long np = i / C;
+        int px = (int)(np % HW);
+        long long n = np / HW;
+        float yy = y[n * y_sn + px * y_sp + c];
+        out[i] = dy[n * dy_sn + px * dy_sp + c] * yy * (1.f - yy);
+    }
+}
+
+extern "C" int savp_sigmoid_bwd(void* stream, SavpView dy, SavpView y, float* out, int64_t N, int32_t HW, int32_t C) {
+    if (!dy.p || !y.p || !out) return SAVP_EINVAL;
+    unsigned nb = nblocks((long long)N * HW * C);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (const float*)dy.p, (long long)dy.sn,
+                       (long long)dy.sp, (const float*)y.p, (long long)y.sn, (long long)y.sp, out, (long long)N, HW, C);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dense layer with few rows (M <= 64): out[m,c] = scale * sum_k x[m,k] W[k,c] + bias[c]    (ops.dense, ops.py:5-16)
+// split over K across workgroups (the implicit-GEMM kernel would put the whole K loop into a single workgroup).
+// Used for the CDNA kernel head (8192 -> 100) and the discriminators' final linear (65536 -> 1).
+__global__ __launch_bounds__(NT) void dense_smallm_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
+                                                          const float* __restrict__ W, const float* bias, const float* scale,
+                                                          float* out, int kc) {
+    const long long k0 = (long long)blockIdx.x * kc;
+    const long long k1 = min(Kd, k0 + kc);
+    const float sc = scale ? *scale : 1.f;
+    for (int o = threadIdx.x; o < M * C; o += NT) {
+        const int m = o / C, c = o % C;
+        const float* xr = x + (long long)m * xs;
+        float acc = 0.f;
+        for (long long k = k0; k < k1; ++k) acc += xr[k] * W[k * C + c];
+        acc *= sc;
+        if (blockIdx.x == 0 && bias) acc += bias[c];
+        unsafeAtomicAdd(out + o, acc);
+    }
+}
+
+extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,
+                              const float* bias, const float* scale, float* out) {
+    if (!x || !W || !out || M < 1 || K < 1 || C < 1) return SAVP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
+    int kc = 128;
+    hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((K + kc - 1) / kc)), dim3(NT), 0, st, x, (long long)x_row_stride, M,
+                       (long long)K, C, W, bias, scale, out, kc);
     return LAUNCH_OK();
 }

@@ -1,0 +1,304 @@
+"""Host-side engine: parameter arenas, per-step weight preparation and conv-layer objects.
+
+Everything numerical is a HIP kernel launched through ``kernels``; this file only owns HBM layout:
+
+* ``ParamStore`` keeps every trainable variable of one optimiser group in ONE flat fp32 arena (16-byte aligned
+  slots, keyed by the reference's TF variable names), with parallel arenas for gradients and Adam moments.  A whole
+  group is updated by one ``savp_adam`` launch and all-reduced as one RCCL bucket.
+* ``ConvLayer`` owns the derived weight layouts of one convolution (pool-/bilinear-folded HWIO kernel, spectral-norm
+  scale, k-contiguous packs for FPROP and DGRAD) and accumulates its weight gradient with ONE WGRAD launch over all
+  timesteps and samples (the time axis is folded into the GEMM's K dimension).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import lib
+from .variables import is_trainable
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class Arena(object):
+    """Flat fp32 device arena with named, 16-byte aligned slots."""
+
+    def __init__(self, shapes, device):
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape in shapes.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            self.offsets[name] = (off, n, tuple(shape))
+            off += _align4(n)
+        self.size = max(off, 4)
+        self.device = device
+        self.flat = torch.zeros(self.size, device=device, dtype=torch.float32)
+        self._views = {}
+
+    def view_of(self, flat, name):
+        off, n, shape = self.offsets[name]
+        return flat[off:off + n].view(shape)
+
+    def __getitem__(self, name):
+        v = self._views.get(name)
+        if v is None:
+            v = self._views[name] = self.view_of(self.flat, name)
+        return v
+
+    def __contains__(self, name):
+        return name in self.offsets
+
+    def names(self):
+        return list(self.offsets.keys())
+
+    def like(self):
+        return torch.zeros_like(self.flat)
+
+
+class ParamGroup(object):
+    """One optimiser group: params, grads, Adam moments, Adam step counter."""
+
+    def __init__(self, shapes, device):
+        self.arena = Arena(shapes, device)
+        self.p = self.arena.flat
+        self.g = self.arena.like()
+        self.m = self.arena.like()
+        self.v = self.arena.like()
+        self.t = 0
+        self._gviews = {}
+
+    def param(self, name):
+        return self.arena[name]
+
+    def grad(self, name):
+        v = self._gviews.get(name)
+        if v is None:
+            v = self._gviews[name] = self.arena.view_of(self.g, name)
+        return v
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def adam_step(self, lr, beta1, beta2, gscale=1.0, eps=1e-8):
+        """tf.train.AdamOptimizer (base_model.py:486-487): lr_t = lr*sqrt(1-b2^t)/(1-b1^t)."""
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
+        K.adam(self.p, self.g, self.m, self.v, lr_t, beta1, beta2, eps=eps, gscale=gscale)
+
+
+class ParamStore(object):
+    """All variables of a model: groups 'g' (scope generator/), 'd' (scope discriminator/, trainable) and 'aux'
+    (non-trainable spectral-norm u vectors)."""
+
+    def __init__(self, specs, values, device):
+        shapes = {'g': OrderedDict(), 'd': OrderedDict(), 'aux': OrderedDict()}
+        self.group_of = {}
+        for name, (shape, _) in specs.items():
+            if not is_trainable(name):
+                grp = 'aux'
+            elif name.startswith('discriminator/'):
+                grp = 'd'
+            else:
+                grp = 'g'
+            shapes[grp][name] = shape
+            self.group_of[name] = grp
+        self.groups = {k: ParamGroup(v, device) for k, v in shapes.items()}
+        self.specs = specs
+        self.device = device
+        self.load(values)
+
+    def load(self, values):
+        for name, val in values.items():
+            if name not in self.group_of:
+                continue
+            t = torch.as_tensor(np.asarray(val, dtype=np.float32))
+            self[name].copy_(t.reshape(self[name].shape))
+
+    def __getitem__(self, name):
+        return self.groups[self.group_of[name]].param(name)
+
+    def __contains__(self, name):
+        return name in self.group_of
+
+    def grad(self, name):
+        return self.groups[self.group_of[name]].grad(name)
+
+    def names(self):
+        return list(self.group_of.keys())
+
+    def to_numpy(self):
+        return OrderedDict((n, self[n].detach().cpu().numpy().copy()) for n in self.specs)
+
+    def grads_to_numpy(self):
+        return OrderedDict((n, self.grad(n).detach().cpu().numpy().copy()) for n in self.specs if self.group_of[n] != 'aux')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolution layers
+# ---------------------------------------------------------------------------------------------------------------
+def same_pad_before(k, s, in_size):
+    """TF SAME padding-before (ops.py:100-107)."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return total // 2
+
+
+class ConvLayer(object):
+    """One convolution of the SAVP graph with its derived weight layouts.
+
+    kind:
+      'conv' : plain cross-correlation (tf.nn.conv2d / conv3d / dense as 1x1), kernel used as is.
+      'pool' : ops.conv_pool2d -- avg-pool folded into the kernel (k -> k+1), stride 2, SAME.
+      'up'   : ops.upsample_conv2d -- bilinear x2 folded into the kernel (3 -> 6), conv2d_transpose stride 2 SAME;
+               executed as the DGRAD mode of the stride-2 forward conv described by ``geom``.
+    ``sn_u`` names the spectral-norm vector of a discriminator layer (kernel is divided by sigma on the fly).
+    """
+
+    def __init__(self, store, kernel_name, bias_name, kind, ksize, stride, pad, sn_u=None):
+        self.store = store
+        self.kernel_name, self.bias_name, self.kind = kernel_name, bias_name, kind
+        W = store[kernel_name]
+        self.W = W
+        self.dW = store.grad(kernel_name) if store.group_of[kernel_name] != 'aux' else None
+        self.bias = store[bias_name] if bias_name else None
+        self.dbias = store.grad(bias_name) if bias_name else None
+        dev = W.device
+        if kind == 'conv':
+            self.cx, self.cy = W.shape[-2], W.shape[-1]
+            self.wf = W                                   # folded == master
+            self.dwf = None                               # wgrad goes straight to the master grad (unless SN)
+            k3 = tuple(ksize)
+        elif kind == 'pool':
+            k, _, cin, cout = W.shape
+            self.cx, self.cy = cin, cout
+            self.wf = torch.empty(k + 1, k + 1, cin, cout, device=dev)
+            self.dwf = torch.zeros_like(self.wf)
+            k3 = (1, k + 1, k + 1)
+        elif kind == 'up':
+            k, _, cin, f = W.shape
+            # forward-conv description F: x-side = hi-res F channels, y-side = lo-res Cin channels
+            self.cx, self.cy = f, cin
+            self.wf = torch.empty(k + 3, k + 3, f, cin, device=dev)
+            self.dwf = torch.zeros_like(self.wf)
+            k3 = (1, k + 3, k + 3)
+        else:
+            raise ValueError(kind)
+        if len(k3) == 2:
+            k3 = (1,) + tuple(k3)
+        s3 = tuple(stride) if len(stride) == 3 else (1,) + tuple(stride)
+        p3 = tuple(pad) if len(pad) == 3 else (0,) + tuple(pad)
+        self.geom = K.ConvGeom(k3, s3, p3)
+        self.taps = k3[0] * k3[1] * k3[2]
+        self.wt = torch.empty(self.cy, self.taps * self.cx, device=dev)
+        self.wd = torch.empty(self.cx, self.taps * self.cy, device=dev)
+        self.sn_u_name = sn_u
+        if sn_u:
+            self.u = store[sn_u]
+            kdim = W.numel() // self.cy
+            self.sn_ws = torch.zeros(K.sn_ws_size(kdim, self.cy), device=dev)
+            self.u_next = torch.empty_like(self.u)
+            self.dwf = torch.zeros_like(W)                # dL/dW_bar, then sn_bwd -> master grad
+        self.need_wt = self.need_wd = True
+
+    # -- weight preparation ---------------------------------------------------------------------------------
+    def prep(self, update_u=False):
+        scale = None
+        if self.kind == 'pool':
+            K.fold_pool(self.W, self.wf, self.W.shape[0])
+        elif self.kind == 'up':
+            k, _, cin, f = self.W.shape
+            K.fold_bilinear(self.W, self.wf, k, cin, f)
+        if self.sn_u_name:
+            K.sn_fwd(self.W, self.u.reshape(-1), self.sn_ws, self.u_next.reshape(-1) if update_u else None)
+            scale = self.sn_ws[1:2]
+        K.pack_weights(self.wf, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale)
+
+    def commit_u(self):
+        """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
+        if self.sn_u_name:
+            self.u.copy_(self.u_next)
+
+    # -- execution ----------------------------------------------------------------------------------------------
+    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True):
+        b = self.bias if use_bias else None
+        if self.kind == 'conv' and x.dim() == 2 and x.shape[0] <= 64 and not act and not beta and y.is_contiguous():
+            # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
+            K.dense_fwd(x, self.W.reshape(-1, self.cy), b, y, scale=self.sn_ws[1:2] if self.sn_u_name else None)
+            return
+        if self.kind == 'up':
+            K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha)
+        else:
+            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha)
+
+    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
+        if self.kind == 'up':
+            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux)
+        else:
+            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux)
+
+    def backward_weights(self, x, dy):
+        """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may
+        carry folded leading (time, batch) dims: [R, (D,) H, W, C]."""
+        target = self.dwf if self.dwf is not None else self.dW
+        if self.kind == 'up':
+            K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
+            bias_src = dy
+        else:
+            K.conv(lib.CONV_WGRAD, self.geom, x, dy, target)
+            bias_src = dy
+        if self.dbias is not None:
+            K.colsum(bias_src, self.dbias)
+
+    def finish_weight_grad(self):
+        """Map the folded / spectrally-normalised kernel gradient back to the master variable and clear it."""
+        if self.dwf is None:
+            return
+        if self.sn_u_name:
+            K.sn_bwd(self.W, self.u.reshape(-1), self.sn_ws, self.dwf, self.dW, beta=1)
+        elif self.kind == 'pool':
+            K.fold_pool(self.dwf, self.dW, self.W.shape[0], adjoint=True)
+        elif self.kind == 'up':
+            k, _, cin, f = self.W.shape
+            K.fold_bilinear(self.dwf, self.dW, k, cin, f, adjoint=True)
+        self.dwf.zero_()
+
+
+class Tape(object):
+    """Minimal reverse-mode tape: forward code appends closures, backward() runs them in reverse."""
+
+    def __init__(self):
+        self.ops = []
+
+    def add(self, fn):
+        self.ops.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.ops):
+            fn()
+        self.ops = []
+
+
+_CONST = {}
+
+
+def const_i32(n, value, device):
+    """Cached int32 device vector of n copies of value (masks for select used as strided copy / accumulate)."""
+    key = (n, value, str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), value, dtype=torch.int32, device=device)
+    return t
+
+
+def copy_view(src, dsts):
+    """Strided channels-last copy src -> each dst (shape [R, spatial..., C])."""
+    K.select(const_i32(src.shape[0], 1, src.device), src, None, dsts)
+
+
+def add_views(srcs, dst):
+    """dst += sum(srcs) on strided channels-last views."""
+    K.select_bwd(const_i32(dst.shape[0], 0, dst.device), srcs, dst)

@@ -221,13 +221,20 @@ def select_bwd(mask, dins, db):
 
 
 def gather_clips(src, dst, t_start, adjoint=False):
-    """src [L,B,H,W,C] contiguous time-major, dst [B,clip,H,W,C] contiguous."""
+    """src [L,B,H,W,C] time-major (a batch-slice of a contiguous [L,B2,...] buffer is allowed), dst [B,clip,H,W,C]
+    contiguous: dst[b,i] = src[t_start[b]+i, b]; adjoint accumulates dst back into src."""
     lib.require_device(src, dst)
     L, B = src.shape[:2]
     clip = dst.shape[1]
     E = src[0, 0].numel()
-    assert src.is_contiguous() and dst.is_contiguous() and dst.shape[0] == B
-    lib.check(_L().savp_gather_clips(lib.stream(), _p(src), _p(dst), _p(t_start), B, clip, E, int(adjoint)), 'savp_gather_clips')
+    assert dst.is_contiguous() and dst.shape[0] == B and src[0, 0].is_contiguous() and src.stride(1) == E
+    lib.check(_L().savp_gather_clips(lib.stream(), _p(src), _p(dst), _p(t_start), B, clip, E, src.stride(0), int(adjoint)),
+              'savp_gather_clips')
+
+
+def sigmoid_bwd(dy, y, out):
+    assert out.is_contiguous()
+    lib.check(_L().savp_sigmoid_bwd(lib.stream(), view(dy), view(y), _p(out), dy.shape[0], _hw(dy), dy.shape[-1]), 'savp_sigmoid_bwd')
 
 
 def axpby(a, x, b, y, out):
@@ -334,9 +341,14 @@ def reparam_bwd(mu, ls_raw, eps, dz, klw, dmu, dls_raw):
 
 
 def lp_loss(pred, target, weight, loss_out=None, dpred=None, p2=False):
-    assert pred.is_contiguous() and target.is_contiguous()
-    lib.check(_L().savp_lp_loss(lib.stream(), pred.numel(), int(p2), _p(pred), _p(target), float(weight), _p(loss_out), _p(dpred)),
-              'savp_lp_loss')
+    """pred/target [R, ...]: rows may be strided (pred = one batch-half of a [T,2B,...] buffer); each row contiguous."""
+    rows = pred.shape[0]
+    row_len = pred[0].numel()
+    assert pred[0].is_contiguous() and target[0].is_contiguous() and target.shape == pred.shape
+    if dpred is not None:
+        assert dpred.stride() == pred.stride()
+    lib.check(_L().savp_lp_loss(lib.stream(), rows, row_len, pred.stride(0), target.stride(0), int(p2), _p(pred), _p(target),
+                                float(weight), _p(loss_out), _p(dpred)), 'savp_lp_loss')
 
 
 def lsgan_loss(logits, label, weight, loss_out=None, dlogits=None, beta=0):
@@ -384,3 +396,11 @@ def sn_bwd(W, u, ws, G, dW, beta=0):
     C = W.shape[-1]
     K = W.numel() // C
     lib.check(_L().savp_sn_bwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(G), _p(dW), int(beta)), 'savp_sn_bwd')
+
+
+def dense_fwd(x, W, bias, out, scale=None):
+    """out[M,C] = scale * x[M,K] @ W[K,C] + bias for few rows (split-K GEMV-like kernel); out contiguous."""
+    M, Kd = x.shape
+    C = W.shape[-1]
+    assert out.is_contiguous() and x.stride(1) == 1 and W.is_contiguous()
+    lib.check(_L().savp_dense_fwd(lib.stream(), _p(x), x.stride(0), M, Kd, C, _p(W), _p(bias), _p(scale), _p(out)), 'savp_dense_fwd')

@@ -155,7 +155,8 @@ register('savp_tile_channels', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView
 register('savp_colsum', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32, c_vp, c_i32])
 register('savp_select', [c_vp, c_i32, c_i32, c_i32, c_vp, SavpView, SavpView, c_i32, _PV])
 register('savp_select_bwd', [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, _PV, SavpView])
-register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32])
+register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_i32])
+register('savp_sigmoid_bwd', [c_vp, SavpView, SavpView, c_vp, c_i64, c_i32, c_i32])
 register('savp_axpby', [c_vp, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp])
 register('savp_fill_view', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32])
 register('savp_adam', [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32])
@@ -169,7 +170,7 @@ register('savp_lstm_z_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp])
-register('savp_lp_loss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])
+register('savp_lp_loss', [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])
 register('savp_lsgan_loss', [c_vp, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp])
@@ -177,3 +178,4 @@ register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
 register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
 register('savp_sn_bwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32])
+register('savp_dense_fwd', [c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp])

@@ -1,0 +1,196 @@
+"""VAE posterior encoder and spectral-norm video discriminator on the HIP kernels.
+
+Mirrors /root/reference/video_prediction/models/networks.py (encoder :12-32, video_sn_discriminator :72-108) and
+the wiring around them in savp_model.py (posterior_fn :21-51, discriminator_given_video_fn :88-126).
+"""
+import torch
+
+from .. import kernels as K
+from .. import lib
+from ..engine import ConvLayer, copy_view
+from ..variables import VIDEO_D_LAYERS, video_discriminator_shapes
+
+EPS_IN = 1e-6
+
+
+class PosteriorEncoder(object):
+    """posterior_fn: frame pairs -> (z_mu, z_log_sigma_sq), flat batch M = (T-1)*B."""
+
+    def __init__(self, store, hp, image_shape, B, train=True, prefix='generator/encoder/'):
+        H, W, C = image_shape
+        self.hp, self.store = hp, store
+        self.T1 = T1 = hp.sequence_length - 1
+        self.B, self.M = B, T1 * B
+        M = self.M
+        dev = store.device
+        self.dev = dev
+        if hp.use_e_rnn or hp.norm_layer != 'instance':
+            raise NotImplementedError('HIP encoder covers use_e_rnn=False, norm_layer=instance')
+        self.pairs = torch.zeros(M, H, W, 2 * C, device=dev)
+        self.C = C
+        self.layers = []
+        cin, h, w = 2 * C, H, W
+        x = self.pairs
+        for i in range(hp.n_layers):
+            cout = hp.nef * min(2 ** i, 4)
+            s = prefix + 'layer_%d/' % (i + 1)
+            L = {'conv': ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (4, 4), (2, 2), (1, 1)),
+                 'x': x, 'normed': i > 0}
+            h, w = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
+            L['y'] = torch.empty(M, h, w, cout, device=dev)            # layer output (after lrelu)
+            L['dy'] = torch.empty(M, h, w, cout, device=dev) if train else None
+            if i > 0:
+                L['pre'] = torch.empty(M, h, w, cout, device=dev)
+                L['dpre'] = torch.empty(M, h, w, cout, device=dev) if train else None
+                L['gamma'], L['beta'] = store[s + 'InstanceNorm/gamma'], store[s + 'InstanceNorm/beta']
+                L['dgamma'], L['dbeta'] = store.grad(s + 'InstanceNorm/gamma'), store.grad(s + 'InstanceNorm/beta')
+                L['mean'], L['rstd'] = torch.empty(M, cout, device=dev), torch.empty(M, cout, device=dev)
+            self.layers.append(L)
+            x = L['y']
+            cin = cout
+        self.hw = h * w
+        self.pooled = torch.zeros(M, cin, device=dev)
+        self.dpooled = torch.empty(M, cin, device=dev) if train else None
+        self.mu_fc = ConvLayer(store, prefix + 'z_mu/dense/kernel', prefix + 'z_mu/dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
+        self.ls_fc = ConvLayer(store, prefix + 'z_log_sigma_sq/dense/kernel', prefix + 'z_log_sigma_sq/dense/bias', 'conv',
+                               (1, 1), (1, 1), (0, 0))
+        nz = hp.nz
+        self.mu = torch.empty(T1, B, nz, device=dev)
+        self.ls_raw = torch.empty(T1, B, nz, device=dev)
+        self.ls = torch.empty(T1, B, nz, device=dev)
+        self.z = torch.empty(T1, B, nz, device=dev)
+        self.dmu = torch.empty(T1, B, nz, device=dev) if train else None
+        self.dls = torch.empty(T1, B, nz, device=dev) if train else None
+        self.kl = torch.zeros(1, device=dev)
+        self.convs = [L['conv'] for L in self.layers] + [self.mu_fc, self.ls_fc]
+
+    def prep_weights(self):
+        for c in self.convs:
+            c.prep()
+
+    def forward(self, images, eps):
+        """images [T,B,H,W,C] contiguous; eps [T1,B,nz].  Returns z_post [T1,B,nz] (and fills mu, ls, kl)."""
+        T1, B, C, M = self.T1, self.B, self.C, self.M
+        a = images[:T1].reshape((M,) + tuple(images.shape[2:]))
+        b = images[1:T1 + 1].reshape((M,) + tuple(images.shape[2:]))
+        copy_view(a, [self.pairs[..., 0:C]])                                   # image_pairs = concat([x_t, x_t+1])  :23
+        copy_view(b, [self.pairs[..., C:2 * C]])
+        for L in self.layers:
+            if not L['normed']:
+                L['conv'].forward(L['x'], L['y'], act=lib.ACT_LRELU, alpha=0.2)            # networks.py:18-19
+            else:
+                L['conv'].forward(L['x'], L['pre'])
+                K.instnorm_act_fwd(L['pre'], L['gamma'], L['beta'], [L['y']], L['mean'], L['rstd'], act='lrelu', alpha=0.2,
+                                   eps=EPS_IN)                                              # networks.py:25-27
+        last = self.layers[-1]['y']
+        self.pooled.zero_()
+        K.colsum(last, self.pooled, scale=1.0 / self.hw, per_row=True)                     # networks.py:30-31
+        self.mu_fc.forward(self.pooled, self.mu.reshape(M, -1))
+        self.ls_fc.forward(self.pooled, self.ls_raw.reshape(M, -1))
+        self.eps = eps
+        self.kl.zero_()
+        K.reparam_fwd(self.mu, self.ls_raw, eps, self.ls, self.z, self.kl)                  # savp_model.py:45-49,712
+        return self.z
+
+    def backward(self, dz, kl_weight):
+        """dz [T1,B,nz] = dL/dz_posterior (may be None); adds the KL term's gradient with weight kl_weight."""
+        M = self.M
+        K.reparam_bwd(self.mu, self.ls_raw, self.eps, dz, kl_weight or 0.0, self.dmu, self.dls)
+        dmu2, dls2 = self.dmu.reshape(M, -1), self.dls.reshape(M, -1)
+        self.mu_fc.backward_data(dmu2, self.dpooled, beta=0)
+        self.ls_fc.backward_data(dls2, self.dpooled, beta=1)
+        self.mu_fc.backward_weights(self.pooled, dmu2)
+        self.ls_fc.backward_weights(self.pooled, dls2)
+        lastL = self.layers[-1]
+        K.tile_channels(self.dpooled, lastL['dy'], scale=1.0 / self.hw)
+        for i in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[i]
+            if L['normed']:
+                K.instnorm_act_bwd(L['pre'], L['gamma'], L['beta'], L['y'], L['mean'], L['rstd'], [L['dy']], L['dpre'],
+                                   L['dgamma'], L['dbeta'], act='lrelu', alpha=0.2, eps=EPS_IN)
+                dpre = L['dpre']
+            else:
+                dpre = L['dy']       # already multiplied by lrelu' in the producing DGRAD epilogue
+            if i > 0:
+                below = self.layers[i - 1]
+                if below['normed']:
+                    L['conv'].backward_data(dpre, below['dy'], beta=0)
+                else:
+                    L['conv'].backward_data(dpre, below['dy'], beta=0, act=lib.ACT_DLRELU_FROM_OUT, alpha=0.2, aux=below['y'])
+            L['conv'].backward_weights(L['x'], dpre)
+        for c in self.convs:
+            c.finish_weight_grad()
+
+
+class VideoDiscriminator(object):
+    """networks.video_sn_discriminator on clips [Nc, clip, H, W, C] (batch-major NDHWC)."""
+
+    def __init__(self, store, hp, image_shape, Nc, prefix, train=True):
+        H, W, C = image_shape
+        self.hp, self.store, self.Nc = hp, store, Nc
+        dev = store.device
+        self.dev = dev
+        layers, flat = video_discriminator_shapes(hp, image_shape)
+        self.clip = torch.zeros(Nc, hp.clip_length, H, W, C, device=dev)
+        self.dclip = torch.empty(Nc, hp.clip_length, H, W, C, device=dev) if train else None
+        self.layers = []
+        x = self.clip
+        for (scope, kshape, st, odhw) in layers:
+            s = prefix + scope + '/'
+            k = kshape[0]
+            L = {'conv': ConvLayer(store, s + 'conv3d/kernel', s + 'bias', 'conv', (k, k, k), st, (1, 1, 1), sn_u=s + 'conv3d/u'),
+                 'x': x}
+            L['y'] = torch.empty((Nc,) + tuple(odhw) + (kshape[-1],), device=dev)
+            L['dy'] = torch.empty_like(L['y']) if train else None
+            self.layers.append(L)
+            x = L['y']
+        s = prefix + 'sn_fc4/'
+        self.fc = ConvLayer(store, s + 'dense/kernel', s + 'dense/bias', 'conv', (1, 1), (1, 1), (0, 0), sn_u=s + 'dense/u')
+        self.flat = flat
+        self.logits = torch.empty(Nc, 1, device=dev)
+        self.dlogits = torch.zeros(Nc, 1, device=dev)
+        self.convs = [L['conv'] for L in self.layers] + [self.fc]
+
+    def prep_weights(self, update_u=False):
+        for c in self.convs:
+            c.prep(update_u=update_u)
+
+    def commit_u(self):
+        for c in self.convs:
+            c.commit_u()
+
+    def features(self):
+        return [L['y'] for L in self.layers]
+
+    def forward(self, n=None):
+        """Run on the first n clips of self.clip (default all).  lrelu(0.1) is fused into each conv epilogue."""
+        n = n or self.Nc
+        for L in self.layers:
+            L['conv'].forward(L['x'][:n], L['y'][:n], act=lib.ACT_LRELU, alpha=0.1)          # networks.py:83-102
+        self.fc.forward(self.layers[-1]['y'][:n].reshape(n, -1), self.logits[:n])           # networks.py:104-105
+        return self.logits
+
+    def backward(self, lo, hi, weights=True, data=True, feature_grads=False):
+        """Back-propagate self.dlogits[lo:hi] (and, if feature_grads, the gradients already stored in each layer's
+        dy[lo:hi]) through samples lo..hi.  weights: accumulate dW/dbias; data: produce self.dclip[lo:hi]."""
+        n = hi - lo
+        top = self.layers[-1]
+        self.fc.backward_data(self.dlogits[lo:hi], top['dy'][lo:hi].reshape(n, -1), beta=1 if feature_grads else 0,
+                              act=lib.ACT_DLRELU_FROM_OUT, alpha=0.1, aux=top['y'][lo:hi].reshape(n, -1))
+        if weights:
+            self.fc.backward_weights(top['y'][lo:hi].reshape(n, -1), self.dlogits[lo:hi])
+        for i in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[i]
+            dpre = L['dy'][lo:hi]                  # = dL/d(conv output before lrelu)
+            if i > 0:
+                below = self.layers[i - 1]
+                L['conv'].backward_data(dpre, below['dy'][lo:hi], beta=1 if feature_grads else 0,
+                                        act=lib.ACT_DLRELU_FROM_OUT, alpha=0.1, aux=below['y'][lo:hi])
+            elif data:
+                L['conv'].backward_data(dpre, self.dclip[lo:hi], beta=0)
+            if weights:
+                L['conv'].backward_weights(L['x'][lo:hi], dpre)
+
+    def finish_weight_grads(self):
+        for c in self.convs:
+            c.finish_weight_grad()

@@ -1,0 +1,362 @@
+"""SAVPCell unrolled over time on the HIP kernels: forward and back-propagation through time.
+
+Mirrors SAVPCell.call (/root/reference/video_prediction/models/savp_model.py:393-686) and its unroll
+(generator_given_z_fn :689-696, tf_utils.unroll_rnn tf_utils.py:134-141) for the published SAVP family
+(conv_pool2d / upsample_conv2d, instance norm, ConvLSTM, CDNA, tile_concat).
+
+MI355X-first layout decisions:
+  * every activation lives in a time-major buffer [T-1, N, H, W, C] that stays resident in HBM for the whole step
+    (288 GB), so back-propagation never recomputes and every weight gradient is ONE split-K GEMM over all
+    timesteps x samples instead of T-1 small ones;
+  * concatenations (tile_concat with z, skip connections, [x, h_prev] of the ConvLSTM, [h_masks, transformed
+    images]) are never materialised by copies: producers write straight into channel slices of the consumer's
+    concat buffer, gradients are read back from the same slices;
+  * the posterior and prior unrolls share weights, so they run as ONE unroll of batch 2B (all ops are per-sample).
+"""
+import torch
+
+from .. import kernels as K
+from .. import lib
+from ..engine import ConvLayer, same_pad_before, copy_view
+from ..variables import layer_specs, num_masks
+
+EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
+
+
+class Act(object):
+    """Time-major activation buffer with an optional gradient twin."""
+
+    def __init__(self, shape, device, grad=True, zero_grad=False):
+        self.v = torch.zeros(shape, device=device, dtype=torch.float32)
+        self.g = None
+        if grad:
+            self.g = torch.zeros(shape, device=device, dtype=torch.float32) if zero_grad else \
+                torch.empty(shape, device=device, dtype=torch.float32)
+
+    def flat(self, t):
+        """[T, N, ...] -> [T*N, ...] view (time folded into the batch for the batched weight gradients)."""
+        return t.reshape((t.shape[0] * t.shape[1],) + tuple(t.shape[2:]))
+
+
+class Norm(object):
+    def __init__(self, store, scope, T1, N, C, device):
+        self.gamma, self.beta = store[scope + 'gamma'], store[scope + 'beta']
+        self.dgamma, self.dbeta = store.grad(scope + 'gamma'), store.grad(scope + 'beta')
+        self.mean = torch.empty(T1, N, C, device=device)
+        self.rstd = torch.empty(T1, N, C, device=device)
+
+
+class SAVPGenerator(object):
+    def __init__(self, store, hp, image_shape, N, train=True, prefix='generator/rnn/savp_cell/'):
+        H, W, C = image_shape
+        self.hp, self.store, self.N, self.H, self.W, self.C = hp, store, N, H, W, C
+        self.T1 = T1 = hp.sequence_length - 1
+        self.train = train
+        dev = store.device
+        self.dev = dev
+        if hp.nz and not hp.use_tile_concat:
+            raise NotImplementedError('use_tile_concat=False')
+        if hp.conv_rnn != 'lstm' or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
+            raise NotImplementedError('HIP path covers conv_rnn=lstm with instance norm (the published SAVP recipes)')
+        if hp.downsample_layer != 'conv_pool2d' or hp.upsample_layer != 'upsample_conv2d' or hp.activation_layer != 'relu':
+            raise NotImplementedError('HIP path covers conv_pool2d / upsample_conv2d / relu')
+        if hp.transformation != 'cdna' or hp.last_frames != 1 or not hp.num_transformed_images:
+            raise NotImplementedError('HIP path covers transformation=cdna, last_frames=1')
+        if hp.where_add != 'all' or hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
+            raise NotImplementedError('HIP path covers where_add=all without ablations')
+        if not (hp.prev_image_background and hp.first_image_background and hp.generate_scratch_image and hp.dependent_mask) \
+                or hp.last_image_background or hp.last_context_image_background or hp.context_images_background:
+            raise NotImplementedError('HIP path covers the default background/scratch/dependent-mask configuration')
+        self.nz = nz = hp.nz
+        self.use_rnn_z = bool(nz and hp.use_rnn_z)
+        zc = nz
+        g = train
+        enc_specs, dec_specs = layer_specs(hp.ngf, H, W)
+        self.ne, self.nd = len(enc_specs), len(dec_specs)
+
+        # ---- layers and their input buffers ----------------------------------------------------------------
+        self.layers = []
+        h_, w_ = H, W
+        prev_f = None
+        for i, (f, use_rnn) in enumerate(enc_specs + dec_specs):
+            L = {'f': f, 'rnn': use_rnn, 'idx': i, 'dec': i >= self.ne}
+            s = prefix + 'h%d/' % i
+            if i < self.ne:
+                cx = 2 * C if i == 0 else prev_f
+                k = 5 if i == 0 else 3
+                L['in'] = Act((T1, N, h_, w_, cx + zc), dev, grad=g)
+                L['zoff_in'] = cx
+                L['conv'] = ConvLayer(store, s + 'conv_pool2d/kernel', s + 'conv_pool2d/bias', 'pool', (k, k), (2, 2),
+                                      (same_pad_before(k + 1, 2, h_), same_pad_before(k + 1, 2, w_)))
+                h_, w_ = h_ // 2, w_ // 2
+            else:
+                j = i - self.ne
+                skip = 0 if j == 0 else self.layers[self.ne - j - 1]['f']
+                cx = prev_f + skip
+                L['in'] = Act((T1, N, h_, w_, cx + zc), dev, grad=g)
+                L['zoff_in'] = cx
+                L['skip_off'] = prev_f
+                h_, w_ = h_ * 2, w_ * 2
+                L['conv'] = ConvLayer(store, s + 'upsample_conv2d/kernel', s + 'upsample_conv2d/bias', 'up', (3, 3), (2, 2),
+                                      (same_pad_before(6, 2, h_), same_pad_before(6, 2, w_)))
+            L['hw'] = (h_, w_)
+            L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g)
+            L['norm'] = Norm(store, s + 'InstanceNorm/', T1, N, f, dev)
+            if use_rnn:
+                r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
+                L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g)
+                L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g)
+                L['c'] = Act((T1, N, h_, w_, f), dev, grad=False)
+                L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
+                L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
+                L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
+                L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
+            else:
+                L['out'] = None
+            self.layers.append(L)
+            prev_f = f
+        nl = len(self.layers)
+        last = self.layers[-1]
+        ngf = hp.ngf
+        self.M = M = num_masks(hp)
+        self.nk = nk = hp.last_frames * hp.num_transformed_images
+        kh, kw = hp.kernel_size
+        self.kh, self.kw = kh, kw
+
+        # ---- heads ------------------------------------------------------------------------------------------
+        sh_, sw_ = H // 2 ** self.ne, W // 2 ** self.ne
+        small_f = self.layers[self.ne - 1]['f']
+        self.hsmall = Act((T1, N, sh_, sw_, small_f), dev, grad=g)
+        self.cdna_dense = ConvLayer(store, prefix + 'cdna_kernels/dense/kernel', prefix + 'cdna_kernels/dense/bias', 'conv',
+                                    (1, 1), (1, 1), (0, 0))
+        self.cdna_raw = Act((T1, N, kh * kw * nk), dev, grad=g)
+        self.cdna_kern = Act((T1, N, kh * kw, nk), dev, grad=g)
+        self.h_last = Act((T1, N, H, W, last['f']), dev, grad=g)
+        s = prefix + 'h%d_scratch/' % nl
+        self.scratch_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+        self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g)
+        self.scratch_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
+        self.scratch_h = Act((T1, N, H, W, ngf), dev, grad=g)
+        s = prefix + 'scratch_image/'
+        self.scratch_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+        self.dscratch_pre = torch.empty(T1, N, H, W, C, device=dev) if g else None
+        s = prefix + 'h%d_masks/' % nl
+        self.masks_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+        self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g)
+        self.masks_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
+        # maskin = [h_masks (ngf) | nk CDNA images | prev image | first image | scratch image]   (savp_model.py:632)
+        self.maskin = Act((T1, N, H, W, ngf + M * C), dev, grad=g)
+        self.o_cdna, self.o_prev = ngf, ngf + nk * C
+        self.o_first, self.o_scratch = ngf + (nk + 1) * C, ngf + (nk + 2) * C
+        s = prefix + 'masks/'
+        self.masks_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+        self.logits = Act((T1, N, H, W, M), dev, grad=g)
+        self.masks = torch.empty(T1, N, H, W, M, device=dev)
+        self.gen = Act((T1, N, H, W, C), dev, grad=g, zero_grad=True)
+        self.dimg_cdna = torch.empty(N, H, W, C, device=dev) if g else None
+
+        # ---- z path -------------------------------------------------------------------------------------------
+        if nz:
+            self.zs = Act((T1, N, nz), dev, grad=g)
+            self.rnn_z = Act((T1, N, nz), dev, grad=g, zero_grad=True)
+            if self.use_rnn_z:
+                z = prefix + 'lstm_z/basic_lstm_cell/'
+                self.zW, self.zb = store[z + 'kernel'], store[z + 'bias']
+                self.dzW, self.dzb = store.grad(z + 'kernel'), store.grad(z + 'bias')
+                self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
+                self.z_cs = torch.empty(T1, N, nz, device=dev)
+        self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
+                     [self.cdna_dense, self.scratch_conv, self.scratch_out, self.masks_conv, self.masks_out]
+        # only FPROP packs needed at inference
+        self._routes()
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _routes(self):
+        """Where the output of layer i (layers[i][-1] in the reference) is written: list of (Act, channel offset)."""
+        ne, nd = self.ne, self.nd
+        for i, L in enumerate(self.layers):
+            r = []
+            if i + 1 < len(self.layers):
+                r.append((self.layers[i + 1]['in'], 0))
+            else:
+                r.append((self.h_last, 0))
+            if i < ne:
+                j = ne - 1 - i              # decoder layer that takes this encoder layer as skip (j > 0)
+                if 1 <= j < nd:
+                    r.append((self.layers[ne + j]['in'], self.layers[ne + j]['skip_off']))
+                if i == ne - 1:
+                    r.append((self.hsmall, 0))
+            L['routes'] = r
+
+    def weight_layers(self):
+        return self.convs
+
+    def prep_weights(self):
+        for c in self.convs:
+            c.prep()
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _out_views(self, L, t):
+        f = L['f']
+        return [buf.v[t][..., off:off + f] for buf, off in L['routes']]
+
+    def _out_grads(self, L, t):
+        f = L['f']
+        return [buf.g[t][..., off:off + f] for buf, off in L['routes']]
+
+    def forward(self, images, zs=None, gt_mask=None, collect_masks=False):
+        """images [T>=T1, N, H, W, C] device fp32 (frame t feeds step t); zs [T1, N, nz]; gt_mask int32 [T1, N]
+        (1 = take the ground-truth frame: self.ground_truth of savp_model.py:333-334).  Fills self.gen.v."""
+        T1, N, C = self.T1, self.N, self.C
+        nz = self.nz
+        ones = torch.ones(N, dtype=torch.int32, device=self.dev)
+        self.images = images
+        self.gt_mask = gt_mask
+        if nz:
+            self.zs.v.copy_(zs)
+            if self.use_rnn_z:
+                K.lstm_z_fwd(self.zs.v, self.zW, self.zb, self.rnn_z.v, self.z_gates, self.z_cs)
+            else:
+                self.rnn_z.v.copy_(self.zs.v)
+            zflat = self.rnn_z.v.reshape(T1 * N, nz)
+            for L in self.layers:
+                b = L['in']
+                K.tile_channels(zflat, b.flat(b.v)[..., L['zoff_in']:L['zoff_in'] + nz])
+                if L['rnn']:
+                    a = L['a']
+                    K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + nz])
+        in0, maskin = self.layers[0]['in'], self.maskin
+        for t in range(T1):
+            # image = tf.where(ground_truth[t], inputs['images'], states['gen_image'])     (savp_model.py:406)
+            prev_gen = self.gen.v[t - 1] if t > 0 else None
+            K.select(gt_mask[t], images[t], prev_gen,
+                     [in0.v[t][..., 0:C], maskin.v[t][..., self.o_prev:self.o_prev + C]])
+            K.select(ones, images[0], None, [in0.v[t][..., C:2 * C], maskin.v[t][..., self.o_first:self.o_first + C]])
+            for L in self.layers:
+                f = L['f']
+                L['conv'].forward(L['in'].v[t], L['pre'].v[t])
+                nrm = L['norm']
+                if L['rnn']:
+                    a = L['a']
+                    K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
+                                       act='relu', eps=EPS_IN)
+                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False)
+                    outs = self._out_views(L, t)
+                    if t + 1 < T1:
+                        outs.append(a.v[t + 1][..., f + nz:f + nz + f])
+                    n1, n2 = L['n1'], L['n2']
+                    K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
+                                         n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
+                                         eps=EPS_IN)
+                else:
+                    K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
+                                       act='relu', eps=EPS_IN)
+            # CDNA kernels from the smallest layer (savp_model.py:546-559) and their application (:580, :893-923)
+            self.cdna_dense.forward(self.hsmall.v[t].reshape(N, -1), self.cdna_raw.v[t])
+            K.cdna_kernels_fwd(self.cdna_raw.v[t], self.cdna_kern.v[t], self.kh, self.kw, self.nk)
+            K.cdna_apply_fwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C],
+                             self.kh, self.kw, self.nk)
+            # scratch image (savp_model.py:561-572): sigmoid fused into the conv epilogue, written into its mask-conv slot
+            self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
+            sn = self.scratch_norm
+            K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
+                               act='relu', eps=EPS_IN)
+            self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + C],
+                                     act=lib.ACT_SIGMOID)
+            # masks (savp_model.py:623-646)
+            self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
+            mn = self.masks_norm
+            K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
+                               act='relu', eps=EPS_IN)
+            self.masks_out.forward(maskin.v[t], self.logits.v[t])
+            K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:], self.gen.v[t],
+                            self.masks[t] if collect_masks else None)
+        return self.gen.v
+
+    # ---------------------------------------------------------------------------------------------------------
+    def backward(self):
+        """BPTT.  Expects self.gen.g (zero-initialised each step by the caller) to hold dL/dgen_images.
+        Accumulates every generator-cell weight gradient into the store and returns dL/dzs [T1, N, nz] (or None)."""
+        T1, N, C, nz = self.T1, self.N, self.C, self.nz
+        ngf = self.hp.ngf
+        in0, maskin = self.layers[0]['in'], self.maskin
+        for t in range(T1 - 1, -1, -1):
+            # composite + masks head
+            K.composite_bwd(self.logits.v[t], maskin.v[t][..., ngf:], self.gen.g[t], self.logits.g[t], maskin.g[t][..., ngf:])
+            K.fill_view(maskin.g[t][..., 0:ngf], 0.0)
+            self.masks_out.backward_data(self.logits.g[t], maskin.g[t], beta=1)
+            mn = self.masks_norm
+            K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
+                               [maskin.g[t][..., 0:ngf]], self.masks_pre.g[t], mn.dgamma, mn.dbeta, act='relu', eps=EPS_IN)
+            self.masks_conv.backward_data(self.masks_pre.g[t], self.h_last.g[t], beta=0)
+            # scratch head
+            K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + C], maskin.v[t][..., self.o_scratch:self.o_scratch + C],
+                          self.dscratch_pre[t])
+            self.scratch_out.backward_data(self.dscratch_pre[t], self.scratch_h.g[t], beta=0)
+            sn = self.scratch_norm
+            K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
+                               [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
+            self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
+            # CDNA
+            K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C],
+                             self.dimg_cdna, self.cdna_kern.g[t], self.kh, self.kw, self.nk)
+            K.cdna_kernels_bwd(self.cdna_raw.v[t], self.cdna_kern.g[t], self.cdna_raw.g[t], self.kh, self.kw, self.nk)
+            self.cdna_dense.backward_data(self.cdna_raw.g[t], self.hsmall.g[t].reshape(N, -1), beta=0)
+            # decoder / encoder ladder in reverse
+            for L in reversed(self.layers):
+                f = L['f']
+                dys = self._out_grads(L, t)
+                nrm = L['norm']
+                if L['rnn']:
+                    a = L['a']
+                    if t + 1 < T1:
+                        dys.append(a.g[t + 1][..., f + nz:f + nz + f])
+                    n1, n2 = L['n1'], L['n2']
+                    dc_new = L['dc'][(t + 1) & 1] if t + 1 < T1 else None
+                    dc_prev = L['dc'][t & 1] if t > 0 else None
+                    K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
+                                         n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
+                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN)
+                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
+                    K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
+                                       [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                else:
+                    y0 = self._out_views(L, t)[0]
+                    K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, y0, nrm.mean[t], nrm.rstd[t], dys, L['pre'].g[t],
+                                       nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0)
+            # d image -> previous step's generated frame where it was fed back (not ground truth)
+            if t > 0:
+                K.select_bwd(self.gt_mask[t], [in0.g[t][..., 0:C], maskin.g[t][..., self.o_prev:self.o_prev + C], self.dimg_cdna],
+                             self.gen.g[t - 1])
+        # ---- weight gradients: one split-K GEMM per layer over all (t, n) ----------------------------------------
+        for L in self.layers:
+            b, pre = L['in'], L['pre']
+            L['conv'].backward_weights(b.flat(b.v), pre.flat(pre.g))
+            if L['rnn']:
+                a, gt = L['a'], L['gates']
+                L['rconv'].backward_weights(a.flat(a.v), gt.flat(gt.g))
+        hs = self.hsmall
+        self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
+        hl = self.h_last
+        self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
+        self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, C))
+        self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
+        self.masks_out.backward_weights(hl.flat(maskin.v), hl.flat(self.logits.g))
+        for c in self.convs:
+            c.finish_weight_grad()
+        # ---- z path ----------------------------------------------------------------------------------------------
+        if not nz:
+            return None
+        drz = self.rnn_z.g
+        drz.zero_()
+        for L in self.layers:
+            b = L['in']
+            K.colsum(b.flat(b.g)[..., L['zoff_in']:L['zoff_in'] + nz], drz, per_row=True)
+            if L['rnn']:
+                a = L['a']
+                K.colsum(a.flat(a.g)[..., L['f']:L['f'] + nz], drz, per_row=True)
+        if self.use_rnn_z:
+            K.lstm_z_bwd(self.zs.v, self.zW, self.rnn_z.v, self.z_gates, self.z_cs, drz, self.zs.g, self.dzW, self.dzb)
+            return self.zs.g
+        return drz

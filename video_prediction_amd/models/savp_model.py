@@ -1,0 +1,445 @@
+"""SAVP model on the MI355X engine: generator_fn / posterior_fn / discriminator_fn plug-ins and the model class.
+
+API surface follows /root/reference/video_prediction/models/savp_model.py: the three plug-in functions keep their
+signatures (``generator_fn(inputs, mode, hparams)``, ``discriminator_fn(inputs, outputs, mode, hparams)``,
+``posterior_fn(inputs, hparams)``), take/return time-major NHWC tensors in ``OrderedDict``s with the reference's keys,
+and ``SAVPVideoPredictionModel`` keeps the constructor/hparams handling of savp_model.py:771-846.  TensorFlow's
+implicit state (variable scopes, random ops, sessions) is made explicit: variables live in a ``ParamStore`` keyed by
+the TF variable names, random draws are passed in a ``noise`` dict (generated from a seeded torch Generator when not
+given), and one ``train_step`` call is one ``sess.run(train_op)``.
+"""
+import collections
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import kernels as K
+from .. import variables as V
+from ..engine import ParamStore, copy_view, add_views
+from .base_model import VideoPredictionModel, learning_rate, kl_weight
+from .hparam_defaults import savp_defaults, SAVP_DEPRECATED_KEYS
+from .networks import PosteriorEncoder, VideoDiscriminator
+from .savp_cell import SAVPGenerator
+
+
+def _image_shape(images):
+    return tuple(images.shape[2:])
+
+
+class SAVPEngine(object):
+    """All device state of one SAVP replica: variables, generator unroll (batch 2B: posterior + prior), posterior
+    encoder, the two video discriminators; implements one training step and inference."""
+
+    def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0'):
+        self.hp, self.mode, self.B = hp, mode, batch_size
+        self.image_shape = tuple(image_shape)
+        self.device = torch.device(device)
+        self.train = mode == 'train'
+        specs = V.variable_specs(hp, image_shape, mode=mode)
+        if values is None:
+            values = V.init_variables(specs, seed=seed)
+        self.store = ParamStore(specs, values, self.device)
+        self.nz = hp.nz
+        B = batch_size
+        self.T, self.T1 = hp.sequence_length, hp.sequence_length - 1
+        H, W, C = image_shape
+        self.N = N = 2 * B if self.nz else B
+        self.gen = SAVPGenerator(self.store, hp, image_shape, N, train=self.train)
+        self.enc = PosteriorEncoder(self.store, hp, image_shape, B, train=self.train) if self.nz else None
+        self.images_tm = torch.empty(self.T, B, H, W, C, device=self.device)
+        self.images_n = torch.empty(self.T, N, H, W, C, device=self.device) if self.nz else self.images_tm
+        self.zs_all = torch.zeros(self.T1, N, self.nz, device=self.device) if self.nz else None
+        self.dz_post = torch.zeros(self.T1, B, self.nz, device=self.device) if (self.nz and self.train) else None
+        self.has_d = self.train and V.uses_discriminator(hp)
+        self.d_gan = self.d_vae = None
+        if self.has_d:
+            if hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight or hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight:
+                raise NotImplementedError('image/images discriminators are not on the HIP path yet (video D only)')
+            if hp.gan_loss_type != 'LSGAN':
+                raise NotImplementedError('gan_loss_type %s' % hp.gan_loss_type)
+            if hp.video_sn_gan_weight:
+                self.d_gan = VideoDiscriminator(self.store, hp, image_shape, 2 * B, 'discriminator/video/')
+            if self.nz and hp.video_sn_vae_gan_weight:
+                pre = 'discriminator/video/' if hp.use_same_discriminator else 'discriminator/encoder/video/'
+                self.d_vae = VideoDiscriminator(self.store, hp, image_shape, 2 * B, pre)
+        self.loss_buf = torch.zeros(16, device=self.device)
+        self.step = 0
+        self.world = 1
+        self.dist = None
+
+    # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
+    def attach_process_group(self, dist_module):
+        """One process per GPU; gradients of each optimiser group are one flat bucket, summed by RCCL and scaled by
+        1/world inside the Adam kernel.  Replica init = broadcast of rank-0 variables (base_model.py:640-646)."""
+        self.dist = dist_module
+        self.world = dist_module.get_world_size()
+        for g in self.store.groups.values():
+            dist_module.broadcast(g.p, src=0)
+
+    def _allreduce(self, group):
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(self.store.groups[group].g)
+
+    # -- input staging -------------------------------------------------------------------------------------------------
+    def set_images(self, images, time_major=False):
+        """images: device fp32 [B,T,H,W,C] (reference layout) or [T,B,H,W,C] if time_major."""
+        T = self.T
+        if time_major:
+            self.images_tm.copy_(images[:T])
+        else:
+            for t in range(T):
+                copy_view(images[:, t], [self.images_tm[t]])                 # transpose_batch_time (tf_utils.py:118-122)
+        if self.nz:
+            B = self.B
+            HW = self.image_shape[0] * self.image_shape[1]
+            C = self.image_shape[2]
+            src = self.images_tm.reshape(T, B * HW, C)
+            copy_view(src, [self.images_n[:, :B].reshape(T, B * HW, C)])
+            copy_view(src, [self.images_n[:, B:].reshape(T, B * HW, C)])
+
+    def default_noise(self, generator=None):
+        """Draw the step's random tensors (eps, prior z, scheduled-sampling masks, clip indices) on the host."""
+        g = generator or torch.Generator().manual_seed(1000 + self.step)
+        hp, B, T1 = self.hp, self.B, self.T1
+        noise = {}
+        if self.nz:
+            noise['eps'] = torch.randn(T1, B, self.nz, generator=g)
+            noise['prior'] = torch.randn(self.T - hp.context_frames, B, self.nz, generator=g)
+        ns = T1 - hp.context_frames
+        if self.train and hp.schedule_sampling != 'none':
+            prob = self.schedule_sampling_prob()
+            for key in ('ground_truth_sampling', 'ground_truth_sampling_enc'):
+                noise[key] = (torch.rand(ns, B, generator=g) < prob) if prob >= 0.001 else torch.zeros(ns, B, dtype=torch.bool)
+        L = T1
+        idx = {}
+        for phase in ('pre', 'post'):
+            idx[phase] = {k: (torch.randint(0, L, (B,), generator=g), torch.randint(0, L - hp.clip_length + 1, (B,), generator=g))
+                          for k in ('enc_real', 'enc_fake', 'real', 'fake')}
+        noise['d_indices_pre'], noise['d_indices_post'] = idx['pre'], idx['post']
+        return noise
+
+    def schedule_sampling_prob(self):
+        """savp_model.py:312-322."""
+        hp = self.hp
+        if hp.schedule_sampling == 'inverse_sigmoid':
+            k = hp.schedule_sampling_k
+            start = hp.schedule_sampling_steps[0]
+            it = float(self.step)
+            return 1.0 if it < start else float(k / (k + np.exp((it - start) / k)))
+        if hp.schedule_sampling == 'linear':
+            start, end = hp.schedule_sampling_steps
+            s = min(max(self.step, start), end)
+            return 1.0 - float(s - start) / float(end - start)
+        return 0.0
+
+    def _gt_mask(self, noise):
+        """self.ground_truth of savp_model.py:333-334 for the 2B-batched unroll -> int32 [T1, N] on device."""
+        hp, B, T1 = self.hp, self.B, self.T1
+        ns = T1 - hp.context_frames
+        halves = []
+        keys = ('ground_truth_sampling_enc', 'ground_truth_sampling') if self.nz else ('ground_truth_sampling',)
+        for key in keys:
+            s = noise.get(key)
+            if s is None or self.mode != 'train' or hp.schedule_sampling == 'none':
+                s = torch.zeros(ns, B, dtype=torch.bool)
+            m = torch.cat([torch.ones(hp.context_frames, B, dtype=torch.bool), torch.as_tensor(s, dtype=torch.bool)], dim=0)
+            halves.append(m)
+        return torch.cat(halves, dim=1).to(torch.int32).to(self.device)
+
+    # -- forward ---------------------------------------------------------------------------------------------------------
+    def prep_generator_weights(self):
+        self.gen.prep_weights()
+        if self.enc:
+            self.enc.prep_weights()
+
+    def forward_generator(self, noise, collect_masks=False):
+        """generator_fn (savp_model.py:699-768).  Returns gen [T1, N, H, W, C]: [:, :B] posterior ('_enc'), [:, B:] prior."""
+        hp, B, T1 = self.hp, self.B, self.T1
+        gt = self._gt_mask(noise)
+        if self.nz:
+            eps = noise['eps'].to(self.device, torch.float32)
+            z_post = self.enc.forward(self.images_tm, eps)
+            nzv = self.nz
+            # zs (2B): posterior half, prior half = [posterior z for the first context_frames-1 steps ; N(0,1)]  (:724-725)
+            copy_view(z_post.reshape(T1, B, nzv), [self.zs_all[:, :B]])
+            c1 = hp.context_frames - 1
+            if c1 > 0:
+                copy_view(z_post[:c1], [self.zs_all[:c1, B:]])
+            prior = noise['prior'].to(self.device, torch.float32)
+            copy_view(prior, [self.zs_all[c1:, B:]])
+            return self.gen.forward(self.images_n, self.zs_all, gt, collect_masks=collect_masks)
+        return self.gen.forward(self.images_n, None, gt, collect_masks=collect_masks)
+
+    # -- one sess.run(train_op) --------------------------------------------------------------------------------------------
+    def _d_clips(self, D, idx_real, idx_fake, fake_half, lo_real, lo_fake):
+        """discriminator_given_video_fn's clip gather (savp_model.py:97-102) into D.clip[lo_real:...] / [lo_fake:...]."""
+        B = self.B
+        dev = self.device
+        real_src = self.images_tm[1:self.T]                                       # inputs['images'][1:]
+        if idx_real is not None:
+            ts = torch.as_tensor(np.asarray(idx_real[1]), dtype=torch.int32).to(dev)
+            K.gather_clips(real_src, D.clip[lo_real:lo_real + B], ts)
+        ts_f = torch.as_tensor(np.asarray(idx_fake[1]), dtype=torch.int32).to(dev)
+        K.gather_clips(fake_half, D.clip[lo_fake:lo_fake + B], ts_f)
+        return ts_f
+
+    def train_step(self, noise=None, return_grads=False):
+        """D Adam update, then G(+E) Adam update against the updated D (base_model.py:486-510).  Returns a dict of
+        device scalars (losses) -- nothing is synchronised unless the caller reads them."""
+        hp, B, T1 = self.hp, self.B, self.T1
+        if noise is None:
+            noise = self.default_noise()
+        lr = learning_rate(hp, self.step)
+        klw = kl_weight(hp, self.step)
+        store = self.store
+        lb = self.loss_buf
+        lb.zero_()
+        self.prep_generator_weights()
+        gen = self.forward_generator(noise)
+        gen_enc, gen_prior = (gen[:, :B], gen[:, B:]) if self.nz else (None, gen)
+        info = OrderedDict()
+        ddesc = []          # (D, weight, name, fake half, index keys)
+        if self.d_gan is not None:
+            ddesc.append((self.d_gan, hp.video_sn_gan_weight, 'video_sn_gan', gen_prior, 'real', 'fake', 0))
+        if self.d_vae is not None:
+            ddesc.append((self.d_vae, hp.video_sn_vae_gan_weight, 'video_sn_vae_gan', gen_enc, 'enc_real', 'enc_fake', 2))
+        # ---------------- discriminator step ---------------------------------------------------------------------------------
+        if ddesc:
+            store.groups['d'].zero_grad()
+            ipre = noise['d_indices_pre']
+            for D, w, name, fake, kr, kf, slot in ddesc:
+                D.prep_weights(update_u=True)
+                self._d_clips(D, ipre[kr], ipre[kf], fake, 0, B)
+                D.forward()
+                K.lsgan_loss(D.logits[0:B], 1.0, w, lb[slot:slot + 1], D.dlogits[0:B])            # discrim_gan_loss_real
+                K.lsgan_loss(D.logits[B:2 * B], 0.0, w, lb[slot + 1:slot + 2], D.dlogits[B:2 * B])  # ..._fake
+                D.backward(0, 2 * B, weights=True, data=False)
+                D.finish_weight_grads()
+            if return_grads:
+                info['d_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'd'}
+            self._allreduce('d')
+            store.groups['d'].adam_step(lr, hp.beta1, hp.beta2, gscale=1.0 / self.world)
+        # ---------------- generator (+ encoder) step --------------------------------------------------------------------------
+        store.groups['g'].zero_grad()
+        self.gen.gen.g.zero_()
+        if ddesc:
+            ipost = noise['d_indices_post']
+            for D, w, name, fake, kr, kf, slot in ddesc:
+                D.prep_weights(update_u=False)                     # updated W, same pre-assign u
+                is_vae = slot == 2
+                wf_cd = hp.vae_gan_feature_cdist_weight if is_vae else hp.gan_feature_cdist_weight
+                wf_l2 = hp.vae_gan_feature_l2_weight if is_vae else hp.gan_feature_l2_weight
+                if wf_l2:
+                    raise NotImplementedError('feature l2 matching')
+                if wf_cd:
+                    ts_f = self._d_clips(D, ipost[kr], ipost[kf], fake, 0, B)
+                    D.forward()
+                    lo, hi = B, 2 * B
+                    for li, L in enumerate(D.layers):
+                        K.cosine_distance(L['y'][lo:hi], L['y'][0:B], wf_cd, lb[8 + slot:9 + slot], L['dy'][lo:hi])
+                else:
+                    ts_f = self._d_clips(D, None, ipost[kf], fake, 0, 0)
+                    D.forward(n=B)
+                    lo, hi = 0, B
+                K.lsgan_loss(D.logits[lo:hi], 1.0, w, lb[4 + slot:5 + slot], D.dlogits[lo:hi])      # gen_*_gan_loss
+                D.backward(lo, hi, weights=False, data=True, feature_grads=bool(wf_cd))
+                gfake = self.gen.gen.g[:, :B] if (is_vae and self.nz) else (self.gen.gen.g[:, B:] if self.nz else self.gen.gen.g)
+                K.gather_clips(gfake, D.dclip[lo:hi], ts_f, adjoint=True)
+        target = self.images_tm[1:self.T]
+        pred = gen_enc if self.nz else gen_prior
+        dpred = self.gen.gen.g[:, :B] if self.nz else self.gen.gen.g
+        if hp.l1_weight:
+            K.lp_loss(pred, target, hp.l1_weight, lb[12:13], dpred, p2=False)
+        if hp.l2_weight:
+            K.lp_loss(pred, target, hp.l2_weight, lb[13:14], dpred, p2=True)
+        dzs = self.gen.backward()
+        if self.nz:
+            c1 = hp.context_frames - 1
+            copy_view(dzs[:, :B], [self.dz_post])
+            if c1 > 0:
+                add_views([dzs[:c1, B:]], self.dz_post[:c1])
+            self.enc.backward(self.dz_post, klw)
+        if return_grads:
+            info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
+        self._allreduce('g')
+        store.groups['g'].adam_step(lr, hp.beta1, hp.beta2, gscale=1.0 / self.world)
+        for D, *_ in ddesc:
+            D.commit_u()
+        self.step += 1
+        # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
+        d_losses, g_losses = OrderedDict(), OrderedDict()
+        for D, w, name, fake, kr, kf, slot in ddesc:
+            d_losses['discrim_%s_loss' % name] = (lb[slot] + lb[slot + 1], w)
+            g_losses['gen_%s_loss' % name] = (lb[4 + slot], w)
+            wf_cd = hp.vae_gan_feature_cdist_weight if slot == 2 else hp.gan_feature_cdist_weight
+            if wf_cd:
+                g_losses['gen_%s_feature_cdist_loss' % name] = (lb[8 + slot], wf_cd)
+        if hp.l1_weight:
+            g_losses['gen_l1_loss'] = (lb[12], hp.l1_weight)
+        if hp.l2_weight:
+            g_losses['gen_l2_loss'] = (lb[13], hp.l2_weight)
+        if self.nz and hp.kl_weight:
+            g_losses['gen_kl_loss'] = (self.enc.kl[0], klw)
+        info['d_losses'], info['g_losses'] = d_losses, g_losses
+        info['d_loss'] = sum(l * w for l, w in d_losses.values()) if d_losses else torch.zeros((), device=self.device)
+        info['g_loss'] = sum(l * w for l, w in g_losses.values())
+        info['learning_rate'] = lr
+        return info
+
+    # -- inference (scripts/generate.py:166: model.outputs['gen_images']) ------------------------------------------------------
+    def generate(self, noise=None, collect_masks=False):
+        if noise is None:
+            noise = self.default_noise()
+        self.prep_generator_weights()
+        gen = self.forward_generator(noise, collect_masks=collect_masks)
+        return gen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plug-in functions with the reference's signatures
+# ---------------------------------------------------------------------------------------------------------------------
+_ENGINES = {}
+
+
+def _engine_for(inputs, mode, hparams, engine=None):
+    images = inputs['images']
+    if engine is not None:
+        return engine
+    T, B = images.shape[:2]
+    key = (id(hparams), mode, tuple(images.shape))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = _ENGINES[key] = SAVPEngine(hparams, tuple(images.shape[2:]), B, mode='train' if mode == 'train' else 'test',
+                                         device=images.device)
+    return eng
+
+
+def posterior_fn(inputs, hparams, engine=None, noise=None):
+    """savp_model.py:21-51.  inputs['images'] time-major [T,B,H,W,C] on the device."""
+    eng = _engine_for(inputs, 'test', hparams, engine)
+    eng.set_images(inputs['images'], time_major=True)
+    eng.enc.prep_weights()
+    nz = hparams.nz
+    eps = (noise or {}).get('eps')
+    if eps is None:
+        eps = torch.zeros(eng.T1, eng.B, nz)
+    eng.enc.forward(eng.images_tm, eps.to(eng.device, torch.float32))
+    return {'zs_mu': eng.enc.mu, 'zs_log_sigma_sq': eng.enc.ls}
+
+
+def generator_fn(inputs, mode, hparams, engine=None, noise=None):
+    """savp_model.py:699-768 (without the visualisation-only gen_images_samples unroll :745-767)."""
+    eng = _engine_for(inputs, mode, hparams, engine)
+    eng.set_images(inputs['images'], time_major=True)
+    if noise is None:
+        noise = eng.default_noise()
+    eng.prep_generator_weights()
+    gen = eng.forward_generator(noise, collect_masks=True)
+    B, C, M = eng.B, eng.image_shape[2], eng.gen.M
+    g = eng.gen
+    timgs = g.maskin.v[..., hparams.ngf:].reshape(g.T1, g.N, g.H, g.W, M, C).permute(0, 1, 2, 3, 5, 4)   # [..., C, M]
+    masks = g.masks.reshape(g.T1, g.N, g.H, g.W, 1, M)
+    outputs = OrderedDict()
+    lo = B if eng.nz else 0
+    outputs['gen_images'] = gen[:, lo:]
+    outputs['transformed_images'] = timgs[:, lo:]
+    outputs['masks'] = masks[:, lo:]
+    gt = eng._gt_mask(noise)
+    outputs['ground_truth_sampling_mean'] = gt[hparams.context_frames:, lo:].float().mean()
+    if eng.nz:
+        outputs['zs_mu_enc'] = eng.enc.mu
+        outputs['zs_log_sigma_sq_enc'] = eng.enc.ls
+        outputs['gen_images_enc'] = gen[:, :B]
+        outputs['transformed_images_enc'] = timgs[:, :B]
+        outputs['masks_enc'] = masks[:, :B]
+        outputs['ground_truth_sampling_mean_enc'] = gt[hparams.context_frames:, :B].float().mean()
+    return outputs
+
+
+def discriminator_fn(inputs, outputs, mode, hparams, engine=None, noise=None):
+    """savp_model.py:129-166: runs the video discriminator(s) on (real, fake) clips; keys
+    discrim_video_sn_{logits,feature%d}_{real,fake,enc_real,enc_fake}."""
+    eng = _engine_for(inputs, mode, hparams, engine)
+    if not eng.has_d:
+        return OrderedDict()
+    if noise is None:
+        noise = eng.default_noise()
+    idx = noise['d_indices_pre']
+    B = eng.B
+    out = OrderedDict()
+    todo = []
+    if eng.d_vae is not None:
+        todo.append((eng.d_vae, outputs['gen_images_enc'], 'enc_real', 'enc_fake', '_enc'))
+    if eng.d_gan is not None:
+        todo.append((eng.d_gan, outputs['gen_images'], 'real', 'fake', ''))
+    for D, fake, kr, kf, sfx in todo:
+        D.prep_weights(update_u=False)
+        eng._d_clips(D, idx[kr], idx[kf], fake, 0, B)
+        D.forward()
+        for part, lo in (('real', 0), ('fake', B)):
+            out['discrim_video_sn_logits%s_%s' % (sfx, part)] = D.logits[lo:lo + B].clone()
+            for i, f in enumerate(D.features()):
+                out['discrim_video_sn_feature%d%s_%s' % (i, sfx, part)] = f[lo:lo + B].transpose(0, 1)
+    return out
+
+
+class SAVPVideoPredictionModel(VideoPredictionModel):
+    """savp_model.py:771-855."""
+
+    def __init__(self, *args, **kwargs):
+        super(SAVPVideoPredictionModel, self).__init__(generator_fn, discriminator_fn, *args, **kwargs)
+        if self.mode != 'train':
+            self.discriminator_fn = None
+        self.deterministic = not self.hparams.nz
+        self.engine = None
+
+    def get_default_hparams_dict(self):
+        return savp_defaults()
+
+    def parse_hparams(self, hparams_dict, hparams):
+        hparams_dict = dict(hparams_dict or {})
+        for k in SAVP_DEPRECATED_KEYS:                     # backwards compatibility (savp_model.py:826-845)
+            hparams_dict.pop(k, None)
+        return super(SAVPVideoPredictionModel, self).parse_hparams(hparams_dict, hparams)
+
+    def build_graph(self, inputs, values=None, seed=4, device='cuda:0'):
+        """inputs: {'images': [B,T,H,W,C] device tensor} (batch-major like the reference's dataset iterator)."""
+        super(SAVPVideoPredictionModel, self).build_graph(inputs)
+        images = inputs['images']
+        B = images.shape[0]
+        self.engine = SAVPEngine(self.hparams, tuple(images.shape[2:]), B, mode=self.mode, values=values, seed=seed,
+                                 device=device)
+        self.saveable_variables = self.engine.store.names()
+        self.post_init_ops = []
+        self.outputs = {}
+        return self
+
+    @property
+    def global_step(self):
+        return self.engine.step if self.engine else 0
+
+    def train_step(self, inputs=None, noise=None):
+        """One ``sess.run(model.train_op)``."""
+        if inputs is not None:
+            self.inputs = inputs
+        self.engine.set_images(self.inputs['images'])
+        info = self.engine.train_step(noise)
+        self.d_losses, self.g_losses = info['d_losses'], info['g_losses']
+        self.d_loss, self.g_loss = info['d_loss'], info['g_loss']
+        return info
+
+    def generate(self, inputs=None, noise=None):
+        """Fills self.outputs['gen_images'] batch-major [B,T-1,H,W,C] (scripts/generate.py:166)."""
+        if inputs is not None:
+            self.inputs = inputs
+        self.engine.set_images(self.inputs['images'])
+        gen = self.engine.generate(noise)
+        lo = self.engine.B if self.engine.nz else 0
+        self.outputs['gen_images'] = gen[:, lo:].transpose(0, 1)
+        if self.engine.nz:
+            self.outputs['gen_images_enc'] = gen[:, :self.engine.B].transpose(0, 1)
+        return self.outputs
+
+    def restore(self, values):
+        self.engine.store.load(values)
