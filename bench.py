@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- SAVP training throughput on MI355X (BASELINE.json metric: train frames/sec, BAIR 64x64 seq30 SAVP).
+
+One "step" = one full reference train step (D Adam update, then G+E Adam update against the updated D:
+/root/reference/video_prediction/models/base_model.py:486-510) on a synthetic BAIR-shaped batch already resident in
+HBM.  Workload at every N: configs[1] of BASELINE.json per GPU (full VAE-GAN, action-free BAIR 64x64x3, seq 30,
+batch 16 per GPU, published ours_savp recipe) -> weak scaling; one process per GPU, gradients all-reduced by RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel family (implicit-GEMM conv on the fp32 MFMA pipe), measured live with HIP events
+                  around the five ConvLSTM gate-conv FPROP launches of every timed step; algorithmic FLOPs per launch
+                  from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the 157.3 TFLOP/s fp32 peak.
+  cpu_baseline -- the CPU oracle (a torch-CPU restatement of the reference step, kind "port") timed on this host's
+                  cores on a bounded sample (one sequence), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+RECIPE = dict(  # hparams/bair_action_free/ours_savp/model_hparams.json of the reference
+    batch_size=16, lr=0.0002, beta1=0.5, beta2=0.999, l1_weight=100.0, l2_weight=0.0, kl_weight=1.0,
+    video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0,
+    state_weight=0.0)
+H, W, C = 64, 64, 3
+SEQ, CONTEXT = 30, 2      # BASELINE.json configs[1]: BAIR action-free, seq 30; context 2 (softmotion_dataset.py:46-54)
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA / vector peak
+
+
+def make_hparams(batch):
+    from video_prediction_amd.models import get_model_class
+    d = dict(RECIPE)
+    d.update(context_frames=CONTEXT, sequence_length=SEQ, batch_size=batch)
+    model = get_model_class('savp')(mode='train', hparams_dict=d)
+    return model
+
+
+def synthetic_batch(batch, seed, device):
+    """Seeded synthetic BAIR-shaped video, uniform[0,1) like convert_image_dtype'd uint8 frames."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((batch, SEQ, H, W, C), dtype=np.float32)
+    return torch.from_numpy(x).to(device)
+
+
+def convlstm_flops(engine):
+    """Algorithmic FLOPs (2*M*N*K) of the ConvLSTM gate convolutions instrumented below, per launch list."""
+    out = []
+    for L in engine.gen.layers:
+        if L['rnn']:
+            h, w = L['hw']
+            a = L['a'].v
+            cin, f = a.shape[-1], L['f']
+            out.append((L['rconv'], 2.0 * engine.N * h * w * (4 * f) * (25 * cin)))
+    return out
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Time the CPU oracle (kind 'port': not TensorFlow, a torch-CPU restatement; see oracle/__init__.py) on one
+    sequence of the same workload: full train step, fp32, B=1."""
+    from oracle import train as OT
+    from video_prediction_amd import variables as V
+    model = make_hparams(1)
+    hp = model.hparams
+    specs = V.variable_specs(hp, (H, W, C), mode='train')
+    vals = V.init_variables(specs, seed=4)
+    P = {k: torch.tensor(v) for k, v in vals.items()}
+    st = OT.init_opt_state(P)
+    rng = np.random.default_rng(0)
+    images = torch.tensor(rng.random((SEQ, 1, H, W, C), dtype=np.float32))
+    T1 = SEQ - 1
+
+    def noise(seed):
+        r = np.random.default_rng(seed)
+        n = {'eps': torch.tensor(r.standard_normal((T1, 1, hp.nz)).astype(np.float32)),
+             'prior': torch.tensor(r.standard_normal((SEQ - CONTEXT, 1, hp.nz)).astype(np.float32))}
+        for ph in ('pre', 'post'):
+            n['d_indices_' + ph] = {k: (r.integers(0, T1, 1), r.integers(0, T1 - hp.clip_length + 1, 1))
+                                    for k in ('enc_real', 'enc_fake', 'real', 'fake')}
+        return n
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    nsteps = 0
+    while True:
+        n = noise(nsteps)
+        P, st, _ = OT.train_step(P, st, {'images': images}, hp, n, n['d_indices_pre'], n['d_indices_post'], step=nsteps)
+        nsteps += 1
+        el = time.time() - t0
+        if el > seconds_budget * 0.5 or nsteps >= 3:
+            break
+    el = time.time() - t0
+    return {'value': nsteps * SEQ / el, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d full train step(s) of 1 sequence (B=1, T=%d, 64x64x3, fp32 torch-CPU oracle), %.1f s' % (nsteps, SEQ, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (BASELINE configs[1]: 16)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the SAVP hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist_mod.init_process_group(backend='nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist = dist_mod
+
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    model = make_hparams(args.batch)
+    hp = model.hparams
+    engine = SAVPEngine(hp, (H, W, C), args.batch, mode='train', seed=4, device=str(device))
+    if dist is not None:
+        engine.attach_process_group(dist)
+    engine.set_images(synthetic_batch(args.batch, 1234 + rank, device))      # inputs resident in HBM before timing
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.train_step()
+    inst = convlstm_flops(engine)
+    for layer, _ in inst:
+        layer.prof = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = engine.train_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # roofline of the dominant kernel family from the live event pairs
+    tot_flops, tot_s, launches = 0.0, 0.0, 0
+    for layer, fl in inst:
+        for e0, e1 in layer.prof:
+            tot_s += e0.elapsed_time(e1) * 1e-3
+            tot_flops += fl
+            launches += 1
+        layer.prof = None
+    achieved = tot_flops / tot_s / 1e12 if tot_s > 0 else 0.0
+    frames = world * args.batch * SEQ * args.steps
+    result = {
+        'metric': 'train frames/sec (whole node), BAIR 64x64 seq30 SAVP',
+        'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SAVP full VAE-GAN (ours_savp recipe), BAIR action-free 64x64x3, seq=30, context=2, '
+                               'batch=%d per GPU, D step + G/E step per train step' % args.batch,
+                   'global_batch': world * args.batch, 'seq_len': SEQ, 'parallelism': 'dp%d' % world,
+                   'sequences_per_s': world * args.batch * args.steps / dt},
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
+                     'kernel': 'conv_fd_kernel (implicit-GEMM fp32 MFMA), ConvLSTM gate conv FPROP x5 layers',
+                     'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None},
+        'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result['cpu_baseline'] = cpu_baseline()
+            except Exception as ex:    # the oracle is only a reported baseline; never fail the bench on it
+                result['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                          'sample': 'failed: %r' % (ex,)}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

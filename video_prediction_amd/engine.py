@@ -203,6 +203,7 @@ class ConvLayer(object):
             self.u_next = torch.empty_like(self.u)
             self.dwf = torch.zeros_like(W)                # dL/dW_bar, then sn_bwd -> master grad
         self.need_wt = self.need_wd = True
+        self.prof = None          # list of (start, end) events when bench.py instruments this layer's forward launches
 
     # -- weight preparation ---------------------------------------------------------------------------------
     def prep(self, update_u=False):
@@ -229,10 +230,16 @@ class ConvLayer(object):
             # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
             K.dense_fwd(x, self.W.reshape(-1, self.cy), b, y, scale=self.sn_ws[1:2] if self.sn_u_name else None)
             return
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.kind == 'up':
             K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha)
         else:
             K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha)
+        if self.prof is not None:
+            e1.record()
+            self.prof.append((e0, e1))
 
     def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
         if self.kind == 'up':
