@@ -189,8 +189,8 @@ def train_step(params, opt_state, inputs, hp, noise, d_indices_pre, d_indices_po
             if g is None:
                 continue
             new_params[k], m[k], v_[k] = tf_ops.adam_update(new_params[k], g, m[k], v_[k], lr, hp.beta1, hp.beta2, t_d)
-        info['d_loss'] = float(d_loss)
-        info['d_losses'] = OrderedDict((k, float(l)) for k, (l, w) in d_losses.items())
+        info['d_loss'] = float(d_loss.detach())
+        info['d_losses'] = OrderedDict((k, float(l.detach())) for k, (l, w) in d_losses.items())
         info['d_grads'] = {k: g for k, g in zip(d_names, grads) if g is not None}
         # post-update discriminator on the (attached) generator outputs, pre-assign u
         P2 = dict(P)
@@ -213,8 +213,8 @@ def train_step(params, opt_state, inputs, hp, noise, d_indices_pre, d_indices_po
         if g is None:
             continue
         new_params[k], m[k], v_[k] = tf_ops.adam_update(new_params[k], g, m[k], v_[k], lr, hp.beta1, hp.beta2, t_g)
-    info['g_loss'] = float(g_loss)
-    info['g_losses'] = OrderedDict((k, float(l)) for k, (l, w) in g_losses.items())
+    info['g_loss'] = float(g_loss.detach())
+    info['g_losses'] = OrderedDict((k, float(l.detach())) for k, (l, w) in g_losses.items())
     info['g_grads'] = {k: g for k, g in zip(g_names, grads) if g is not None}
     info['gen_images'] = gen_outputs['gen_images'].detach()
     if 'gen_images_enc' in gen_outputs:

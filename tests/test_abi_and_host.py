@@ -1,0 +1,110 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/savp_hip.h declares (no compute calls
+without a GPU), the product never imports the oracle, hparams / model-class behaviour mirrors the reference."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'savp_hip.h')).read()
+    return sorted(set(re.findall(r'\b(savp_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from video_prediction_amd import lib
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), 'libsavp_hip.so does not export %s' % s
+    # every symbol the Python side binds is declared in the header, and vice versa (savp_version is bound separately)
+    bound = set(lib.EXPORTS) | {'savp_version'}
+    assert bound == set(syms), (sorted(bound - set(syms)), sorted(set(syms) - bound))
+    assert hip_lib.savp_version().startswith(b'savp_hip')
+
+
+def test_ops_fail_loudly_without_device():
+    import torch
+    from video_prediction_amd import kernels as K, lib
+    x = torch.zeros(1, 4, 4, 4)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        K.conv(lib.CONV_FPROP, K.ConvGeom((3, 3), (1, 1), (1, 1)), x, x, torch.zeros(9 * 16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'video_prediction_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), '%s imports the oracle' % f
+
+
+def test_hparams_parsing_like_contrib_hparams():
+    from video_prediction_amd.hparams import HParams
+    hp = HParams(a=1, b=2.0, c='x', d=(1, 2), e=True)
+    hp.override_from_dict({'a': 3, 'd': [5, 6]})
+    hp.parse('b=0.5,c=hello,d=[7,8],e=false')
+    assert hp.a == 3 and hp.b == 0.5 and hp.c == 'hello' and hp.d == (7, 8) and hp.e is False
+    assert hp.values()['a'] == 3
+    with pytest.raises(ValueError):
+        hp.override_from_dict({'nope': 1})
+    with pytest.raises(ValueError):
+        hp.parse('nope=1')
+
+
+def test_model_class_surface():
+    from video_prediction_amd.models import get_model_class
+    M = get_model_class('savp')
+    with pytest.raises(ValueError, match='mode must be train or test'):
+        M(mode='val', hparams_dict=dict(context_frames=2, sequence_length=12))
+    with pytest.raises(ValueError, match='context_frames'):
+        M(mode='train')
+    with pytest.raises(ValueError, match='Invalid model'):
+        get_model_class('nope')
+    # published ours_savp recipe (hparams/bair_action_free/ours_savp/model_hparams.json) incl. a deprecated key
+    recipe = {"batch_size": 16, "lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "l1_weight": 100.0, "l2_weight": 0.0,
+              "kl_weight": 1.0, "video_sn_vae_gan_weight": 0.1, "video_sn_gan_weight": 0.1,
+              "vae_gan_feature_cdist_weight": 10.0, "gan_feature_cdist_weight": 0.0, "state_weight": 0.0, "gan_weight": 1.0}
+    m = M(mode='train', hparams_dict=dict(recipe, context_frames=2, sequence_length=30), hparams='nz=8,kernel_size=[5,5]')
+    assert m.hparams.lr == 0.0002 and m.hparams.nz == 8 and m.hparams.kernel_size == (5, 5)
+    assert m.hparams.transformation == 'cdna' and m.hparams.conv_rnn == 'lstm' and m.hparams.ngf == 32
+    assert not m.deterministic
+    t = M(mode='test', hparams_dict=dict(recipe, context_frames=2, sequence_length=30))
+    assert t.discriminator_fn is None
+
+
+def test_reference_recipes_load_unchanged_when_reference_is_mounted():
+    import glob
+    import json
+    from video_prediction_amd.models import get_model_class
+    files = glob.glob('/root/reference/hparams/*/ours_*/model_hparams.json')
+    if not files:
+        pytest.skip('reference not mounted (GPU box)')
+    M = get_model_class('savp')
+    for f in files:
+        d = json.load(open(f))
+        m = M(mode='train', hparams_dict=dict(d, context_frames=2, sequence_length=12))
+        for k, v in d.items():
+            assert getattr(m.hparams, k) == v
+
+
+def test_variable_inventory_matches_survey_counts():
+    # BAIR SAVP = 79 G+E tensors / 7.35 M params, 32 D tensors / 10.29 M params (trainable)
+    import numpy as np
+    from video_prediction_amd import variables as V
+    from video_prediction_amd.models import get_model_class
+    m = get_model_class('savp')(mode='train', hparams_dict=dict(context_frames=2, sequence_length=30, video_sn_gan_weight=0.1,
+                                                                  video_sn_vae_gan_weight=0.1))
+    specs = V.variable_specs(m.hparams, (64, 64, 3))
+    g = [(n, s) for n, (s, _) in specs.items() if n.startswith('generator/')]
+    d = [(n, s) for n, (s, _) in specs.items() if n.startswith('discriminator/') and V.is_trainable(n)]
+    assert len(g) == 79 and len(d) == 32
+    assert abs(sum(int(np.prod(s)) for _, s in g) / 1e6 - 7.35) < 0.01
+    assert abs(sum(int(np.prod(s)) for _, s in d) / 1e6 - 10.29) < 0.01
+    assert specs['generator/rnn/savp_cell/lstm_h2/basic_conv2dlstm_cell/kernel'][0] == (5, 5, 264, 512)
+    assert specs['discriminator/encoder/video/sn_fc4/dense/kernel'][0] == (65536, 1)

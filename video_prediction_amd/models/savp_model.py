@@ -70,16 +70,15 @@ class SAVPEngine(object):
 
     # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
     def attach_process_group(self, dist_module):
-        """One process per GPU; gradients of each optimiser group are one flat bucket, summed by RCCL and scaled by
-        1/world inside the Adam kernel.  Replica init = broadcast of rank-0 variables (base_model.py:640-646)."""
+        """One process per GPU; see parallel.ReplicaGroup."""
+        from ..parallel import ReplicaGroup
+        self.replicas = ReplicaGroup(self.store, dist_module)
         self.dist = dist_module
-        self.world = dist_module.get_world_size()
-        for g in self.store.groups.values():
-            dist_module.broadcast(g.p, src=0)
+        self.world = self.replicas.world
 
     def _allreduce(self, group):
-        if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(self.store.groups[group].g)
+        if self.world > 1:
+            self.replicas.allreduce_grads(group)
 
     # -- input staging -------------------------------------------------------------------------------------------------
     def set_images(self, images, time_major=False):
