@@ -39,6 +39,7 @@ const char* savp_version(void);
  *   given the saved activation output `aux`, same view as the output].
  * ------------------------------------------------------------------------------------------------------------ */
 enum { SAVP_CONV_FPROP = 0, SAVP_CONV_DGRAD = 1, SAVP_CONV_WGRAD = 2 };
+enum { SAVP_PREC_F32 = 0, SAVP_PREC_BF16 = 1 };   /* multiply precision; accumulation is always fp32 */
 enum { SAVP_ACT_NONE = 0, SAVP_ACT_LRELU = 1, SAVP_ACT_SIGMOID = 2, SAVP_ACT_DLRELU_FROM_OUT = 3 };
 
 typedef struct SavpConvArgs {
@@ -53,6 +54,7 @@ typedef struct SavpConvArgs {
     float alpha;
     int32_t splitk;                /* WGRAD: number of K splits (>=1); 0 = pick automatically */
     int32_t tile;                  /* 0 = auto; else (WM<<4)|WN with tile = 64*WM x 64*WN */
+    int32_t precision;             /* SAVP_PREC_F32: exact fp32 MFMA; SAVP_PREC_BF16: operands rounded to bf16 in LDS */
     void* x; int64_t x_sn, x_sd, x_sh, x_sw;
     void* y; int64_t y_sn, y_sd, y_sh, y_sw;
     void* w;

@@ -29,6 +29,7 @@ def timeit(fn, iters=20):
 
 def main():
     res = []
+    K.set_conv_precision(os.environ.get('PREC', 'f32'))
     for name, N, H, W, Cx, Cy, k in SHAPES:
         x = torch.randn(N, H, W, Cx, device=DEV)
         y = torch.randn(N, H, W, Cy, device=DEV)

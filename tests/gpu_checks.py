@@ -76,7 +76,8 @@ CONV_CASES = [
 ]
 
 
-def check_conv(cases=None, seed=0, tiles=(0,)):
+def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
+    tol = tol or TOL_OP
     out = []
     rng = np.random.default_rng(seed)
     for case in CONV_CASES:
@@ -97,16 +98,16 @@ def check_conv(cases=None, seed=0, tiles=(0,)):
             xd, wd_, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
             # FPROP (+bias)
             yd = torch.empty(y.shape, device=DEV, dtype=torch.float32)
-            K.conv(lib.CONV_FPROP, geom, xd, yd, dev(pack_wt(w.detach())), bias=bd, tile=tile)
-            out.append((tag + '/fprop', rel_err(yd, y), TOL_OP))
+            K.conv(lib.CONV_FPROP, geom, xd, yd, dev(pack_wt(w.detach())), bias=bd, tile=tile, precision=precision)
+            out.append((tag + '/fprop', rel_err(yd, y), tol))
             # DGRAD
             dxd = torch.full(x.shape, float('nan'), device=DEV, dtype=torch.float32)
-            K.conv(lib.CONV_DGRAD, geom, dxd, dyd, dev(pack_wd(w.detach())), tile=tile)
-            out.append((tag + '/dgrad', rel_err(dxd, x.grad), TOL_OP))
+            K.conv(lib.CONV_DGRAD, geom, dxd, dyd, dev(pack_wd(w.detach())), tile=tile, precision=precision)
+            out.append((tag + '/dgrad', rel_err(dxd, x.grad), tol))
             # WGRAD
             dwd = torch.zeros(w.shape, device=DEV, dtype=torch.float32)
-            K.conv(lib.CONV_WGRAD, geom, xd, dyd, dwd, tile=tile)
-            out.append((tag + '/wgrad', rel_err(dwd, w.grad), TOL_OP))
+            K.conv(lib.CONV_WGRAD, geom, xd, dyd, dwd, tile=tile, precision=precision)
+            out.append((tag + '/wgrad', rel_err(dwd, w.grad), tol))
     torch.cuda.synchronize()
     return out
 
@@ -553,7 +554,13 @@ def check_weight_prep(seed=7):
     return out
 
 
-ALL_CHECKS = [('conv', check_conv), ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
+def check_conv_bf16():
+    """bf16-operand / fp32-accumulate mode of the implicit-GEMM kernel: per-op rel <= 1e-2."""
+    res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11))
+    return [('bf16/' + n, e, t) for (n, e, t) in res]
+
+
+ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
               ('lstm', check_lstm), ('util', check_util), ('cdna_composite', check_cdna_composite),
               ('small', check_small), ('weight_prep', check_weight_prep)]
 

@@ -49,3 +49,8 @@ def test_small_ops():
 def test_weight_prep_and_spectral_norm():
     from tests import gpu_checks
     _run(gpu_checks.check_weight_prep)
+
+
+def test_conv_bf16_mode():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv_bf16)

@@ -7,6 +7,8 @@ from tests.gpu_model_checks import make_hparams
 from video_prediction_amd.models.savp_model import SAVPEngine
 
 def main():
+    from video_prediction_amd import kernels as K
+    K.set_conv_precision(os.environ.get('PREC', 'f32'))
     B = int(os.environ.get('B', 16)); T = int(os.environ.get('T', 30)); steps = int(os.environ.get('STEPS', 3))
     hp = make_hparams(context_frames=2, sequence_length=T, batch_size=B, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,

@@ -23,6 +23,8 @@
 #include "savp_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define BK 32
 #define BKP 36          // padded K row (floats) for the row-major-K LDS layout
@@ -42,6 +44,7 @@ struct ConvP {
     const float* bias;
     const float* aux;
     int splitk;
+    int bf16;
     unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
 };
 
@@ -81,13 +84,19 @@ __device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out,
     return g;
 }
 
-template <int WM, int WN, bool VEC>
+// BF16 = true: operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while staging into LDS and multiplied on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate); K-tile 64.  BF16 = false: exact fp32 on v_mfma_f32_32x32x2_f32; K-tile 32.
+template <int WM, int WN, bool VEC, bool BF16>
 __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int RA = BM / 32, RB = BN / 32;        // float4 rows fetched per thread for A / B
+    constexpr int BKT = BF16 ? 64 : 32;                // K-tile
+    constexpr int KV = BKT / 4;                        // float4 columns per row
+    constexpr int RP = NTHREADS / KV;                  // rows covered per pass
+    constexpr int RA = BM / RP, RB = BN / RP;          // float4 rows fetched per thread for A / B
+    constexpr int ROWB = BF16 ? (BKT + 8) * 2 : BKP * 4;   // LDS row stride in bytes (padded: conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                  // [2][BM][BKP]
-    float* Bs = smem + 2 * BM * BKP;                   // [2][BN][BKP]
+    char* As = reinterpret_cast<char*>(smem);          // [2][BM] rows
+    char* Bs = As + 2 * BM * ROWB;                     // [2][BN] rows
 
     const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
     // phase decode (DGRAD only): blockIdx.z -> (fd, fh, fw)
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int kv = tid & 7, r0 = tid >> 3;
+    const int kv = tid % KV, r0 = tid / KV;
 
     // ---- per-thread A rows --------------------------------------------------------------------------------
     long long a_base[RA];
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     bool a_ok[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        int m = m0 + r0 + 32 * j;
+        int m = m0 + r0 + RP * j;
         a_ok[j] = m < Mtot;
         int mm = a_ok[j] ? m : 0;
         int qw = mm % gw.Mdim; mm /= gw.Mdim;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     long long b_base[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        int n = n0 + r0 + 32 * j;
+        int n = n0 + r0 + RP * j;
         b_ok[j] = n < Nout;
         b_base[j] = (long long)(b_ok[j] ? n : 0) * ldb;
     }
@@ -177,8 +186,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                 if (b_ok[j] && kok) v = ldg4(wt + b_base[j] + woff);
                 rb[j] = v;
             }
-            // advance by BK
-            kc += BK;
+            // advance by the K-tile
+            kc += BKT;
             while (kc >= Cred) {
                 kc -= Cred;
                 if (++jw >= gw.nt) { jw = 0; if (++jh >= gh.nt) { jh = 0; ++jd; } }
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
             float av[RA][4], bv[RB][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int k = kt * BK + kv * 4 + e;
+                int k = kt * BKT + kv * 4 + e;
                 bool kok = k < K;
                 int kk = kok ? k : 0;
                 int c = kk % Cred; int tap = kk / Cred;
@@ -213,12 +222,25 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
         }
     };
     auto stage = [&](int buf) {
-        float* a = As + buf * BM * BKP;
-        float* b = Bs + buf * BN * BKP;
+        char* a = As + buf * BM * ROWB;
+        char* b = Bs + buf * BN * ROWB;
+        if (BF16) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(a + (r0 + 32 * j) * BKP + kv * 4) = ra[j];
+            for (int j = 0; j < RA; ++j) {
+                bf16x4 v = {(__bf16)ra[j].x, (__bf16)ra[j].y, (__bf16)ra[j].z, (__bf16)ra[j].w};
+                *reinterpret_cast<bf16x4*>(a + (r0 + RP * j) * ROWB + kv * 8) = v;
+            }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(b + (r0 + 32 * j) * BKP + kv * 4) = rb[j];
+            for (int j = 0; j < RB; ++j) {
+                bf16x4 v = {(__bf16)rb[j].x, (__bf16)rb[j].y, (__bf16)rb[j].z, (__bf16)rb[j].w};
+                *reinterpret_cast<bf16x4*>(b + (r0 + RP * j) * ROWB + kv * 8) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(a + (r0 + RP * j) * ROWB + kv * 16) = ra[j];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(b + (r0 + RP * j) * ROWB + kv * 16) = rb[j];
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
 
     const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (K + BKT - 1) / BKT;
 
     if (nk > 0) {
         fetch(0);
@@ -241,33 +263,51 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) fetch(kt + 1);
-        const float* a = As + cur * BM * BKP;
-        const float* b = Bs + cur * BN * BKP;
+        const char* a = As + cur * BM * ROWB;
+        const char* b = Bs + cur * BN * ROWB;
+        if (BF16) {
 #pragma unroll
-        for (int c8 = 0; c8 < BK / 8; ++c8) {
-            float4 af[WM], bf[WN];
+            for (int ks = 0; ks < BKT / 16; ++ks) {
+                bf16x8 af[WM], bf[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(a + (wm0 + i * 32 + l31) * BKP + c8 * 8 + khalf * 4);
+                for (int i = 0; i < WM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(a + (wm0 + i * 32 + l31) * ROWB + (ks * 16 + khalf * 8) * 2);
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(b + (wn0 + j * 32 + l31) * BKP + c8 * 8 + khalf * 4);
+                for (int j = 0; j < WN; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(b + (wn0 + j * 32 + l31) * ROWB + (ks * 16 + khalf * 8) * 2);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int c8 = 0; c8 < BKT / 8; ++c8) {
+                float4 af[WM], bf[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    af[i] = *reinterpret_cast<const float4*>(a + (wm0 + i * 32 + l31) * ROWB + (c8 * 8 + khalf * 4) * 4);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    bf[j] = *reinterpret_cast<const float4*>(b + (wn0 + j * 32 + l31) * ROWB + (c8 * 8 + khalf * 4) * 4);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (kt + 1 < nk) stage(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: destination row offsets through LDS -------------------------------------------------------
-    long long* rowoff = reinterpret_cast<long long*>(smem);     // [BM], -1 = invalid
+    long long* rowoff = reinterpret_cast<long long*>(smem);     // [BM], -1 = invalid (safe: last barrier of the loop passed)
     float* __restrict__ dst = p.out;
     const long long d_sn = dgrad ? p.x_sn : p.y_sn;
     const long long d_sd = dgrad ? p.x_sd : p.y_sd, d_sh = dgrad ? p.x_sh : p.y_sh, d_sw = dgrad ? p.x_sw : p.y_sw;
@@ -468,6 +508,175 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(ConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// WGRAD, bf16 operands (fp32 accumulate).  Same GEMM as above, K-tile = 64 pixels.  Both operands are pixel-major in
+// HBM, the MFMA wants k(=pixel)-contiguous fragments: each thread loads a 4(pixel) x 4(channel) fp32 block (float4 per
+// pixel), transposes it in registers, rounds to bf16 and writes four 8-byte rows into the row-major-K LDS tile
+// (lanes run along k first -> conflict-free ds_write_b64).  Requires Cx % 4 == 0 and Cy % 4 == 0.
+// ------------------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BKT = 64;
+    constexpr int ROWB = (BKT + 8) * 2;
+    constexpr int PA = BM / 64, PB = BN / 64;          // passes of 16 row-quads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = reinterpret_cast<char*>(smem);
+    char* Bs = As + 2 * BM * ROWB;
+
+    const int M = p.kd * p.kh * p.kw * p.Cx;
+    const int Nn = p.Cy;
+    const int HWo = p.Ho * p.Wo, DHWo = p.Do * HWo;
+    const int Ktot = p.N * DHWo;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ktiles = (Ktot + BKT - 1) / BKT;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt_begin = blockIdx.z * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+
+    const float* __restrict__ X = p.x;
+    const float* __restrict__ Y = p.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = tid & 15, rq0 = tid >> 4;           // k-quad (4 pixels), row-quad within a pass
+
+    int a_c[PA], a_td[PA], a_th[PA], a_tw[PA]; bool a_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        int m = m0 + 4 * (rq0 + 16 * j);
+        a_ok[j] = m < M;
+        int mm = a_ok[j] ? m : 0;
+        a_c[j] = mm % p.Cx; int tap = mm / p.Cx;
+        a_tw[j] = tap % p.kw; tap /= p.kw;
+        a_th[j] = tap % p.kh; a_td[j] = tap / p.kh;
+    }
+    int b_n[PB]; bool b_ok[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) { b_n[j] = n0 + 4 * (rq0 + 16 * j); b_ok[j] = b_n[j] < Nn; }
+
+    float4 ra[PA][4], rb[PB][4];
+
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = kt * BKT + kq * 4 + i;
+            const bool pok = pix < Ktot;
+            unsigned up = (unsigned)(pok ? pix : 0);
+            int n = (int)fastdiv(up, p.magDHW); unsigned r = up - (unsigned)n * DHWo;
+            int od = (int)fastdiv(r, p.magHW); r -= (unsigned)od * HWo;
+            int oy = (int)fastdiv(r, p.magW); int ox = (int)(r - (unsigned)oy * p.Wo);
+            const long long nb = (long long)n * p.x_sn;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                int zd = od * p.sd - p.pd + a_td[j], zh = oy * p.sh - p.ph + a_th[j], zw = ox * p.sw - p.pw + a_tw[j];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pok && a_ok[j] && (unsigned)zd < (unsigned)p.D && (unsigned)zh < (unsigned)p.H && (unsigned)zw < (unsigned)p.W)
+                    v = ldg4(X + nb + zd * p.x_sd + zh * p.x_sh + zw * p.x_sw + a_c[j]);
+                ra[j][i] = v;
+            }
+            const float* q = Y + (long long)n * p.y_sn + od * p.y_sd + oy * p.y_sh + ox * p.y_sw;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pok && b_ok[j]) v = ldg4(q + b_n[j]);
+                rb[j][i] = v;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        char* a = As + buf * BM * ROWB;
+        char* b = Bs + buf * BN * ROWB;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            char* base = a + (4 * (rq0 + 16 * j)) * ROWB + kq * 8;
+            bf16x4 v0 = {(__bf16)ra[j][0].x, (__bf16)ra[j][1].x, (__bf16)ra[j][2].x, (__bf16)ra[j][3].x};
+            bf16x4 v1 = {(__bf16)ra[j][0].y, (__bf16)ra[j][1].y, (__bf16)ra[j][2].y, (__bf16)ra[j][3].y};
+            bf16x4 v2 = {(__bf16)ra[j][0].z, (__bf16)ra[j][1].z, (__bf16)ra[j][2].z, (__bf16)ra[j][3].z};
+            bf16x4 v3 = {(__bf16)ra[j][0].w, (__bf16)ra[j][1].w, (__bf16)ra[j][2].w, (__bf16)ra[j][3].w};
+            *reinterpret_cast<bf16x4*>(base) = v0;
+            *reinterpret_cast<bf16x4*>(base + ROWB) = v1;
+            *reinterpret_cast<bf16x4*>(base + 2 * ROWB) = v2;
+            *reinterpret_cast<bf16x4*>(base + 3 * ROWB) = v3;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            char* base = b + (4 * (rq0 + 16 * j)) * ROWB + kq * 8;
+            bf16x4 v0 = {(__bf16)rb[j][0].x, (__bf16)rb[j][1].x, (__bf16)rb[j][2].x, (__bf16)rb[j][3].x};
+            bf16x4 v1 = {(__bf16)rb[j][0].y, (__bf16)rb[j][1].y, (__bf16)rb[j][2].y, (__bf16)rb[j][3].y};
+            bf16x4 v2 = {(__bf16)rb[j][0].z, (__bf16)rb[j][1].z, (__bf16)rb[j][2].z, (__bf16)rb[j][3].z};
+            bf16x4 v3 = {(__bf16)rb[j][0].w, (__bf16)rb[j][1].w, (__bf16)rb[j][2].w, (__bf16)rb[j][3].w};
+            *reinterpret_cast<bf16x4*>(base) = v0;
+            *reinterpret_cast<bf16x4*>(base + ROWB) = v1;
+            *reinterpret_cast<bf16x4*>(base + 2 * ROWB) = v2;
+            *reinterpret_cast<bf16x4*>(base + 3 * ROWB) = v3;
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    fetch(kt_begin);
+    stage(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) fetch(kt + 1);
+        const char* a = As + cur * BM * ROWB;
+        const char* b = Bs + cur * BN * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            bf16x8 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(a + (wm0 + i * 32 + l31) * ROWB + (ks * 16 + khalf * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8*>(b + (wn0 + j * 32 + l31) * ROWB + (ks * 16 + khalf * 8) * 2);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt_end) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* __restrict__ dW = p.out;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= Nn) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row < M) unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+            }
+    }
+}
+
+template <int WM, int WN>
+static hipError_t launch_wg_bf16(const ConvP& p, dim3 grid, hipStream_t st) {
+    size_t lds = (size_t)2 * (64 * WM + 64 * WN) * (64 + 8) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WM, WN>), grid, dim3(NTHREADS), lds, st, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------------------
 static unsigned long long magic40(int d) {
@@ -475,17 +684,25 @@ static unsigned long long magic40(int d) {
     return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
 }
 
+template <int WM, int WN, bool VEC, bool BF16>
+static hipError_t launch_fd1(const ConvP& p, dim3 grid, hipStream_t st) {
+    constexpr int BKT = BF16 ? 64 : 32;
+    constexpr size_t rowb = BF16 ? (BKT + 8) * 2 : BKP * 4;
+    size_t lds = (size_t)2 * (64 * WM + 64 * WN) * rowb;
+    if (lds < (size_t)64 * WM * sizeof(long long)) lds = (size_t)64 * WM * sizeof(long long);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, VEC, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_fd_kernel<WM, WN, VEC, BF16>), grid, dim3(NTHREADS), lds, st, p);
+    return hipGetLastError();
+}
+
 template <int WM, int WN>
 static hipError_t launch_fd(const ConvP& p, bool vec, dim3 grid, hipStream_t st) {
-    size_t lds = (size_t)2 * (64 * WM + 64 * WN) * BKP * sizeof(float);
-    if (vec) {
-        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_fd_kernel<WM, WN, true>), grid, dim3(NTHREADS), lds, st, p);
-    } else {
-        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_fd_kernel<WM, WN, false>), grid, dim3(NTHREADS), lds, st, p);
-    }
-    return hipGetLastError();
+    if (p.bf16) return vec ? launch_fd1<WM, WN, true, true>(p, grid, st) : launch_fd1<WM, WN, false, true>(p, grid, st);
+    return vec ? launch_fd1<WM, WN, true, false>(p, grid, st) : launch_fd1<WM, WN, false, false>(p, grid, st);
 }
 
 template <int WM, int WN>
@@ -538,6 +755,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.w = (const float*)a->w;
     p.bias = a->bias; p.aux = a->aux;
     p.splitk = 1;
+    p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
     if (a->tile) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
@@ -580,7 +798,9 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         }
         const int BM = 64 * wm, BN = 64 * wn;
         const long long tiles = ((M + BM - 1) / BM) * ((a->Cy + BN - 1) / BN);
-        const long long ktiles = (Ktot + BK - 1) / BK;
+        const bool wbf16 = p.bf16 && va && vb;
+        const int bkt = wbf16 ? 64 : BK;
+        const long long ktiles = (Ktot + bkt - 1) / bkt;
         int splitk = a->splitk;
         if (splitk <= 0) {
             long long want = (512 + tiles - 1) / tiles;           // ~2 workgroups per CU
@@ -592,7 +812,12 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         if (splitk < 1) splitk = 1;
         p.splitk = splitk;
         dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a->Cy + BN - 1) / BN), (unsigned)splitk);
-        if (wm == 2 && wn == 2) err = launch_wg<2, 2>(p, va, vb, grid, st);
+        if (wbf16) {
+            if (wm == 2 && wn == 2) err = launch_wg_bf16<2, 2>(p, grid, st);
+            else if (wm == 2 && wn == 1) err = launch_wg_bf16<2, 1>(p, grid, st);
+            else if (wm == 1 && wn == 2) err = launch_wg_bf16<1, 2>(p, grid, st);
+            else err = launch_wg_bf16<1, 1>(p, grid, st);
+        } else if (wm == 2 && wn == 2) err = launch_wg<2, 2>(p, va, vb, grid, st);
         else if (wm == 2 && wn == 1) err = launch_wg<2, 1>(p, va, vb, grid, st);
         else if (wm == 1 && wn == 2) err = launch_wg<1, 2>(p, va, vb, grid, st);
         else err = launch_wg<1, 1>(p, va, vb, grid, st);

@@ -41,7 +41,14 @@ class ConvGeom(object):
         return tuple((i + pb + pa - k) // s + 1 for i, k, s, pb, pa in zip((D, H, W), self.k, self.s, self.p, pad_after))
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0):
+PRECISION = {'value': 0}      # 0 = fp32 (exact), 1 = bf16 operands / fp32 accumulate; set with set_conv_precision
+
+
+def set_conv_precision(name):
+    PRECISION['value'] = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
+
+
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h."""
     lib.require_device(x, y, w, bias, aux)
     a = lib.SavpConvArgs()
@@ -56,6 +63,7 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     a.sd, a.sh, a.sw = geom.s
     a.pd, a.ph, a.pw = geom.p
     a.beta, a.act, a.alpha, a.splitk, a.tile = int(beta), int(act), float(alpha), int(splitk), int(tile)
+    a.precision = PRECISION['value'] if precision is None else int(precision)
     a.x, a.y, a.w = x.data_ptr(), y.data_ptr(), w.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
     a.aux = aux.data_ptr() if aux is not None else None

@@ -26,7 +26,7 @@ class SavpConvArgs(ctypes.Structure):
         ('kd', c_i32), ('kh', c_i32), ('kw', c_i32),
         ('sd', c_i32), ('sh', c_i32), ('sw', c_i32),
         ('pd', c_i32), ('ph', c_i32), ('pw', c_i32),
-        ('beta', c_i32), ('act', c_i32), ('alpha', c_f32), ('splitk', c_i32), ('tile', c_i32),
+        ('beta', c_i32), ('act', c_i32), ('alpha', c_f32), ('splitk', c_i32), ('tile', c_i32), ('precision', c_i32),
         ('x', c_vp), ('x_sn', c_i64), ('x_sd', c_i64), ('x_sh', c_i64), ('x_sw', c_i64),
         ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
         ('w', c_vp), ('bias', c_vp), ('aux', c_vp),
