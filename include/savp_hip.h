@@ -163,13 +163,16 @@ int savp_cdna_apply_fwd(void* stream, const SavpCdnaArgs* a);
 int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a);
 typedef struct SavpCompositeArgs {
     int32_t N, HW, M, C;
-    const float* logits;           /* [N*HW, M] */
+    const float* logits;           /* [N*HW, logits_stride], first M columns are the mask logits */
+    int32_t logits_stride;
     SavpView timgs;                /* [N,HW,M*C], channel m*C+c */
     SavpView gen;                  /* [N,HW,C] */
     float* masks;                  /* optional [N*HW, M] */
     SavpView dgen;
-    float* dlogits;
-    SavpView dtimgs; int32_t dt_beta;
+    float* dlogits;                /* bwd: [N*HW, logits_stride] (pad columns zeroed) */
+    SavpView drow;                 /* bwd: gradient of the WHOLE mask-conv input row [N,HW,row_channels]: channels
+                                      [timgs_offset, timgs_offset+M*C) get mask_k*dgen, all others are written as 0 */
+    int32_t timgs_offset, row_channels;
 } SavpCompositeArgs;
 int savp_composite_fwd(void* stream, const SavpCompositeArgs* a);
 int savp_composite_bwd(void* stream, const SavpCompositeArgs* a);

@@ -397,11 +397,19 @@ def check_cdna_composite(seed=5):
         out.append((tag + '/masks', rel_err(md, masks), TOL_OP))
         amism = int((md.argmax(dim=-1).cpu() != masks.argmax(dim=-1)).sum())
         out.append((tag + '/mask_argmax_mismatches', float(amism), 0.0))
-        dl = torch.empty(N, H, W, M, device=DEV)
-        dbig = torch.zeros(N, H, W, 32 + M * C, device=DEV)
-        K.composite_bwd(ld, tv, dev(dgen), dl, dbig[..., 32:])
-        out.append((tag + '/dlogits', rel_err(dl, logits.grad), 5e-5))
-        out.append((tag + '/dtimgs', rel_err(dbig[..., 32:], timgs.grad), 5e-5))
+        # padded logits row (stride 8) and whole-row gradient write
+        l8 = torch.full((N, H, W, 8), 7.0, device=DEV)
+        l8[..., :M] = ld
+        g8 = torch.empty(N, H, W, C, device=DEV)
+        K.composite_fwd(l8, tv, g8, None, M=M)
+        out.append((tag + '/gen_padded_logits', rel_err(g8, gen), TOL_OP))
+        dl = torch.full((N, H, W, 8), float('nan'), device=DEV)
+        dbig = torch.full((N, H, W, 32 + M * C + 3), float('nan'), device=DEV)
+        K.composite_bwd(l8, tv, dev(dgen), dl, dbig, 32, M=M)
+        out.append((tag + '/dlogits', rel_err(dl[..., :M], logits.grad), 5e-5))
+        out.append((tag + '/dlogits_pad_zero', float(dl[..., M:].abs().max()), 0.0))
+        out.append((tag + '/dtimgs', rel_err(dbig[..., 32:32 + M * C], timgs.grad), 5e-5))
+        out.append((tag + '/drow_rest_zero', float(dbig[..., :32].abs().max() + dbig[..., 32 + M * C:].abs().max()), 0.0))
     torch.cuda.synchronize()
     return out
 

@@ -63,7 +63,7 @@ def test_full_size_properties_bair_b16_t30():
     masks = eng.gen.masks
     assert float((masks.sum(-1) - 1).abs().max()) < 1e-5                                  # softmax masks sum to one
     ngf, M, C = hp.ngf, eng.gen.M, 3
-    timgs = eng.gen.maskin.v[..., ngf:].reshape(T - 1, 2 * B, 64, 64, M, C)
+    timgs = eng.gen.maskin.v[..., ngf:ngf + M * C].reshape(T - 1, 2 * B, 64, 64, M, C)
     assert bool((gen <= timgs.max(dim=-2).values + 1e-5).all()) and bool((gen >= timgs.min(dim=-2).values - 1e-5).all())
     # every op is per-sample: the first two sequences give the same prediction when run alone
     eng2 = SAVPEngine(hp, (64, 64, 3), 2, mode='test', seed=4)

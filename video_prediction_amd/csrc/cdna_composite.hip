@@ -265,81 +265,103 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
 #define MAXM 16
 struct CompP {
     int N, HW, M, C;
-    const float* logits;
+    const float* logits; int ls;           // [N*HW, ls] (ls >= M: row stride, padded for aligned conv stores)
     const float* timgs; long long t_sn, t_sp;
     float* gen; long long g_sn, g_sp;
     float* masks;                          // optional [N*HW, M]
     const float* dgen; long long dg_sn, dg_sp;
-    float* dlogits;                        // [N*HW, M]
-    float* dtimgs; long long dt_sn, dt_sp; int dt_beta;
+    float* dlogits;                        // [N*HW, ls] (pad columns written as 0)
+    float* drow; long long dr_sn, dr_sp;   // gradient row of the whole mask-conv input buffer [N,HW,rowc]
+    int toff, rowc;                        // timgs live at channels [toff, toff+M*C); everything else is written as 0
 };
 
+template <int TM, int TC>
 __global__ void composite_fwd_kernel(CompP p) {
+    const int M = TM ? TM : p.M, C = TC ? TC : p.C;
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= (long long)p.N * p.HW) return;
     const int n = (int)(i / p.HW), px = (int)(i % p.HW);
-    const float* lg = p.logits + i * p.M;
-    float m[MAXM];
+    const float* lg = p.logits + i * p.ls;
+    float m[TM ? TM : MAXM];
     float mx = -3.4e38f;
-    for (int k = 0; k < p.M; ++k) { m[k] = lg[k]; mx = fmaxf(mx, m[k]); }
+#pragma unroll
+    for (int k = 0; k < M; ++k) { m[k] = lg[k]; mx = fmaxf(mx, m[k]); }
     float s = 0.f;
-    for (int k = 0; k < p.M; ++k) { m[k] = __expf(m[k] - mx); s += m[k]; }
+#pragma unroll
+    for (int k = 0; k < M; ++k) { m[k] = __expf(m[k] - mx); s += m[k]; }
     const float inv = 1.f / s;
     const float* t = p.timgs + (long long)n * p.t_sn + (long long)px * p.t_sp;
-    float g[MAXC];
+    float g[TC ? TC : MAXC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) g[c] = 0.f;
-    for (int k = 0; k < p.M; ++k) {
+    for (int c = 0; c < C; ++c) g[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
         m[k] *= inv;
-        for (int c = 0; c < p.C; ++c) g[c] += m[k] * t[k * p.C + c];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] += m[k] * t[k * C + c];
     }
     float* go = p.gen + (long long)n * p.g_sn + (long long)px * p.g_sp;
-    for (int c = 0; c < p.C; ++c) go[c] = g[c];
-    if (p.masks)
-        for (int k = 0; k < p.M; ++k) p.masks[i * p.M + k] = m[k];
+#pragma unroll
+    for (int c = 0; c < C; ++c) go[c] = g[c];
+    if (p.masks) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) p.masks[i * M + k] = m[k];
+    }
 }
 
+template <int TM, int TC>
 __global__ void composite_bwd_kernel(CompP p) {
+    const int M = TM ? TM : p.M, C = TC ? TC : p.C;
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= (long long)p.N * p.HW) return;
     const int n = (int)(i / p.HW), px = (int)(i % p.HW);
-    const float* lg = p.logits + i * p.M;
-    float m[MAXM], sk[MAXM];
+    const float* lg = p.logits + i * p.ls;
+    float m[TM ? TM : MAXM], sk[TM ? TM : MAXM];
     float mx = -3.4e38f;
-    for (int k = 0; k < p.M; ++k) { m[k] = lg[k]; mx = fmaxf(mx, m[k]); }
+#pragma unroll
+    for (int k = 0; k < M; ++k) { m[k] = lg[k]; mx = fmaxf(mx, m[k]); }
     float s = 0.f;
-    for (int k = 0; k < p.M; ++k) { m[k] = __expf(m[k] - mx); s += m[k]; }
+#pragma unroll
+    for (int k = 0; k < M; ++k) { m[k] = __expf(m[k] - mx); s += m[k]; }
     const float inv = 1.f / s;
     const float* t = p.timgs + (long long)n * p.t_sn + (long long)px * p.t_sp;
     const float* dg = p.dgen + (long long)n * p.dg_sn + (long long)px * p.dg_sp;
-    float* dt = p.dtimgs + (long long)n * p.dt_sn + (long long)px * p.dt_sp;
-    float d[MAXC];
-    for (int c = 0; c < p.C; ++c) d[c] = dg[c];
+    float* dr = p.drow + (long long)n * p.dr_sn + (long long)px * p.dr_sp;
+    float d[TC ? TC : MAXC];
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = dg[c];
+    for (int c = 0; c < p.toff; ++c) dr[c] = 0.f;
+    for (int c = p.toff + M * C; c < p.rowc; ++c) dr[c] = 0.f;
     float dot = 0.f;
-    for (int k = 0; k < p.M; ++k) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
         m[k] *= inv;
         float a = 0.f;
-        for (int c = 0; c < p.C; ++c) {
-            a += d[c] * t[k * p.C + c];
-            float v = m[k] * d[c];
-            dt[k * p.C + c] = p.dt_beta ? dt[k * p.C + c] + v : v;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            a += d[c] * t[k * C + c];
+            dr[p.toff + k * C + c] = m[k] * d[c];
         }
         sk[k] = a;
         dot += m[k] * a;
     }
-    for (int k = 0; k < p.M; ++k) p.dlogits[i * p.M + k] = m[k] * (sk[k] - dot);
+    float* dl = p.dlogits + i * p.ls;
+#pragma unroll
+    for (int k = 0; k < M; ++k) dl[k] = m[k] * (sk[k] - dot);
+    for (int k = M; k < p.ls; ++k) dl[k] = 0.f;
 }
 
 static int fill_comp(CompP& p, const SavpCompositeArgs* a) {
-    if (!a || a->M > MAXM || a->C > MAXC || a->M < 1 || a->C < 1) return SAVP_EINVAL;
+    if (!a || a->M > MAXM || a->C > MAXC || a->M < 1 || a->C < 1 || a->logits_stride < a->M) return SAVP_EINVAL;
     p.N = a->N; p.HW = a->HW; p.M = a->M; p.C = a->C;
-    p.logits = a->logits;
+    p.logits = a->logits; p.ls = a->logits_stride;
     p.timgs = (const float*)a->timgs.p; p.t_sn = a->timgs.sn; p.t_sp = a->timgs.sp;
     p.gen = (float*)a->gen.p; p.g_sn = a->gen.sn; p.g_sp = a->gen.sp;
     p.masks = a->masks;
     p.dgen = (const float*)a->dgen.p; p.dg_sn = a->dgen.sn; p.dg_sp = a->dgen.sp;
     p.dlogits = a->dlogits;
-    p.dtimgs = (float*)a->dtimgs.p; p.dt_sn = a->dtimgs.sn; p.dt_sp = a->dtimgs.sp; p.dt_beta = a->dt_beta;
+    p.drow = (float*)a->drow.p; p.dr_sn = a->drow.sn; p.dr_sp = a->drow.sp;
+    p.toff = a->timgs_offset; p.rowc = a->row_channels;
     return SAVP_OK;
 }
 
@@ -348,7 +370,10 @@ extern "C" int savp_composite_fwd(void* stream, const SavpCompositeArgs* a) {
     int rc = fill_comp(p, a);
     if (rc) return rc;
     long long tot = (long long)a->N * a->HW;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, p);
+    dim3 grid((unsigned)((tot + NT - 1) / NT));
+    if (a->M == 7 && a->C == 3) hipLaunchKernelGGL((composite_fwd_kernel<7, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else if (a->M == 7 && a->C == 1) hipLaunchKernelGGL((composite_fwd_kernel<7, 1>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_fwd_kernel<0, 0>), grid, dim3(NT), 0, (hipStream_t)stream, p);
     return LAUNCH_OK();
 }
 
@@ -356,7 +381,11 @@ extern "C" int savp_composite_bwd(void* stream, const SavpCompositeArgs* a) {
     CompP p;
     int rc = fill_comp(p, a);
     if (rc) return rc;
+    if (!p.drow || !p.dlogits || a->timgs_offset + a->M * a->C > a->row_channels) return SAVP_EINVAL;
     long long tot = (long long)a->N * a->HW;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, p);
+    dim3 grid((unsigned)((tot + NT - 1) / NT));
+    if (a->M == 7 && a->C == 3) hipLaunchKernelGGL((composite_bwd_kernel<7, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else if (a->M == 7 && a->C == 1) hipLaunchKernelGGL((composite_bwd_kernel<7, 1>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_bwd_kernel<0, 0>), grid, dim3(NT), 0, (hipStream_t)stream, p);
     return LAUNCH_OK();
 }

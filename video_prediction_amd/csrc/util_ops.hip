@@ -297,20 +297,55 @@ extern "C" int savp_sigmoid_bwd(void* stream, SavpView dy, SavpView y, float* ou
 // dense layer with few rows (M <= 64): out[m,c] = scale * sum_k x[m,k] W[k,c] + bias[c]    (ops.dense, ops.py:5-16)
 // split over K across workgroups (the implicit-GEMM kernel would put the whole K loop into a single workgroup).
 // Used for the CDNA kernel head (8192 -> 100) and the discriminators' final linear (65536 -> 1).
+// one workgroup = one K-chunk of 64 rows of W: x-chunk [M][64] and W-chunk [64][C] are staged in LDS, thread (c, g)
+// accumulates the outputs of column c for the samples m = g, g+G, ... ; partial sums are atomically added to out.
+#define DKC 64
 __global__ __launch_bounds__(NT) void dense_smallm_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
                                                           const float* __restrict__ W, const float* bias, const float* scale,
-                                                          float* out, int kc) {
-    const long long k0 = (long long)blockIdx.x * kc;
-    const long long k1 = min(Kd, k0 + kc);
+                                                          float* out) {
+    extern __shared__ float dsm[];
+    float* xsh = dsm;                 // [M][DKC]
+    float* wsh = dsm + M * DKC;       // [DKC][C]
+    const long long k0 = (long long)blockIdx.x * DKC;
+    const int kn = (int)min((long long)DKC, Kd - k0);
+    for (int i = threadIdx.x; i < M * DKC; i += NT) {
+        int m = i / DKC, k = i % DKC;
+        xsh[i] = k < kn ? x[(long long)m * xs + k0 + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < DKC * C; i += NT) {
+        int k = i / C;
+        wsh[i] = k < kn ? W[(k0 + k) * C + (i % C)] : 0.f;
+    }
+    __syncthreads();
     const float sc = scale ? *scale : 1.f;
-    for (int o = threadIdx.x; o < M * C; o += NT) {
-        const int m = o / C, c = o % C;
-        const float* xr = x + (long long)m * xs;
-        float acc = 0.f;
-        for (long long k = k0; k < k1; ++k) acc += xr[k] * W[k * C + c];
-        acc *= sc;
-        if (blockIdx.x == 0 && bias) acc += bias[c];
-        unsafeAtomicAdd(out + o, acc);
+    // thread -> (column c, sample group g); CT columns per pass
+    const int CT = C >= NT ? NT : C;
+    const int G = NT / CT;                     // sample groups
+    const int c0 = threadIdx.x % CT, g = threadIdx.x / CT;
+    if (g >= G) return;
+    for (int c = c0; c < C; c += CT) {
+        for (int mb = g; mb < M; mb += G * 8) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            for (int k = 0; k < DKC; ++k) {
+                const float w = wsh[k * C + c];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = mb + i * G;
+                    if (m < M) acc[i] += xsh[m * DKC + k] * w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + i * G;
+                if (m < M) {
+                    float v = acc[i] * sc;
+                    if (blockIdx.x == 0 && bias) v += bias[c];
+                    unsafeAtomicAdd(out + (long long)m * C + c, v);
+                }
+            }
+        }
     }
 }
 
@@ -319,8 +354,9 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
     if (!x || !W || !out || M < 1 || K < 1 || C < 1) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
-    int kc = 128;
-    hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((K + kc - 1) / kc)), dim3(NT), 0, st, x, (long long)x_row_stride, M,
-                       (long long)K, C, W, bias, scale, out, kc);
+    if (M > 64 || C > 256) return SAVP_EINVAL;
+    size_t lds = (size_t)(M * DKC + DKC * C) * sizeof(float);
+    hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((K + DKC - 1) / DKC)), dim3(NT), lds, st, x, (long long)x_row_stride, M,
+                       (long long)K, C, W, bias, scale, out);
     return LAUNCH_OK();
 }

@@ -158,7 +158,7 @@ class ConvLayer(object):
     ``sn_u`` names the spectral-norm vector of a discriminator layer (kernel is divided by sigma on the fly).
     """
 
-    def __init__(self, store, kernel_name, bias_name, kind, ksize, stride, pad, sn_u=None):
+    def __init__(self, store, kernel_name, bias_name, kind, ksize, stride, pad, sn_u=None, cx_pad=None, cy_pad=None):
         self.store = store
         self.kernel_name, self.bias_name, self.kind = kernel_name, bias_name, kind
         W = store[kernel_name]
@@ -193,6 +193,22 @@ class ConvLayer(object):
         p3 = tuple(pad) if len(pad) == 3 else (0,) + tuple(pad)
         self.geom = K.ConvGeom(k3, s3, p3)
         self.taps = k3[0] * k3[1] * k3[2]
+        # optional zero-padding of the channel counts the kernel sees (activation buffers padded to multiples of 4 so
+        # that every conv takes the float4 / MFMA-bf16 path: 14 -> 16 input channels of h0, 53 -> 56 of the mask conv ...)
+        self.cx0, self.cy0 = self.cx, self.cy
+        self.padded = False
+        if (cx_pad and cx_pad != self.cx) or (cy_pad and cy_pad != self.cy):
+            if kind == 'up' or sn_u:
+                raise NotImplementedError('channel padding for upsample / spectral-norm layers')
+            self.padded = True
+            self.cx, self.cy = cx_pad or self.cx, cy_pad or self.cy
+            self.wfp = torch.zeros(self.taps, self.cx, self.cy, device=dev)
+            self.dwfp = torch.zeros(self.taps, self.cx, self.cy, device=dev)
+            self.dw_tmp = torch.empty(self.taps, self.cx0, self.cy0, device=dev)
+            if self.bias is not None:
+                self.bias_master, self.dbias_master = self.bias, self.dbias
+                self.bias = torch.zeros(self.cy, device=dev)
+                self.dbias = torch.zeros(self.cy, device=dev)
         self.wt = torch.empty(self.cy, self.taps * self.cx, device=dev)
         self.wd = torch.empty(self.cx, self.taps * self.cy, device=dev)
         self.sn_u_name = sn_u
@@ -216,7 +232,13 @@ class ConvLayer(object):
         if self.sn_u_name:
             K.sn_fwd(self.W, self.u.reshape(-1), self.sn_ws, self.u_next.reshape(-1) if update_u else None)
             scale = self.sn_ws[1:2]
-        K.pack_weights(self.wf, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale)
+        src = self.wf
+        if self.padded:
+            copy_view(self.wf.reshape(self.taps, self.cx0, self.cy0), [self.wfp[:, :self.cx0, :self.cy0]])
+            if self.bias is not None:
+                K.axpby(1.0, self.bias_master, 0.0, None, self.bias[:self.cy0])
+            src = self.wfp
+        K.pack_weights(src, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale)
 
     def commit_u(self):
         """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
@@ -250,7 +272,7 @@ class ConvLayer(object):
     def backward_weights(self, x, dy):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may
         carry folded leading (time, batch) dims: [R, (D,) H, W, C]."""
-        target = self.dwf if self.dwf is not None else self.dW
+        target = self.dwfp if self.padded else (self.dwf if self.dwf is not None else self.dW)
         if self.kind == 'up':
             K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
             bias_src = dy
@@ -262,6 +284,14 @@ class ConvLayer(object):
 
     def finish_weight_grad(self):
         """Map the folded / spectrally-normalised kernel gradient back to the master variable and clear it."""
+        if self.padded:
+            copy_view(self.dwfp[:, :self.cx0, :self.cy0], [self.dw_tmp])
+            tgt = self.dwf if self.dwf is not None else self.dW
+            K.axpby(1.0, self.dw_tmp.reshape(-1), 1.0, tgt.reshape(-1), tgt.reshape(-1))
+            self.dwfp.zero_()
+            if self.bias is not None:
+                K.axpby(1.0, self.dbias[:self.cy0], 1.0, self.dbias_master, self.dbias_master)
+                self.dbias.zero_()
         if self.dwf is None:
             return
         if self.sn_u_name:

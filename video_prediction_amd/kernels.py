@@ -296,28 +296,35 @@ def cdna_apply_bwd(img, kern, dout, dimg, dkern, kh, kw, K, dimg_beta=0):
     lib.check(_L().savp_cdna_apply_bwd(lib.stream(), ctypes.byref(a)), 'savp_cdna_apply_bwd')
 
 
-def _comp_args(logits, timgs, C):
+def _comp_args(logits, timgs, C, M):
     a = lib.SavpCompositeArgs()
-    a.N, a.HW, a.M, a.C = logits.shape[0], _hw(logits), logits.shape[-1], C
+    a.N, a.HW, a.M, a.C = logits.shape[0], _hw(logits), M, C
     assert logits.is_contiguous()
     a.logits = _p(logits)
+    a.logits_stride = logits.shape[-1]
     a.timgs = view(timgs)
     return a
 
 
-def composite_fwd(logits, timgs, gen, masks=None):
-    a = _comp_args(logits, timgs, gen.shape[-1])
+def composite_fwd(logits, timgs, gen, masks=None, M=None):
+    """logits [N,H,W,ls] (first M columns used), timgs view [N,H,W,M*C]."""
+    M = M or logits.shape[-1]
+    a = _comp_args(logits, timgs, gen.shape[-1], M)
     a.gen = view(gen)
     a.masks = _p(masks)
     lib.check(_L().savp_composite_fwd(lib.stream(), ctypes.byref(a)), 'savp_composite_fwd')
 
 
-def composite_bwd(logits, timgs, dgen, dlogits, dtimgs, dt_beta=0):
-    a = _comp_args(logits, timgs, dgen.shape[-1])
+def composite_bwd(logits, timgs, dgen, dlogits, drow, timgs_offset, M=None):
+    """Writes dlogits and the whole gradient row `drow` [N,H,W,rowc] of the mask-conv input (zeros outside the
+    transformed-image channels)."""
+    M = M or logits.shape[-1]
+    a = _comp_args(logits, timgs, dgen.shape[-1], M)
     a.dgen = view(dgen)
+    assert dlogits.is_contiguous() and dlogits.shape == logits.shape
     a.dlogits = _p(dlogits)
-    a.dtimgs = view(dtimgs)
-    a.dt_beta = int(dt_beta)
+    a.drow = view(drow)
+    a.timgs_offset, a.row_channels = int(timgs_offset), drow.shape[-1]
     lib.check(_L().savp_composite_bwd(lib.stream(), ctypes.byref(a)), 'savp_composite_bwd')
 
 

@@ -145,8 +145,8 @@ class SavpCdnaArgs(ctypes.Structure):
 class SavpCompositeArgs(ctypes.Structure):
     _fields_ = [
         ('N', c_i32), ('HW', c_i32), ('M', c_i32), ('C', c_i32),
-        ('logits', c_vp), ('timgs', SavpView), ('gen', SavpView), ('masks', c_vp),
-        ('dgen', SavpView), ('dlogits', c_vp), ('dtimgs', SavpView), ('dt_beta', c_i32),
+        ('logits', c_vp), ('logits_stride', c_i32), ('timgs', SavpView), ('gen', SavpView), ('masks', c_vp),
+        ('dgen', SavpView), ('dlogits', c_vp), ('drow', SavpView), ('timgs_offset', c_i32), ('row_channels', c_i32),
     ]
 
 

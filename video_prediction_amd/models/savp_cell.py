@@ -23,6 +23,10 @@ from ..variables import layer_specs, num_masks
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
 
 
+def ceil4(n):
+    return (n + 3) // 4 * 4
+
+
 class Act(object):
     """Time-major activation buffer with an optional gradient twin."""
 
@@ -84,10 +88,11 @@ class SAVPGenerator(object):
             if i < self.ne:
                 cx = 2 * C if i == 0 else prev_f
                 k = 5 if i == 0 else 3
-                L['in'] = Act((T1, N, h_, w_, cx + zc), dev, grad=g)
+                L['in'] = Act((T1, N, h_, w_, ceil4(cx + zc)), dev, grad=g)      # pad channels stay zero
                 L['zoff_in'] = cx
                 L['conv'] = ConvLayer(store, s + 'conv_pool2d/kernel', s + 'conv_pool2d/bias', 'pool', (k, k), (2, 2),
-                                      (same_pad_before(k + 1, 2, h_), same_pad_before(k + 1, 2, w_)))
+                                      (same_pad_before(k + 1, 2, h_), same_pad_before(k + 1, 2, w_)),
+                                      cx_pad=ceil4(cx + zc))
                 h_, w_ = h_ // 2, w_ // 2
             else:
                 j = i - self.ne
@@ -138,19 +143,23 @@ class SAVPGenerator(object):
         self.scratch_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
         self.scratch_h = Act((T1, N, H, W, ngf), dev, grad=g)
         s = prefix + 'scratch_image/'
-        self.scratch_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
-        self.dscratch_pre = torch.empty(T1, N, H, W, C, device=dev) if g else None
+        self.Cs = Cs = ceil4(C)                       # scratch conv writes a 4-aligned channel group into its maskin slot
+        self.scratch_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1), cy_pad=Cs)
+        self.dscratch_pre = torch.empty(T1, N, H, W, Cs, device=dev) if g else None
         s = prefix + 'h%d_masks/' % nl
         self.masks_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
         self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g)
         self.masks_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
         # maskin = [h_masks (ngf) | nk CDNA images | prev image | first image | scratch image]   (savp_model.py:632)
-        self.maskin = Act((T1, N, H, W, ngf + M * C), dev, grad=g)
+        self.Cmask = Cmask = ceil4(ngf + M * C + (Cs - C))        # scratch slot is last: room for its padded write
+        self.Ml = Ml = ceil4(M)                                    # padded logits row
+        self.maskin = Act((T1, N, H, W, Cmask), dev, grad=g)
         self.o_cdna, self.o_prev = ngf, ngf + nk * C
         self.o_first, self.o_scratch = ngf + (nk + 1) * C, ngf + (nk + 2) * C
         s = prefix + 'masks/'
-        self.masks_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
-        self.logits = Act((T1, N, H, W, M), dev, grad=g)
+        self.masks_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1),
+                                   cx_pad=Cmask, cy_pad=Ml)
+        self.logits = Act((T1, N, H, W, Ml), dev, grad=g)
         self.masks = torch.empty(T1, N, H, W, M, device=dev)
         self.gen = Act((T1, N, H, W, C), dev, grad=g, zero_grad=True)
         self.dimg_cdna = torch.empty(N, H, W, C, device=dev) if g else None
@@ -261,7 +270,7 @@ class SAVPGenerator(object):
             sn = self.scratch_norm
             K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
                                act='relu', eps=EPS_IN)
-            self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + C],
+            self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs],
                                      act=lib.ACT_SIGMOID)
             # masks (savp_model.py:623-646)
             self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
@@ -269,8 +278,8 @@ class SAVPGenerator(object):
             K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
                                act='relu', eps=EPS_IN)
             self.masks_out.forward(maskin.v[t], self.logits.v[t])
-            K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:], self.gen.v[t],
-                            self.masks[t] if collect_masks else None)
+            K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:self.hp.ngf + self.M * C], self.gen.v[t],
+                            self.masks[t] if collect_masks else None, M=self.M)
         return self.gen.v
 
     # ---------------------------------------------------------------------------------------------------------
@@ -282,16 +291,16 @@ class SAVPGenerator(object):
         in0, maskin = self.layers[0]['in'], self.maskin
         for t in range(T1 - 1, -1, -1):
             # composite + masks head
-            K.composite_bwd(self.logits.v[t], maskin.v[t][..., ngf:], self.gen.g[t], self.logits.g[t], maskin.g[t][..., ngf:])
-            K.fill_view(maskin.g[t][..., 0:ngf], 0.0)
+            K.composite_bwd(self.logits.v[t], maskin.v[t][..., ngf:ngf + self.M * C], self.gen.g[t], self.logits.g[t], maskin.g[t],
+                            ngf, M=self.M)
             self.masks_out.backward_data(self.logits.g[t], maskin.g[t], beta=1)
             mn = self.masks_norm
             K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
                                [maskin.g[t][..., 0:ngf]], self.masks_pre.g[t], mn.dgamma, mn.dbeta, act='relu', eps=EPS_IN)
             self.masks_conv.backward_data(self.masks_pre.g[t], self.h_last.g[t], beta=0)
             # scratch head
-            K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + C], maskin.v[t][..., self.o_scratch:self.o_scratch + C],
-                          self.dscratch_pre[t])
+            K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + self.Cs],
+                          maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs], self.dscratch_pre[t])
             self.scratch_out.backward_data(self.dscratch_pre[t], self.scratch_h.g[t], beta=0)
             sn = self.scratch_norm
             K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
@@ -340,7 +349,7 @@ class SAVPGenerator(object):
         self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
         hl = self.h_last
         self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
-        self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, C))
+        self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
         self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
         self.masks_out.backward_weights(hl.flat(maskin.v), hl.flat(self.logits.g))
         for c in self.convs:

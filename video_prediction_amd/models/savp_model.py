@@ -337,7 +337,7 @@ def generator_fn(inputs, mode, hparams, engine=None, noise=None):
     gen = eng.forward_generator(noise, collect_masks=True)
     B, C, M = eng.B, eng.image_shape[2], eng.gen.M
     g = eng.gen
-    timgs = g.maskin.v[..., hparams.ngf:].reshape(g.T1, g.N, g.H, g.W, M, C).permute(0, 1, 2, 3, 5, 4)   # [..., C, M]
+    timgs = g.maskin.v[..., hparams.ngf:hparams.ngf + M * C].reshape(g.T1, g.N, g.H, g.W, M, C).permute(0, 1, 2, 3, 5, 4)   # [..., C, M]
     masks = g.masks.reshape(g.T1, g.N, g.H, g.W, 1, M)
     outputs = OrderedDict()
     lo = B if eng.nz else 0
