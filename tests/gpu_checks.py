@@ -367,6 +367,16 @@ def check_cdna_composite(seed=5):
         dk = torch.empty(N, kh * kw, Kk, device=DEV)
         K.cdna_apply_bwd(imgd, kd, dev(dout), dimg, dk, kh, kw, Kk)
         out.append((tag + '/dimg', rel_err(dimg, img.grad), 5e-5))
+        # same through a 16-byte aligned channel slice of a wider buffer (the layout the generator uses: fast kernels)
+        dwide = torch.zeros(N, H, W, 32 + 4 * ((Kk * C + 3) // 4) + 4, device=DEV)
+        dwide[..., 32:32 + Kk * C] = dev(dout)
+        dimg2 = torch.empty(N, H, W, C, device=DEV)
+        dk2 = torch.full((N, kh * kw, Kk), float('nan'), device=DEV)
+        K.cdna_apply_bwd(imgd, kd, dwide[..., 32:32 + Kk * C], dimg2, dk2, kh, kw, Kk)
+        out.append((tag + '/dimg_fast', rel_err(dimg2, img.grad), 5e-5))
+        draw2 = torch.empty(N, kh * kw * Kk, device=DEV)
+        K.cdna_kernels_bwd(rawd, dk2, draw2, kh, kw, Kk)
+        out.append((tag + '/draw_fast', rel_err(draw2.reshape(N, kh, kw, Kk), raw.grad), 5e-5))
         draw = torch.empty(N, kh * kw * Kk, device=DEV)
         K.cdna_kernels_bwd(rawd, dk, draw, kh, kw, Kk)
         out.append((tag + '/draw', rel_err(draw.reshape(N, kh, kw, Kk), raw.grad), 5e-5))

@@ -227,6 +227,121 @@ __global__ __launch_bounds__(NT) void cdna_apply_bwd_kern_kernel(CdnaP p) {
     }
 }
 
+// ---- specialised (compile-time kh,kw,K,C) backward kernels: fully unrolled, vector loads of the K*C gradient row -----
+template <int KH, int KW, int TK, int TC>
+__global__ __launch_bounds__(NT) void cdna_bwd_img_fast_kernel(CdnaP p) {
+    __shared__ float sk[KH * KW * TK];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < KH * KW * TK; i += NT) sk[i] = p.kern[(long long)n * KH * KW * TK + i];
+    __syncthreads();
+    const int px = blockIdx.x * NT + threadIdx.x;
+    if (px >= p.H * p.W) return;
+    const int sy = px / p.W, sx = px % p.W;
+    constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2, PB = KH - 1 - PT, PR = KW - 1 - PL;
+    int qy[3], nqy = 0, qx[3], nqx = 0;
+    qy[nqy++] = sy;
+    if (-sy - 1 >= -PT) qy[nqy++] = -sy - 1;
+    if (2 * p.H - 1 - sy < p.H + PB && 2 * p.H - 1 - sy >= p.H) qy[nqy++] = 2 * p.H - 1 - sy;
+    qx[nqx++] = sx;
+    if (-sx - 1 >= -PL) qx[nqx++] = -sx - 1;
+    if (2 * p.W - 1 - sx < p.W + PR && 2 * p.W - 1 - sx >= p.W) qx[nqx++] = 2 * p.W - 1 - sx;
+    float acc[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[c] = 0.f;
+    const float* dout = p.dout + (long long)n * p.do_sn;
+    for (int a = 0; a < nqy; ++a)
+        for (int b = 0; b < nqx; ++b) {
+#pragma unroll
+            for (int u = 0; u < KH; ++u) {
+                const int y = qy[a] - u + PT;
+                if (y < 0 || y >= p.H) continue;
+#pragma unroll
+                for (int v = 0; v < KW; ++v) {
+                    const int x = qx[b] - v + PL;
+                    if (x < 0 || x >= p.W) continue;
+                    const float* d = dout + (long long)(y * p.W + x) * p.do_sp;
+                    float dv[TK * TC];
+                    if ((TK * TC) % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < TK * TC / 4; ++q) {
+                            float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                            dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < TK * TC; ++q) dv[q] = d[q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        const float w = sk[(u * KW + v) * TK + k];
+#pragma unroll
+                        for (int c = 0; c < TC; ++c) acc[c] += dv[k * TC + c] * w;
+                    }
+                }
+            }
+        }
+    float* di = p.dimg + (long long)n * p.di_sn + (long long)px * p.di_sp;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) di[c] = p.dimg_beta ? di[c] + acc[c] : acc[c];
+}
+
+// grid (pixel chunks, N): every thread accumulates all taps x K for its pixels, block-reduces and atomically adds.
+template <int KH, int KW, int TK, int TC>
+__global__ __launch_bounds__(NT) void cdna_bwd_kern_fast_kernel(CdnaP p, int chunk) {
+    constexpr int NV = KH * KW * TK;
+    __shared__ float sh[4 * NV];
+    const int n = blockIdx.y;
+    constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    const float* im = p.img + (long long)n * p.i_sn;
+    const float* dout = p.dout + (long long)n * p.do_sn;
+    const int p0 = blockIdx.x * chunk, p1 = min(p.H * p.W, p0 + chunk);
+    for (int px = p0 + threadIdx.x; px < p1; px += NT) {
+        const int y = px / p.W, x = px % p.W;
+        float dv[TK * TC];
+        const float* d = dout + (long long)px * p.do_sp;
+        if ((TK * TC) % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < TK * TC / 4; ++q) {
+                float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < TK * TC; ++q) dv[q] = d[q];
+        }
+#pragma unroll
+        for (int u = 0; u < KH; ++u) {
+            const int yy = sym(y + u - PT, p.H);
+#pragma unroll
+            for (int v = 0; v < KW; ++v) {
+                const float* q = im + (long long)(yy * p.W + sym(x + v - PL, p.W)) * p.i_sp;
+                float pix[TC];
+#pragma unroll
+                for (int c = 0; c < TC; ++c) pix[c] = q[c];
+#pragma unroll
+                for (int k = 0; k < TK; ++k) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) s += pix[c] * dv[k * TC + c];
+                    acc[(u * KW + v) * TK + k] += s;
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = wsum(acc[i]);
+        if (lane == 0) sh[wave * NV + i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += NT)
+        unsafeAtomicAdd(p.dkern + (long long)n * NV + i, sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i]);
+}
+
 static int fill_cdna(CdnaP& p, const SavpCdnaArgs* a) {
     if (!a || a->kh * a->kw > MAXTAPS || a->K > MAXK || a->C > MAXC || a->K < 1 || a->C < 1) return SAVP_EINVAL;
     p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.K = a->K; p.kh = a->kh; p.kw = a->kw;
@@ -252,10 +367,26 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
     CdnaP p;
     int rc = fill_cdna(p, a);
     if (rc) return rc;
-    if (p.dimg)
-        hipLaunchKernelGGL(cdna_apply_bwd_img_kernel, dim3((a->H * a->W + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream, p);
-    if (p.dkern)
-        hipLaunchKernelGGL(cdna_apply_bwd_kern_kernel, dim3(a->K, a->N), dim3(NT), 0, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = ((uintptr_t)a->dout.p % 16 == 0) && (a->dout.sn % 4 == 0) && (a->dout.sp % 4 == 0);
+    const int fast = (a->kh == 5 && a->kw == 5 && a->K == 4 && a->C == 3 && al) ? 3 : ((a->kh == 5 && a->kw == 5 && a->K == 4 && a->C == 1 && al) ? 1 : 0);
+    dim3 gimg((a->H * a->W + NT - 1) / NT, a->N);
+    if (p.dimg) {
+        if (fast == 3) hipLaunchKernelGGL((cdna_bwd_img_fast_kernel<5, 5, 4, 3>), gimg, dim3(NT), 0, st, p);
+        else if (fast == 1) hipLaunchKernelGGL((cdna_bwd_img_fast_kernel<5, 5, 4, 1>), gimg, dim3(NT), 0, st, p);
+        else hipLaunchKernelGGL(cdna_apply_bwd_img_kernel, gimg, dim3(NT), 0, st, p);
+    }
+    if (p.dkern) {
+        if (fast) {
+            const int chunk = 512;
+            hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            dim3 gk((a->H * a->W + chunk - 1) / chunk, a->N);
+            if (fast == 3) hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 3>), gk, dim3(NT), 0, st, p, chunk);
+            else hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 1>), gk, dim3(NT), 0, st, p, chunk);
+        } else {
+            hipLaunchKernelGGL(cdna_apply_bwd_kern_kernel, dim3(a->K, a->N), dim3(NT), 0, st, p);
+        }
+    }
     return LAUNCH_OK();
 }
 
