@@ -9,6 +9,7 @@ from video_prediction_amd.models.savp_model import SAVPEngine
 def main():
     from video_prediction_amd import kernels as K
     K.set_conv_precision(os.environ.get('PREC', 'f32'))
+    K.enable_autotune(os.environ.get('TUNE', '1') == '1')
     B = int(os.environ.get('B', 16)); T = int(os.environ.get('T', 30)); steps = int(os.environ.get('STEPS', 3))
     hp = make_hparams(context_frames=2, sequence_length=T, batch_size=B, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
@@ -24,6 +25,9 @@ def main():
         info = eng.train_step()
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
+    if os.environ.get('TUNELOG'):
+        for key, cfg in K.AUTOTUNE['log']:
+            print('tuned', key[:1], key[2:11], '->', hex(cfg[0]), cfg[1])
     print('step %.1f ms  -> %.1f frames/s ; d_loss %.4f g_loss %.4f ; mem %.1f GB' % (dt * 1e3, B * T / dt, float(info['d_loss']), float(info['g_loss']), torch.cuda.max_memory_allocated() / 2**30))
 
 if __name__ == '__main__':

@@ -99,8 +99,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     char* Bs = As + 2 * BM * ROWB;                     // [2][BN] rows
 
     const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
-    // phase decode (DGRAD only): blockIdx.z -> (fd, fh, fw)
-    int fz = blockIdx.z;
+    // blockIdx.z = phase * splitk + split ; phase decode (DGRAD only) -> (fd, fh, fw)
+    const int split = blockIdx.z % p.splitk;
+    int fz = blockIdx.z / p.splitk;
     int fw = dgrad ? fz % p.sw : 0; fz = dgrad ? fz / p.sw : 0;
     int fh = dgrad ? fz % p.sh : 0; fz = dgrad ? fz / p.sh : 0;
     int fd = fz;
@@ -155,9 +156,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
         b_base[j] = (long long)(b_ok[j] ? n : 0) * ldb;
     }
     // ---- K state (vector path): this thread's float4 sits at k = kt*32 + kv*4 -------------------------------
+    // split-K: this workgroup reduces K-tiles [kt_begin, kt_end)
+    const int nk_all = (K + BKT - 1) / BKT;
+    const int kt_per = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt_begin = split * kt_per;
+    const int kt_end = min(nk_all, kt_begin + kt_per);
     int kc = 0, jd = 0, jh = 0, jw = 0;     // channel offset, reduced tap indices
     if (VEC) {
-        int k = kv * 4;
+        int k = kt_begin * BKT + kv * 4;
         kc = k % Cred; int tap = k / Cred;
         jw = tap % max(gw.nt, 1); tap /= max(gw.nt, 1);
         jh = tap % max(gh.nt, 1); jd = tap / max(gh.nt, 1);
@@ -253,16 +259,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
 
     const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int nk = (K + BKT - 1) / BKT;
-
-    if (nk > 0) {
-        fetch(0);
+    if (kt_begin < kt_end) {
+        fetch(kt_begin);
         stage(0);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) fetch(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) fetch(kt + 1);
         const char* a = As + cur * BM * ROWB;
         const char* b = Bs + cur * BN * ROWB;
         if (BF16) {
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                     }
             }
         }
-        if (kt + 1 < nk) stage(cur ^ 1);
+        if (kt + 1 < kt_end) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn0 + j * 32 + l31;
         if (col >= Nout) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        const float bias = (p.bias && split == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -339,6 +343,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                 if (off < 0) continue;
                 float v = acc[i][j][r] + bias;
                 float* q = dst + off + col;
+                if (p.splitk > 1) {               // partial sums: destination pre-zeroed (or beta) by the launcher
+                    unsafeAtomicAdd(q, v);
+                    continue;
+                }
                 if (p.beta) v += *q;
                 if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
                 else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -779,7 +787,34 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
         if (!wm) pick_tile(Mmax * phases, Nout, wm, wn);
         const int BM = 64 * wm, BN = 64 * wn;
-        dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((Nout + BN - 1) / BN), (unsigned)phases);
+        // split-K (plain epilogue only): fills the chip when M*N is small and K is long (8x8 / 16x16 ConvLSTM layers)
+        int splitk = a->splitk;
+        const long long tiles = ((Mmax + BM - 1) / BM) * ((Nout + BN - 1) / BN) * phases;
+        const long long taps_max = (long long)a->kd * a->kh * a->kw / (dg ? phases : 1);
+        const long long nkt = (taps_max * Cred + (p.bf16 ? 63 : 31)) / (p.bf16 ? 64 : 32);
+        const bool can_split = (a->act == SAVP_ACT_NONE);
+        if (!can_split) splitk = 1;
+        else if (splitk <= 0) {
+            splitk = 1;
+            if (tiles <= 192 && nkt >= 16) {
+                long long s1 = 512 / tiles, s2 = nkt / 8;
+                splitk = (int)(s1 < s2 ? s1 : s2);
+                if (splitk < 1) splitk = 1;
+                if (splitk > 16) splitk = 16;
+            }
+        }
+        if (splitk > 1 && !a->beta) {
+            // destination must be one dense block so that it can be cleared with a single memset
+            const long long dD = dg ? a->D : a->Do, dH = dg ? a->H : a->Ho, dW_ = dg ? a->W : a->Wo;
+            const long long s_n = dg ? a->x_sn : a->y_sn, s_d = dg ? a->x_sd : a->y_sd, s_h = dg ? a->x_sh : a->y_sh,
+                            s_w = dg ? a->x_sw : a->y_sw;
+            const bool dense = (s_w == Nout) && (s_h == dW_ * Nout) && (dD == 1 || s_d == dH * dW_ * Nout) &&
+                               (s_n == dD * dH * dW_ * Nout);
+            if (dense) hipMemsetAsync(p.out, 0, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
+            else splitk = 1;
+        }
+        p.splitk = splitk;
+        dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((Nout + BN - 1) / BN), (unsigned)(phases * splitk));
         if (wm == 2 && wn == 2) err = launch_fd<2, 2>(p, vec, grid, st);
         else if (wm == 2 && wn == 1) err = launch_fd<2, 1>(p, vec, grid, st);
         else if (wm == 1 && wn == 2) err = launch_fd<1, 2>(p, vec, grid, st);

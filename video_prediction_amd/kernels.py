@@ -48,9 +48,16 @@ def set_conv_precision(name):
     PRECISION['value'] = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None):
-    """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h."""
-    lib.require_device(x, y, w, bias, aux)
+AUTOTUNE = {'enabled': False, 'cache': {}, 'log': []}
+
+
+def enable_autotune(flag=True):
+    """First use of every distinct conv problem times the tile / split-K candidates on the device and caches the best.
+    (Launch-time selection only: every candidate computes the same result up to fp32 summation order.)"""
+    AUTOTUNE['enabled'] = bool(flag)
+
+
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -74,6 +81,71 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
         dst = x if mode == lib.CONV_DGRAD else y
         if aux.stride() != dst.stride() or aux.shape != dst.shape:
             raise ValueError('aux must be addressed like the destination')
+    return a
+
+
+def _tune(a, mode, dst, w):
+    """Time candidate (tile, splitk) pairs for this problem; returns the fastest."""
+    fn = lib.get().savp_conv
+    st = lib.stream()
+    tiles = (0x22, 0x21, 0x12, 0x11)
+    if mode == lib.CONV_WGRAD:
+        cands = [(t, sk) for t in tiles for sk in (0,)]
+        scratch = torch.zeros_like(w)
+        real_w = a.w
+        a.w = scratch.data_ptr()
+    else:
+        splits = (1, 2, 4, 8) if a.act == 0 else (1,)
+        cands = [(t, sk) for t in tiles for sk in splits]
+        real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
+        scratch = None
+        if a.beta:                       # never accumulate tuning runs into the real destination
+            scratch = torch.empty_like(dst)
+            if scratch.stride() != dst.stride():
+                scratch = torch.empty(dst.untyped_storage().size() // 4, device=dst.device)  # same addressing
+            if mode == lib.CONV_DGRAD:
+                a.x = scratch.data_ptr()
+            else:
+                a.y = scratch.data_ptr()
+            a.beta = 0
+    best, best_t = None, 1e30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for tile, sk in cands:
+        a.tile, a.splitk = tile, sk
+        if fn(st, ctypes.byref(a)) != 0:
+            continue
+        e0.record()
+        fn(st, ctypes.byref(a))
+        fn(st, ctypes.byref(a))
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = (tile, sk), t
+    if mode == lib.CONV_WGRAD:
+        a.w = real_w
+    else:
+        a.beta = real_beta
+        if mode == lib.CONV_DGRAD:
+            a.x = real_dst
+        else:
+            a.y = real_dst
+    return best or (0, 0)
+
+
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None):
+    """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h."""
+    lib.require_device(x, y, w, bias, aux)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision)
+    if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
+        key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
+               a.x_sw, a.y_sw, bias is not None)
+        cfg = AUTOTUNE['cache'].get(key)
+        if cfg is None:
+            dst = x if mode == lib.CONV_DGRAD else y
+            cfg = AUTOTUNE['cache'][key] = _tune(a, mode, dst, w)
+            AUTOTUNE['log'].append((key, cfg))
+        a.tile, a.splitk = cfg
     lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
 
 
