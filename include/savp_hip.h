@@ -87,6 +87,7 @@ typedef struct SavpInormArgs {
     int32_t ndy; SavpView dy[4];
     SavpView dx; int32_t dx_beta;
     float* dgamma; float* dbeta;
+    float* ws;                     /* optional scratch [N*C*2]; when given and HW >= 2048 the coalesced two-kernel path is used */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);

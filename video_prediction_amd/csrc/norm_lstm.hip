@@ -158,6 +158,154 @@ __global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large planes (H*W >= 2048, e.g. the 64x64x32 decoder / head layers): statistics by a fully coalesced reduction
+// with per-(n,c) atomics, then an elementwise apply pass.  Every lane reads 16 B of a full pixel row, so HBM/L2
+// lines are used completely (the one-workgroup-per-(n,4ch) kernels above use 16 B of each 128-B line).
+// Sums are taken around the first pixel's value (shifted variance) to keep E[x^2]-E[x]^2 well conditioned.
+//   ws layout per call: [N][C][2] floats, zeroed by the launcher.
+// ------------------------------------------------------------------------------------------------------------
+#define CHUNK 256
+__global__ __launch_bounds__(NT) void inorm_stats_kernel(InormP p, float* ws) {
+    extern __shared__ float sh[];                 // [rows][2*C]
+    const int n = blockIdx.y, C = p.C, C4 = C / 4;
+    const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
+    const float* x = p.x + (long long)n * p.x_sn;
+    const float4 k = ld4(x + c4 * 4);             // shift = pixel 0
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    const int p0 = blockIdx.x * CHUNK, p1 = min(p.HW, p0 + CHUNK);
+    if (prow < rows)
+        for (int px = p0 + prow; px < p1; px += rows) {
+            float4 v = ld4(x + (long long)px * p.x_sp + c4 * 4);
+            v.x -= k.x; v.y -= k.y; v.z -= k.z; v.w -= k.w;
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    if (prow < rows) {
+        float* d = sh + prow * 2 * C + c4 * 4;
+        d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+        d[C] = q.x; d[C + 1] = q.y; d[C + 2] = q.z; d[C + 3] = q.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += sh[r * 2 * C + i];
+        const int c = i % C, which = i / C;
+        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* ws) {
+    const int n = blockIdx.y, C = p.C, C4 = C / 4;
+    const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
+    if (prow >= rows) return;
+    const float* x = p.x + (long long)n * p.x_sn;
+    const float4 k = ld4(x + c4 * 4);
+    const float inv = 1.f / (float)p.HW;
+    float m[4], r[4];
+    const float kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* w = ws + ((long long)n * C + c4 * 4 + e) * 2;
+        const float ms = w[0] * inv;
+        const float var = fmaxf(w[1] * inv - ms * ms, 0.f);
+        m[e] = kk[e] + ms; r[e] = rsqrtf(var + p.eps);
+    }
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p.mean[(long long)n * C + c4 * 4 + e] = m[e]; p.rstd[(long long)n * C + c4 * 4 + e] = r[e]; }
+    }
+    const float4 g = ld4(p.gamma + c4 * 4), b = ld4(p.beta + c4 * 4);
+    const int p0 = blockIdx.x * CHUNK, p1 = min(p.HW, p0 + CHUNK);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float4 v = ld4(x + (long long)px * p.x_sp + c4 * 4);
+        float4 o;
+        o.x = act_fwd((v.x - m[0]) * r[0] * g.x + b.x, p.act, p.alpha);
+        o.y = act_fwd((v.y - m[1]) * r[1] * g.y + b.y, p.act, p.alpha);
+        o.z = act_fwd((v.z - m[2]) * r[2] * g.z + b.z, p.act, p.alpha);
+        o.w = act_fwd((v.w - m[3]) * r[3] * g.w + b.w, p.act, p.alpha);
+        for (int kq = 0; kq < p.nout; ++kq) st4(p.out[kq] + (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + c4 * 4, o);
+    }
+}
+
+__device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c0, const float* yo, const float* x, const float m[4],
+                                           const float r[4], float4& xh) {
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < p.ndy; ++k) {
+        float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + c0);
+        d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+    }
+    float4 y = ld4(yo + (long long)px * p.y_sp + c0);
+    d.x *= act_grad_from_out(y.x, p.act, p.alpha); d.y *= act_grad_from_out(y.y, p.act, p.alpha);
+    d.z *= act_grad_from_out(y.z, p.act, p.alpha); d.w *= act_grad_from_out(y.w, p.act, p.alpha);
+    float4 v = ld4(x + (long long)px * p.x_sp + c0);
+    xh.x = (v.x - m[0]) * r[0]; xh.y = (v.y - m[1]) * r[1]; xh.z = (v.z - m[2]) * r[2]; xh.w = (v.w - m[3]) * r[3];
+    return d;
+}
+
+__global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, float* ws) {
+    extern __shared__ float sh[];
+    const int n = blockIdx.y, C = p.C, C4 = C / 4;
+    const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
+    const float* x = p.x + (long long)n * p.x_sn;
+    const float* yo = p.yout + (long long)n * p.y_sn;
+    float m[4], r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m[e] = p.mean[(long long)n * C + c4 * 4 + e]; r[e] = p.rstd[(long long)n * C + c4 * 4 + e]; }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    const int p0 = blockIdx.x * CHUNK, p1 = min(p.HW, p0 + CHUNK);
+    if (prow < rows)
+        for (int px = p0 + prow; px < p1; px += rows) {
+            float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, yo, x, m, r, xh);
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+            q.x += d.x * xh.x; q.y += d.y * xh.y; q.z += d.z * xh.z; q.w += d.w * xh.w;
+        }
+    if (prow < rows) {
+        float* d = sh + prow * 2 * C + c4 * 4;
+        d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+        d[C] = q.x; d[C + 1] = q.y; d[C + 2] = q.z; d[C + 3] = q.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+        float t = 0.f;
+        for (int rr = 0; rr < rows; ++rr) t += sh[rr * 2 * C + i];
+        const int c = i % C, which = i / C;
+        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, t);
+        unsafeAtomicAdd((which ? p.dgamma : p.dbeta) + c, t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const float* ws) {
+    const int n = blockIdx.y, C = p.C, C4 = C / 4;
+    const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
+    if (prow >= rows) return;
+    const float* x = p.x + (long long)n * p.x_sn;
+    const float* yo = p.yout + (long long)n * p.y_sn;
+    float m[4], r[4], s1[4], s2[4];
+    const float inv = 1.f / (float)p.HW;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m[e] = p.mean[(long long)n * C + c4 * 4 + e]; r[e] = p.rstd[(long long)n * C + c4 * 4 + e];
+        s1[e] = ws[((long long)n * C + c4 * 4 + e) * 2] * inv; s2[e] = ws[((long long)n * C + c4 * 4 + e) * 2 + 1] * inv;
+    }
+    const float4 g = ld4(p.gamma + c4 * 4);
+    float* dx = p.dx + (long long)n * p.dx_sn + c4 * 4;
+    const int p0 = blockIdx.x * CHUNK, p1 = min(p.HW, p0 + CHUNK);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, yo, x, m, r, xh);
+        float4 o;
+        o.x = g.x * r[0] * (d.x - s1[0] - xh.x * s2[0]);
+        o.y = g.y * r[1] * (d.y - s1[1] - xh.y * s2[1]);
+        o.z = g.z * r[2] * (d.z - s1[2] - xh.z * s2[2]);
+        o.w = g.w * r[3] * (d.w - s1[3] - xh.w * s2[3]);
+        float* qq = dx + (long long)px * p.dx_sp;
+        if (p.dx_beta) { float4 t = ld4(qq); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        st4(qq, o);
+    }
+}
+
+static bool use_large_plane_path(const SavpInormArgs* a) { return a->ws && a->HW >= 2048 && a->C % 4 == 0 && a->C <= 256 && (NT % (a->C / 4) == 0); }
+
 extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     if (!a || a->C % 4 || a->nout < 1 || a->nout > 4) return SAVP_EINVAL;
     InormP p;
@@ -167,6 +315,15 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     p.nout = a->nout;
     for (int i = 0; i < a->nout; ++i) { p.out[i] = (float*)a->out[i].p; p.o_sn[i] = a->out[i].sn; p.o_sp[i] = a->out[i].sp; }
     p.mean = a->mean; p.rstd = a->rstd;
+    if (use_large_plane_path(a)) {
+        hipStream_t st = (hipStream_t)stream;
+        hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        dim3 grid((a->HW + CHUNK - 1) / CHUNK, a->N);
+        size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
+        hipLaunchKernelGGL(inorm_stats_kernel, grid, dim3(NT), lds, st, p, a->ws);
+        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws);
+        return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    }
     hipLaunchKernelGGL(inorm_fwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }
@@ -183,6 +340,15 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
     p.yout = (const float*)a->out[0].p; p.y_sn = a->out[0].sn; p.y_sp = a->out[0].sp;
     p.dx = (float*)a->dx.p; p.dx_sn = a->dx.sn; p.dx_sp = a->dx.sp; p.dx_beta = a->dx_beta;
     p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+    if (use_large_plane_path(a)) {
+        hipStream_t st = (hipStream_t)stream;
+        hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        dim3 grid((a->HW + CHUNK - 1) / CHUNK, a->N);
+        size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
+        hipLaunchKernelGGL(inorm_bwd_stats_kernel, grid, dim3(NT), lds, st, p, a->ws);
+        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws);
+        return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    }
     hipLaunchKernelGGL(inorm_bwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }

@@ -184,8 +184,21 @@ def _set_views(arr, tensors):
         arr[i] = view(t)
 
 
+_INORM_WS = {}
+
+
+def _inorm_ws(x):
+    n = x.shape[0] * x.shape[-1] * 2
+    key = (str(x.device), n)
+    t = _INORM_WS.get(key)
+    if t is None:
+        t = _INORM_WS[key] = torch.zeros(n, device=x.device)
+    return t
+
+
 def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6):
     a = lib.SavpInormArgs()
+    a.ws = _inorm_ws(x).data_ptr()
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)
@@ -199,6 +212,7 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
 def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, dx_beta=0, act='relu', alpha=0.0,
                      eps=1e-6):
     a = lib.SavpInormArgs()
+    a.ws = _inorm_ws(x).data_ptr()
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)

@@ -112,7 +112,7 @@ class SavpInormArgs(ctypes.Structure):
         ('x', SavpView), ('gamma', c_vp), ('beta', c_vp),
         ('nout', c_i32), ('out', SavpView * 4), ('mean', c_vp), ('rstd', c_vp),
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
-        ('dgamma', c_vp), ('dbeta', c_vp),
+        ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp),
     ]
 
 
