@@ -7,9 +7,10 @@ HBM.  Workload at every N: configs[1] of BASELINE.json per GPU (full VAE-GAN, ac
 batch 16 per GPU, published ours_savp recipe) -> weak scaling; one process per GPU, gradients all-reduced by RCCL.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel family (implicit-GEMM conv on the fp32 MFMA pipe), measured live with HIP events
+  roofline     -- the dominant kernel family (implicit-GEMM conv on the MFMA pipe), measured live with HIP events
                   around the five ConvLSTM gate-conv FPROP launches of every timed step; algorithmic FLOPs per launch
-                  from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the 157.3 TFLOP/s fp32 peak.
+                  from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the dense MFMA peak of the
+                  datapath in use (bf16: 2.5 PFLOP/s; --precision f32: 157.3 TFLOP/s).
   cpu_baseline -- the CPU oracle (a torch-CPU restatement of the reference step, kind "port") timed on this host's
                   cores on a bounded sample (one sequence), rank 0 at N=1 only.
 """
@@ -31,7 +32,7 @@ RECIPE = dict(  # hparams/bair_action_free/ours_savp/model_hparams.json of the r
     state_weight=0.0)
 H, W, C = 64, 64, 3
 SEQ, CONTEXT = 30, 2      # BASELINE.json configs[1]: BAIR action-free, seq 30; context 2 (softmotion_dataset.py:46-54)
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA / vector peak
+PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}  # MI355X_MICROARCH.md: fp32 MFMA / vector peak; dense bf16 MFMA peak
 
 
 def make_hparams(batch):
@@ -106,6 +107,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (BASELINE configs[1]: 16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16',
+                    help='conv multiply precision: bf16 operands / fp32 accumulate (BASELINE configs[1]) or exact fp32')
+    ap.add_argument('--no-autotune', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -123,7 +127,10 @@ def main():
         dist_mod.init_process_group(backend='nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
         dist = dist_mod
 
+    from video_prediction_amd import kernels as K
     from video_prediction_amd.models.savp_model import SAVPEngine
+    K.set_conv_precision(args.precision)
+    K.enable_autotune(not args.no_autotune)      # tile / split-K selection happens during the warm-up steps
     model = make_hparams(args.batch)
     hp = model.hparams
     engine = SAVPEngine(hp, (H, W, C), args.batch, mode='train', seed=4, device=str(device))
@@ -166,14 +173,14 @@ def main():
         'metric': 'train frames/sec (whole node), BAIR 64x64 seq30 SAVP',
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'SAVP full VAE-GAN (ours_savp recipe), BAIR action-free 64x64x3, seq=30, context=2, '
                                'batch=%d per GPU, D step + G/E step per train step' % args.batch,
                    'global_batch': world * args.batch, 'seq_len': SEQ, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt},
-        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
-                     'kernel': 'conv_fd_kernel (implicit-GEMM fp32 MFMA), ConvLSTM gate conv FPROP x5 layers',
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_TFLOPS[args.precision], 'traffic': None,
+                     'kernel': 'conv_fd_kernel (implicit-GEMM, %s MFMA), ConvLSTM gate conv FPROP x5 layers' % args.precision,
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }

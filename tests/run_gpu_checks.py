@@ -17,7 +17,7 @@ def main():
     results = {}
     nbad = 0
     from tests import gpu_model_checks
-    checks = list(gpu_checks.ALL_CHECKS) + [('model_fwd', gpu_model_checks.check_model_small), ('model_train', gpu_model_checks.check_train_small)]
+    checks = list(gpu_checks.ALL_CHECKS) + [('model_fwd', gpu_model_checks.check_model_small), ('model_train', gpu_model_checks.check_train_small), ('model_bf16', gpu_model_checks.check_model_bf16)]
     for name, fn in checks:
         if only and name not in only:
             continue

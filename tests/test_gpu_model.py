@@ -19,6 +19,11 @@ def test_generator_forward_vs_oracle():
     _assert_ok(G.check_model_small())
 
 
+def test_generator_forward_bf16_mode_vs_oracle():
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_model_bf16())
+
+
 def test_train_step_vs_oracle():
     from tests import gpu_model_checks as G
     _assert_ok(G.check_train_small())
