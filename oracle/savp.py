@@ -608,7 +608,16 @@ def discriminator_given_video_fn(vs, targets, hp, t_sample, t_start, sn_state=No
         for i, f in enumerate(feats[:-1]):
             outputs['discrim_video_sn_feature%d' % i] = f
     if hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight:
-        raise NotImplementedError('images_sn discriminator')
+        # tf_utils.with_flat_batch(networks.image_sn_discriminator)(clip_sample)   savp_model.py:119-125
+        ts = torch.as_tensor(t_start, dtype=torch.long)
+        idx = ts[None, :] + torch.arange(clip_length)[:, None]
+        clip_sample = targets[idx, ar[None, :]]                               # [clip,B,H,W,C]
+        flat = clip_sample.reshape((clip_length * B,) + tuple(clip_sample.shape[2:]))
+        feats = image_sn_discriminator(vs.sub('images'), flat, ndf=hp.ndf, sn_state=sn_state)
+        feats = [f.reshape((clip_length, B) + tuple(f.shape[1:])) for f in feats]
+        outputs['discrim_images_sn_logits'] = feats[-1]
+        for i, f in enumerate(feats[:-1]):
+            outputs['discrim_images_sn_feature%d' % i] = f
     return outputs
 
 

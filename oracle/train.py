@@ -92,6 +92,8 @@ def generator_loss_fn(hp, inputs, outputs, kl_w):
     for infix, w, wf_l2, wf_cd, sfx, nm in (
             ('_image_sn', hp.image_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),
             ('_video_sn', hp.video_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),
+            ('_images_sn', hp.images_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),
+            ('_images_sn', hp.images_sn_vae_gan_weight, hp.vae_gan_feature_l2_weight, hp.vae_gan_feature_cdist_weight, '_enc', 'vae_gan'),
             ('_image_sn', hp.image_sn_vae_gan_weight, hp.vae_gan_feature_l2_weight, hp.vae_gan_feature_cdist_weight, '_enc', 'vae_gan'),
             ('_video_sn', hp.video_sn_vae_gan_weight, hp.vae_gan_feature_l2_weight, hp.vae_gan_feature_cdist_weight, '_enc', 'vae_gan')):
         if not w:
@@ -123,6 +125,8 @@ def discriminator_loss_fn(hp, inputs, outputs):
     losses = OrderedDict()
     for infix, w, sfx, nm in (('_image_sn', hp.image_sn_gan_weight, '', 'gan'),
                               ('_video_sn', hp.video_sn_gan_weight, '', 'gan'),
+                              ('_images_sn', hp.images_sn_gan_weight, '', 'gan'),
+                              ('_images_sn', hp.images_sn_vae_gan_weight, '_enc', 'vae_gan'),
                               ('_image_sn', hp.image_sn_vae_gan_weight, '_enc', 'vae_gan'),
                               ('_video_sn', hp.video_sn_vae_gan_weight, '_enc', 'vae_gan')):
         if not w:
@@ -169,7 +173,8 @@ def train_step(params, opt_state, inputs, hp, noise, d_indices_pre, d_indices_po
 
     gen_outputs = savp.generator_fn(gvs, inputs, mode, hp, noise)
     has_d = bool(hp.video_sn_gan_weight or hp.video_sn_vae_gan_weight or
-                 hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight)
+                 hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight or
+                 hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight)
     info = OrderedDict()
     new_params = {k: v.detach().clone() for k, v in params.items()}
     m, v_ = dict(opt_state['m']), dict(opt_state['v'])

@@ -199,6 +199,10 @@ def check_model_small():
 def check_train_small():
     res = []
     res += check_train_step(B=2, T=6, nz=8, steps=2, tag='train_savp')
+    # image + per-frame images discriminators next to the video one (networks.py:35-69, savp_model.py:105-125)
+    res += check_train_step(B=2, T=6, nz=8, steps=1, tag='train_all_discriminators', image_sn_gan_weight=0.1,
+                            image_sn_vae_gan_weight=0.1, images_sn_gan_weight=0.05, images_sn_vae_gan_weight=0.05,
+                            gan_feature_cdist_weight=1.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)
     return res

@@ -8,7 +8,7 @@ import torch
 from .. import kernels as K
 from .. import lib
 from ..engine import ConvLayer, copy_view
-from ..variables import VIDEO_D_LAYERS, video_discriminator_shapes
+from ..variables import VIDEO_D_LAYERS, video_discriminator_shapes, image_discriminator_shapes
 
 EPS_IN = 1e-6
 
@@ -122,33 +122,52 @@ class PosteriorEncoder(object):
             c.finish_weight_grad()
 
 
-class VideoDiscriminator(object):
-    """networks.video_sn_discriminator on clips [Nc, clip, H, W, C] (batch-major NDHWC)."""
+class SNDiscriminator(object):
+    """Spectral-norm discriminators of networks.py on batch-major clips [Nc, clip, H, W, C]:
+      kind 'video'  : video_sn_discriminator (:72-108), 3-D convs over the whole clip;
+      kind 'image'  : image_sn_discriminator (:35-69) on ONE sampled frame per sequence (clip length 1);
+      kind 'images' : image_sn_discriminator applied to every frame of the clip (with_flat_batch, savp_model.py:119-125).
+    Rows lo:hi of every method are in units of sequences."""
 
-    def __init__(self, store, hp, image_shape, Nc, prefix, train=True):
+    def __init__(self, store, hp, image_shape, Nc, prefix, kind='video', train=True):
         H, W, C = image_shape
-        self.hp, self.store, self.Nc = hp, store, Nc
+        self.hp, self.store, self.Nc, self.kind = hp, store, Nc, kind
         dev = store.device
         self.dev = dev
-        layers, flat = video_discriminator_shapes(hp, image_shape)
-        self.clip = torch.zeros(Nc, hp.clip_length, H, W, C, device=dev)
-        self.dclip = torch.empty(Nc, hp.clip_length, H, W, C, device=dev) if train else None
+        self.frames = 1 if kind == 'image' else hp.clip_length
+        self.rows_per_seq = self.frames if kind == 'images' else 1
+        self.clip = torch.zeros(Nc, self.frames, H, W, C, device=dev)
+        self.dclip = torch.empty(Nc, self.frames, H, W, C, device=dev) if train else None
         self.layers = []
-        x = self.clip
-        for (scope, kshape, st, odhw) in layers:
+        if kind == 'video':
+            layers, flat = video_discriminator_shapes(hp, image_shape)
+            x = self.clip
+            R = Nc
+        else:
+            layers, flat = image_discriminator_shapes(hp, image_shape)
+            R = Nc * self.frames
+            x = self.clip.reshape(R, H, W, C)
+            self.x0 = x
+            self.dx0 = self.dclip.reshape(R, H, W, C) if train else None
+        self.R = R
+        for (scope, kshape, st, odims) in layers:
             s = prefix + scope + '/'
             k = kshape[0]
-            L = {'conv': ConvLayer(store, s + 'conv3d/kernel', s + 'bias', 'conv', (k, k, k), st, (1, 1, 1), sn_u=s + 'conv3d/u'),
-                 'x': x}
-            L['y'] = torch.empty((Nc,) + tuple(odhw) + (kshape[-1],), device=dev)
+            if kind == 'video':
+                conv = ConvLayer(store, s + 'conv3d/kernel', s + 'bias', 'conv', (k, k, k), st, (1, 1, 1), sn_u=s + 'conv3d/u')
+            else:
+                conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (k, k), (st, st), (1, 1),
+                                 sn_u=s + 'conv2d/u')
+            L = {'conv': conv, 'x': x}
+            L['y'] = torch.empty((R,) + tuple(odims) + (kshape[-1],), device=dev)
             L['dy'] = torch.empty_like(L['y']) if train else None
             self.layers.append(L)
             x = L['y']
         s = prefix + 'sn_fc4/'
         self.fc = ConvLayer(store, s + 'dense/kernel', s + 'dense/bias', 'conv', (1, 1), (1, 1), (0, 0), sn_u=s + 'dense/u')
         self.flat = flat
-        self.logits = torch.empty(Nc, 1, device=dev)
-        self.dlogits = torch.zeros(Nc, 1, device=dev)
+        self.logits = torch.empty(R, 1, device=dev)
+        self.dlogits = torch.zeros(R, 1, device=dev)
         self.convs = [L['conv'] for L in self.layers] + [self.fc]
 
     def prep_weights(self, update_u=False):
@@ -162,17 +181,21 @@ class VideoDiscriminator(object):
     def features(self):
         return [L['y'] for L in self.layers]
 
+    def rows(self, lo, hi):
+        return lo * self.rows_per_seq, hi * self.rows_per_seq
+
     def forward(self, n=None):
-        """Run on the first n clips of self.clip (default all).  lrelu(0.1) is fused into each conv epilogue."""
-        n = n or self.Nc
+        """Run on the first n sequences of self.clip (default all).  lrelu(0.1) is fused into each conv epilogue."""
+        n = (n or self.Nc) * self.rows_per_seq
         for L in self.layers:
-            L['conv'].forward(L['x'][:n], L['y'][:n], act=lib.ACT_LRELU, alpha=0.1)          # networks.py:83-102
-        self.fc.forward(self.layers[-1]['y'][:n].reshape(n, -1), self.logits[:n])           # networks.py:104-105
+            L['conv'].forward(L['x'][:n], L['y'][:n], act=lib.ACT_LRELU, alpha=0.1)          # networks.py:45-64 / 83-102
+        self.fc.forward(self.layers[-1]['y'][:n].reshape(n, -1), self.logits[:n])           # networks.py:66-67 / 104-105
         return self.logits
 
     def backward(self, lo, hi, weights=True, data=True, feature_grads=False):
-        """Back-propagate self.dlogits[lo:hi] (and, if feature_grads, the gradients already stored in each layer's
-        dy[lo:hi]) through samples lo..hi.  weights: accumulate dW/dbias; data: produce self.dclip[lo:hi]."""
+        """Back-propagate self.dlogits (and, if feature_grads, the gradients already stored in each layer's dy) through
+        sequences lo..hi.  weights: accumulate dW/dbias; data: produce self.dclip[lo:hi]."""
+        lo, hi = self.rows(lo, hi)
         n = hi - lo
         top = self.layers[-1]
         self.fc.backward_data(self.dlogits[lo:hi], top['dy'][lo:hi].reshape(n, -1), beta=1 if feature_grads else 0,
@@ -187,10 +210,14 @@ class VideoDiscriminator(object):
                 L['conv'].backward_data(dpre, below['dy'][lo:hi], beta=1 if feature_grads else 0,
                                         act=lib.ACT_DLRELU_FROM_OUT, alpha=0.1, aux=below['y'][lo:hi])
             elif data:
-                L['conv'].backward_data(dpre, self.dclip[lo:hi], beta=0)
+                dst = self.dclip if self.kind == 'video' else self.dx0
+                L['conv'].backward_data(dpre, dst[lo:hi], beta=0)
             if weights:
                 L['conv'].backward_weights(L['x'][lo:hi], dpre)
 
     def finish_weight_grads(self):
         for c in self.convs:
             c.finish_weight_grad()
+
+
+VideoDiscriminator = SNDiscriminator

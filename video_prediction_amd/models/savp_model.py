@@ -19,7 +19,7 @@ from .. import variables as V
 from ..engine import ParamStore, copy_view, add_views
 from .base_model import VideoPredictionModel, learning_rate, kl_weight
 from .hparam_defaults import savp_defaults, SAVP_DEPRECATED_KEYS
-from .networks import PosteriorEncoder, VideoDiscriminator
+from .networks import PosteriorEncoder, SNDiscriminator
 from .savp_cell import SAVPGenerator
 
 
@@ -52,18 +52,34 @@ class SAVPEngine(object):
         self.zs_all = torch.zeros(self.T1, N, self.nz, device=self.device) if self.nz else None
         self.dz_post = torch.zeros(self.T1, B, self.nz, device=self.device) if (self.nz and self.train) else None
         self.has_d = self.train and V.uses_discriminator(hp)
-        self.d_gan = self.d_vae = None
+        # (discriminator, loss weight, loss-name infix, operates on the posterior ('_enc') unroll?, clip index keys)
+        self.discs = []
         if self.has_d:
-            if hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight or hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight:
-                raise NotImplementedError('image/images discriminators are not on the HIP path yet (video D only)')
             if hp.gan_loss_type != 'LSGAN':
                 raise NotImplementedError('gan_loss_type %s' % hp.gan_loss_type)
-            if hp.video_sn_gan_weight:
-                self.d_gan = VideoDiscriminator(self.store, hp, image_shape, 2 * B, 'discriminator/video/')
-            if self.nz and hp.video_sn_vae_gan_weight:
-                pre = 'discriminator/video/' if hp.use_same_discriminator else 'discriminator/encoder/video/'
-                self.d_vae = VideoDiscriminator(self.store, hp, image_shape, 2 * B, pre)
-        self.loss_buf = torch.zeros(16, device=self.device)
+            slot = 0
+            for enc in ((True, False) if self.nz else (False,)):       # encoder scope first (savp_model.py:130-147)
+                pre = 'discriminator/' + ('encoder/' if (enc and not hp.use_same_discriminator) else '')
+                for kind, infix, w_gan, w_vae in (('image', 'image_sn', hp.image_sn_gan_weight, hp.image_sn_vae_gan_weight),
+                                                  ('video', 'video_sn', hp.video_sn_gan_weight, hp.video_sn_vae_gan_weight),
+                                                  ('images', 'images_sn', hp.images_sn_gan_weight, hp.images_sn_vae_gan_weight)):
+                    if not (w_gan or w_vae):
+                        continue                                            # network not instantiated (savp_model.py:105,112,119)
+                    if enc and hp.use_same_discriminator:
+                        D = [d for d in self.discs if d['kind'] == kind and not d['enc']]
+                        D = D[0]['D'] if D else None
+                    else:
+                        D = None
+                    if D is None:
+                        D = SNDiscriminator(self.store, hp, image_shape, 2 * B, pre + kind + '/', kind=kind)
+                    self.discs.append(dict(D=D, kind=kind, enc=enc, w=(w_vae if enc else w_gan), infix=infix,
+                                           name='%s_%s' % (infix, 'vae_gan' if enc else 'gan'),
+                                           kr='enc_real' if enc else 'real', kf='enc_fake' if enc else 'fake', slot=slot))
+                    slot += 6
+            self.loss_buf_size = max(16, slot + 8)
+        self.d_gan = next((d['D'] for d in self.discs if d['kind'] == 'video' and not d['enc']), None)
+        self.d_vae = next((d['D'] for d in self.discs if d['kind'] == 'video' and d['enc']), None)
+        self.loss_buf = torch.zeros(getattr(self, 'loss_buf_size', 16), device=self.device)
         self.step = 0
         self.world = 1
         self.dist = None
@@ -172,14 +188,16 @@ class SAVPEngine(object):
 
     # -- one sess.run(train_op) --------------------------------------------------------------------------------------------
     def _d_clips(self, D, idx_real, idx_fake, fake_half, lo_real, lo_fake):
-        """discriminator_given_video_fn's clip gather (savp_model.py:97-102) into D.clip[lo_real:...] / [lo_fake:...]."""
+        """discriminator_given_video_fn's frame / clip gather (savp_model.py:93-102) into D.clip[lo_real:...] and
+        D.clip[lo_fake:...].  idx = (t_sample[B], t_start[B]); the image discriminator uses t_sample, the others t_start."""
         B = self.B
         dev = self.device
+        which = 0 if D.kind == 'image' else 1
         real_src = self.images_tm[1:self.T]                                       # inputs['images'][1:]
         if idx_real is not None:
-            ts = torch.as_tensor(np.asarray(idx_real[1]), dtype=torch.int32).to(dev)
+            ts = torch.as_tensor(np.asarray(idx_real[which]), dtype=torch.int32).to(dev)
             K.gather_clips(real_src, D.clip[lo_real:lo_real + B], ts)
-        ts_f = torch.as_tensor(np.asarray(idx_fake[1]), dtype=torch.int32).to(dev)
+        ts_f = torch.as_tensor(np.asarray(idx_fake[which]), dtype=torch.int32).to(dev)
         K.gather_clips(fake_half, D.clip[lo_fake:lo_fake + B], ts_f)
         return ts_f
 
@@ -198,22 +216,29 @@ class SAVPEngine(object):
         gen = self.forward_generator(noise)
         gen_enc, gen_prior = (gen[:, :B], gen[:, B:]) if self.nz else (None, gen)
         info = OrderedDict()
-        ddesc = []          # (D, weight, name, fake half, index keys)
-        if self.d_gan is not None:
-            ddesc.append((self.d_gan, hp.video_sn_gan_weight, 'video_sn_gan', gen_prior, 'real', 'fake', 0))
-        if self.d_vae is not None:
-            ddesc.append((self.d_vae, hp.video_sn_vae_gan_weight, 'video_sn_vae_gan', gen_enc, 'enc_real', 'enc_fake', 2))
+        discs = self.discs
+        for d in discs:
+            d['fake'] = gen_enc if d['enc'] else gen_prior
         # ---------------- discriminator step ---------------------------------------------------------------------------------
-        if ddesc:
+        if discs:
             store.groups['d'].zero_grad()
             ipre = noise['d_indices_pre']
-            for D, w, name, fake, kr, kf, slot in ddesc:
-                D.prep_weights(update_u=True)
-                self._d_clips(D, ipre[kr], ipre[kf], fake, 0, B)
+            prepped = set()
+            for d in discs:
+                D, w, slot = d['D'], d['w'], d['slot']
+                if id(D) not in prepped:
+                    D.prep_weights(update_u=True)
+                    prepped.add(id(D))
+                if not w:
+                    continue
+                self._d_clips(D, ipre[d['kr']], ipre[d['kf']], d['fake'], 0, B)
                 D.forward()
-                K.lsgan_loss(D.logits[0:B], 1.0, w, lb[slot:slot + 1], D.dlogits[0:B])            # discrim_gan_loss_real
-                K.lsgan_loss(D.logits[B:2 * B], 0.0, w, lb[slot + 1:slot + 2], D.dlogits[B:2 * B])  # ..._fake
+                r0, r1 = D.rows(0, B)
+                f0, f1 = D.rows(B, 2 * B)
+                K.lsgan_loss(D.logits[r0:r1], 1.0, w, lb[slot:slot + 1], D.dlogits[r0:r1])            # discrim_*_loss real
+                K.lsgan_loss(D.logits[f0:f1], 0.0, w, lb[slot + 1:slot + 2], D.dlogits[f0:f1])        # ... fake
                 D.backward(0, 2 * B, weights=True, data=False)
+            for D in {id(d['D']): d['D'] for d in discs}.values():
                 D.finish_weight_grads()
             if return_grads:
                 info['d_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'd'}
@@ -222,26 +247,34 @@ class SAVPEngine(object):
         # ---------------- generator (+ encoder) step --------------------------------------------------------------------------
         store.groups['g'].zero_grad()
         self.gen.gen.g.zero_()
-        if ddesc:
+        if discs:
             ipost = noise['d_indices_post']
-            for D, w, name, fake, kr, kf, slot in ddesc:
-                D.prep_weights(update_u=False)                     # updated W, same pre-assign u
-                is_vae = slot == 2
+            prepped = set()
+            for d in discs:
+                D, w, slot, is_vae = d['D'], d['w'], d['slot'], d['enc']
+                if id(D) not in prepped:
+                    D.prep_weights(update_u=False)                 # updated W, same pre-assign u
+                    prepped.add(id(D))
+                if not w:
+                    continue
                 wf_cd = hp.vae_gan_feature_cdist_weight if is_vae else hp.gan_feature_cdist_weight
                 wf_l2 = hp.vae_gan_feature_l2_weight if is_vae else hp.gan_feature_l2_weight
                 if wf_l2:
                     raise NotImplementedError('feature l2 matching')
                 if wf_cd:
-                    ts_f = self._d_clips(D, ipost[kr], ipost[kf], fake, 0, B)
+                    ts_f = self._d_clips(D, ipost[d['kr']], ipost[d['kf']], d['fake'], 0, B)
                     D.forward()
                     lo, hi = B, 2 * B
-                    for li, L in enumerate(D.layers):
-                        K.cosine_distance(L['y'][lo:hi], L['y'][0:B], wf_cd, lb[8 + slot:9 + slot], L['dy'][lo:hi])
+                    r0, r1 = D.rows(0, B)
+                    f0, f1 = D.rows(lo, hi)
+                    for L in D.layers:
+                        K.cosine_distance(L['y'][f0:f1], L['y'][r0:r1], wf_cd, lb[slot + 3:slot + 4], L['dy'][f0:f1])
                 else:
-                    ts_f = self._d_clips(D, None, ipost[kf], fake, 0, 0)
+                    ts_f = self._d_clips(D, None, ipost[d['kf']], d['fake'], 0, 0)
                     D.forward(n=B)
                     lo, hi = 0, B
-                K.lsgan_loss(D.logits[lo:hi], 1.0, w, lb[4 + slot:5 + slot], D.dlogits[lo:hi])      # gen_*_gan_loss
+                    f0, f1 = D.rows(lo, hi)
+                K.lsgan_loss(D.logits[f0:f1], 1.0, w, lb[slot + 2:slot + 3], D.dlogits[f0:f1])      # gen_*_gan_loss
                 D.backward(lo, hi, weights=False, data=True, feature_grads=bool(wf_cd))
                 gfake = self.gen.gen.g[:, :B] if (is_vae and self.nz) else (self.gen.gen.g[:, B:] if self.nz else self.gen.gen.g)
                 K.gather_clips(gfake, D.dclip[lo:hi], ts_f, adjoint=True)
@@ -249,9 +282,9 @@ class SAVPEngine(object):
         pred = gen_enc if self.nz else gen_prior
         dpred = self.gen.gen.g[:, :B] if self.nz else self.gen.gen.g
         if hp.l1_weight:
-            K.lp_loss(pred, target, hp.l1_weight, lb[12:13], dpred, p2=False)
+            K.lp_loss(pred, target, hp.l1_weight, lb[-2:-1], dpred, p2=False)
         if hp.l2_weight:
-            K.lp_loss(pred, target, hp.l2_weight, lb[13:14], dpred, p2=True)
+            K.lp_loss(pred, target, hp.l2_weight, lb[-1:], dpred, p2=True)
         dzs = self.gen.backward()
         if self.nz:
             c1 = hp.context_frames - 1
@@ -263,21 +296,24 @@ class SAVPEngine(object):
             info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
         self._allreduce('g')
         store.groups['g'].adam_step(lr, hp.beta1, hp.beta2, gscale=1.0 / self.world)
-        for D, *_ in ddesc:
+        for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
         self.step += 1
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
         d_losses, g_losses = OrderedDict(), OrderedDict()
-        for D, w, name, fake, kr, kf, slot in ddesc:
+        for d in discs:
+            w, slot, name = d['w'], d['slot'], d['name']
+            if not w:
+                continue
             d_losses['discrim_%s_loss' % name] = (lb[slot] + lb[slot + 1], w)
-            g_losses['gen_%s_loss' % name] = (lb[4 + slot], w)
-            wf_cd = hp.vae_gan_feature_cdist_weight if slot == 2 else hp.gan_feature_cdist_weight
+            g_losses['gen_%s_loss' % name] = (lb[slot + 2], w)
+            wf_cd = hp.vae_gan_feature_cdist_weight if d['enc'] else hp.gan_feature_cdist_weight
             if wf_cd:
-                g_losses['gen_%s_feature_cdist_loss' % name] = (lb[8 + slot], wf_cd)
+                g_losses['gen_%s_feature_cdist_loss' % name] = (lb[slot + 3], wf_cd)
         if hp.l1_weight:
-            g_losses['gen_l1_loss'] = (lb[12], hp.l1_weight)
+            g_losses['gen_l1_loss'] = (lb[-2], hp.l1_weight)
         if hp.l2_weight:
-            g_losses['gen_l2_loss'] = (lb[13], hp.l2_weight)
+            g_losses['gen_l2_loss'] = (lb[-1], hp.l2_weight)
         if self.nz and hp.kl_weight:
             g_losses['gen_kl_loss'] = (self.enc.kl[0], klw)
         info['d_losses'], info['g_losses'] = d_losses, g_losses
@@ -367,19 +403,18 @@ def discriminator_fn(inputs, outputs, mode, hparams, engine=None, noise=None):
     idx = noise['d_indices_pre']
     B = eng.B
     out = OrderedDict()
-    todo = []
-    if eng.d_vae is not None:
-        todo.append((eng.d_vae, outputs['gen_images_enc'], 'enc_real', 'enc_fake', '_enc'))
-    if eng.d_gan is not None:
-        todo.append((eng.d_gan, outputs['gen_images'], 'real', 'fake', ''))
-    for D, fake, kr, kf, sfx in todo:
+    for d in eng.discs:
+        D, sfx = d['D'], ('_enc' if d['enc'] else '')
+        fake = outputs['gen_images_enc'] if d['enc'] else outputs['gen_images']
         D.prep_weights(update_u=False)
-        eng._d_clips(D, idx[kr], idx[kf], fake, 0, B)
+        eng._d_clips(D, idx[d['kr']], idx[d['kf']], fake, 0, B)
         D.forward()
         for part, lo in (('real', 0), ('fake', B)):
-            out['discrim_video_sn_logits%s_%s' % (sfx, part)] = D.logits[lo:lo + B].clone()
+            r0, r1 = D.rows(lo, lo + B)
+            out['discrim_%s_logits%s_%s' % (d['infix'], sfx, part)] = D.logits[r0:r1].clone()
             for i, f in enumerate(D.features()):
-                out['discrim_video_sn_feature%d%s_%s' % (i, sfx, part)] = f[lo:lo + B].transpose(0, 1)
+                fv = f[r0:r1]
+                out['discrim_%s_feature%d%s_%s' % (d['infix'], i, sfx, part)] = fv.transpose(0, 1) if D.kind == 'video' else fv
     return out
 
 

@@ -63,7 +63,8 @@ def num_masks(hp):
 
 def uses_discriminator(hp):
     return bool(hp.video_sn_gan_weight or hp.video_sn_vae_gan_weight or
-                hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight)
+                hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight or
+                hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight)
 
 
 def generator_variable_specs(hp, image_shape):
@@ -246,14 +247,17 @@ def discriminator_variable_specs(hp, image_shape):
         prefixes.append('discriminator/encoder/')
     prefixes.append('discriminator/')
     for p in prefixes:
-        if hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight:
+        for sub, on in (('image/', hp.image_sn_gan_weight or hp.image_sn_vae_gan_weight),
+                        ('images/', hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight)):
+            if not on:
+                continue
             layers, flat = image_discriminator_shapes(hp, image_shape)
             for scope, kshape, st, _ in layers:
-                s = p + 'image/' + scope + '/'
+                s = p + sub + scope + '/'
                 specs[s + 'conv2d/kernel'] = (kshape, 'tn0.02')
                 specs[s + 'conv2d/u'] = ((1, kshape[-1]), 'tn1')
                 specs[s + 'conv2d/bias'] = ((kshape[-1],), 'zeros')
-            s = p + 'image/sn_fc4/'
+            s = p + sub + 'sn_fc4/'
             specs[s + 'dense/kernel'] = ((flat, 1), 'tn0.02')
             specs[s + 'dense/u'] = ((1, 1), 'tn1')
             specs[s + 'dense/bias'] = ((1,), 'zeros')
