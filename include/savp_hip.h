@@ -210,6 +210,36 @@ int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float*
 int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, const float* G, float* dW,
                 int32_t beta);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * warp_dna.hip: the alternative pixel transformations (hparams.transformation = 'flow' / 'dna').
+ * image_warp: flow_ops.image_warp (flow_ops.py:4-79) for K flows at once; flows [N,H,W,2K] (x components then y).
+ * dna_apply : per-pixel kernels incl. identity / relu-shift / normalisation (savp_model.py:541-544,556-559,858-890);
+ *             raw [N,H*W,kh*kw*K] is the conv output, kern receives the normalised kernels (needed by bwd).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct SavpWarpArgs {
+    int32_t N, H, W, C, K;
+    SavpView img;
+    const float* flows;
+    SavpView out;                  /* [N,H,W,K*C] */
+    SavpView dout;
+    float* dflows;                 /* bwd: [N,H,W,2K] overwritten */
+    float* dimg;                   /* bwd: [N,H,W,C] contiguous, overwritten (zeroed + atomics); may be NULL */
+} SavpWarpArgs;
+int savp_image_warp_fwd(void* stream, const SavpWarpArgs* a);
+int savp_image_warp_bwd(void* stream, const SavpWarpArgs* a);
+typedef struct SavpDnaArgs {
+    int32_t N, H, W, C, K, kh, kw;
+    SavpView img;
+    const float* raw;
+    float* kern;
+    SavpView out;
+    SavpView dout;
+    float* draw;
+    SavpView dimg; int32_t dimg_beta;
+} SavpDnaArgs;
+int savp_dna_apply_fwd(void* stream, const SavpDnaArgs* a);
+int savp_dna_apply_bwd(void* stream, const SavpDnaArgs* a);
+
 #ifdef __cplusplus
 }
 #endif

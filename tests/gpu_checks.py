@@ -572,6 +572,57 @@ def check_weight_prep(seed=7):
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# flow warp + DNA
+# ---------------------------------------------------------------------------------------------------------------
+def check_warp_dna(seed=8):
+    out = []
+    rng = np.random.default_rng(seed)
+    for (N, H, W, C, Kk) in [(2, 16, 12, 3, 4), (2, 8, 8, 1, 2)]:
+        img = torch.tensor(rng.random((N, H, W, C)), dtype=torch.float64, requires_grad=True)
+        flows = (rnd(rng, N, H, W, 2, Kk) * 2.5).requires_grad_(True)          # [N,H,W,2,K] as in savp_model.py:530
+        outs = OS.apply_flows(img, flows)
+        ref = torch.cat(outs, dim=-1)
+        dout = rnd(rng, *ref.shape)
+        (ref * dout).sum().backward()
+        tag = 'warp_%dx%dx%d' % (H, W, C)
+        fl = dev(flows).reshape(N, H, W, 2 * Kk)
+        big = torch.zeros(N, H, W, 8 + Kk * C, device=DEV)
+        K.image_warp_fwd(dev(img), fl, big[..., 8:], Kk)
+        out.append((tag + '/fwd', rel_err(big[..., 8:], ref), TOL_OP))
+        dfl = torch.empty(N, H, W, 2 * Kk, device=DEV)
+        dimg = torch.empty(N, H, W, C, device=DEV)
+        K.image_warp_bwd(dev(img), fl, dev(dout), dfl, dimg, Kk)
+        out.append((tag + '/dflows', rel_err(dfl.reshape(N, H, W, 2, Kk), flows.grad), 5e-5))
+        out.append((tag + '/dimg', rel_err(dimg, img.grad), 5e-5))
+    for (N, H, W, C, Kk) in [(2, 12, 10, 3, 4), (1, 8, 8, 1, 4)]:
+        kh = kw = 5
+        img = torch.tensor(rng.random((N, H, W, C)), dtype=torch.float64, requires_grad=True)
+        raw = (rnd(rng, N, H, W, kh, kw, Kk) * 0.3).requires_grad_(True)
+        ident = torch.as_tensor(OS.identity_kernel((kh, kw)))
+        kern = raw + ident[None, None, None, :, :, None]
+        kern = torch.relu(kern - OS.RELU_SHIFT) + OS.RELU_SHIFT
+        kern = kern / kern.sum(dim=(3, 4), keepdim=True)
+        ref = torch.cat(OS.apply_dna_kernels(img, kern), dim=-1)
+        dout = rnd(rng, *ref.shape)
+        (ref * dout).sum().backward()
+        tag = 'dna_%dx%dx%d' % (H, W, C)
+        rawd = dev(raw).reshape(N, H, W, kh * kw * Kk)
+        kd = torch.empty_like(rawd)
+        od = torch.empty(N, H, W, Kk * C, device=DEV)
+        K.dna_apply_fwd(dev(img), rawd, kd, od, kh, kw, Kk)
+        out.append((tag + '/fwd', rel_err(od, ref), TOL_OP))
+        out.append((tag + '/kern', rel_err(kd.reshape(N, H, W, kh, kw, Kk), kern), TOL_OP))
+        draw = torch.empty_like(rawd)
+        dimg = torch.empty(N, H, W, C, device=DEV)
+        K.dna_apply_bwd(dev(img), rawd, kd, dev(dout), draw, dimg, kh, kw, Kk)
+        out.append((tag + '/draw', rel_err(draw.reshape(N, H, W, kh, kw, Kk), raw.grad), 5e-5))
+        out.append((tag + '/dimg', rel_err(dimg, img.grad), 5e-5))
+    torch.cuda.synchronize()
+    return out
+
+
 def check_conv_bf16():
     """bf16-operand / fp32-accumulate mode of the implicit-GEMM kernel: per-op rel <= 1e-2."""
     res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11))
@@ -580,7 +631,7 @@ def check_conv_bf16():
 
 ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
               ('lstm', check_lstm), ('util', check_util), ('cdna_composite', check_cdna_composite),
-              ('small', check_small), ('weight_prep', check_weight_prep)]
+              ('small', check_small), ('weight_prep', check_weight_prep), ('warp_dna', check_warp_dna)]
 
 
 def failures(results):

@@ -55,8 +55,8 @@ def make_noise(hp, B, seed=1, sampling=True):
     return noise
 
 
-def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None):
-    hp = make_hparams(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid')
+def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, **over):
+    hp = make_hparams(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid', **over)
     specs = V.variable_specs(hp, (H, W, C), mode='test')
     vals = V.init_variables(specs, seed=4)
     # perturb norm params / biases so that they matter
@@ -92,14 +92,15 @@ def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None):
     safe = (top2[..., 0] - top2[..., 1]) > 1e-5
     mism = (masks[:, lo:].squeeze(-2).argmax(-1).cpu() != m_ref.argmax(-1)) & safe
     out.append((tag + '/mask_argmax_mismatch_frac', float(mism.sum()) / float(safe.sum()), 0.0))
-    kern_ref = ref['_kernels']                                   # [T1,B,5,5,4]
-    kern = g.cdna_kern.v.reshape(g.T1, g.N, 5, 5, 4)[:, lo:]
-    out.append((tag + '/cdna_kernels', rel(kern, kern_ref), 1e-3))
-    kr = kern_ref.reshape(g.T1, B, 25, 4)
-    t2 = kr.topk(2, dim=2).values
-    safe = (t2[:, :, 0] - t2[:, :, 1]) > 1e-5
-    mism = (kern.reshape(g.T1, B, 25, 4).argmax(2).cpu() != kr.argmax(2)) & safe
-    out.append((tag + '/cdna_tap_argmax_mismatch', float(mism.sum()), 0.0))
+    if hp.transformation == 'cdna':
+        kern_ref = ref['_kernels']                                   # [T1,B,5,5,4]
+        kern = g.cdna_kern.v.reshape(g.T1, g.N, 5, 5, 4)[:, lo:]
+        out.append((tag + '/cdna_kernels', rel(kern, kern_ref), 1e-3))
+        kr = kern_ref.reshape(g.T1, B, 25, 4)
+        t2 = kr.topk(2, dim=2).values
+        safe = (t2[:, :, 0] - t2[:, :, 1]) > 1e-5
+        mism = (kern.reshape(g.T1, B, 25, 4).argmax(2).cpu() != kr.argmax(2)) & safe
+        out.append((tag + '/cdna_tap_argmax_mismatch', float(mism.sum()), 0.0))
     if nz:
         out.append((tag + '/gen_images_enc', rel(gen[:, :B], ref['gen_images_enc']), 1e-3))
         out.append((tag + '/zs_mu', rel(eng.enc.mu, ref['zs_mu_enc']), 1e-4))
@@ -146,9 +147,9 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
             P32 = {k: v.float() for k, v in P.items()}
             n32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in noise.items()}
             _, _, info32 = OT.train_step(P32, OT.init_opt_state(P32), {'images': images.float()}, hp, n32,
-                                         noise['d_indices_pre'], noise['d_indices_post'], step=it)
+                                         noise.get('d_indices_pre'), noise.get('d_indices_post'), step=it)
         P_before = P
-        P, st, info_ref = OT.train_step(P, st, {'images': images}, hp, noise, noise['d_indices_pre'], noise['d_indices_post'],
+        P, st, info_ref = OT.train_step(P, st, {'images': images}, hp, noise, noise.get('d_indices_pre'), noise.get('d_indices_post'),
                                         step=it)
         info = eng.train_step(noise, return_grads=(it == 0))
         torch.cuda.synchronize()
@@ -193,6 +194,8 @@ def check_model_small():
     res += check_generator_forward(nz=0, B=2, T=5)
     res += check_generator_forward(nz=8, B=2, T=4)
     res += check_generator_forward(nz=0, B=1, T=3, H=64, W=64, C=1, tag='gen_fwd_gray')
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_flow', transformation='flow')
+    res += check_generator_forward(nz=0, B=1, T=4, tag='gen_fwd_dna', transformation='dna')
     return res
 
 
@@ -203,6 +206,9 @@ def check_train_small():
     res += check_train_step(B=2, T=6, nz=8, steps=1, tag='train_all_discriminators', image_sn_gan_weight=0.1,
                             image_sn_vae_gan_weight=0.1, images_sn_gan_weight=0.05, images_sn_vae_gan_weight=0.05,
                             gan_feature_cdist_weight=1.0)
+    for tf in ('flow', 'dna'):
+        res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_' + tf, transformation=tf, video_sn_vae_gan_weight=0.0,
+                                video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)
     return res

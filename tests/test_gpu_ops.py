@@ -54,3 +54,8 @@ def test_weight_prep_and_spectral_norm():
 def test_conv_bf16_mode():
     from tests import gpu_checks
     _run(gpu_checks.check_conv_bf16)
+
+
+def test_flow_warp_and_dna():
+    from tests import gpu_checks
+    _run(gpu_checks.check_warp_dna)

@@ -505,3 +505,56 @@ def dense_fwd(x, W, bias, out, scale=None):
     C = W.shape[-1]
     assert out.is_contiguous() and x.stride(1) == 1 and W.is_contiguous()
     lib.check(_L().savp_dense_fwd(lib.stream(), _p(x), x.stride(0), M, Kd, C, _p(W), _p(bias), _p(scale), _p(out)), 'savp_dense_fwd')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# flow warp / DNA
+# ---------------------------------------------------------------------------------------------------------------
+def _warp_args(img, flows, K_):
+    a = lib.SavpWarpArgs()
+    a.N, a.H, a.W, a.C = img.shape
+    a.K = K_
+    a.img = view(img)
+    assert flows.is_contiguous() and flows.shape[-1] == 2 * K_
+    a.flows = _p(flows)
+    return a
+
+
+def image_warp_fwd(img, flows, out, K_):
+    a = _warp_args(img, flows, K_)
+    a.out = view(out)
+    lib.check(_L().savp_image_warp_fwd(lib.stream(), ctypes.byref(a)), 'savp_image_warp_fwd')
+
+
+def image_warp_bwd(img, flows, dout, dflows, dimg, K_):
+    a = _warp_args(img, flows, K_)
+    a.dout = view(dout)
+    assert dflows.is_contiguous() and (dimg is None or dimg.is_contiguous())
+    a.dflows, a.dimg = _p(dflows), _p(dimg)
+    lib.check(_L().savp_image_warp_bwd(lib.stream(), ctypes.byref(a)), 'savp_image_warp_bwd')
+
+
+def _dna_args(img, raw, kern, kh, kw, K_):
+    a = lib.SavpDnaArgs()
+    a.N, a.H, a.W, a.C = img.shape
+    a.K, a.kh, a.kw = K_, kh, kw
+    a.img = view(img)
+    assert raw.is_contiguous() and kern.is_contiguous()
+    a.raw, a.kern = _p(raw), _p(kern)
+    return a
+
+
+def dna_apply_fwd(img, raw, kern, out, kh, kw, K_):
+    a = _dna_args(img, raw, kern, kh, kw, K_)
+    a.out = view(out)
+    lib.check(_L().savp_dna_apply_fwd(lib.stream(), ctypes.byref(a)), 'savp_dna_apply_fwd')
+
+
+def dna_apply_bwd(img, raw, kern, dout, draw, dimg, kh, kw, K_, dimg_beta=0):
+    a = _dna_args(img, raw, kern, kh, kw, K_)
+    a.dout = view(dout)
+    a.draw = _p(draw)
+    if dimg is not None:
+        a.dimg = view(dimg)
+    a.dimg_beta = int(dimg_beta)
+    lib.check(_L().savp_dna_apply_bwd(lib.stream(), ctypes.byref(a)), 'savp_dna_apply_bwd')

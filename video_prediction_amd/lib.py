@@ -179,3 +179,20 @@ register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
 register('savp_sn_bwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32])
 register('savp_dense_fwd', [c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp])
+
+
+class SavpWarpArgs(ctypes.Structure):
+    _fields_ = [('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('K', c_i32), ('img', SavpView), ('flows', c_vp),
+                ('out', SavpView), ('dout', SavpView), ('dflows', c_vp), ('dimg', c_vp)]
+
+
+class SavpDnaArgs(ctypes.Structure):
+    _fields_ = [('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('K', c_i32), ('kh', c_i32), ('kw', c_i32),
+                ('img', SavpView), ('raw', c_vp), ('kern', c_vp), ('out', SavpView), ('dout', SavpView), ('draw', c_vp),
+                ('dimg', SavpView), ('dimg_beta', c_i32)]
+
+
+register('savp_image_warp_fwd', [c_vp, ctypes.POINTER(SavpWarpArgs)])
+register('savp_image_warp_bwd', [c_vp, ctypes.POINTER(SavpWarpArgs)])
+register('savp_dna_apply_fwd', [c_vp, ctypes.POINTER(SavpDnaArgs)])
+register('savp_dna_apply_bwd', [c_vp, ctypes.POINTER(SavpDnaArgs)])

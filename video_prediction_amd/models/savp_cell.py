@@ -64,8 +64,10 @@ class SAVPGenerator(object):
             raise NotImplementedError('HIP path covers conv_rnn=lstm with instance norm (the published SAVP recipes)')
         if hp.downsample_layer != 'conv_pool2d' or hp.upsample_layer != 'upsample_conv2d' or hp.activation_layer != 'relu':
             raise NotImplementedError('HIP path covers conv_pool2d / upsample_conv2d / relu')
-        if hp.transformation != 'cdna' or hp.last_frames != 1 or not hp.num_transformed_images:
-            raise NotImplementedError('HIP path covers transformation=cdna, last_frames=1')
+        if hp.transformation not in ('cdna', 'flow', 'dna') or hp.last_frames != 1 or not hp.num_transformed_images:
+            raise NotImplementedError('HIP path covers transformation in (cdna, flow, dna) with last_frames=1')
+        if tuple(hp.dilation_rate) != (1, 1):
+            raise NotImplementedError('dilation_rate != (1, 1)')
         if hp.where_add != 'all' or hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
             raise NotImplementedError('HIP path covers where_add=all without ablations')
         if not (hp.prev_image_background and hp.first_image_background and hp.generate_scratch_image and hp.dependent_mask) \
@@ -129,14 +131,37 @@ class SAVPGenerator(object):
         self.kh, self.kw = kh, kw
 
         # ---- heads ------------------------------------------------------------------------------------------
-        sh_, sw_ = H // 2 ** self.ne, W // 2 ** self.ne
-        small_f = self.layers[self.ne - 1]['f']
-        self.hsmall = Act((T1, N, sh_, sw_, small_f), dev, grad=g)
-        self.cdna_dense = ConvLayer(store, prefix + 'cdna_kernels/dense/kernel', prefix + 'cdna_kernels/dense/bias', 'conv',
-                                    (1, 1), (1, 1), (0, 0))
-        self.cdna_raw = Act((T1, N, kh * kw * nk), dev, grad=g)
-        self.cdna_kern = Act((T1, N, kh * kw, nk), dev, grad=g)
+        self.tf = hp.transformation
         self.h_last = Act((T1, N, H, W, last['f']), dev, grad=g)
+        tf_convs = []
+        if self.tf == 'cdna':
+            sh_, sw_ = H // 2 ** self.ne, W // 2 ** self.ne
+            small_f = self.layers[self.ne - 1]['f']
+            self.hsmall = Act((T1, N, sh_, sw_, small_f), dev, grad=g)
+            self.cdna_dense = ConvLayer(store, prefix + 'cdna_kernels/dense/kernel', prefix + 'cdna_kernels/dense/bias', 'conv',
+                                        (1, 1), (1, 1), (0, 0))
+            self.cdna_raw = Act((T1, N, kh * kw * nk), dev, grad=g)
+            self.cdna_kern = Act((T1, N, kh * kw, nk), dev, grad=g)
+            tf_convs = [self.cdna_dense]
+        else:
+            # flow: h_flow = relu(IN(conv3x3)); flows = conv3x3 -> 2*nk   (savp_model.py:522-530)
+            # dna : h_dna_kernel = relu(IN(conv3x3)); kernels = conv3x3 -> kh*kw*nk   (:534-544)
+            hs, os_, cy = (('h%d_flow/' % nl, 'flows/', 2 * nk) if self.tf == 'flow' else
+                           ('h%d_dna_kernel/' % nl, 'dna_kernels/', kh * kw * nk))
+            s = prefix + hs
+            self.tf_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+            self.tf_pre = Act((T1, N, H, W, ngf), dev, grad=g)
+            self.tf_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
+            self.tf_h = Act((T1, N, H, W, ngf), dev, grad=g)
+            self.tf_out = ConvLayer(store, prefix + os_ + 'conv2d/kernel', prefix + os_ + 'conv2d/bias', 'conv', (3, 3), (1, 1),
+                                    (1, 1), cy_pad=ceil4(cy))
+            self.tf_cy = ceil4(cy)
+            self.tf_raw = Act((T1, N, H, W, self.tf_cy), dev, grad=g)
+            if self.tf == 'dna':
+                if self.tf_cy != cy:
+                    raise NotImplementedError('dna with kh*kw*nk not a multiple of 4')
+                self.dna_kern = torch.empty(T1, N, H, W, cy, device=dev)
+            tf_convs = [self.tf_conv, self.tf_out]
         s = prefix + 'h%d_scratch/' % nl
         self.scratch_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
         self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g)
@@ -175,7 +200,7 @@ class SAVPGenerator(object):
                 self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
                 self.z_cs = torch.empty(T1, N, nz, device=dev)
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
-                     [self.cdna_dense, self.scratch_conv, self.scratch_out, self.masks_conv, self.masks_out]
+                     tf_convs + [self.scratch_conv, self.scratch_out, self.masks_conv, self.masks_out]
         # only FPROP packs needed at inference
         self._routes()
 
@@ -193,7 +218,7 @@ class SAVPGenerator(object):
                 j = ne - 1 - i              # decoder layer that takes this encoder layer as skip (j > 0)
                 if 1 <= j < nd:
                     r.append((self.layers[ne + j]['in'], self.layers[ne + j]['skip_off']))
-                if i == ne - 1:
+                if i == ne - 1 and self.tf == 'cdna':
                     r.append((self.hsmall, 0))
             L['routes'] = r
 
@@ -260,11 +285,22 @@ class SAVPGenerator(object):
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
-            # CDNA kernels from the smallest layer (savp_model.py:546-559) and their application (:580, :893-923)
-            self.cdna_dense.forward(self.hsmall.v[t].reshape(N, -1), self.cdna_raw.v[t])
-            K.cdna_kernels_fwd(self.cdna_raw.v[t], self.cdna_kern.v[t], self.kh, self.kw, self.nk)
-            K.cdna_apply_fwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C],
-                             self.kh, self.kw, self.nk)
+            tslot = maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C]
+            if self.tf == 'cdna':
+                # CDNA kernels from the smallest layer (savp_model.py:546-559) and their application (:580, :893-923)
+                self.cdna_dense.forward(self.hsmall.v[t].reshape(N, -1), self.cdna_raw.v[t])
+                K.cdna_kernels_fwd(self.cdna_raw.v[t], self.cdna_kern.v[t], self.kh, self.kw, self.nk)
+                K.cdna_apply_fwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], tslot, self.kh, self.kw, self.nk)
+            else:
+                self.tf_conv.forward(self.h_last.v[t], self.tf_pre.v[t])
+                tn = self.tf_norm
+                K.instnorm_act_fwd(self.tf_pre.v[t], tn.gamma, tn.beta, [self.tf_h.v[t]], tn.mean[t], tn.rstd[t], act='relu',
+                                   eps=EPS_IN)
+                self.tf_out.forward(self.tf_h.v[t], self.tf_raw.v[t])
+                if self.tf == 'flow':
+                    K.image_warp_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], tslot, self.nk)            # apply_flows :955-965
+                else:
+                    K.dna_apply_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], tslot, self.kh, self.kw, self.nk)
             # scratch image (savp_model.py:561-572): sigmoid fused into the conv epilogue, written into its mask-conv slot
             self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
             sn = self.scratch_norm
@@ -306,11 +342,24 @@ class SAVPGenerator(object):
             K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
                                [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
             self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
-            # CDNA
-            K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C],
-                             self.dimg_cdna, self.cdna_kern.g[t], self.kh, self.kw, self.nk)
-            K.cdna_kernels_bwd(self.cdna_raw.v[t], self.cdna_kern.g[t], self.cdna_raw.g[t], self.kh, self.kw, self.nk)
-            self.cdna_dense.backward_data(self.cdna_raw.g[t], self.hsmall.g[t].reshape(N, -1), beta=0)
+            # pixel transformation head
+            dslot = maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C]
+            if self.tf == 'cdna':
+                K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], dslot, self.dimg_cdna, self.cdna_kern.g[t], self.kh,
+                                 self.kw, self.nk)
+                K.cdna_kernels_bwd(self.cdna_raw.v[t], self.cdna_kern.g[t], self.cdna_raw.g[t], self.kh, self.kw, self.nk)
+                self.cdna_dense.backward_data(self.cdna_raw.g[t], self.hsmall.g[t].reshape(N, -1), beta=0)
+            else:
+                if self.tf == 'flow':
+                    K.image_warp_bwd(in0.v[t][..., 0:C], self.tf_raw.v[t], dslot, self.tf_raw.g[t], self.dimg_cdna, self.nk)
+                else:
+                    K.dna_apply_bwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], dslot, self.tf_raw.g[t],
+                                    self.dimg_cdna, self.kh, self.kw, self.nk)
+                self.tf_out.backward_data(self.tf_raw.g[t], self.tf_h.g[t], beta=0)
+                tn = self.tf_norm
+                K.instnorm_act_bwd(self.tf_pre.v[t], tn.gamma, tn.beta, self.tf_h.v[t], tn.mean[t], tn.rstd[t], [self.tf_h.g[t]],
+                                   self.tf_pre.g[t], tn.dgamma, tn.dbeta, act='relu', eps=EPS_IN)
+                self.tf_conv.backward_data(self.tf_pre.g[t], self.h_last.g[t], beta=1)
             # decoder / encoder ladder in reverse
             for L in reversed(self.layers):
                 f = L['f']
@@ -345,9 +394,13 @@ class SAVPGenerator(object):
             if L['rnn']:
                 a, gt = L['a'], L['gates']
                 L['rconv'].backward_weights(a.flat(a.v), gt.flat(gt.g))
-        hs = self.hsmall
-        self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
         hl = self.h_last
+        if self.tf == 'cdna':
+            hs = self.hsmall
+            self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
+        else:
+            self.tf_conv.backward_weights(hl.flat(hl.v), hl.flat(self.tf_pre.g))
+            self.tf_out.backward_weights(hl.flat(self.tf_h.v), hl.flat(self.tf_raw.g))
         self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
         self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
         self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
