@@ -240,6 +240,34 @@ typedef struct SavpDnaArgs {
 int savp_dna_apply_fwd(void* stream, const SavpDnaArgs* a);
 int savp_dna_apply_bwd(void* stream, const SavpDnaArgs* a);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * gru.hip: fused gate blocks of Conv2DGRUCell (rnn_ops.py:234-267, instance norm, separate_norms=False).
+ *  gates stage : pre [N,HW,2F] -> r,u = sigmoid(IN(pre)); writes u [N,HW,F] and r*h into the candidate conv's input slot
+ *  output stage: pre [N,HW,F]  -> c = tanh(IN(pre)); h' = u*h + (1-u)*c written to nout destinations
+ *  backward    : out_bwd gives dpre(F), du and dh = u*dh' (overwrites); gates_bwd gives dpre(2F) and dh += d(rh)*r (accumulates)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct SavpGruArgs {
+    int32_t N, HW, F;
+    float eps;
+    const float* pre;
+    SavpView h;
+    const float *gamma, *beta;
+    float *mean, *rstd;
+    float* u;
+    SavpView rh;
+    int32_t nout; SavpView out[4];
+    int32_t ndy; SavpView dy[4];
+    float* dpre;
+    float* du;
+    SavpView dh;
+    SavpView drh;
+    float *dgamma, *dbeta;
+} SavpGruArgs;
+int savp_convgru_gates_fwd(void* stream, const SavpGruArgs* a);
+int savp_convgru_out_fwd(void* stream, const SavpGruArgs* a);
+int savp_convgru_out_bwd(void* stream, const SavpGruArgs* a);
+int savp_convgru_gates_bwd(void* stream, const SavpGruArgs* a);
+
 #ifdef __cplusplus
 }
 #endif

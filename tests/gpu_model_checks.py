@@ -196,6 +196,7 @@ def check_model_small():
     res += check_generator_forward(nz=0, B=1, T=3, H=64, W=64, C=1, tag='gen_fwd_gray')
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_flow', transformation='flow')
     res += check_generator_forward(nz=0, B=1, T=4, tag='gen_fwd_dna', transformation='dna')
+    res += check_generator_forward(nz=8, B=2, T=4, tag='gen_fwd_gru', conv_rnn='gru')
     return res
 
 
@@ -206,6 +207,8 @@ def check_train_small():
     res += check_train_step(B=2, T=6, nz=8, steps=1, tag='train_all_discriminators', image_sn_gan_weight=0.1,
                             image_sn_vae_gan_weight=0.1, images_sn_gan_weight=0.05, images_sn_vae_gan_weight=0.05,
                             gan_feature_cdist_weight=1.0)
+    res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_gru', conv_rnn='gru', video_sn_vae_gan_weight=0.0,
+                            video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     for tf in ('flow', 'dna'):
         res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_' + tf, transformation=tf, video_sn_vae_gan_weight=0.0,
                                 video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)

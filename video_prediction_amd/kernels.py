@@ -558,3 +558,47 @@ def dna_apply_bwd(img, raw, kern, dout, draw, dimg, kh, kw, K_, dimg_beta=0):
         a.dimg = view(dimg)
     a.dimg_beta = int(dimg_beta)
     lib.check(_L().savp_dna_apply_bwd(lib.stream(), ctypes.byref(a)), 'savp_dna_apply_bwd')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ConvGRU gate blocks
+# ---------------------------------------------------------------------------------------------------------------
+def _gru_args(pre, h, gamma, beta, mean, rstd, F, eps):
+    a = lib.SavpGruArgs()
+    a.N, a.HW, a.F, a.eps = pre.shape[0], _hw(pre), F, float(eps)
+    assert pre.is_contiguous()
+    a.pre = _p(pre)
+    a.h = view(h)
+    a.gamma, a.beta, a.mean, a.rstd = _p(gamma), _p(beta), _p(mean), _p(rstd)
+    return a
+
+
+def convgru_gates_fwd(pre, h, gamma, beta, mean, rstd, u, rh, eps=1e-6):
+    a = _gru_args(pre, h, gamma, beta, mean, rstd, pre.shape[-1] // 2, eps)
+    a.u, a.rh = _p(u), view(rh)
+    lib.check(_L().savp_convgru_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_gates_fwd')
+
+
+def convgru_out_fwd(pre, h, gamma, beta, mean, rstd, u, outs, eps=1e-6):
+    a = _gru_args(pre, h, gamma, beta, mean, rstd, pre.shape[-1], eps)
+    a.u = _p(u)
+    a.nout = len(outs)
+    _set_views(a.out, outs)
+    lib.check(_L().savp_convgru_out_fwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_out_fwd')
+
+
+def convgru_out_bwd(pre, h, gamma, beta, mean, rstd, u, dys, dpre, du, dh, dgamma, dbeta, eps=1e-6):
+    a = _gru_args(pre, h, gamma, beta, mean, rstd, pre.shape[-1], eps)
+    a.u = _p(u)
+    a.ndy = len(dys)
+    _set_views(a.dy, dys)
+    a.dpre, a.du, a.dh = _p(dpre), _p(du), view(dh)
+    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    lib.check(_L().savp_convgru_out_bwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_out_bwd')
+
+
+def convgru_gates_bwd(pre, h, gamma, beta, mean, rstd, du, drh, dpre, dh, dgamma, dbeta, eps=1e-6):
+    a = _gru_args(pre, h, gamma, beta, mean, rstd, pre.shape[-1] // 2, eps)
+    a.du, a.drh, a.dpre, a.dh = _p(du), view(drh), _p(dpre), view(dh)
+    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    lib.check(_L().savp_convgru_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_gates_bwd')

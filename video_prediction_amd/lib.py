@@ -196,3 +196,14 @@ register('savp_image_warp_fwd', [c_vp, ctypes.POINTER(SavpWarpArgs)])
 register('savp_image_warp_bwd', [c_vp, ctypes.POINTER(SavpWarpArgs)])
 register('savp_dna_apply_fwd', [c_vp, ctypes.POINTER(SavpDnaArgs)])
 register('savp_dna_apply_bwd', [c_vp, ctypes.POINTER(SavpDnaArgs)])
+
+
+class SavpGruArgs(ctypes.Structure):
+    _fields_ = [('N', c_i32), ('HW', c_i32), ('F', c_i32), ('eps', c_f32), ('pre', c_vp), ('h', SavpView),
+                ('gamma', c_vp), ('beta', c_vp), ('mean', c_vp), ('rstd', c_vp), ('u', c_vp), ('rh', SavpView),
+                ('nout', c_i32), ('out', SavpView * 4), ('ndy', c_i32), ('dy', SavpView * 4), ('dpre', c_vp), ('du', c_vp),
+                ('dh', SavpView), ('drh', SavpView), ('dgamma', c_vp), ('dbeta', c_vp)]
+
+
+for _n in ('savp_convgru_gates_fwd', 'savp_convgru_out_fwd', 'savp_convgru_out_bwd', 'savp_convgru_gates_bwd'):
+    register(_n, [c_vp, ctypes.POINTER(SavpGruArgs)])

@@ -17,7 +17,7 @@ import torch
 
 from .. import kernels as K
 from .. import lib
-from ..engine import ConvLayer, same_pad_before, copy_view
+from ..engine import ConvLayer, same_pad_before, copy_view, add_views
 from ..variables import layer_specs, num_masks
 
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
@@ -60,8 +60,8 @@ class SAVPGenerator(object):
         self.dev = dev
         if hp.nz and not hp.use_tile_concat:
             raise NotImplementedError('use_tile_concat=False')
-        if hp.conv_rnn != 'lstm' or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
-            raise NotImplementedError('HIP path covers conv_rnn=lstm with instance norm (the published SAVP recipes)')
+        if hp.conv_rnn not in ('lstm', 'gru') or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
+            raise NotImplementedError('HIP path covers conv_rnn in (lstm, gru) with instance norm')
         if hp.downsample_layer != 'conv_pool2d' or hp.upsample_layer != 'upsample_conv2d' or hp.activation_layer != 'relu':
             raise NotImplementedError('HIP path covers conv_pool2d / upsample_conv2d / relu')
         if hp.transformation not in ('cdna', 'flow', 'dna') or hp.last_frames != 1 or not hp.num_transformed_images:
@@ -109,7 +109,22 @@ class SAVPGenerator(object):
             L['hw'] = (h_, w_)
             L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g)
             L['norm'] = Norm(store, s + 'InstanceNorm/', T1, N, f, dev)
-            if use_rnn:
+            if use_rnn and hp.conv_rnn == 'gru':
+                # Conv2DGRUCell (rnn_ops.py:174-267): a = [x | z | h_prev | r*h_prev]; the gates conv reads the first
+                # f+zc+f channels of the same buffer (a channel-slice view), the candidate conv reads all of it
+                r = prefix + 'gru_h%d/conv2dgru_cell/' % i
+                L['cin1'] = f + zc + f
+                L['a'] = Act((T1, N, h_, w_, f + zc + 2 * f), dev, grad=g)
+                L['gates'] = Act((T1, N, h_, w_, 2 * f), dev, grad=g)
+                L['cand'] = Act((T1, N, h_, w_, f), dev, grad=g)
+                L['u'] = torch.empty(T1, N, h_, w_, f, device=dev)
+                L['du'] = torch.empty(N, h_, w_, f, device=dev) if g else None
+                L['dh_tmp'] = torch.empty(N, h_, w_, f, device=dev) if g else None
+                L['rconv'] = ConvLayer(store, r + 'gates/kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
+                L['cconv'] = ConvLayer(store, r + 'candidate/kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
+                L['n1'] = Norm(store, r + 'gates/reset_update/', T1, N, 2 * f, dev)
+                L['n2'] = Norm(store, r + 'candidate/state/', T1, N, f, dev)
+            elif use_rnn:
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
                 L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g)
                 L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g)
@@ -199,7 +214,9 @@ class SAVPGenerator(object):
                 self.dzW, self.dzb = store.grad(z + 'kernel'), store.grad(z + 'bias')
                 self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
                 self.z_cs = torch.empty(T1, N, nz, device=dev)
+        self.gru = hp.conv_rnn == 'gru'
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
+                     [L['cconv'] for L in self.layers if L['rnn'] and self.gru] + \
                      tf_convs + [self.scratch_conv, self.scratch_out, self.masks_conv, self.masks_out]
         # only FPROP packs needed at inference
         self._routes()
@@ -270,7 +287,22 @@ class SAVPGenerator(object):
                 f = L['f']
                 L['conv'].forward(L['in'].v[t], L['pre'].v[t])
                 nrm = L['norm']
-                if L['rnn']:
+                if L['rnn'] and self.gru:
+                    a = L['a']
+                    hs, rs_, cin1 = f + nz, f + nz + f, L['cin1']
+                    K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
+                                       act='relu', eps=EPS_IN)
+                    n1, n2 = L['n1'], L['n2']
+                    hprev = a.v[t][..., hs:hs + f]
+                    L['rconv'].forward(a.v[t][..., 0:cin1], L['gates'].v[t], use_bias=False)
+                    K.convgru_gates_fwd(L['gates'].v[t], hprev, n1.gamma, n1.beta, n1.mean[t], n1.rstd[t], L['u'][t],
+                                        a.v[t][..., rs_:rs_ + f], eps=EPS_IN)
+                    L['cconv'].forward(a.v[t], L['cand'].v[t], use_bias=False)
+                    outs = self._out_views(L, t)
+                    if t + 1 < T1:
+                        outs.append(a.v[t + 1][..., hs:hs + f])
+                    K.convgru_out_fwd(L['cand'].v[t], hprev, n2.gamma, n2.beta, n2.mean[t], n2.rstd[t], L['u'][t], outs, eps=EPS_IN)
+                elif L['rnn']:
                     a = L['a']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
@@ -365,7 +397,24 @@ class SAVPGenerator(object):
                 f = L['f']
                 dys = self._out_grads(L, t)
                 nrm = L['norm']
-                if L['rnn']:
+                if L['rnn'] and self.gru:
+                    a = L['a']
+                    hs, rs_, cin1 = f + nz, f + nz + f, L['cin1']
+                    if t + 1 < T1:
+                        dys.append(a.g[t + 1][..., hs:hs + f])
+                    n1, n2 = L['n1'], L['n2']
+                    hprev = a.v[t][..., hs:hs + f]
+                    K.convgru_out_bwd(L['cand'].v[t], hprev, n2.gamma, n2.beta, n2.mean[t], n2.rstd[t], L['u'][t], dys,
+                                      L['cand'].g[t], L['du'], L['dh_tmp'], n2.dgamma, n2.dbeta, eps=EPS_IN)
+                    L['cconv'].backward_data(L['cand'].g[t], a.g[t], beta=0)
+                    add_views([L['dh_tmp']], a.g[t][..., hs:hs + f])
+                    K.convgru_gates_bwd(L['gates'].v[t], hprev, n1.gamma, n1.beta, n1.mean[t], n1.rstd[t], L['du'],
+                                        a.g[t][..., rs_:rs_ + f], L['gates'].g[t], a.g[t][..., hs:hs + f], n1.dgamma, n1.dbeta,
+                                        eps=EPS_IN)
+                    L['rconv'].backward_data(L['gates'].g[t], a.g[t][..., 0:cin1], beta=1)
+                    K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
+                                       [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                elif L['rnn']:
                     a = L['a']
                     if t + 1 < T1:
                         dys.append(a.g[t + 1][..., f + nz:f + nz + f])
@@ -391,7 +440,11 @@ class SAVPGenerator(object):
         for L in self.layers:
             b, pre = L['in'], L['pre']
             L['conv'].backward_weights(b.flat(b.v), pre.flat(pre.g))
-            if L['rnn']:
+            if L['rnn'] and self.gru:
+                a, gt, cd = L['a'], L['gates'], L['cand']
+                L['rconv'].backward_weights(a.flat(a.v)[..., 0:L['cin1']], gt.flat(gt.g))
+                L['cconv'].backward_weights(a.flat(a.v), cd.flat(cd.g))
+            elif L['rnn']:
                 a, gt = L['a'], L['gates']
                 L['rconv'].backward_weights(a.flat(a.v), gt.flat(gt.g))
         hl = self.h_last
