@@ -193,6 +193,9 @@ int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, con
                      const float* dz, float klw, float* dmu, float* dls_raw);
 int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride, int32_t p2,
                  const float* pred, const float* target, float weight, float* loss_out, float* dpred);
+/* type 0 LSGAN, 1 GAN (sigmoid cross-entropy), 2 SNGAN (softplus hinge-free form), losses.py:29-54 */
+int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, float* loss_out,
+                  float* dlogits, int32_t beta);
 int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out, float* dlogits,
                     int32_t beta);
 int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,

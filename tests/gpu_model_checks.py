@@ -175,6 +175,10 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
                     else:
                         e = _l2rel(got, gref)
                         tol = max(20.0 * _l2rel(info32[key][name], gref), 2e-3)
+                        # heavily cancelling sums (e.g. real/fake bias gradients of a discriminator at init) are judged on
+                        # their absolute error relative to the largest gradient of the group
+                        if float((got.detach().double().cpu() - gref).abs().max()) <= 2e-5 * gmax:
+                            e = min(e, tol)
                     if e / tol > worst_excess:
                         worst_excess, worst_name, worst_err = e / tol, name, e
                 out.append((t + '/%s_grads_worst_err_over_tol[%s]' % (grp, worst_name.split('/', 1)[-1][-36:]), worst_excess, 1.0))

@@ -227,15 +227,31 @@ extern "C" int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t
     return LAUNCH_OK();
 }
 
-// LSGAN on logits [n]: loss_out += mean((l-label)^2); dlogits (=|+=) weight*2*(l-label)/n
-__global__ void lsgan_kernel(int n, const float* logits, float label, float weight, float* loss_out, float* dlogits, int beta) {
+// GAN losses on logits [n] (losses.py:29-54).  type 0 LSGAN: mean((l-label)^2); 1 GAN: mean sigmoid cross-entropy with
+// constant labels; 2 SNGAN: mean softplus(l) for label 0, mean softplus(-l) for label 1.
+// loss_out += loss ; dlogits (=|+=) weight * dloss/dlogits
+__device__ __forceinline__ float softplus_(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+__global__ void gan_loss_kernel(int n, int type, const float* logits, float label, float weight, float* loss_out, float* dlogits,
+                                int beta) {
     __shared__ float sh[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float d = logits[i] - label;
-        acc += d * d;
+        const float l = logits[i];
+        float g;
+        if (type == 0) {
+            const float d = l - label;
+            acc += d * d;
+            g = 2.f * d;
+        } else if (type == 1) {
+            // max(l,0) - l*z + log(1+exp(-|l|))   (tf.nn.sigmoid_cross_entropy_with_logits)
+            acc += softplus_(l) - l * label;
+            g = 1.f / (1.f + __expf(-l)) - label;
+        } else {
+            acc += (label == 0.f) ? softplus_(l) : softplus_(-l);
+            g = 1.f / (1.f + __expf(-l)) - ((label == 0.f) ? 0.f : 1.f);
+        }
         if (dlogits) {
-            float g = weight * 2.f * d / (float)n;
+            g *= weight / (float)n;
             dlogits[i] = beta ? dlogits[i] + g : g;
         }
     }
@@ -243,11 +259,18 @@ __global__ void lsgan_kernel(int n, const float* logits, float label, float weig
     if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t / (float)n);
 }
 
+extern "C" int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, float* loss_out,
+                             float* dlogits, int32_t beta) {
+    if (!logits || n < 1 || type < 0 || type > 2) return SAVP_EINVAL;
+    if (type == 2 && label != 0.f && label != 1.f) return SAVP_EINVAL;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, n, type, logits, label, weight, loss_out, dlogits,
+                       beta);
+    return LAUNCH_OK();
+}
+
 extern "C" int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out,
                                float* dlogits, int32_t beta) {
-    if (!logits || n < 1) return SAVP_EINVAL;
-    hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, n, logits, label, weight, loss_out, dlogits, beta);
-    return LAUNCH_OK();
+    return savp_gan_loss(stream, n, 0, logits, label, weight, loss_out, dlogits, beta);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -602,3 +602,12 @@ def convgru_gates_bwd(pre, h, gamma, beta, mean, rstd, du, drh, dpre, dh, dgamma
     a.du, a.drh, a.dpre, a.dh = _p(du), view(drh), _p(dpre), view(dh)
     a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
     lib.check(_L().savp_convgru_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_gates_bwd')
+
+
+GAN_TYPES = {'LSGAN': 0, 'GAN': 1, 'SNGAN': 2}
+
+
+def gan_loss(logits, label, weight, gan_loss_type='LSGAN', loss_out=None, dlogits=None, beta=0):
+    """losses.gan_loss (losses.py:29-54): value accumulated into loss_out, weighted gradient into dlogits."""
+    lib.check(_L().savp_gan_loss(lib.stream(), logits.numel(), GAN_TYPES[gan_loss_type], _p(logits), float(label), float(weight),
+                                 _p(loss_out), _p(dlogits), int(beta)), 'savp_gan_loss')

@@ -207,3 +207,4 @@ class SavpGruArgs(ctypes.Structure):
 
 for _n in ('savp_convgru_gates_fwd', 'savp_convgru_out_fwd', 'savp_convgru_out_bwd', 'savp_convgru_gates_bwd'):
     register(_n, [c_vp, ctypes.POINTER(SavpGruArgs)])
+register('savp_gan_loss', [c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])

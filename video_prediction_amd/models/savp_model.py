@@ -55,8 +55,8 @@ class SAVPEngine(object):
         # (discriminator, loss weight, loss-name infix, operates on the posterior ('_enc') unroll?, clip index keys)
         self.discs = []
         if self.has_d:
-            if hp.gan_loss_type != 'LSGAN':
-                raise NotImplementedError('gan_loss_type %s' % hp.gan_loss_type)
+            if hp.gan_loss_type not in K.GAN_TYPES:
+                raise ValueError('Unknown GAN loss type %s' % hp.gan_loss_type)
             slot = 0
             for enc in ((True, False) if self.nz else (False,)):       # encoder scope first (savp_model.py:130-147)
                 pre = 'discriminator/' + ('encoder/' if (enc and not hp.use_same_discriminator) else '')
@@ -235,8 +235,8 @@ class SAVPEngine(object):
                 D.forward()
                 r0, r1 = D.rows(0, B)
                 f0, f1 = D.rows(B, 2 * B)
-                K.lsgan_loss(D.logits[r0:r1], 1.0, w, lb[slot:slot + 1], D.dlogits[r0:r1])            # discrim_*_loss real
-                K.lsgan_loss(D.logits[f0:f1], 0.0, w, lb[slot + 1:slot + 2], D.dlogits[f0:f1])        # ... fake
+                K.gan_loss(D.logits[r0:r1], 1.0, w, hp.gan_loss_type, lb[slot:slot + 1], D.dlogits[r0:r1])    # discrim_*_loss real
+                K.gan_loss(D.logits[f0:f1], 0.0, w, hp.gan_loss_type, lb[slot + 1:slot + 2], D.dlogits[f0:f1])  # ... fake
                 D.backward(0, 2 * B, weights=True, data=False)
             for D in {id(d['D']): d['D'] for d in discs}.values():
                 D.finish_weight_grads()
@@ -259,23 +259,26 @@ class SAVPEngine(object):
                     continue
                 wf_cd = hp.vae_gan_feature_cdist_weight if is_vae else hp.gan_feature_cdist_weight
                 wf_l2 = hp.vae_gan_feature_l2_weight if is_vae else hp.gan_feature_l2_weight
-                if wf_l2:
-                    raise NotImplementedError('feature l2 matching')
-                if wf_cd:
+                if wf_cd or wf_l2:
                     ts_f = self._d_clips(D, ipost[d['kr']], ipost[d['kf']], d['fake'], 0, B)
                     D.forward()
                     lo, hi = B, 2 * B
                     r0, r1 = D.rows(0, B)
                     f0, f1 = D.rows(lo, hi)
                     for L in D.layers:
-                        K.cosine_distance(L['y'][f0:f1], L['y'][r0:r1], wf_cd, lb[slot + 3:slot + 4], L['dy'][f0:f1])
+                        if wf_cd:       # losses.cosine_distance over the channel axis (base_model.py:794-797,821-824)
+                            K.cosine_distance(L['y'][f0:f1], L['y'][r0:r1], wf_cd, lb[slot + 3:slot + 4], L['dy'][f0:f1])
+                        else:
+                            L['dy'][f0:f1].zero_()
+                        if wf_l2:       # losses.l2_loss between fake and real features (base_model.py:790-793,817-820)
+                            K.lp_loss(L['y'][f0:f1], L['y'][r0:r1], wf_l2, lb[slot + 4:slot + 5], L['dy'][f0:f1], p2=True)
                 else:
                     ts_f = self._d_clips(D, None, ipost[d['kf']], d['fake'], 0, 0)
                     D.forward(n=B)
                     lo, hi = 0, B
                     f0, f1 = D.rows(lo, hi)
-                K.lsgan_loss(D.logits[f0:f1], 1.0, w, lb[slot + 2:slot + 3], D.dlogits[f0:f1])      # gen_*_gan_loss
-                D.backward(lo, hi, weights=False, data=True, feature_grads=bool(wf_cd))
+                K.gan_loss(D.logits[f0:f1], 1.0, w, hp.gan_loss_type, lb[slot + 2:slot + 3], D.dlogits[f0:f1])   # gen_*_gan_loss
+                D.backward(lo, hi, weights=False, data=True, feature_grads=bool(wf_cd or wf_l2))
                 gfake = self.gen.gen.g[:, :B] if (is_vae and self.nz) else (self.gen.gen.g[:, B:] if self.nz else self.gen.gen.g)
                 K.gather_clips(gfake, D.dclip[lo:hi], ts_f, adjoint=True)
         target = self.images_tm[1:self.T]
@@ -310,6 +313,9 @@ class SAVPEngine(object):
             wf_cd = hp.vae_gan_feature_cdist_weight if d['enc'] else hp.gan_feature_cdist_weight
             if wf_cd:
                 g_losses['gen_%s_feature_cdist_loss' % name] = (lb[slot + 3], wf_cd)
+            wf_l2 = hp.vae_gan_feature_l2_weight if d['enc'] else hp.gan_feature_l2_weight
+            if wf_l2:
+                g_losses['gen_%s_feature_l2_loss' % name] = (lb[slot + 4], wf_l2)
         if hp.l1_weight:
             g_losses['gen_l1_loss'] = (lb[-2], hp.l1_weight)
         if hp.l2_weight:
