@@ -1,0 +1,48 @@
+"""ConvLSTM gate-conv FPROP launches (the five layers at N=32, BAIR) for PMC collection.
+  python tests/pmc_conv.py tune    -> writes gpurun_out/pmc_tuned.json (autotuned tile/split per layer)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tests/pmc_conv.py run
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from video_prediction_amd import kernels as K, lib
+
+LAYERS = [('lstm_h0', 32, 32, 72, 128), ('lstm_h1', 16, 16, 136, 256), ('lstm_h2', 8, 8, 264, 512),
+          ('lstm_h3', 16, 16, 136, 256), ('lstm_h4', 32, 32, 72, 128)]
+N = 32
+PATH = os.path.join(ROOT, 'gpurun_out', 'pmc_tuned.json')
+
+
+def main():
+    mode = sys.argv[1]
+    prec = os.environ.get('PREC', 'bf16')
+    K.set_conv_precision(prec)
+    geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
+    bufs = []
+    for name, H, W, Cx, Cy in LAYERS:
+        x = torch.randn(N, H, W, Cx, device='cuda')
+        y = torch.empty(N, H, W, Cy, device='cuda')
+        w = torch.randn(Cy, 25 * Cx, device='cuda') * 0.05
+        bufs.append((name, x, y, w))
+    if mode == 'tune':
+        K.enable_autotune(True)
+        out = {}
+        for name, x, y, w in bufs:
+            K.conv(lib.CONV_FPROP, geom, x, y, w)
+        for (key, cfg), (name, *_r) in zip(K.AUTOTUNE['log'], bufs):
+            out[name] = list(cfg)
+        os.makedirs(os.path.dirname(PATH), exist_ok=True)
+        json.dump({prec: out}, open(PATH, 'w'))
+        print(out)
+    else:
+        cfgs = json.load(open(PATH))[prec]
+        for name, x, y, w in bufs:
+            tile, sk = cfgs[name]
+            for _ in range(3):
+                K.conv(lib.CONV_FPROP, geom, x, y, w, tile=tile, splitk=sk)
+        torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    main()

@@ -45,6 +45,7 @@ struct ConvP {
     const float* aux;
     int splitk;
     int bf16;
+    int tm, tn;          // tile counts (1-D XCD-aware launch grids)
     unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
 };
 
@@ -54,6 +55,14 @@ __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// XCD-aware workgroup -> logical id map (MI355X: hardware block b runs on XCD b % 8, each XCD has a private L2).
+// Consecutive LOGICAL ids land on the same XCD, so tiles that share an operand (same weight column block, neighbouring
+// pixel rows, same K split) hit one L2 instead of being fetched once per XCD.  Bijective for any n (speed only).
+__device__ __forceinline__ int xcd_logical(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // FPROP / DGRAD kernel.  GEMM: C[M = grid pixels][N = dst channels] = A[M][K=(taps,Cred)] * B[K][N]
@@ -115,8 +124,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     const int K = ntaps * Cred;
     const int ldb = p.kd * p.kh * p.kw * Cred;        // packed weight row length
     const int Mtot = p.N * gd.Mdim * gh.Mdim * gw.Mdim;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // logical tile id: n-tile major so that the tiles sharing a weight block are consecutive (-> same XCD L2)
+    const int tlog = xcd_logical(blockIdx.x, p.tm * p.tn);
+    const int m0 = (tlog % p.tm) * BM;
+    const int n0 = (tlog / p.tm) * BN;
     if (m0 >= Mtot) return;                            // uniform per workgroup (phase with fewer pixels)
 
     const float* __restrict__ src = dgrad ? p.y : p.x;
@@ -375,11 +386,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(ConvP p) {
     const int Nn = p.Cy;
     const int HWo = p.Ho * p.Wo, DHWo = p.Do * HWo;
     const int Ktot = p.N * DHWo;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // 1-D grid: logical id = split * (tm*tn) + tile, so the tiles of one K split (same pixels) share an XCD L2
+    const int llog = xcd_logical(blockIdx.x, p.tm * p.tn * p.splitk);
+    const int zsplit = llog / (p.tm * p.tn), tl = llog % (p.tm * p.tn);
+    const int m0 = (tl % p.tm) * BM, n0 = (tl / p.tm) * BN;
     // K range of this split (multiple of BK)
     const int ktiles = (Ktot + BK - 1) / BK;
     const int per = (ktiles + p.splitk - 1) / p.splitk;
-    const int kt_begin = blockIdx.z * per;
+    const int kt_begin = zsplit * per;
     const int kt_end = min(ktiles, kt_begin + per);
     if (kt_begin >= kt_end) return;
 
@@ -535,10 +549,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
     const int Nn = p.Cy;
     const int HWo = p.Ho * p.Wo, DHWo = p.Do * HWo;
     const int Ktot = p.N * DHWo;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int llog = xcd_logical(blockIdx.x, p.tm * p.tn * p.splitk);
+    const int zsplit = llog / (p.tm * p.tn), tl = llog % (p.tm * p.tn);
+    const int m0 = (tl % p.tm) * BM, n0 = (tl / p.tm) * BN;
     const int ktiles = (Ktot + BKT - 1) / BKT;
     const int per = (ktiles + p.splitk - 1) / p.splitk;
-    const int kt_begin = blockIdx.z * per;
+    const int kt_begin = zsplit * per;
     const int kt_end = min(ktiles, kt_begin + per);
     if (kt_begin >= kt_end) return;
 
@@ -762,7 +778,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.y = (const float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
     p.w = (const float*)a->w;
     p.bias = a->bias; p.aux = a->aux;
-    p.splitk = 1;
+    p.splitk = 1; p.tm = p.tn = 1;
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
@@ -814,7 +830,8 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
             else splitk = 1;
         }
         p.splitk = splitk;
-        dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((Nout + BN - 1) / BN), (unsigned)(phases * splitk));
+        p.tm = (int)((Mmax + BM - 1) / BM); p.tn = (int)((Nout + BN - 1) / BN);
+        dim3 grid((unsigned)(p.tm * p.tn), 1, (unsigned)(phases * splitk));
         if (wm == 2 && wn == 2) err = launch_fd<2, 2>(p, vec, grid, st);
         else if (wm == 2 && wn == 1) err = launch_fd<2, 1>(p, vec, grid, st);
         else if (wm == 1 && wn == 2) err = launch_fd<1, 2>(p, vec, grid, st);
@@ -846,7 +863,8 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         if (splitk > ktiles) splitk = (int)ktiles;
         if (splitk < 1) splitk = 1;
         p.splitk = splitk;
-        dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a->Cy + BN - 1) / BN), (unsigned)splitk);
+        p.tm = (int)((M + BM - 1) / BM); p.tn = (int)((a->Cy + BN - 1) / BN);
+        dim3 grid((unsigned)(p.tm * p.tn * splitk), 1, 1);
         if (wbf16) {
             if (wm == 2 && wn == 2) err = launch_wg_bf16<2, 2>(p, grid, st);
             else if (wm == 2 && wn == 1) err = launch_wg_bf16<2, 1>(p, grid, st);
