@@ -60,6 +60,7 @@ typedef struct SavpConvArgs {
     void* w;
     const float* bias;             /* per destination channel, or NULL */
     const float* aux;              /* act==3: saved activation, addressed like the destination */
+    const void* w_bf16;            /* optional bf16 copy of w (FPROP/DGRAD, SAVP_PREC_BF16): halves the weight stream */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
@@ -205,7 +206,9 @@ int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, co
  * weight_prep.hip: packing for the conv kernel, conv_pool2d / upsample_conv2d kernel folding (ops.py:838-842,
  * 697-704) and spectral normalisation with its full gradient (ops.py:1020-1049).
  * ------------------------------------------------------------------------------------------------------------ */
-int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale, float* wt, float* wd);
+/* wt_bf16 / wd_bf16: optional bf16 copies (same layouts) consumed by savp_conv in SAVP_PREC_BF16 mode */
+int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale, float* wt, float* wd,
+                      void* wt_bf16, void* wd_bf16);
 int savp_fold_pool(void* stream, const float* in, float* out, int32_t k, int64_t C, int32_t adjoint);
 int savp_fold_bilinear(void* stream, const float* in, float* out, int32_t k, int32_t Cin, int32_t F, int32_t adjoint);
 /* ws: 8 + 2C + 2K floats; after fwd ws[0]=sigma, ws[1]=1/sigma; u_new receives u_final */

@@ -100,6 +100,15 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
             yd = torch.empty(y.shape, device=DEV, dtype=torch.float32)
             K.conv(lib.CONV_FPROP, geom, xd, yd, dev(pack_wt(w.detach())), bias=bd, tile=tile, precision=precision)
             out.append((tag + '/fprop', rel_err(yd, y), tol))
+            if precision == 1:      # bf16 pre-packed weight stream
+                yd2 = torch.empty(y.shape, device=DEV, dtype=torch.float32)
+                wtp = dev(pack_wt(w.detach()))
+                K.conv(lib.CONV_FPROP, geom, xd, yd2, wtp, bias=bd, tile=tile, precision=1, w16=wtp.to(torch.bfloat16))
+                out.append((tag + '/fprop_w16', rel_err(yd2, y), tol))
+                dx2 = torch.full(x.shape, float('nan'), device=DEV, dtype=torch.float32)
+                wdp = dev(pack_wd(w.detach()))
+                K.conv(lib.CONV_DGRAD, geom, dx2, dyd, wdp, tile=tile, precision=1, w16=wdp.to(torch.bfloat16))
+                out.append((tag + '/dgrad_w16', rel_err(dx2, x.grad), tol))
             # DGRAD
             dxd = torch.full(x.shape, float('nan'), device=DEV, dtype=torch.float32)
             K.conv(lib.CONV_DGRAD, geom, dxd, dyd, dev(pack_wd(w.detach())), tile=tile, precision=precision)

@@ -40,6 +40,7 @@ struct ConvP {
     const float* x; long long x_sn, x_sd, x_sh, x_sw;
     const float* y; long long y_sn, y_sd, y_sh, y_sw;
     const float* w;
+    const unsigned short* w16;   // optional bf16 copy of the packed weights (same layout)
     float* out;          // destination (y for FPROP, x for DGRAD, dW for WGRAD)
     const float* bias;
     const float* aux;
@@ -95,7 +96,9 @@ __device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out,
 
 // BF16 = true: operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while staging into LDS and multiplied on
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate); K-tile 64.  BF16 = false: exact fp32 on v_mfma_f32_32x32x2_f32; K-tile 32.
-template <int WM, int WN, bool VEC, bool BF16>
+// WB16 = true (bf16 mode only): the weight operand is read from a pre-packed bf16 copy (16-byte loads of 8 k values,
+// no conversion, half the L2 traffic and staging instructions of the fp32 stream).
+template <int WM, int WN, bool VEC, bool BF16, bool WB16>
 __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int BKT = BF16 ? 64 : 32;                // K-tile
@@ -181,8 +184,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
     }
 
     float4 ra[RA], rb[RB];
+    // bf16 weight stream: thread -> (row r0b + 32*j, 8-wide k chunk kvb)
+    constexpr int RB16 = BN / 32;
+    const int kvb = tid & 7, r0b = tid >> 3;
+    uint4 rb16[WB16 ? RB16 : 1];
+    long long bb16[WB16 ? RB16 : 1];
+    bool bok16[WB16 ? RB16 : 1];
+    int kcb = 0, jdb = 0, jhb = 0, jwb = 0;
+    if (WB16) {
+#pragma unroll
+        for (int j = 0; j < RB16; ++j) {
+            int n = n0 + r0b + 32 * j;
+            bok16[j] = n < Nout;
+            bb16[j] = (long long)(bok16[j] ? n : 0) * ldb;
+        }
+        int k = kt_begin * BKT + kvb * 8;
+        kcb = k % Cred; int tap = k / Cred;
+        jwb = tap % max(gw.nt, 1); tap /= max(gw.nt, 1);
+        jhb = tap % max(gh.nt, 1); jdb = tap / max(gh.nt, 1);
+    }
 
     auto fetch = [&](int kt) {
+        if (WB16) {
+            const bool kokb = (jdb < gd.nt) && (ntaps > 0);
+            const int ta = gd.t0 + jdb * gd.tstep, tu = gh.t0 + jhb * gh.tstep, tv = gw.t0 + jwb * gw.tstep;
+            const long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + kcb;
+#pragma unroll
+            for (int j = 0; j < RB16; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (bok16[j] && kokb) v = *reinterpret_cast<const uint4*>(p.w16 + bb16[j] + woff);
+                rb16[j] = v;
+            }
+            kcb += BKT;
+            while (kcb >= Cred) {
+                kcb -= Cred;
+                if (++jwb >= gw.nt) { jwb = 0; if (++jhb >= gh.nt) { jhb = 0; ++jdb; } }
+            }
+        }
         if (VEC) {
             const bool kok = (jd < gd.nt) && (ntaps > 0);
             const int zd0 = jd * gd.jstep, zh0 = jh * gh.jstep, zw0 = jw * gw.jstep;
@@ -197,11 +235,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
             }
             const int ta = gd.t0 + jd * gd.tstep, tu = gh.t0 + jh * gh.tstep, tv = gw.t0 + jw * gw.tstep;
             const long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + kc;
+            if (!WB16) {
 #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b_ok[j] && kok) v = ldg4(wt + b_base[j] + woff);
-                rb[j] = v;
+                for (int j = 0; j < RB; ++j) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (b_ok[j] && kok) v = ldg4(wt + b_base[j] + woff);
+                    rb[j] = v;
+                }
             }
             // advance by the K-tile
             kc += BKT;
@@ -247,10 +287,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                 bf16x4 v = {(__bf16)ra[j].x, (__bf16)ra[j].y, (__bf16)ra[j].z, (__bf16)ra[j].w};
                 *reinterpret_cast<bf16x4*>(a + (r0 + RP * j) * ROWB + kv * 8) = v;
             }
+            if (WB16) {
 #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                bf16x4 v = {(__bf16)rb[j].x, (__bf16)rb[j].y, (__bf16)rb[j].z, (__bf16)rb[j].w};
-                *reinterpret_cast<bf16x4*>(b + (r0 + RP * j) * ROWB + kv * 8) = v;
+                for (int j = 0; j < RB16; ++j) *reinterpret_cast<uint4*>(b + (r0b + 32 * j) * ROWB + kvb * 16) = rb16[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    bf16x4 v = {(__bf16)rb[j].x, (__bf16)rb[j].y, (__bf16)rb[j].z, (__bf16)rb[j].w};
+                    *reinterpret_cast<bf16x4*>(b + (r0 + RP * j) * ROWB + kv * 8) = v;
+                }
             }
         } else {
 #pragma unroll
@@ -708,7 +753,7 @@ static unsigned long long magic40(int d) {
     return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
 }
 
-template <int WM, int WN, bool VEC, bool BF16>
+template <int WM, int WN, bool VEC, bool BF16, bool WB16 = false>
 static hipError_t launch_fd1(const ConvP& p, dim3 grid, hipStream_t st) {
     constexpr int BKT = BF16 ? 64 : 32;
     constexpr size_t rowb = BF16 ? (BKT + 8) * 2 : BKP * 4;
@@ -716,15 +761,16 @@ static hipError_t launch_fd1(const ConvP& p, dim3 grid, hipStream_t st) {
     if (lds < (size_t)64 * WM * sizeof(long long)) lds = (size_t)64 * WM * sizeof(long long);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, VEC, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fd_kernel<WM, WN, VEC, BF16, WB16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_fd_kernel<WM, WN, VEC, BF16>), grid, dim3(NTHREADS), lds, st, p);
+    hipLaunchKernelGGL((conv_fd_kernel<WM, WN, VEC, BF16, WB16>), grid, dim3(NTHREADS), lds, st, p);
     return hipGetLastError();
 }
 
 template <int WM, int WN>
 static hipError_t launch_fd(const ConvP& p, bool vec, dim3 grid, hipStream_t st) {
+    if (p.bf16 && vec && p.w16) return launch_fd1<WM, WN, true, true, true>(p, grid, st);
     if (p.bf16) return vec ? launch_fd1<WM, WN, true, true>(p, grid, st) : launch_fd1<WM, WN, false, true>(p, grid, st);
     return vec ? launch_fd1<WM, WN, true, false>(p, grid, st) : launch_fd1<WM, WN, false, false>(p, grid, st);
 }
@@ -777,6 +823,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.x = (const float*)a->x; p.x_sn = a->x_sn; p.x_sd = a->x_sd; p.x_sh = a->x_sh; p.x_sw = a->x_sw;
     p.y = (const float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
     p.w = (const float*)a->w;
+    p.w16 = nullptr;
     p.bias = a->bias; p.aux = a->aux;
     p.splitk = 1; p.tm = p.tn = 1;
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
@@ -792,6 +839,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         const int Cred = dg ? a->Cy : a->Cx;
         const int Nout = dg ? a->Cx : a->Cy;
         const bool vec = (Cred % 4 == 0) && (dg ? ys4 : xs4) && aligned16(a->w);
+        if (a->w_bf16 && (Cred % 8 == 0) && aligned16(a->w_bf16)) p.w16 = (const unsigned short*)a->w_bf16;
         long long Mmax;
         int phases = 1;
         if (dg) {

@@ -31,7 +31,7 @@ __device__ __forceinline__ float block_sum1(float v, float* sh) {
 
 // src [T, Cx, Cy]
 __global__ void pack_weights_kernel(const float* __restrict__ src, long long T, int Cx, int Cy, const float* scale, float* wt,
-                                    float* wd) {
+                                    float* wd, __bf16* wt16, __bf16* wd16) {
     const long long total = T * Cx * Cy;
     const float s = scale ? *scale : 1.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -42,16 +42,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, long long T, 
         float v = src[i] * s;
         if (wt) wt[(long long)cy * (T * Cx) + t * Cx + cx] = v;
         if (wd) wd[(long long)cx * (T * Cy) + t * Cy + cy] = v;
+        if (wt16) wt16[(long long)cy * (T * Cx) + t * Cx + cx] = (__bf16)v;
+        if (wd16) wd16[(long long)cx * (T * Cy) + t * Cy + cy] = (__bf16)v;
     }
 }
 
 extern "C" int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale,
-                                 float* wt, float* wd) {
-    if (!src || (!wt && !wd)) return SAVP_EINVAL;
+                                 float* wt, float* wd, void* wt_bf16, void* wd_bf16) {
+    if (!src || (!wt && !wd && !wt_bf16 && !wd_bf16)) return SAVP_EINVAL;
     long long total = (long long)T * Cx * Cy;
     unsigned nb = (unsigned)((total + NT - 1) / NT);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, src, (long long)T, Cx, Cy, scale, wt, wd);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, src, (long long)T, Cx, Cy, scale, wt, wd,
+                       (__bf16*)wt_bf16, (__bf16*)wd_bf16);
     return LAUNCH_OK();
 }
 

@@ -211,6 +211,9 @@ class ConvLayer(object):
                 self.dbias = torch.zeros(self.cy, device=dev)
         self.wt = torch.empty(self.cy, self.taps * self.cx, device=dev)
         self.wd = torch.empty(self.cx, self.taps * self.cy, device=dev)
+        # bf16 copies of the packed weights for the bf16 MFMA mode (half the weight stream, no in-kernel conversion)
+        self.wt16 = torch.empty(self.cy, self.taps * self.cx, device=dev, dtype=torch.bfloat16)
+        self.wd16 = torch.empty(self.cx, self.taps * self.cy, device=dev, dtype=torch.bfloat16)
         self.sn_u_name = sn_u
         if sn_u:
             self.u = store[sn_u]
@@ -238,7 +241,9 @@ class ConvLayer(object):
             if self.bias is not None:
                 K.axpby(1.0, self.bias_master, 0.0, None, self.bias[:self.cy0])
             src = self.wfp
-        K.pack_weights(src, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale)
+        b16 = K.PRECISION['value'] == 1
+        K.pack_weights(src, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale,
+                       wt16=self.wt16 if (b16 and self.need_wt) else None, wd16=self.wd16 if (b16 and self.need_wd) else None)
 
     def commit_u(self):
         """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
@@ -256,18 +261,18 @@ class ConvLayer(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.kind == 'up':
-            K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha)
+            K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16)
         else:
-            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha)
+            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16)
         if self.prof is not None:
             e1.record()
             self.prof.append((e0, e1))
 
     def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
         if self.kind == 'up':
-            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux)
+            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16)
         else:
-            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux)
+            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16)
 
     def backward_weights(self, x, dy):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may

@@ -57,7 +57,7 @@ def enable_autotune(flag=True):
     AUTOTUNE['enabled'] = bool(flag)
 
 
-def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision):
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -74,6 +74,7 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     a.x, a.y, a.w = x.data_ptr(), y.data_ptr(), w.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
     a.aux = aux.data_ptr() if aux is not None else None
+    a.w_bf16 = w16.data_ptr() if w16 is not None else None
     taps = geom.k[0] * geom.k[1] * geom.k[2]
     if w.numel() != taps * Cx * Cy:
         raise ValueError('weight has %d elements, expected %d' % (w.numel(), taps * Cx * Cy))
@@ -133,13 +134,13 @@ def _tune(a, mode, dst, w):
     return best or (0, 0)
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None):
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h."""
     lib.require_device(x, y, w, bias, aux)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16)
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
-               a.x_sw, a.y_sw, bias is not None)
+               a.x_sw, a.y_sw, bias is not None, w16 is not None)
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
@@ -467,11 +468,13 @@ def cosine_distance(f0, f1, weight, loss_out=None, df0=None, beta=0, eps=1e-10):
 # ---------------------------------------------------------------------------------------------------------------
 # weight prep
 # ---------------------------------------------------------------------------------------------------------------
-def pack_weights(src, wt=None, wd=None, scale=None):
-    """src HWIO [..., Cx, Cy] contiguous -> wt [Cy, taps*Cx] and/or wd [Cx, taps*Cy]; scale = device scalar tensor."""
+def pack_weights(src, wt=None, wd=None, scale=None, wt16=None, wd16=None):
+    """src HWIO [..., Cx, Cy] contiguous -> wt [Cy, taps*Cx] and/or wd [Cx, taps*Cy]; scale = device scalar tensor;
+    wt16/wd16: optional bf16 copies (torch.bfloat16 tensors)."""
     Cx, Cy = src.shape[-2], src.shape[-1]
     T = src.numel() // (Cx * Cy)
-    lib.check(_L().savp_pack_weights(lib.stream(), _p(src), T, Cx, Cy, _p(scale), _p(wt), _p(wd)), 'savp_pack_weights')
+    lib.check(_L().savp_pack_weights(lib.stream(), _p(src), T, Cx, Cy, _p(scale), _p(wt), _p(wd), _p(wt16), _p(wd16)),
+              'savp_pack_weights')
 
 
 def fold_pool(inp, out, k, adjoint=False):

@@ -29,7 +29,7 @@ class SavpConvArgs(ctypes.Structure):
         ('beta', c_i32), ('act', c_i32), ('alpha', c_f32), ('splitk', c_i32), ('tile', c_i32), ('precision', c_i32),
         ('x', c_vp), ('x_sn', c_i64), ('x_sd', c_i64), ('x_sh', c_i64), ('x_sw', c_i64),
         ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
-        ('w', c_vp), ('bias', c_vp), ('aux', c_vp),
+        ('w', c_vp), ('bias', c_vp), ('aux', c_vp), ('w_bf16', c_vp),
     ]
 
 
@@ -173,7 +173,7 @@ register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32,
 register('savp_lp_loss', [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])
 register('savp_lsgan_loss', [c_vp, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
-register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp])
+register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
 register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
