@@ -211,9 +211,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
             const long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + kcb;
 #pragma unroll
             for (int j = 0; j < RB16; ++j) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (bok16[j] && kokb) v = *reinterpret_cast<const uint4*>(p.w16 + bb16[j] + woff);
-                rb16[j] = v;
+                const bool ok = bok16[j] && kokb;
+                uint4 v = *reinterpret_cast<const uint4*>(p.w16 + (ok ? bb16[j] + woff : 0ll));
+                rb16[j] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             }
             kcb += BKT;
             while (kcb >= Cred) {
@@ -229,18 +229,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                 int zd = a_cd[j] + zd0, zh = a_ch[j] + zh0, zw = a_cw[j] + zw0;
                 bool ok = a_ok[j] && kok && (unsigned)zd < (unsigned)gd.srcN && (unsigned)zh < (unsigned)gh.srcN &&
                           (unsigned)zw < (unsigned)gw.srcN;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v = ldg4(src + a_base[j] + (long long)zd * s_sd + (long long)zh * s_sh + (long long)zw * s_sw + kc);
-                ra[j] = v;
+                // branch-free: out-of-image taps read a safe address and are zeroed by a select, so all gathers of a K-tile
+                // are issued back to back (a branch per load serialised them and cost an s_cbranch each)
+                const long long off = ok ? (a_base[j] + (long long)zd * s_sd + (long long)zh * s_sh + (long long)zw * s_sw + kc) : 0ll;
+                float4 v = ldg4(src + off);
+                ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const int ta = gd.t0 + jd * gd.tstep, tu = gh.t0 + jh * gh.tstep, tv = gw.t0 + jw * gw.tstep;
             const long long woff = (long long)((ta * p.kh + tu) * p.kw + tv) * Cred + kc;
             if (!WB16) {
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (b_ok[j] && kok) v = ldg4(wt + b_base[j] + woff);
-                    rb[j] = v;
+                    const bool ok = b_ok[j] && kok;
+                    float4 v = ldg4(wt + (ok ? b_base[j] + woff : 0ll));
+                    rb[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             // advance by the K-tile
@@ -315,14 +317,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
 
     const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
     const int l31 = lane & 31, khalf = lane >> 5;
+    // software pipeline: LDS holds tile kt (cur) while the registers hold tile kt+1 whose global loads were issued one
+    // whole iteration earlier (right after the previous stage), so they fly under a barrier + a full MFMA block.
     if (kt_begin < kt_end) {
         fetch(kt_begin);
         stage(0);
+        if (kt_begin + 1 < kt_end) fetch(kt_begin + 1);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) fetch(kt + 1);
         const char* a = As + cur * BM * ROWB;
         const char* b = Bs + cur * BN * ROWB;
         if (BF16) {
@@ -362,7 +366,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                     }
             }
         }
-        if (kt + 1 < kt_end) stage(cur ^ 1);
+        if (kt + 1 < kt_end) {
+            stage(cur ^ 1);
+            if (kt + 2 < kt_end) fetch(kt + 2);
+        }
         __syncthreads();
     }
 
