@@ -174,6 +174,28 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restric
     }
 }
 
+// narrow matrices (C <= 16, e.g. the discriminators' final linear [65536, 1]): one THREAD per row
+__global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                                 float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                                 float* dotz) {
+    __shared__ float sh[4];
+    float sqacc = 0.f, dzacc = 0.f;
+    for (long long k = blockIdx.x * (long long)NT + threadIdx.x; k < K; k += (long long)gridDim.x * NT) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += W[k * C + c] * x[c];
+        s *= xscale;
+        y[k] = s;
+        sqacc += s * s;
+        if (z) dzacc += s * z[k];
+    }
+    float t = block_sum1(sqacc, sh);
+    if (threadIdx.x == 0 && sq) unsafeAtomicAdd(sq, t);
+    if (dotz) {
+        float t2 = block_sum1(dzacc, sh);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotz, t2);
+    }
+}
+
 // y[c] += sum_k W[k,c] x[k]   (atomic; y zeroed by the caller)
 __global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
                                                           float* __restrict__ y, int rows_per_block) {
@@ -213,8 +235,15 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
     float* a = ws + 8 + 2 * C;
     unsigned nb = (unsigned)((K + 3) / 4);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7, (const float*)nullptr,
-                       (float*)nullptr);
+    if (C <= 16) {
+        unsigned nbn = (unsigned)((K + NT - 1) / NT);
+        if (nbn > 1024) nbn = 1024;
+        hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7,
+                           (const float*)nullptr, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7, (const float*)nullptr,
+                           (float*)nullptr);
+    }
     int rpb = 64;
     hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
                        (const float*)a, ws + 8, rpb);
@@ -268,8 +297,15 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
     unsigned nr = (unsigned)((K + 3) / 4);
     if (nr > 2048) nr = 2048;
     // wb = W b ; ws[6] = a . wb
-    hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
-                       (float*)nullptr, (const float*)a, ws + 6);
+    if (C <= 16) {
+        unsigned nbn = (unsigned)((K + NT - 1) / NT);
+        if (nbn > 1024) nbn = 1024;
+        hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f,
+                           a + K, (float*)nullptr, (const float*)a, ws + 6);
+    } else {
+        hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
+                           (float*)nullptr, (const float*)a, ws + 6);
+    }
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nb), dim3(NT), 0, st, G, (long long)K, C, u, (const float*)ws, dW, beta);
     return LAUNCH_OK();
 }
