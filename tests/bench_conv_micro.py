@@ -37,9 +37,12 @@ def main():
         geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
         flops = 2.0 * N * H * W * Cx * Cy * k * k
         for mode, mname in ((lib.CONV_FPROP, 'fprop'), (lib.CONV_DGRAD, 'dgrad'), (lib.CONV_WGRAD, 'wgrad')):
-            for tile in (0, 0x22, 0x21, 0x12, 0x11):
+            bf = os.environ.get('PREC', 'f32') == 'bf16' and mode != lib.CONV_WGRAD
+            w16 = w.to(torch.bfloat16) if bf else None
+            tiles = (0, 0x122, 0x121, 0x112, 0x111, 0x222, 0x221, 0x212, 0x211) if bf else (0, 0x22, 0x21, 0x12, 0x11)
+            for tile in tiles:
                 try:
-                    t = timeit(lambda: K.conv(mode, geom, x, y, w, tile=tile))
+                    t = timeit(lambda: K.conv(mode, geom, x, y, w, tile=tile, w16=w16))
                 except Exception as ex:
                     print(name, mname, hex(tile), 'ERR', ex)
                     continue

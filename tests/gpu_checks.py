@@ -73,7 +73,32 @@ CONV_CASES = [
     ('dense_65536_1', 4, (1, 1, 1), 16384, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), (0, 0, 0)),
     ('enc4x4s2', 5, (1, 16, 16), 64, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1), (0, 1, 1)),
     ('odd_sizes', 3, (1, 13, 10), 20, 36, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1)),
+    ('lstm5x5_16', 2, (1, 16, 16), 136, 256, (1, 5, 5), (1, 1, 1), (0, 2, 2), (0, 2, 2)),
+    ('s1_odd', 3, (1, 13, 10), 24, 40, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1)),
+    ('s1_odd5', 2, (1, 19, 21), 40, 72, (1, 5, 5), (1, 1, 1), (0, 2, 2), (0, 2, 2)),
 ]
+
+
+def patch_lds_bytes(cred, kh, kw, wm, wn, nw=4):
+    """LDS bytes of the patch conv kernel (mirror of conv_patch_try in csrc/conv_patch.hip)."""
+    cp16 = (cred + 15) // 16 * 16
+    best = None
+    c0 = (cp16 + 95) // 96
+    for c in range(c0, c0 + 3):
+        kk = (cp16 // 16 + c - 1) // c
+        if kk < 1 or kk > 6:
+            continue
+        cost = c * (kk + 1.5)
+        if best is None or cost < best[0]:
+            best = (cost, c, kk)
+    if best is None:
+        return 1 << 30
+    _, nch, nks = best
+    cpad = nch * nks * 16
+    ph, pw, cp = 2 * nw * wm + kh - 1, 8 + kw - 1, cpad + 8
+    x = (8 - (pw * (cp // 8)) % 16 + 16) % 16
+    pitch = pw * cp + 8 * x
+    return ph * pitch * 2 + 2 * 64 * wn * (nks * 16 + 8) * 2
 
 
 def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
@@ -96,6 +121,24 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
         for tile in tiles:
             tag = name + ('' if tile == 0 else '_t%x' % tile)
             xd, wd_, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+            if tile & 0x200:          # LDS patch kernel forced: 2-D stride-1, channels % 8, bf16 weight copy only
+                if not (precision == 1 and dhw[0] == 1 and k[0] == 1 and tuple(s) == (1, 1, 1) and Cx % 8 == 0 and Cy % 8 == 0):
+                    continue
+                # the kernel parks a (8*WM+kh-1) x (8+kw-1) pixel patch of ALL reduction channels in LDS; shapes whose patch
+                # does not fit 160 KB are (correctly) refused with EINVAL under a forced tile -> not part of this sweep
+                wm_, wn_ = (tile >> 4) & 15, tile & 15
+                fits = lambda cred: patch_lds_bytes(cred, k[1], k[2], wm_, wn_, 8 if tile & 0x400 else 4) <= 160 * 1024
+                if not (fits(Cx) and fits(Cy)):
+                    continue
+                yd2 = torch.empty(y.shape, device=DEV, dtype=torch.float32)
+                wtp = dev(pack_wt(w.detach()))
+                K.conv(lib.CONV_FPROP, geom, xd, yd2, wtp, bias=bd, tile=tile, precision=1, w16=wtp.to(torch.bfloat16))
+                out.append((tag + '/fprop_w16', rel_err(yd2, y), tol))
+                dx2 = torch.full(x.shape, float('nan'), device=DEV, dtype=torch.float32)
+                wdp = dev(pack_wd(w.detach()))
+                K.conv(lib.CONV_DGRAD, geom, dx2, dyd, wdp, tile=tile, precision=1, w16=wdp.to(torch.bfloat16))
+                out.append((tag + '/dgrad_w16', rel_err(dx2, x.grad), tol))
+                continue
             # FPROP (+bias)
             yd = torch.empty(y.shape, device=DEV, dtype=torch.float32)
             K.conv(lib.CONV_FPROP, geom, xd, yd, dev(pack_wt(w.detach())), bias=bd, tile=tile, precision=precision)
@@ -634,7 +677,7 @@ def check_warp_dna(seed=8):
 
 def check_conv_bf16():
     """bf16-operand / fp32-accumulate mode of the implicit-GEMM kernel: per-op rel <= 1e-2."""
-    res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11))
+    res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11, 0x212, 0x221, 0x122, 0x612, 0x621, 0x611))   # 0x2xx: LDS patch kernel (0x6xx: 8 waves), 0x1xx: generic
     return [('bf16/' + n, e, t) for (n, e, t) in res]
 
 

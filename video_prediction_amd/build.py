@@ -10,7 +10,8 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OUT = os.path.join(HERE, 'libsavp_hip.so')
 BUILD = os.path.join(CSRC, 'build')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-Wno-unused-value']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-Wno-unused-value'] + \
+        os.environ.get('SAVP_EXTRA_FLAGS', '').split()
 
 
 def _newer(src, dst, extra=()):

@@ -1,0 +1,90 @@
+// conv_common.h -- shared declarations of the convolution kernels (conv_igemm.hip, conv_patch.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savp_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BK 32
+#define BKP 36          // padded K row (floats) for the row-major-K LDS layout
+#define NTHREADS 256
+
+struct ConvP {
+    int mode;
+    int N, D, H, W, Cx;
+    int Do, Ho, Wo, Cy;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    int beta, act;
+    float alpha;
+    const float* x; long long x_sn, x_sd, x_sh, x_sw;
+    const float* y; long long y_sn, y_sd, y_sh, y_sw;
+    const float* w;
+    const unsigned short* w16;   // optional bf16 copy of the packed weights (same layout)
+    float* out;          // destination (y for FPROP, x for DGRAD, dW for WGRAD)
+    const float* bias;
+    const float* aux;
+    int splitk;
+    int bf16;
+    int tm, tn;          // tile counts (1-D XCD-aware launch grids)
+    unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
+    // patch kernel (conv_patch.hip): LDS geometry chosen by the launcher
+    int s1_cp, s1_pitch, s1_nch;              // patch pixel stride / row pitch (bf16 elements), weight slabs per tap
+    unsigned long long s1_magC4, s1_magPW;    // fastdiv by (padded channels / 4) and by the patch width
+};
+
+__device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
+    // floor(p / d) for p < 2^24, d < 2^16 with magic = ceil(2^40 / d)
+    return (unsigned)(((unsigned long long)p * magic) >> 40);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// XCD-aware workgroup -> logical id map (MI355X: hardware block b runs on XCD b % 8, each XCD has a private L2).
+// Consecutive LOGICAL ids land on the same XCD, so tiles that share an operand (same weight column block, neighbouring
+// pixel rows, same K split) hit one L2 instead of being fetched once per XCD.  Bijective for any n (speed only).
+__device__ __forceinline__ int xcd_logical(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+
+struct DimGeom {          // one spatial dimension of the (possibly phase-restricted) problem
+    int Mdim;             // extent of the M-grid along this dim
+    int base, mstep;      // source coord = base + m*mstep + j*jstep
+    int jstep;
+    int nt;               // number of (reduced) taps
+    int t0, tstep;        // full weight tap index = t0 + j*tstep
+    int ob, os;           // destination coord = ob + m*os
+    int srcN;             // source extent (bounds)
+};
+
+__device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out, int k, int s, int p) {
+    DimGeom g;
+    if (!dgrad) {
+        g.Mdim = Out; g.base = -p; g.mstep = s; g.jstep = 1; g.nt = k; g.t0 = 0; g.tstep = 1;
+        g.ob = 0; g.os = 1; g.srcN = In;
+    } else {
+        int u0 = (f + p) % s;
+        g.nt = (k > u0) ? (k - u0 + s - 1) / s : 0;
+        g.base = (f + p - u0) / s; g.mstep = 1; g.jstep = -1;
+        g.t0 = u0; g.tstep = s;
+        g.Mdim = (In > f) ? (In - f + s - 1) / s : 0;
+        g.ob = f; g.os = s; g.srcN = Out;
+    }
+    return g;
+}
+
+// ceil(2^40 / d): magic number of fastdiv()
+static inline unsigned long long magic40(int d) {
+    if (d <= 0) d = 1;
+    return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// conv_patch.hip: LDS patch kernel for 2-D stride-1 FPROP/DGRAD in bf16.  Returns true when it handled the call
+// (*rc = SAVP_* status); false = not applicable, the caller falls back to the generic kernel.
+bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced, hipStream_t st, int* rc);

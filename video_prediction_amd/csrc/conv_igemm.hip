@@ -22,78 +22,11 @@
 #include <stdint.h>
 #include "savp_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-#define BK 32
-#define BKP 36          // padded K row (floats) for the row-major-K LDS layout
-#define NTHREADS 256
-
-struct ConvP {
-    int mode;
-    int N, D, H, W, Cx;
-    int Do, Ho, Wo, Cy;
-    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
-    int beta, act;
-    float alpha;
-    const float* x; long long x_sn, x_sd, x_sh, x_sw;
-    const float* y; long long y_sn, y_sd, y_sh, y_sw;
-    const float* w;
-    const unsigned short* w16;   // optional bf16 copy of the packed weights (same layout)
-    float* out;          // destination (y for FPROP, x for DGRAD, dW for WGRAD)
-    const float* bias;
-    const float* aux;
-    int splitk;
-    int bf16;
-    int tm, tn;          // tile counts (1-D XCD-aware launch grids)
-    unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
-};
-
-__device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
-    // floor(p / d) for p < 2^24, d < 2^16 with magic = ceil(2^40 / d)
-    return (unsigned)(((unsigned long long)p * magic) >> 40);
-}
-
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// XCD-aware workgroup -> logical id map (MI355X: hardware block b runs on XCD b % 8, each XCD has a private L2).
-// Consecutive LOGICAL ids land on the same XCD, so tiles that share an operand (same weight column block, neighbouring
-// pixel rows, same K split) hit one L2 instead of being fetched once per XCD.  Bijective for any n (speed only).
-__device__ __forceinline__ int xcd_logical(int b, int n) {
-    const int q = n >> 3, r = n & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
+#include "conv_common.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // FPROP / DGRAD kernel.  GEMM: C[M = grid pixels][N = dst channels] = A[M][K=(taps,Cred)] * B[K][N]
 // ------------------------------------------------------------------------------------------------------------
-struct DimGeom {          // one spatial dimension of the (possibly phase-restricted) problem
-    int Mdim;             // extent of the M-grid along this dim
-    int base, mstep;      // source coord = base + m*mstep + j*jstep
-    int jstep;
-    int nt;               // number of (reduced) taps
-    int t0, tstep;        // full weight tap index = t0 + j*tstep
-    int ob, os;           // destination coord = ob + m*os
-    int srcN;             // source extent (bounds)
-};
-
-__device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out, int k, int s, int p) {
-    DimGeom g;
-    if (!dgrad) {
-        g.Mdim = Out; g.base = -p; g.mstep = s; g.jstep = 1; g.nt = k; g.t0 = 0; g.tstep = 1;
-        g.ob = 0; g.os = 1; g.srcN = In;
-    } else {
-        int u0 = (f + p) % s;
-        g.nt = (k > u0) ? (k - u0 + s - 1) / s : 0;
-        g.base = (f + p - u0) / s; g.mstep = 1; g.jstep = -1;
-        g.t0 = u0; g.tstep = s;
-        g.Mdim = (In > f) ? (In - f + s - 1) / s : 0;
-        g.ob = f; g.os = s; g.srcN = Out;
-    }
-    return g;
-}
-
 // BF16 = true: operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while staging into LDS and multiplied on
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate); K-tile 64.  BF16 = false: exact fp32 on v_mfma_f32_32x32x2_f32; K-tile 32.
 // WB16 = true (bf16 mode only): the weight operand is read from a pre-packed bf16 copy (16-byte loads of 8 k values,
@@ -755,10 +688,6 @@ static hipError_t launch_wg_bf16(const ConvP& p, dim3 grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------------------
-static unsigned long long magic40(int d) {
-    if (d <= 0) d = 1;
-    return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
-}
 
 template <int WM, int WN, bool VEC, bool BF16, bool WB16 = false>
 static hipError_t launch_fd1(const ConvP& p, dim3 grid, hipStream_t st) {
@@ -799,7 +728,6 @@ static hipError_t launch_wg(const ConvP& p, bool va, bool vb, dim3 grid, hipStre
     return hipGetLastError();
 }
 
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static void pick_tile(long long M, long long N, int& wm, int& wn) {
     // cost model: rounds over the 256 CUs x tile area x a re-read penalty for small tiles
@@ -836,7 +764,8 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
-    if (a->tile) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
+    const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel
+    if (a->tile & 0xff) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
     hipError_t err;
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
@@ -856,6 +785,12 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
             Mmax = (long long)a->N * a->Do * a->Ho * a->Wo;
         }
         if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
+        // ---- LDS patch kernel (conv_patch.hip): 2-D stride-1 convs in bf16 with pre-packed bf16 weights --------------
+        if (algo != 1) {
+            int rc = SAVP_OK;
+            if (conv_patch_try(p, a, wm, wn, algo == 2, st, &rc)) return rc;
+            if (algo == 2) return SAVP_EINVAL;
+        }
         if (!wm) pick_tile(Mmax * phases, Nout, wm, wn);
         const int BM = 64 * wm, BN = 64 * wn;
         // split-K (plain epilogue only): fills the chip when M*N is small and K is long (8x8 / 16x16 ConvLSTM layers)

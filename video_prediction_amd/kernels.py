@@ -97,7 +97,9 @@ def _tune(a, mode, dst, w):
         a.w = scratch.data_ptr()
     else:
         splits = (1, 2, 4, 8) if a.act == 0 else (1,)
-        cands = [(t, sk) for t in tiles for sk in splits]
+        # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
+        # (0x6xx = patch kernel with 8 waves per workgroup)
+        cands = [(alg | t, sk) for alg in (0x100, 0x200, 0x600) for t in tiles for sk in splits]
         real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
         scratch = None
         if a.beta:                       # never accumulate tuning runs into the real destination
