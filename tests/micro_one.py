@@ -10,19 +10,22 @@ def main():
     K.set_conv_precision('bf16')
     sh = dict((s[0], s) for s in SHAPES)[os.environ.get('SHAPE', 'lstm_h0')]
     name, N, H, W, Cx, Cy, k = sh
-    mode = {'fprop': lib.CONV_FPROP, 'dgrad': lib.CONV_DGRAD}[os.environ.get('MODE', 'fprop')]
+    mode = {'fprop': lib.CONV_FPROP, 'dgrad': lib.CONV_DGRAD, 'wgrad': lib.CONV_WGRAD}[os.environ.get('MODE', 'fprop')]
+    N = int(os.environ.get('NIMG', N))
     tile = int(os.environ.get('TILE', '0x222'), 16)
     sk = int(os.environ.get('SK', '0'))
     x = torch.randn(N, H, W, Cx, device='cuda'); y = torch.randn(N, H, W, Cy, device='cuda')
     w = torch.randn(k * k * Cx * Cy, device='cuda') * 0.05
-    w16 = w.to(torch.bfloat16)
+    w16 = w.to(torch.bfloat16) if mode != lib.CONV_WGRAD else None
+    if mode == lib.CONV_WGRAD:
+        w = w.view(k, k, Cx, Cy)
     geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
     fn = lambda: K.conv(mode, geom, x, y, w, tile=tile, w16=w16, splitk=sk)
     for _ in range(3): fn()
     torch.cuda.synchronize()
     # launch back-to-back inside a graph-free loop but measure GPU time with events around many launches
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    it = 50
+    it = int(os.environ.get('ITERS', 50))
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(it): fn()

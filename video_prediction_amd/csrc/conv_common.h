@@ -85,6 +85,24 @@ static inline unsigned long long magic40(int d) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Developer aid: build with SAVP_EXTRA_FLAGS=-DSAVP_CONV_ABLATE and set SAVP_ABLATE=<bits> to switch off parts of a kernel
+// (1 global loads, 2 MFMAs, 4 patch staging, 8 epilogue, 16 everything, 32 main loop, 64 LDS staging) when attributing
+// its time.  Not compiled into the shipped library.
+#ifdef SAVP_CONV_ABLATE
+#include <stdlib.h>
+static __constant__ int g_ablate;
+#define ABL(bit) (g_ablate & (bit))
+static inline void ablate_init() {
+    static bool done = false;
+    if (!done) { const char* e = getenv("SAVP_ABLATE"); int v = e ? atoi(e) : 0; hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof(int)); done = true; }
+}
+#else
+#define ABL(bit) false
+static inline void ablate_init() {}
+#endif
+
 // conv_patch.hip: LDS patch kernel for 2-D stride-1 FPROP/DGRAD in bf16.  Returns true when it handled the call
 // (*rc = SAVP_* status); false = not applicable, the caller falls back to the generic kernel.
 bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced, hipStream_t st, int* rc);
+// conv_wgrad_patch.hip: LDS patch WGRAD (2-D stride-1, bf16); same contract.
+bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc);

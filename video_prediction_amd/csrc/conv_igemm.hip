@@ -565,6 +565,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
     float4 ra[PA][4], rb[PB][4];
 
     auto fetch = [&](int kt) {
+        if (ABL(1)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pix = kt * BKT + kq * 4 + i;
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
         }
     };
     auto stage = [&](int buf) {
+        if (ABL(64)) return;
         char* a = As + buf * BM * ROWB;
         char* b = Bs + buf * BN * ROWB;
 #pragma unroll
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
         const char* a = As + cur * BM * ROWB;
         const char* b = Bs + cur * BN * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
+        for (int ks = 0; ks < (ABL(2) ? 0 : BKT / 16); ++ks) {
             bf16x8 af[WM], bf[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
@@ -767,6 +769,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel
     if (a->tile & 0xff) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
     hipError_t err;
+    ablate_init();
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
@@ -828,6 +831,11 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         else err = launch_fd<1, 1>(p, vec, grid, st);
     } else if (a->mode == SAVP_CONV_WGRAD) {
         p.out = (float*)a->w;
+        if (algo != 1) {                                   // LDS patch WGRAD (conv_wgrad_patch.hip)
+            int rc = SAVP_OK;
+            if (conv_wgrad_patch_try(p, a, st, &rc)) return rc;
+            if (algo == 2) return SAVP_EINVAL;
+        }
         const long long M = (long long)a->kd * a->kh * a->kw * a->Cx;
         const long long Ktot = (long long)a->N * a->Do * a->Ho * a->Wo;
         // fastdiv exactness domain: p * d < 2^40 for every (pixel index p, divisor d)

@@ -19,16 +19,6 @@
 #include "conv_common.h"
 #include <type_traits>
 
-// Developer aid: build with SAVP_EXTRA_FLAGS=-DSAVP_CONV_ABLATE and set SAVP_ABLATE=<bits> to switch off parts of the kernel
-// (1 weight loads, 2 MFMAs, 4 patch staging, 8 epilogue, 16 everything, 32 main loop) when attributing its time.  Not compiled
-// into the shipped library.
-#ifdef SAVP_CONV_ABLATE
-#include <stdlib.h>
-__constant__ int g_ablate;
-#define ABL(bit) (g_ablate & (bit))
-#else
-#define ABL(bit) false
-#endif
 
 // NW waves per workgroup in an (NW/2) x 2 grid, each wave owns a 32 WM x 32 WN block of the BM x BN tile.
 template <int NW, int WM, int WN, int NKS>
@@ -359,9 +349,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     p.splitk = splitk;
     dim3 grid((unsigned)(p.tm * p.tn), 1, (unsigned)splitk);
     hipError_t err;
-#ifdef SAVP_CONV_ABLATE
-    { static bool done = false; if (!done) { const char* e = getenv("SAVP_ABLATE"); int v = e ? atoi(e) : 0; hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof(int)); done = true; } }
-#endif
+    ablate_init();
     err = (nw == 8) ? launch_patch_tile<8>(p, wm, wn, nks, grid, lds, st) : launch_patch_tile<4>(p, wm, wn, nks, grid, lds, st);
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
     return true;

@@ -1,0 +1,263 @@
+// conv_wgrad_patch.hip -- weight gradient of stride-1 2-D convolutions on the bf16 MFMA pipe, LDS-patch formulation.
+//
+//   dW[u, v, cx, cy] = sum over (n, oy, ox) of x[n, oy + u - ph, ox + v - pw, cx] * dy[n, oy, ox, cy]
+//
+// The generic WGRAD kernel (conv_igemm.hip) is an im2col GEMM whose 128x128 output tiles each re-gather their operands
+// from L2: measured on the ConvLSTM layers it spends 72 % of its time in those loads (14 GB of L2->CU traffic for a
+// 0.76 GB problem).  Here the reduction runs over 8x8 pixel tiles of one image at a time: the x patch (tile + halo) and
+// the dy tile are converted to bf16 and parked in LDS ONCE, and every (tap, 16-channel group) row block of dW reads its A
+// operand from that patch at a tap-shifted address.  Both operands are pixel-major in LDS while the MFMA wants
+// k(=pixel)-contiguous fragments: ds_read_b64_tr_b16 (the gfx950 transpose read: within 16 lanes, lane t supplies the
+// address of [pixel t>>2][4 channels t&3] and receives channel t of the 4 pixels) delivers exactly the
+// v_mfma_f32_32x32x16_bf16 operand layout with no register shuffles.
+//
+// Work split: M' rows of dW are 16-channel groups ordered [cx16][tap]; a workgroup (4 waves x MTW row tiles of 32) owns a
+// chunk of channel groups x ALL taps x 32 output channels and accumulates in AGPRs (MTW = 16 -> the full 256) over its
+// share of the pixel tiles; the result is added to dW with fp32 atomics.  LDS pixel strides are 64 (mod 256) bytes so
+// that the 8 row segments of a 32-lane transpose read fall into distinct bank groups.
+#include "conv_common.h"
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+#define LDS_AS __attribute__((address_space(3)))
+
+struct WgP {
+    const float* x; const float* y; float* dw;
+    long long x_sn, y_sn;
+    int x_sh, x_sw, y_sh, y_sw;
+    int H, W, Ho, Wo, Cx, Cy, ph, pw, kw;
+    int taps, G16, CG, S;              // taps, 16-channel groups of Cx, groups per chunk, pixel splits
+    int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
+    int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
+    unsigned long long magC4, magPW, magTaps, magTHW, magTW;
+};
+
+// NW waves x MTW row tiles (32 rows of dW each) per workgroup.  NPF = float4 prefetch registers per thread for the patch.
+template <int NW, int MTW, int NPF>
+__global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
+    constexpr int NT = 64 * NW;
+    constexpr int NPD = (64 * 8 + NT - 1) / NT;                // float4 prefetch registers for the dy tile (64 px x 32 ch)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = blockIdx.y, mc = blockIdx.z, sp = blockIdx.x;
+    const int ca = mc * q.CG;                                  // first 16-channel group of this chunk
+    const int cgc = min(q.CG, q.G16 - ca);                     // groups in this chunk
+    const int ngroups = cgc * q.taps;                          // (cx16, tap) row groups of this workgroup
+    const int cy0 = nb * 32;
+    const int patch_elems = q.PH * q.pitch;
+    __bf16* patch = reinterpret_cast<__bf16*>(smem);           // [2][PH * pitch]
+    __bf16* dyt = patch + 2 * patch_elems;                     // [2][64 * 32]
+
+    // pixel tiles of this split
+    const int per = (q.PT + q.S - 1) / q.S;
+    const int t_begin = sp * per, t_end = min(q.PT, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    // ---- staging maps, packed into one register per slot: LDS offset | c4 << 15 | py << 21 | px << 25 | valid << 29 ----
+    unsigned pinfo[NPF];
+    {
+        const int c4n = q.CG * 4;
+        const int ptotal = q.PH * q.PW * c4n;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + NT * i;
+            const int pix = (int)fastdiv((unsigned)idx, q.magC4);
+            const int c4 = idx - pix * c4n;
+            const int pyy = (int)fastdiv((unsigned)pix, q.magPW);
+            const int pxx = pix - pyy * q.PW;
+            const bool ok = idx < ptotal;
+            pinfo[i] = ok ? ((unsigned)(pyy * q.pitch + pxx * q.CP + c4 * 4) | ((unsigned)c4 << 15) | ((unsigned)pyy << 21) |
+                             ((unsigned)pxx << 25) | (1u << 29)) : 0u;
+        }
+    }
+    float4 pf[NPF], pd[NPD];
+    auto fetch = [&](int t) {
+        const int img = (int)fastdiv((unsigned)t, q.magTHW);
+        const int r = t - img * q.tHW;
+        const int ty = (int)fastdiv((unsigned)r, q.magTW);
+        const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
+        const float* __restrict__ xs = q.x + (long long)img * q.x_sn + (long long)(oy0 - q.ph) * q.x_sh + (long long)(ox0 - q.pw) * q.x_sw + ca * 16;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            unsigned inf = pinfo[i];
+            asm volatile("" : "+v"(inf));                      // keep the unpacking inside the loop (register pressure)
+            const int c = (int)((inf >> 15) & 63u) << 2, pyy = (int)((inf >> 21) & 15u), pxx = (int)((inf >> 25) & 15u);
+            const bool ok = (inf >> 29) && (unsigned)(oy0 - q.ph + pyy) < (unsigned)q.H && (unsigned)(ox0 - q.pw + pxx) < (unsigned)q.W &&
+                            ca * 16 + c < q.Cx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = ldg4(xs + pyy * q.x_sh + pxx * q.x_sw + c);
+            pf[i] = v;
+        }
+        const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw + cy0;
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            const int idx = tid + NT * i;                      // 64 pixels x 8 float4
+            const int px = idx >> 3, c = (idx & 7) << 2;
+            const bool ok = idx < 512 && oy0 + (px >> 3) < q.Ho && ox0 + (px & 7) < q.Wo && cy0 + c < q.Cy;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = ldg4(ys + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c);
+            pd[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        __bf16* pa = patch + buf * patch_elems;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            unsigned inf = pinfo[i];
+            asm volatile("" : "+v"(inf));
+            if (inf >> 29) {
+                bf16x4 o = {(__bf16)pf[i].x, (__bf16)pf[i].y, (__bf16)pf[i].z, (__bf16)pf[i].w};
+                *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffu)) = o;
+            }
+        }
+        __bf16* pb = dyt + buf * 64 * 32;
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < 512) {
+                bf16x4 o = {(__bf16)pd[i].x, (__bf16)pd[i].y, (__bf16)pd[i].z, (__bf16)pd[i].w};
+                *reinterpret_cast<bf16x4*>(pb + (idx >> 3) * 32 + ((idx & 7) << 2)) = o;
+            }
+        }
+    };
+
+    // ---- per-lane operand addressing ----------------------------------------------------------------------------
+    // k-step s covers tile pixels 16 s .. 16 s + 15; this lane's transpose read j (0/1) touches pixel
+    //   k = 8 (lane>>5) + 4 j + ((lane&15)>>2)  ->  tile row 2 s + (lane>>5), tile column 4 j + ((lane&15)>>2)
+    const int h = lane >> 5, g = (lane >> 4) & 1, r4 = (lane & 15) >> 2, c4 = (lane & 3) << 2;
+    const int a_lane = h * q.pitch + r4 * q.CP + c4;           // elements
+    const int b_lane = (8 * h + r4) * 32 + 16 * g + c4;
+    int a_tile[MTW];                                           // tap shift + local channel offset of this lane's row group
+    const int nt = min(MTW, max(0, (ngroups + 1) / 2 - wave * MTW));   // valid row tiles of this wave
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int lg = 2 * (wave * MTW + i) + g;               // local row group
+        const int lgc = min(lg, ngroups - 1);
+        const int cl = (int)fastdiv((unsigned)lgc, q.magTaps);
+        const int tap = lgc - cl * q.taps;
+        const int u = tap / q.kw, v = tap - u * q.kw;
+        a_tile[i] = (a_lane + u * q.pitch + v * q.CP + cl * 16) * 2;   // bytes
+    }
+
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    fetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        stage(buf);
+        __syncthreads();
+        if (t + 1 < t_end) fetch(t + 1);
+        const LDS_AS char* pa = (const LDS_AS char*)(patch + buf * patch_elems);
+        const LDS_AS char* pb = (const LDS_AS char*)(dyt + buf * 64 * 32) + b_lane * 2;
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const bf16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024));
+            const bf16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024 + 256));
+            const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            const LDS_AS char* pa0 = pa + 4 * s * q.pitch;     // 2 s rows of the patch, bytes
+            const LDS_AS char* pa1 = pa0 + 8 * q.CP;           // + 4 pixels
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                if (i >= nt) break;                            // wave-uniform
+                const bf16x4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa0 + a_tile[i]));
+                const bf16x4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa1 + a_tile[i]));
+                const bf16x8 afr = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: acc[i][r] of lane (l31 = column cy, khalf) is row (r&3) + 8 (r>>2) + 4 khalf of row tile i ----------
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int cy = cy0 + l31;
+    if (cy >= q.Cy) return;
+    float* __restrict__ dW = q.dw;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        if (i >= nt) break;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                       // the two 16-row groups of the tile
+            const int lg = 2 * (wave * MTW + i) + hh;
+            if (lg >= ngroups) continue;
+            const int cl = (int)fastdiv((unsigned)lg, q.magTaps);
+            const int tap = lg - cl * q.taps;
+            float* __restrict__ base = dW + ((long long)tap * q.Cx + (ca + cl) * 16) * q.Cy + cy;
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) {
+                const int m = (r & 3) + 8 * ((r >> 2) & 1) + 4 * khalf;   // row within the 16-row group
+                if ((ca + cl) * 16 + m < q.Cx) unsafeAtomicAdd(base + (long long)m * q.Cy, acc[i][r]);
+            }
+        }
+    }
+}
+
+template <int NW, int MTW, int NPF>
+static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st) {
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipFuncSetAttribute((const void*)wgrad_patch_kernel<NW, MTW, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((wgrad_patch_kernel<NW, MTW, NPF>), grid, dim3(64 * NW), lds, st, q);
+    return hipGetLastError();
+}
+
+// Returns true when the call was handled (2-D, stride 1, bf16 precision, channel counts % 4, <= 8 taps per side).
+bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
+    const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
+    const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
+    if (!(p.bf16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->Cx % 4 == 0 &&
+          a->Cy % 4 == 0 && xs4 && ys4 && a->kh <= 8 && a->kw <= 8 && a->Ho * a->Wo >= 64))
+        return false;
+    if (a->x_sh * (long long)(a->H + 8) >= (1ll << 31) || a->y_sh * (long long)(a->Ho + 8) >= (1ll << 31)) return false;
+    WgP q;
+    q.x = (const float*)a->x; q.y = (const float*)a->y; q.dw = (float*)a->w;
+    q.x_sn = a->x_sn; q.y_sn = a->y_sn;
+    q.x_sh = (int)a->x_sh; q.x_sw = (int)a->x_sw; q.y_sh = (int)a->y_sh; q.y_sw = (int)a->y_sw;
+    q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw;
+    q.taps = a->kh * a->kw;
+    q.G16 = (a->Cx + 15) / 16;
+    q.PH = 8 + a->kh - 1; q.PW = 8 + a->kw - 1;
+    // workgroup shape: 8 waves x 8 row tiles (64 tiles = 128 row groups) for the big layers, 4 x 8 / 4 x 4 for small ones
+    const int groups_all = q.taps * q.G16;
+    int nw, mtw;
+    if (groups_all <= 32) { nw = 4; mtw = 4; } else if (groups_all <= 64) { nw = 4; mtw = 8; } else { nw = 8; mtw = 8; }
+    const int nthreads = 64 * nw;
+    const int npf_max = (nw == 8) ? 8 : 16;
+    const int cg_pf = (npf_max * nthreads) / (4 * q.PH * q.PW);  // prefetch-register bound on the channel groups
+    int cg = (2 * nw * mtw) / q.taps;                            // row groups per workgroup / taps
+    if (cg > q.G16) cg = q.G16;
+    if (cg > cg_pf) cg = cg_pf;
+    if (cg < 1) return false;
+    q.CG = cg;
+    const int MC = (q.G16 + cg - 1) / cg, NB = (a->Cy + 31) / 32;
+    // pixel stride: CP / 16 = 2 or 6 (mod 8) -> the 8 row segments of a 32-lane transpose read hit distinct bank groups
+    int cpu = cg;
+    while ((cpu % 8) != 2 && (cpu % 8) != 6) ++cpu;
+    q.CP = cpu * 16;
+    q.pitch = q.PW * q.CP;
+    if (q.PH * q.pitch >= 32768) return false;                   // packed LDS offsets are 15 bits
+    const int tH = (a->Ho + 7) / 8;
+    q.tW = (a->Wo + 7) / 8; q.tHW = tH * q.tW;
+    q.PT = a->N * q.tHW;
+    long long s = 768 / ((long long)NB * MC);
+    if (s < 1) s = 1;
+    if (s > q.PT) s = q.PT;
+    q.S = (int)s;
+    q.magC4 = magic40(cg * 4); q.magPW = magic40(q.PW); q.magTaps = magic40(q.taps);
+    q.magTHW = magic40(q.tHW); q.magTW = magic40(q.tW);
+    if ((double)q.PT * q.tHW >= 1099511627776.0) return false;
+    const size_t lds = (size_t)2 * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
+    if (lds > 160 * 1024) return false;
+    const int npf = (q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
+    dim3 grid((unsigned)q.S, (unsigned)NB, (unsigned)MC);
+    hipError_t err;
+    if (nw == 8) err = (npf <= 4) ? launch_wgp<8, 8, 4>(q, grid, lds, st) : launch_wgp<8, 8, 8>(q, grid, lds, st);
+    else if (mtw == 8) err = (npf <= 8) ? launch_wgp<4, 8, 8>(q, grid, lds, st) : launch_wgp<4, 8, 16>(q, grid, lds, st);
+    else err = (npf <= 8) ? launch_wgp<4, 4, 8>(q, grid, lds, st) : launch_wgp<4, 4, 16>(q, grid, lds, st);
+    *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
+    return true;
+}
