@@ -76,10 +76,13 @@ CONV_CASES = [
     ('lstm5x5_16', 2, (1, 16, 16), 136, 256, (1, 5, 5), (1, 1, 1), (0, 2, 2), (0, 2, 2)),
     ('s1_odd', 3, (1, 13, 10), 24, 40, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1)),
     ('s1_odd5', 2, (1, 19, 21), 40, 72, (1, 5, 5), (1, 1, 1), (0, 2, 2), (0, 2, 2)),
+    ('s2_odd3', 3, (1, 13, 10), 24, 40, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1)),
+    ('s2_odd5', 2, (1, 21, 18), 40, 24, (1, 5, 5), (1, 2, 2), (0, 2, 2), (0, 2, 2)),
+    ('up6x6s2', 2, (1, 32, 32), 32, 72, (1, 6, 6), (1, 2, 2), (0, 2, 2), (0, 2, 2)),
 ]
 
 
-def patch_lds_bytes(cred, kh, kw, wm, wn, nw=4):
+def patch_lds_bytes(cred, kh, kw, wm, wn, nw=4, sh=1, sw=1, dgrad=False):
     """LDS bytes of the patch conv kernel (mirror of conv_patch_try in csrc/conv_patch.hip)."""
     cp16 = (cred + 15) // 16 * 16
     best = None
@@ -95,7 +98,10 @@ def patch_lds_bytes(cred, kh, kw, wm, wn, nw=4):
         return 1 << 30
     _, nch, nks = best
     cpad = nch * nks * 16
-    ph, pw, cp = 2 * nw * wm + kh - 1, 8 + kw - 1, cpad + 8
+    th = 2 * nw * wm
+    ph = th + (kh + sh - 1) // sh - 1 if dgrad else (th - 1) * sh + kh
+    pw = 8 + (kw + sw - 1) // sw - 1 if dgrad else 7 * sw + kw
+    cp = cpad + 8
     x = (8 - (pw * (cp // 8)) % 16 + 16) % 16
     pitch = pw * cp + 8 * x
     return ph * pitch * 2 + 2 * 64 * wn * (nks * 16 + 8) * 2
@@ -122,13 +128,14 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
             tag = name + ('' if tile == 0 else '_t%x' % tile)
             xd, wd_, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
             if tile & 0x200:          # LDS patch kernel forced: 2-D stride-1, channels % 8, bf16 weight copy only
-                if not (precision == 1 and dhw[0] == 1 and k[0] == 1 and tuple(s) == (1, 1, 1) and Cx % 8 == 0 and Cy % 8 == 0):
+                if not (precision == 1 and dhw[0] == 1 and k[0] == 1 and s[0] == 1 and k[1] >= s[1] and k[2] >= s[2] and
+                        Cx % 8 == 0 and Cy % 8 == 0):
                     continue
                 # the kernel parks a (8*WM+kh-1) x (8+kw-1) pixel patch of ALL reduction channels in LDS; shapes whose patch
                 # does not fit 160 KB are (correctly) refused with EINVAL under a forced tile -> not part of this sweep
                 wm_, wn_ = (tile >> 4) & 15, tile & 15
-                fits = lambda cred: patch_lds_bytes(cred, k[1], k[2], wm_, wn_, 8 if tile & 0x400 else 4) <= 160 * 1024
-                if not (fits(Cx) and fits(Cy)):
+                fits = lambda cred, dg: patch_lds_bytes(cred, k[1], k[2], wm_, wn_, 8 if tile & 0x400 else 4, s[1], s[2], dg) <= 160 * 1024
+                if not (fits(Cx, False) and fits(Cy, True)):
                     continue
                 yd2 = torch.empty(y.shape, device=DEV, dtype=torch.float32)
                 wtp = dev(pack_wt(w.detach()))

@@ -32,6 +32,7 @@ struct ConvP {
     unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
     // patch kernel (conv_patch.hip): LDS geometry chosen by the launcher
     int s1_cp, s1_pitch, s1_nch;              // patch pixel stride / row pitch (bf16 elements), weight slabs per tap
+    int s1_ph, s1_pw, s1_th, s1_tw;           // patch rows / columns, tiles per image (rows, columns)
     unsigned long long s1_magC4, s1_magPW;    // fastdiv by (padded channels / 4) and by the patch width
 };
 

@@ -32,15 +32,19 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
-    const DimGeom gh = make_geom(dgrad, 0, p.H, p.Ho, p.kh, 1, p.ph);
-    const DimGeom gw = make_geom(dgrad, 0, p.W, p.Wo, p.kw, 1, p.pw);
+    // blockIdx.y = output phase of a strided DGRAD (conv2d_transpose): each phase is a dense stride-1 problem over its
+    // own taps t0 + j*s, so no MAC is spent on the zeros of the transposed convolution
+    const int fh = dgrad ? (int)blockIdx.y / p.sw : 0, fw = dgrad ? (int)blockIdx.y % p.sw : 0;
+    const DimGeom gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
+    const DimGeom gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
     const int Cred = dgrad ? p.Cy : p.Cx;
     const int Nout = dgrad ? p.Cx : p.Cy;
-    const int kh = p.kh, kw = p.kw;
-    const int ldb = kh * kw * Cred;
+    const int kh = gh.nt, kw = gw.nt;                      // (reduced) taps of this phase
+    const int ldb = p.kh * p.kw * Cred;
     const int Hm = gh.Mdim, Wm = gw.Mdim;
-    const int tW = (Wm + TW - 1) / TW, tH = (Hm + TH - 1) / TH;
-    const int PH = TH + kh - 1, PW = TW + kw - 1;
+    const int tW = p.s1_tw, tH = p.s1_th;                  // tiles per image (of the largest phase)
+    const int PW = p.s1_pw;                                // patch columns: (TW-1)*mstep + (nt-1)*|jstep| + 1 (max over phases)
+    const int PH = p.s1_ph;
     const int nch = p.s1_nch, CP = p.s1_cp, pitch = p.s1_pitch;
     const int Cpad = nch * CKB;
     __bf16* patch = reinterpret_cast<__bf16*>(smem);
@@ -54,9 +58,10 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     const int img = mt / (tH * tW);
     const int trem = mt - img * (tH * tW);
     const int oy0 = (trem / tW) * TH, ox0 = (trem % tW) * TW;
+    if (oy0 >= Hm || ox0 >= Wm || kh <= 0 || kw <= 0) return;     // smaller phase / phase without taps (uniform)
     // patch origin in source coordinates: smallest tap displacement
-    const int org_h = oy0 + (gh.jstep > 0 ? gh.base : gh.base - (kh - 1));
-    const int org_w = ox0 + (gw.jstep > 0 ? gw.base : gw.base - (kw - 1));
+    const int org_h = gh.base + oy0 * gh.mstep + (gh.jstep > 0 ? 0 : (kh - 1) * gh.jstep);
+    const int org_w = gw.base + ox0 * gw.mstep + (gw.jstep > 0 ? 0 : (kw - 1) * gw.jstep);
 
     const float* __restrict__ src = (dgrad ? p.y : p.x) + (long long)img * (dgrad ? p.y_sn : p.x_sn);
     const int s_sh = (int)(dgrad ? p.y_sh : p.x_sh), s_sw = (int)(dgrad ? p.y_sw : p.x_sw);
@@ -83,8 +88,10 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         loff[q] = (ALLIN || slot < SLOTS) ? r * BROW + k8 * 8 : -1;
     }
     uint4 rb[Q];
-    int f_cc = it_begin % nch, f_tap = it_begin / nch;
+    int f_cc = it_begin % nch;
+    int f_jh = (it_begin / nch) / kw, f_jw = (it_begin / nch) % kw;
     auto fetch = [&]() {
+        const int f_tap = (gh.t0 + f_jh * gh.tstep) * p.kw + (gw.t0 + f_jw * gw.tstep);    // full weight tap
         const unsigned short* wp = p.w16 + (f_tap * Cred + f_cc * CKB);
         if (ABL(1)) return;
         if (f_cc == nch - 1) {
@@ -97,7 +104,10 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) rb[q] = *reinterpret_cast<const uint4*>(wp + goffF[q]);
         }
-        if (++f_cc == nch) { f_cc = 0; ++f_tap; }
+        if (++f_cc == nch) {
+            f_cc = 0;
+            if (++f_jw == kw) { f_jw = 0; ++f_jh; }
+        }
     };
     auto stage = [&](auto curc) {
         constexpr int cur = decltype(curc)::value;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     {
         const int c4n = Cpad >> 2;
         const int total = PH * PW * c4n;
-#pragma unroll 4
+#pragma unroll 16
         for (int idx = tid; idx < (ABL(4) ? 0 : total); idx += NT) {
             const int pix = (int)fastdiv((unsigned)idx, p.s1_magC4);
             const int c = (idx - pix * c4n) << 2;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int row = wm0 + i * 32 + l31;
-        arow[i] = (row >> 3) * pitch + (row & 7) * CP + khalf * 8;
+        arow[i] = (row >> 3) * gh.mstep * pitch + (row & 7) * gw.mstep * CP + khalf * 8;
     }
     const int brow0 = (wn0 + l31) * BROW + khalf * 8;
 
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     int c_jh = c_tap / kw, c_jw = c_tap - (c_tap / kw) * kw;
     auto compute = [&](auto curc) {
         constexpr int cur = decltype(curc)::value;
-        const int pu = gh.jstep > 0 ? c_jh : kh - 1 - c_jh;
-        const int pv = gw.jstep > 0 ? c_jw : kw - 1 - c_jw;
+        const int pu = gh.jstep > 0 ? c_jh * gh.jstep : (kh - 1 - c_jh) * -gh.jstep;
+        const int pv = gw.jstep > 0 ? c_jw * gw.jstep : (kw - 1 - c_jw) * -gw.jstep;
         const __bf16* a = patch + (pu * pitch + pv * CP + c_cc * CKB);
         const __bf16* b = Bs + cur * BN * BROW + brow0;
         bf16x8 af[NKS][WM], bf[NKS][WN];
@@ -203,9 +213,11 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     if (ABL(8) && acc[0][0][0] != 123.f) return;
     const long long d_sn = dgrad ? p.x_sn : p.y_sn;
     const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
-    const int py0 = oy0 + (wm0 >> 3), px0 = ox0 + 4 * khalf;
+    const int py0 = oy0 + (wm0 >> 3), px0 = ox0 + 4 * khalf;       // M-grid coordinates of this lane's first pixel
     const int col0 = n0 + wn0 + l31;
-    float* __restrict__ dst = p.out + (long long)img * d_sn + (long long)py0 * d_sh + (long long)px0 * d_sw + col0;
+    float* __restrict__ dst = p.out + (long long)img * d_sn + (long long)(gh.ob + py0 * gh.os) * d_sh +
+                              (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
+    const int e_sh = d_sh * gh.os, e_sw = d_sw * gw.os;            // destination strides of one M-grid step
     const bool full = (oy0 + TH <= Hm) && (ox0 + TW <= Wm);
     const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
     if (plain && full) {
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    dst[(4 * i + (r >> 2)) * d_sh + (r & 3) * d_sw + 32 * j] = acc[i][j][r] + bias;
+                    dst[(4 * i + (r >> 2)) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
         }
         return;
     }
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!full && (py0 + 4 * i + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
-                const int off = (4 * i + (r >> 2)) * d_sh + (r & 3) * d_sw + 32 * j;
+                const int off = (4 * i + (r >> 2)) * e_sh + (r & 3) * e_sw + 32 * j;
                 float v = acc[i][j][r] + bias;
                 if (p.splitk > 1) {
                     unsafeAtomicAdd(dst + off, v);
@@ -289,10 +301,12 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     const long long ssn = dg ? a->y_sn : a->x_sn, ssh = dg ? a->y_sh : a->x_sh, ssw = dg ? a->y_sw : a->x_sw;
     const void* sptr = dg ? a->y : a->x;
     const bool src4 = (ssn % 4 == 0) && (ssh % 4 == 0) && (ssw % 4 == 0) && aligned16(sptr);
-    if (!(p.bf16 && p.w16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh == 1 && a->sw == 1 &&
-          (Cred % 8 == 0) && src4))
+    if (!(p.bf16 && p.w16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh <= 4 && a->sw <= 4 &&
+          a->kh >= a->sh && a->kw >= a->sw && (Cred % 8 == 0) && src4))
         return false;
-    const int Hm = dg ? a->H : a->Ho, Wm = dg ? a->W : a->Wo;
+    // M-grid of the (largest) output phase; strided DGRAD runs sh*sw phases as blockIdx.y
+    const int phases = dg ? a->sh * a->sw : 1;
+    const int Hm = dg ? (a->H + a->sh - 1) / a->sh : a->Ho, Wm = dg ? (a->W + a->sw - 1) / a->sw : a->Wo;
     const long long dH = Hm, dW_ = Wm;
     const long long d_sn = dg ? a->x_sn : a->y_sn, d_sh = dg ? a->x_sh : a->y_sh, d_sw = dg ? a->x_sw : a->y_sw;
     // 32-bit in-image offsets (source and destination) and weight offsets
@@ -317,7 +331,12 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     }
     if (!nch) return false;
     const int Cpad = nch * nks * 16;
-    const int TH = 2 * nw * wm, PH = TH + a->kh - 1, PW = 8 + a->kw - 1;
+    // patch extent per dim: (tile-1)*mstep + (taps-1)*|jstep| + 1 ; FPROP: mstep = stride, jstep = 1 ; DGRAD: mstep = 1,
+    // taps = ceil(k / stride) per phase, jstep = -1
+    const int TH = 2 * nw * wm;
+    const int PH = dg ? TH + (a->kh + a->sh - 1) / a->sh - 1 : (TH - 1) * a->sh + a->kh;
+    const int PW = dg ? 8 + (a->kw + a->sw - 1) / a->sw - 1 : 7 * a->sw + a->kw;
+    p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + TH - 1) / TH; p.s1_tw = tW;
     const int CP = Cpad + 8;
     const int x = (8 - (PW * (CP / 8)) % 16 + 16) % 16;          // row pitch = 8 (mod 16) 16-byte slots
     const int pitch = PW * CP + 8 * x;
@@ -328,7 +347,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     const int BN = 64 * wn;
     p.tm = a->N * ((Hm + TH - 1) / TH) * tW; p.tn = (Nout + BN - 1) / BN;
     const long long tiles = (long long)p.tm * p.tn;
-    const long long iters = (long long)a->kh * a->kw * nch;
+    const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch;
     int splitk = a->splitk;
     if (a->act != SAVP_ACT_NONE) splitk = 1;
     else if (splitk <= 0) {
@@ -347,7 +366,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         else splitk = 1;
     }
     p.splitk = splitk;
-    dim3 grid((unsigned)(p.tm * p.tn), 1, (unsigned)splitk);
+    dim3 grid((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     hipError_t err;
     ablate_init();
     err = (nw == 8) ? launch_patch_tile<8>(p, wm, wn, nks, grid, lds, st) : launch_patch_tile<4>(p, wm, wn, nks, grid, lds, st);
