@@ -24,7 +24,7 @@ struct WgP {
     const float* x; const float* y; float* dw;
     long long x_sn, y_sn;
     int x_sh, x_sw, y_sh, y_sw;
-    int H, W, Ho, Wo, Cx, Cy, ph, pw, kw;
+    int H, W, Ho, Wo, Cx, Cy, ph, pw, kw, sh, sw;
     int taps, G16, CG, S;              // taps, 16-channel groups of Cx, groups per chunk, pixel splits
     int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
     int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int t_begin = sp * per, t_end = min(q.PT, t_begin + per);
     if (t_begin >= t_end) return;
 
-    // ---- staging maps, packed into one register per slot: LDS offset | c4 << 15 | py << 21 | px << 25 | valid << 29 ----
+    // ---- staging maps, packed into one register per slot: LDS offset | c4 << 15 | py << 21 | px << 26 | valid << 31 ----
     unsigned pinfo[NPF];
     {
         const int c4n = q.CG * 4;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             const int pxx = pix - pyy * q.PW;
             const bool ok = idx < ptotal;
             pinfo[i] = ok ? ((unsigned)(pyy * q.pitch + pxx * q.CP + c4 * 4) | ((unsigned)c4 << 15) | ((unsigned)pyy << 21) |
-                             ((unsigned)pxx << 25) | (1u << 29)) : 0u;
+                             ((unsigned)pxx << 26) | (1u << 31)) : 0u;
         }
     }
     float4 pf[NPF], pd[NPD];
@@ -75,13 +75,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         const int r = t - img * q.tHW;
         const int ty = (int)fastdiv((unsigned)r, q.magTW);
         const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
-        const float* __restrict__ xs = q.x + (long long)img * q.x_sn + (long long)(oy0 - q.ph) * q.x_sh + (long long)(ox0 - q.pw) * q.x_sw + ca * 16;
+        const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw;       // patch origin in the input plane
+        const float* __restrict__ xs = q.x + (long long)img * q.x_sn + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw + ca * 16;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             unsigned inf = pinfo[i];
             asm volatile("" : "+v"(inf));                      // keep the unpacking inside the loop (register pressure)
-            const int c = (int)((inf >> 15) & 63u) << 2, pyy = (int)((inf >> 21) & 15u), pxx = (int)((inf >> 25) & 15u);
-            const bool ok = (inf >> 29) && (unsigned)(oy0 - q.ph + pyy) < (unsigned)q.H && (unsigned)(ox0 - q.pw + pxx) < (unsigned)q.W &&
+            const int c = (int)((inf >> 15) & 63u) << 2, pyy = (int)((inf >> 21) & 31u), pxx = (int)((inf >> 26) & 31u);
+            const bool ok = (inf >> 31) && (unsigned)(iy0 + pyy) < (unsigned)q.H && (unsigned)(ix0 + pxx) < (unsigned)q.W &&
                             ca * 16 + c < q.Cx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) v = ldg4(xs + pyy * q.x_sh + pxx * q.x_sw + c);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         for (int i = 0; i < NPF; ++i) {
             unsigned inf = pinfo[i];
             asm volatile("" : "+v"(inf));
-            if (inf >> 29) {
+            if (inf >> 31) {
                 bf16x4 o = {(__bf16)pf[i].x, (__bf16)pf[i].y, (__bf16)pf[i].z, (__bf16)pf[i].w};
                 *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffu)) = o;
             }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     // k-step s covers tile pixels 16 s .. 16 s + 15; this lane's transpose read j (0/1) touches pixel
     //   k = 8 (lane>>5) + 4 j + ((lane&15)>>2)  ->  tile row 2 s + (lane>>5), tile column 4 j + ((lane&15)>>2)
     const int h = lane >> 5, g = (lane >> 4) & 1, r4 = (lane & 15) >> 2, c4 = (lane & 3) << 2;
-    const int a_lane = h * q.pitch + r4 * q.CP + c4;           // elements
+    const int a_lane = h * q.sh * q.pitch + r4 * q.sw * q.CP + c4;   // elements (output pixel -> input pixel: x stride)
     const int b_lane = (8 * h + r4) * 32 + 16 * g + c4;
     int a_tile[MTW];                                           // tap shift + local channel offset of this lane's row group
     const int nt = min(MTW, max(0, (ngroups + 1) / 2 - wave * MTW));   // valid row tiles of this wave
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             const bf16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024));
             const bf16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024 + 256));
             const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            const LDS_AS char* pa0 = pa + 4 * s * q.pitch;     // 2 s rows of the patch, bytes
-            const LDS_AS char* pa1 = pa0 + 8 * q.CP;           // + 4 pixels
+            const LDS_AS char* pa0 = pa + 4 * s * q.sh * q.pitch;   // output rows 2 s of the tile (bytes)
+            const LDS_AS char* pa1 = pa0 + 8 * q.sw * q.CP;         // + 4 output pixels
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 if (i >= nt) break;                            // wave-uniform
@@ -209,7 +210,7 @@ static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
-    if (!(p.bf16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->Cx % 4 == 0 &&
+    if (!(p.bf16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh <= 2 && a->sw <= 2 && a->Cx % 4 == 0 &&
           a->Cy % 4 == 0 && xs4 && ys4 && a->kh <= 8 && a->kw <= 8 && a->Ho * a->Wo >= 64))
         return false;
     if (a->x_sh * (long long)(a->H + 8) >= (1ll << 31) || a->y_sh * (long long)(a->Ho + 8) >= (1ll << 31)) return false;
@@ -217,10 +218,11 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.x = (const float*)a->x; q.y = (const float*)a->y; q.dw = (float*)a->w;
     q.x_sn = a->x_sn; q.y_sn = a->y_sn;
     q.x_sh = (int)a->x_sh; q.x_sw = (int)a->x_sw; q.y_sh = (int)a->y_sh; q.y_sw = (int)a->y_sw;
-    q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw;
+    q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw; q.sh = a->sh; q.sw = a->sw;
     q.taps = a->kh * a->kw;
     q.G16 = (a->Cx + 15) / 16;
-    q.PH = 8 + a->kh - 1; q.PW = 8 + a->kw - 1;
+    q.PH = 7 * a->sh + a->kh; q.PW = 7 * a->sw + a->kw;           // input rows / columns under an 8x8 output tile
+    if (q.PH > 31 || q.PW > 31) return false;                    // packed staging map: 5 bits per coordinate
     // workgroup shape: 8 waves x 8 row tiles (64 tiles = 128 row groups) for the big layers, 4 x 8 / 4 x 4 for small ones
     const int groups_all = q.taps * q.G16;
     int nw, mtw;
