@@ -59,7 +59,8 @@ typedef struct SavpConvArgs {
     void* x; int64_t x_sn, x_sd, x_sh, x_sw;
     void* y; int64_t y_sn, y_sd, y_sh, y_sw;
     void* w;
-    const float* bias;             /* per destination channel, or NULL */
+    const float* bias;             /* FPROP/DGRAD: per destination channel, or NULL.  WGRAD: if not NULL the bias gradient is
+                                      accumulated as well: bias[c] += sum over all pixels of y[..., c] (y pixel-contiguous) */
     const float* aux;              /* act==3: saved activation, addressed like the destination */
     const void* w_bf16;            /* optional bf16 copy of w (FPROP/DGRAD, SAVP_PREC_BF16): halves the weight stream */
 } SavpConvArgs;

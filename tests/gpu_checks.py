@@ -120,6 +120,7 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
         b = rnd(rng, Cy)
         x.requires_grad_(True)
         w.requires_grad_(True)
+        b.requires_grad_(True)
         y = _ref_conv(x, w, k, s, p, pa) + b
         dy = rnd(rng, *y.shape)
         (y * dy).sum().backward()
@@ -165,8 +166,10 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
             out.append((tag + '/dgrad', rel_err(dxd, x.grad), tol))
             # WGRAD
             dwd = torch.zeros(w.shape, device=DEV, dtype=torch.float32)
-            K.conv(lib.CONV_WGRAD, geom, xd, dyd, dwd, tile=tile, precision=precision)
+            dbd = torch.zeros(Cy, device=DEV, dtype=torch.float32)
+            K.conv(lib.CONV_WGRAD, geom, xd, dyd, dwd, bias=dbd, tile=tile, precision=precision)
             out.append((tag + '/wgrad', rel_err(dwd, w.grad), tol))
+            out.append((tag + '/wgrad_bias', rel_err(dbd, b.grad), TOL_OP))
     torch.cuda.synchronize()
     return out
 

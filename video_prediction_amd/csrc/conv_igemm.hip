@@ -872,6 +872,14 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         else if (wm == 2 && wn == 1) err = launch_wg<2, 1>(p, va, vb, grid, st);
         else if (wm == 1 && wn == 2) err = launch_wg<1, 2>(p, va, vb, grid, st);
         else err = launch_wg<1, 1>(p, va, vb, grid, st);
+        if (a->bias && err == hipSuccess) {                // bias gradient: column sums of y (separate pass on this path)
+            const long long px = (long long)a->Do * a->Ho * a->Wo;
+            const bool joint = (a->y_sh == a->Wo * a->y_sw) && (a->Do == 1 || a->y_sd == a->Ho * a->y_sh);
+            if (!joint) return SAVP_EINVAL;
+            SavpView yv; yv.p = (void*)a->y; yv.sn = a->y_sn; yv.sp = a->y_sw;
+            int rc2 = savp_colsum(stream, yv, a->N, (int32_t)px, a->Cy, 1.f, (float*)a->bias, 0);
+            if (rc2 != SAVP_OK) return rc2;
+        }
     } else {
         return SAVP_EINVAL;
     }

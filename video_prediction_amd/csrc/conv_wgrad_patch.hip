@@ -21,7 +21,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
 #define LDS_AS __attribute__((address_space(3)))
 
 struct WgP {
-    const float* x; const float* y; float* dw;
+    const float* x; const float* y; float* dw; float* db;
     long long x_sn, y_sn;
     int x_sh, x_sw, y_sh, y_sw;
     int H, W, Ho, Wo, Cx, Cy, ph, pw, kw, sh, sw;
@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         }
     }
     float4 pf[NPF], pd[NPD];
+    // bias gradient = column sums of dy, taken from the tiles as they stream by (fp32, before the bf16 rounding); one M chunk only
+    const bool do_db = (q.db != nullptr) && (mc == 0);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int t) {
         const int img = (int)fastdiv((unsigned)t, q.magTHW);
         const int r = t - img * q.tHW;
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) v = ldg4(ys + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c);
             pd[i] = v;
+            if (do_db) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
         }
     };
     auto stage = [&](int buf) {
@@ -171,6 +175,20 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         }
     }
 
+    if (do_db) {                                               // every slot of this thread is channel quad (tid & 7)
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, m); bsum.y += __shfl_xor(bsum.y, m);
+            bsum.z += __shfl_xor(bsum.z, m); bsum.w += __shfl_xor(bsum.w, m);
+        }
+        const int c = cy0 + (lane << 2);
+        if (lane < 8) {
+            if (c < q.Cy) unsafeAtomicAdd(q.db + c, bsum.x);
+            if (c + 1 < q.Cy) unsafeAtomicAdd(q.db + c + 1, bsum.y);
+            if (c + 2 < q.Cy) unsafeAtomicAdd(q.db + c + 2, bsum.z);
+            if (c + 3 < q.Cy) unsafeAtomicAdd(q.db + c + 3, bsum.w);
+        }
+    }
     // ---- epilogue: acc[i][r] of lane (l31 = column cy, khalf) is row (r&3) + 8 (r>>2) + 4 khalf of row tile i ----------
     const int l31 = lane & 31, khalf = lane >> 5;
     const int cy = cy0 + l31;
@@ -215,7 +233,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
         return false;
     if (a->x_sh * (long long)(a->H + 8) >= (1ll << 31) || a->y_sh * (long long)(a->Ho + 8) >= (1ll << 31)) return false;
     WgP q;
-    q.x = (const float*)a->x; q.y = (const float*)a->y; q.dw = (float*)a->w;
+    q.x = (const float*)a->x; q.y = (const float*)a->y; q.dw = (float*)a->w; q.db = (float*)a->bias;
     q.x_sn = a->x_sn; q.y_sn = a->y_sn;
     q.x_sh = (int)a->x_sh; q.x_sw = (int)a->x_sw; q.y_sh = (int)a->y_sh; q.y_sw = (int)a->y_sw;
     q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw; q.sh = a->sh; q.sw = a->sw;

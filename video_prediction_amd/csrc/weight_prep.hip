@@ -174,6 +174,44 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restric
     }
 }
 
+// Same product for C = 4 * LPR with LPR a power of two <= 64 (every spectrally normalised conv of the model: 32..256 output
+// channels): LPR lanes x float4 cover one row, a wave covers 64/LPR consecutive rows per pass = 1 KB of contiguous memory,
+// two passes in flight.  (The one-element-per-lane kernel above spends its time in shuffles and exposed load latency.)
+__global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                              float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                              float* dotz) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpr = C >> 2, rpw = 64 / lpr;
+    const int c4 = lane & (lpr - 1), sub = lane / lpr;
+    const float4 xv = *reinterpret_cast<const float4*>(x + c4 * 4);
+    float sqacc = 0.f, dzacc = 0.f;
+    const long long stride = (long long)gridDim.x * 4 * rpw;
+    for (long long k0 = ((long long)blockIdx.x * 4 + wave) * rpw; k0 < K; k0 += 2 * stride) {
+        const long long ka = k0 + sub, kb = k0 + stride + sub;
+        float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
+        if (ka < K) wa = *reinterpret_cast<const float4*>(W + ka * C + c4 * 4);
+        if (kb < K) wb = *reinterpret_cast<const float4*>(W + kb * C + c4 * 4);
+        float sa = wa.x * xv.x + wa.y * xv.y + wa.z * xv.z + wa.w * xv.w;
+        float sb = wb.x * xv.x + wb.y * xv.y + wb.z * xv.z + wb.w * xv.w;
+        for (int o = lpr >> 1; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+        if (c4 == 0) {
+            sa *= xscale; sb *= xscale;
+            if (ka < K) { y[ka] = sa; sqacc += sa * sa; if (z) dzacc += sa * z[ka]; }
+            if (kb < K) { y[kb] = sb; sqacc += sb * sb; if (z) dzacc += sb * z[kb]; }
+        }
+    }
+    sqacc = wsum(sqacc); dzacc = wsum(dzacc);
+    if (lane == 0) {
+        if (sq) unsafeAtomicAdd(sq, sqacc);
+        if (dotz) unsafeAtomicAdd(dotz, dzacc);
+    }
+}
+
+static bool sn_vec_ok(const float* W, const float* x, int C) {
+    const int lpr = C >> 2;
+    return (C % 4 == 0) && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ((((uintptr_t)W) | ((uintptr_t)x)) & 15) == 0;
+}
+
 // narrow matrices (C <= 16, e.g. the discriminators' final linear [65536, 1]): one THREAD per row
 __global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
                                                                  float xscale, float* __restrict__ y, float* sq, const float* z,
@@ -205,6 +243,31 @@ __global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restric
         float s = 0.f;
         for (long long k = k0; k < k1; ++k) s += W[k * C + c] * x[k];
         unsafeAtomicAdd(y + c, s);
+    }
+}
+
+// vectorised variant (C = 4 * LPR, LPR a power of two <= 64): thread = (column quad, row slot), float4 loads of full rows,
+// LDS reduction over the row slots, one atomic per column and block
+__global__ __launch_bounds__(NT) void sn_gemv_cols_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                              float* __restrict__ y, int rows_per_block) {
+    __shared__ float4 sh[NT];
+    const int lpr = C >> 2, slots = NT / lpr;
+    const int c4 = threadIdx.x & (lpr - 1), sub = threadIdx.x / lpr;
+    const long long k0 = (long long)blockIdx.x * rows_per_block;
+    const long long k1 = min(K, k0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long k = k0 + sub; k < k1; k += slots) {
+        const float4 w = *reinterpret_cast<const float4*>(W + k * C + c4 * 4);
+        const float xv = x[k];
+        acc.x += w.x * xv; acc.y += w.y * xv; acc.z += w.z * xv; acc.w += w.w * xv;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < lpr) {
+        float4 t = sh[threadIdx.x];
+        for (int r = 1; r < slots; ++r) { const float4 v = sh[r * lpr + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        unsafeAtomicAdd(y + c4 * 4, t.x); unsafeAtomicAdd(y + c4 * 4 + 1, t.y);
+        unsafeAtomicAdd(y + c4 * 4 + 2, t.z); unsafeAtomicAdd(y + c4 * 4 + 3, t.w);
     }
 }
 
@@ -240,13 +303,26 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
         if (nbn > 1024) nbn = 1024;
         hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7,
                            (const float*)nullptr, (float*)nullptr);
+    } else if (sn_vec_ok(W, u, C)) {
+        const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);     // rows per block pass pair
+        unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
+        hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7,
+                           (const float*)nullptr, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7, (const float*)nullptr,
                            (float*)nullptr);
     }
-    int rpb = 64;
-    hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
-                       (const float*)a, ws + 8, rpb);
+    if (sn_vec_ok(W, W, C)) {
+        int rpb = (int)((K + 511) / 512);                    // ~512 blocks, at least one pass of the row slots
+        const int slots = NT / (C >> 2);
+        if (rpb < 4 * slots) rpb = 4 * slots;
+        hipLaunchKernelGGL(sn_gemv_cols_vec_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
+                           (const float*)a, ws + 8, rpb);
+    } else {
+        int rpb = 64;
+        hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
+                           (const float*)a, ws + 8, rpb);
+    }
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(NT), 0, st, ws, C, u_new);
     return LAUNCH_OK();
 }
@@ -302,6 +378,11 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
         if (nbn > 1024) nbn = 1024;
         hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f,
                            a + K, (float*)nullptr, (const float*)a, ws + 6);
+    } else if (sn_vec_ok(W, ws + 8, C)) {
+        const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);
+        unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
+        hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
+                           (float*)nullptr, (const float*)a, ws + 6);
     } else {
         hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
                            (float*)nullptr, (const float*)a, ws + 6);

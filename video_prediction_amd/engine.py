@@ -281,11 +281,10 @@ class ConvLayer(object):
         if self.kind == 'up':
             K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
             bias_src = dy
-        else:
-            K.conv(lib.CONV_WGRAD, self.geom, x, dy, target)
-            bias_src = dy
-        if self.dbias is not None:
-            K.colsum(bias_src, self.dbias)
+            if self.dbias is not None:
+                K.colsum(bias_src, self.dbias)
+        else:       # bias gradient = column sums of dy: fused into the WGRAD pass (include/savp_hip.h, SavpConvArgs.bias)
+            K.conv(lib.CONV_WGRAD, self.geom, x, dy, target, bias=self.dbias)
 
     def finish_weight_grad(self):
         """Map the folded / spectrally-normalised kernel gradient back to the master variable and clear it."""

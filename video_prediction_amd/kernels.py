@@ -94,8 +94,9 @@ def _tune(a, mode, dst, w):
     if mode == lib.CONV_WGRAD:
         cands = [(t, sk) for t in tiles for sk in (0,)]
         scratch = torch.zeros_like(w)
-        real_w = a.w
+        real_w, real_bias = a.w, a.bias
         a.w = scratch.data_ptr()
+        a.bias = None                    # tuning runs must not accumulate into the real bias gradient
     else:
         splits = (1, 2, 4, 8) if a.act == 0 else (1,)
         # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
@@ -129,7 +130,7 @@ def _tune(a, mode, dst, w):
         if t < best_t:
             best, best_t = (tile, sk), t
     if mode == lib.CONV_WGRAD:
-        a.w = real_w
+        a.w, a.bias = real_w, real_bias
     else:
         a.beta = real_beta
         if mode == lib.CONV_DGRAD:
