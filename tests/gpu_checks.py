@@ -611,7 +611,7 @@ def check_weight_prep(seed=7):
     K.fold_bilinear(dev(g), dw, 3, 10, 6, adjoint=True)
     out.append(('fold_bilinear_adj', rel_err(dw, w.grad), 1e-6))
     # spectral norm
-    for shape in [(3, 3, 3, 16, 32), (4, 4, 4, 8, 16), (640, 1)]:
+    for shape in [(3, 3, 3, 16, 32), (4, 4, 4, 8, 16), (640, 1), (4, 4, 4, 16, 128), (3, 3, 3, 8, 24), (2, 2, 5, 256)]:
         W = (rnd(rng, *shape) * 0.05).requires_grad_(True)
         C = shape[-1]
         u = rnd(rng, 1, C)
