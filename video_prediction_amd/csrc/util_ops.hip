@@ -302,50 +302,61 @@ extern "C" int savp_sigmoid_bwd(void* stream, SavpView dy, SavpView y, float* ou
 #define DKC 64
 __global__ __launch_bounds__(NT) void dense_smallm_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
                                                           const float* __restrict__ W, const float* bias, const float* scale,
-                                                          float* out) {
+                                                          float* out, int nsub) {
     extern __shared__ float dsm[];
     float* xsh = dsm;                 // [M][DKC]
     float* wsh = dsm + M * DKC;       // [DKC][C]
-    const long long k0 = (long long)blockIdx.x * DKC;
-    const int kn = (int)min((long long)DKC, Kd - k0);
-    for (int i = threadIdx.x; i < M * DKC; i += NT) {
-        int m = i / DKC, k = i % DKC;
-        xsh[i] = k < kn ? x[(long long)m * xs + k0 + k] : 0.f;
-    }
-    for (int i = threadIdx.x; i < DKC * C; i += NT) {
-        int k = i / C;
-        wsh[i] = k < kn ? W[(k0 + k) * C + (i % C)] : 0.f;
-    }
-    __syncthreads();
-    const float sc = scale ? *scale : 1.f;
+    float* osh = wsh + DKC * C;       // [M][C] partial outputs of this workgroup (nsub K-chunks): one atomic per output and
+                                      // workgroup -- with one chunk per workgroup the 128-way atomic contention on the
+                                      // 3200 outputs of the CDNA head was the whole cost of the layer
+    for (int i = threadIdx.x; i < M * C; i += NT) osh[i] = 0.f;
     // thread -> (column c, sample group g); CT columns per pass
     const int CT = C >= NT ? NT : C;
     const int G = NT / CT;                     // sample groups
     const int c0 = threadIdx.x % CT, g = threadIdx.x / CT;
-    if (g >= G) return;
-    for (int c = c0; c < C; c += CT) {
-        for (int mb = g; mb < M; mb += G * 8) {
-            float acc[8];
+    for (int sub = 0; sub < nsub; ++sub) {
+        const long long k0 = ((long long)blockIdx.x * nsub + sub) * DKC;
+        if (k0 >= Kd) break;                   // uniform
+        const int kn = (int)min((long long)DKC, Kd - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < M * DKC; i += NT) {
+            int m = i / DKC, k = i % DKC;
+            xsh[i] = k < kn ? x[(long long)m * xs + k0 + k] : 0.f;
+        }
+        for (int i = threadIdx.x; i < DKC * C; i += NT) {
+            int k = i / C;
+            wsh[i] = k < kn ? W[(k0 + k) * C + (i % C)] : 0.f;
+        }
+        __syncthreads();
+        if (g < G) {
+            for (int c = c0; c < C; c += CT) {
+                for (int mb = g; mb < M; mb += G * 8) {
+                    float acc[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-            for (int k = 0; k < DKC; ++k) {
-                const float w = wsh[k * C + c];
+                    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+                    for (int k = 0; k < DKC; ++k) {
+                        const float w = wsh[k * C + c];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = mb + i * G;
-                    if (m < M) acc[i] += xsh[m * DKC + k] * w;
-                }
-            }
+                        for (int i = 0; i < 8; ++i) {
+                            const int m = mb + i * G;
+                            if (m < M) acc[i] += xsh[m * DKC + k] * w;
+                        }
+                    }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mb + i * G;
-                if (m < M) {
-                    float v = acc[i] * sc;
-                    if (blockIdx.x == 0 && bias) v += bias[c];
-                    unsafeAtomicAdd(out + (long long)m * C + c, v);
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = mb + i * G;
+                        if (m < M) osh[m * C + c] += acc[i];          // (m, c) is owned by exactly one thread
+                    }
                 }
             }
         }
+    }
+    __syncthreads();
+    const float sc = scale ? *scale : 1.f;
+    for (int i = threadIdx.x; i < M * C; i += NT) {
+        float v = osh[i] * sc;
+        if (blockIdx.x == 0 && bias) v += bias[i % C];
+        unsafeAtomicAdd(out + i, v);
     }
 }
 
@@ -355,8 +366,11 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
     if (M > 64 || C > 256) return SAVP_EINVAL;
-    size_t lds = (size_t)(M * DKC + DKC * C) * sizeof(float);
-    hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((K + DKC - 1) / DKC)), dim3(NT), lds, st, x, (long long)x_row_stride, M,
-                       (long long)K, C, W, bias, scale, out);
+    size_t lds = (size_t)(M * DKC + DKC * C + M * C) * sizeof(float);
+    const long long chunks = (K + DKC - 1) / DKC;
+    int nsub = (int)((chunks + 255) / 256);                    // at most ~256 workgroups (fewer atomics for very long K)
+    if (nsub < 1) nsub = 1;
+    hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((chunks + nsub - 1) / nsub)), dim3(NT), lds, st, x, (long long)x_row_stride, M,
+                       (long long)K, C, W, bias, scale, out, nsub);
     return LAUNCH_OK();
 }
