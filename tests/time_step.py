@@ -10,6 +10,8 @@ def main():
     from video_prediction_amd import kernels as K
     K.set_conv_precision(os.environ.get('PREC', 'f32'))
     K.enable_autotune(os.environ.get('TUNE', '1') == '1')
+    if os.environ.get('LOAD_TUNE'):
+        print('loaded %d tuned problems' % K.load_tuning(os.environ['LOAD_TUNE']))
     B = int(os.environ.get('B', 16)); T = int(os.environ.get('T', 30)); steps = int(os.environ.get('STEPS', 3))
     hp = make_hparams(context_frames=2, sequence_length=T, batch_size=B, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
@@ -25,6 +27,8 @@ def main():
         info = eng.train_step()
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
+    if os.environ.get('SAVE_TUNE'):
+        K.save_tuning(os.environ['SAVE_TUNE'])
     if os.environ.get('TUNELOG'):
         for key, cfg in K.AUTOTUNE['log']:
             print('tuned', key[:1], key[2:11], '->', hex(cfg[0]), cfg[1])

@@ -52,6 +52,24 @@ AUTOTUNE = {'enabled': False, 'cache': {}, 'log': []}
 CONV_CALL_LOG = None
 
 
+def save_tuning(path):
+    """Write the (problem -> (tile, splitk)) table found by the autotuner as JSON (keys are reprs of the problem tuples)."""
+    import json
+    with open(path, 'w') as f:
+        json.dump({repr(k): list(v) for k, v in AUTOTUNE['cache'].items()}, f, indent=0, sort_keys=True)
+
+
+def load_tuning(path):
+    """Pre-load a table written by save_tuning(); problems found in it are never timed again.  Returns #entries."""
+    import ast
+    import json
+    with open(path) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        AUTOTUNE['cache'][ast.literal_eval(k)] = (int(v[0]), int(v[1]))
+    return len(d)
+
+
 def enable_autotune(flag=True):
     """First use of every distinct conv problem times the tile / split-K candidates on the device and caches the best.
     (Launch-time selection only: every candidate computes the same result up to fp32 summation order.)"""
@@ -88,6 +106,7 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
 
 def _tune(a, mode, dst, w):
     """Time candidate (tile, splitk) pairs for this problem; returns the fastest."""
+    torch.cuda.synchronize()             # nothing else in flight (other streams would distort the timings)
     fn = lib.get().savp_conv
     st = lib.stream()
     tiles = (0x22, 0x21, 0x12, 0x11)
