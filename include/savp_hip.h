@@ -117,6 +117,8 @@ typedef struct SavpLstmArgs {
     float* dgates;
     float* dc_prev;
     float *dgamma1, *dbeta1, *dgamma2, *dbeta2;
+    float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(11 + HW) floats: selects the coalesced three-pass forward
+                                      (F a power of two in [16, 256]); NULL = single fused kernel (HW <= 1024) */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);

@@ -302,6 +302,19 @@ def check_lstm(seed=3):
         out.append((tag + '/c', rel_err(c_new, cn), TOL_OP))
         out.append((tag + '/h', rel_err(h1, hn), TOL_OP))
         out.append((tag + '/h2', rel_err(h2, hn), TOL_OP))
+        # coalesced three-pass forward (selected by the workspace): same outputs and saved statistics
+        if F >= 16:
+            ws = torch.empty(K.lstm_ws_floats(N, H * W, F), device=DEV)
+            c_ws = torch.empty(N, H, W, F, device=DEV)
+            hbig2 = torch.zeros(N, H, W, 2 * F + 8, device=DEV)
+            stats2 = [torch.empty_like(t) for t in stats]
+            K.convlstm_gates_fwd(gd, cd, p[0], p[1], p[2], p[3], c_ws, [hbig2[..., :F], hbig2[..., F + 8:]], stats2, ws=ws)
+            out.append((tag + '/c_ws', rel_err(c_ws, cn), TOL_OP))
+            out.append((tag + '/h_ws', rel_err(hbig2[..., :F], hn), TOL_OP))
+            out.append((tag + '/h2_ws', rel_err(hbig2[..., F + 8:], hn), TOL_OP))
+            out.append((tag + '/pad_untouched_ws', float(hbig2[..., F:F + 8].abs().max()), 0.0))
+            for nm, a_, b_ in zip(('mean1', 'rstd1', 'mean2', 'rstd2'), stats2, stats):
+                out.append((tag + '/%s_ws' % nm, rel_err(a_, b_.double().cpu()), 1e-5))
         dgates = torch.empty(N, H, W, 4 * F, device=DEV)
         dcp = torch.empty(N, H, W, F, device=DEV)
         dpar = [torch.zeros(4 * F, device=DEV), torch.zeros(4 * F, device=DEV), torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)]
@@ -310,6 +323,17 @@ def check_lstm(seed=3):
         out.append((tag + '/dc_prev', rel_err(dcp, c.grad), 1e-4))
         for nm, got, ref in zip(('dg1', 'db1', 'dg2', 'db2'), dpar, (g1.grad, b1.grad, g2.grad, b2.grad)):
             out.append((tag + '/' + nm, rel_err(got, ref), 1e-4))
+        if F >= 16:                       # coalesced three-pass backward
+            dgates2 = torch.empty(N, H, W, 4 * F, device=DEV)
+            dcp2 = torch.empty(N, H, W, F, device=DEV)
+            dpar2 = [torch.zeros_like(t) for t in dpar]
+            K.convlstm_gates_bwd(gd, cd, p[0], p[1], p[2], p[3], stats, [dev(dh1), dev(dh2)], dev(dcn), dgates2, dcp2, dpar2, ws=ws)
+            out.append((tag + '/dgates_ws', rel_err(dgates2, gates.grad), 1e-4))
+            out.append((tag + '/dc_prev_ws', rel_err(dcp2, c.grad), 1e-4))
+            for nm, got, ref in zip(('dg1', 'db1', 'dg2', 'db2'), dpar2, (g1.grad, b1.grad, g2.grad, b2.grad)):
+                out.append((tag + '/' + nm + '_ws', rel_err(got, ref), 1e-4))
+            K.convlstm_gates_bwd(gd, cd, p[0], p[1], p[2], p[3], stats, [dev(dh1)], None, dgates2, None, dpar2, ws=ws)   # no dc in/out
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     return out
 

@@ -633,8 +633,332 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Coalesced three-pass forward of the ConvLSTM gate block (used when the caller supplies a workspace).
+// The fused kernel above assigns (sample, 4 channels) to a workgroup, i.e. every lane reads 16 B of a different
+// 128-B line (the gate tensor is pixel-major with 4F channels per pixel) -- measured ~1 TB/s.  Here a workgroup takes
+// a chunk of pixels x ALL channels, lanes run along the channel axis (full lines per wave instruction) and the two
+// per-sample reductions go through small per-(n, c) workspaces:
+//   pass 1  inorm_stats_kernel on the gate tensor (C = 4F)                    -> ws1 [N][4F][2]  shifted sums
+//   pass 2  lstm_cell_kernel: normalise gates, c_pre, sigmoid(o); c_pre statistics -> ws2 [N][F][2], k2 [N][F]
+//   pass 3  lstm_out_kernel: normalise c_pre, h = tanh(c) * sigmoid(o), write c_new and the h destinations
+// Shifted sums (shift = the value at pixel 0) keep E[x^2] - E[x]^2 well conditioned, exactly as the instance-norm path.
+// ------------------------------------------------------------------------------------------------------------
+struct LstmWs { float* s1; float* s2; float* k2; float* so; };
+
+__global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int chunk) {
+    extern __shared__ float sh[];                     // [rows][2*F]
+    const int n = blockIdx.y, F = p.F, F4 = F / 4;
+    const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
+    const int c0 = fq * 4;
+    const float* g0 = p.gates + (long long)n * p.HW * 4 * F;
+    const float inv = 1.f / (float)p.HW;
+    float mu[16], rs[16], ga[16], be[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 k = ld4(g0 + q * F + c0);            // shift of pass 1 = pixel 0
+        const float kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* s = w.s1 + ((long long)n * 4 * F + q * F + c0 + c) * 2;
+            const float ms = s[0] * inv;
+            const float var = fmaxf(s[1] * inv - ms * ms, 0.f);
+            mu[q * 4 + c] = kk[c] + ms; rs[q * 4 + c] = rsqrtf(var + p.eps);
+            ga[q * 4 + c] = p.g1[q * F + c0 + c]; be[q * 4 + c] = p.b1[q * F + c0 + c];
+        }
+    }
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            p.mean1[(long long)n * 4 * F + (i >> 2) * F + c0 + (i & 3)] = mu[i];
+            p.rstd1[(long long)n * 4 * F + (i >> 2) * F + c0 + (i & 3)] = rs[i];
+        }
+    }
+    auto cell = [&](int px, float (&cn)[4], float (&so)[4]) {
+        const float* q = g0 + (long long)px * 4 * F + c0;
+        const float4 gi = ld4(q), gj = ld4(q + F), gf = ld4(q + 2 * F), go = ld4(q + 3 * F);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)px * p.cp_sp + c0);
+        const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, jv[4] = {gj.x, gj.y, gj.z, gj.w};
+        const float fv[4] = {gf.x, gf.y, gf.z, gf.w}, ov[4] = {go.x, go.y, go.z, go.w};
+        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = (iv[c] - mu[c]) * rs[c] * ga[c] + be[c];
+            const float jn = (jv[c] - mu[4 + c]) * rs[4 + c] * ga[4 + c] + be[4 + c];
+            const float fn = (fv[c] - mu[8 + c]) * rs[8 + c] * ga[8 + c] + be[8 + c];
+            const float on = (ov[c] - mu[12 + c]) * rs[12 + c] * ga[12 + c] + be[12 + c];
+            cn[c] = cpv[c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+            so[c] = sigmoidf_(on);
+        }
+    };
+    float k2[4], dummy[4];
+    cell(0, k2, dummy);                               // shift of the second reduction = c_pre at pixel 0 (same in every block)
+    if (blockIdx.x == 0 && prow == 0) st4(w.k2 + (long long)n * F + c0, make_float4(k2[0], k2[1], k2[2], k2[3]));
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float cn[4], so[4];
+        cell(px, cn, so);
+        st4(p.c_new + ((long long)n * p.HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(w.so + ((long long)n * p.HW + px) * F + c0, make_float4(so[0], so[1], so[2], so[3]));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float d = cn[c] - k2[c]; s[c] += d; qq[c] += d * d; }
+    }
+    float* d = sh + prow * 2 * F + c0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { d[c] = s[c]; d[F + c] = qq[c]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * F; i += NT) {
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += sh[r * 2 * F + i];
+        unsafeAtomicAdd(w.s2 + ((long long)n * F + (i % F)) * 2 + (i / F), t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void lstm_out_kernel(LstmP p, LstmWs w, int chunk) {
+    const int n = blockIdx.y, F = p.F, F4 = F / 4;
+    const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
+    const int c0 = fq * 4;
+    const float inv = 1.f / (float)p.HW;
+    const float4 k2 = ld4(w.k2 + (long long)n * F + c0);
+    const float kk[4] = {k2.x, k2.y, k2.z, k2.w};
+    float m2[4], r2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* s = w.s2 + ((long long)n * F + c0 + c) * 2;
+        const float ms = s[0] * inv;
+        const float var = fmaxf(s[1] * inv - ms * ms, 0.f);
+        m2[c] = kk[c] + ms; r2[c] = rsqrtf(var + p.eps);
+    }
+    if (blockIdx.x == 0 && prow == 0) {
+        st4(p.mean2 + (long long)n * F + c0, make_float4(m2[0], m2[1], m2[2], m2[3]));
+        st4(p.rstd2 + (long long)n * F + c0, make_float4(r2[0], r2[1], r2[2], r2[3]));
+    }
+    const float4 g2 = ld4(p.g2 + c0), b2 = ld4(p.b2 + c0);
+    const float g2v[4] = {g2.x, g2.y, g2.z, g2.w}, b2v[4] = {b2.x, b2.y, b2.z, b2.w};
+    const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float* cq = p.c_new + ((long long)n * p.HW + px) * F + c0;
+        const float4 cpre = ld4(cq), so = ld4(w.so + ((long long)n * p.HW + px) * F + c0);
+        const float cv[4] = {cpre.x, cpre.y, cpre.z, cpre.w}, sv[4] = {so.x, so.y, so.z, so.w};
+        float cn[4], hv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cn[c] = (cv[c] - m2[c]) * r2[c] * g2v[c] + b2v[c];
+            hv[c] = tanhf_(cn[c]) * sv[c];
+        }
+        st4(cq, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        for (int k = 0; k < p.nh; ++k) st4(p.h[k] + (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Coalesced three-pass backward (same thread mapping as lstm_cell_kernel; workspace r2 [N][F][2], r1 [N][4F][2],
+// dz2 [N][HW][F]; the raw gate gradients are parked in the dgates output between passes 2 and 3):
+//   pass 1  dz2 = d c_new (total), d o_n ; r2 = sum dz2, sum dz2 * x2 over the plane
+//   pass 2  d c_pre through the second norm, d c_prev, raw d(i, j, f) ; r1 = sum dg, sum dg * xh ; dgamma2 / dbeta2
+//   pass 3  dgates through the first norm ; dgamma1 / dbeta1
+// ------------------------------------------------------------------------------------------------------------
+struct LstmBws { float* r2; float* r1; float* dz2; };
+
+struct LstmLane {            // per-thread constants of the (sample, 4 channels) column this thread owns
+    float mu[16], rs[16], ga[16], be[16], mu2[4], rs2[4], g2[4], b2[4];
+};
+
+__device__ __forceinline__ void lstm_lane_load(const LstmP& p, int n, int c0, LstmLane& L) {
+    const int F = p.F;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long o = (long long)n * 4 * F + q * F + c0 + c;
+            L.mu[q * 4 + c] = p.mean1[o]; L.rs[q * 4 + c] = p.rstd1[o];
+            L.ga[q * 4 + c] = p.g1[q * F + c0 + c]; L.be[q * 4 + c] = p.b1[q * F + c0 + c];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        L.mu2[c] = p.mean2[(long long)n * F + c0 + c]; L.rs2[c] = p.rstd2[(long long)n * F + c0 + c];
+        L.g2[c] = p.g2[c0 + c]; L.b2[c] = p.b2[c0 + c];
+    }
+}
+
+// normalised gates xh[16] and previous cell state of pixel px
+__device__ __forceinline__ void lstm_load_px(const LstmP& p, const LstmLane& L, int n, int px, int c0, float (&xh)[16], float (&cp)[4]) {
+    const int F = p.F;
+    const float* q = p.gates + ((long long)n * p.HW + px) * 4 * F + c0;
+    const float4 a0 = ld4(q), a1 = ld4(q + F), a2 = ld4(q + 2 * F), a3 = ld4(q + 3 * F);
+    const float raw[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xh[i] = (raw[i] - L.mu[i]) * L.rs[i];
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.c_prev) c = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)px * p.cp_sp + c0);
+    cp[0] = c.x; cp[1] = c.y; cp[2] = c.z; cp[3] = c.w;
+}
+
+__global__ __launch_bounds__(NT) void lstm_bwd1_kernel(LstmP p, LstmBws w, int chunk) {
+    extern __shared__ float sh[];                     // [rows][2*F]
+    const int n = blockIdx.y, F = p.F, F4 = F / 4;
+    const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
+    const int c0 = fq * 4;
+    LstmLane L;
+    lstm_lane_load(p, n, c0, L);
+    float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float xh[16], cp[4];
+        lstm_load_px(p, L, n, px, c0, xh, cp);
+        float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < p.ndh; ++k) {
+            const float4 t = ld4(p.dh[k] + (long long)n * p.dh_sn[k] + (long long)px * p.dh_sp[k] + c0);
+            dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+        }
+        float4 dcn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.dc_new) dcn = ld4(p.dc_new + ((long long)n * p.HW + px) * F + c0);
+        const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, dcnv[4] = {dcn.x, dcn.y, dcn.z, dcn.w};
+        float dz[4], don[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = xh[c] * L.ga[c] + L.be[c];
+            const float jn = xh[4 + c] * L.ga[4 + c] + L.be[4 + c];
+            const float fn = xh[8 + c] * L.ga[8 + c] + L.be[8 + c];
+            const float on = xh[12 + c] * L.ga[12 + c] + L.be[12 + c];
+            const float cpre = cp[c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+            const float x2 = (cpre - L.mu2[c]) * L.rs2[c];
+            const float th = tanhf_(x2 * L.g2[c] + L.b2[c]), so = sigmoidf_(on);
+            dz[c] = dhv[c] * so * (1.f - th * th) + dcnv[c];
+            don[c] = dhv[c] * th * so * (1.f - so);
+            ra[c] += dz[c]; rb[c] += dz[c] * x2;
+        }
+        st4(w.dz2 + ((long long)n * p.HW + px) * F + c0, make_float4(dz[0], dz[1], dz[2], dz[3]));
+        st4(p.dgates + ((long long)n * p.HW + px) * 4 * F + 3 * F + c0, make_float4(don[0], don[1], don[2], don[3]));
+    }
+    float* d = sh + prow * 2 * F + c0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { d[c] = ra[c]; d[F + c] = rb[c]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * F; i += NT) {
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += sh[r * 2 * F + i];
+        unsafeAtomicAdd(w.r2 + ((long long)n * F + (i % F)) * 2 + (i / F), t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void lstm_bwd2_kernel(LstmP p, LstmBws w, int chunk) {
+    extern __shared__ float sh[];                     // [rows][8*F]
+    const int n = blockIdx.y, F = p.F, F4 = F / 4;
+    const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
+    const int c0 = fq * 4;
+    LstmLane L;
+    lstm_lane_load(p, n, c0, L);
+    const float inv = 1.f / (float)p.HW;
+    float r2a[4], r2b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        r2a[c] = w.r2[((long long)n * F + c0 + c) * 2]; r2b[c] = w.r2[((long long)n * F + c0 + c) * 2 + 1];
+    }
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { unsafeAtomicAdd(p.db2 + c0 + c, r2a[c]); unsafeAtomicAdd(p.dg2 + c0 + c, r2b[c]); }
+    }
+    float r1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r1[i] = 0.f;
+    const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        float xh[16], cp[4];
+        lstm_load_px(p, L, n, px, c0, xh, cp);
+        const float4 dz4 = ld4(w.dz2 + ((long long)n * p.HW + px) * F + c0);
+        const float dz[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+        float* gq = p.dgates + ((long long)n * p.HW + px) * 4 * F + c0;
+        const float4 don4 = ld4(gq + 3 * F);
+        const float don[4] = {don4.x, don4.y, don4.z, don4.w};
+        float dg[16], dcp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = xh[c] * L.ga[c] + L.be[c];
+            const float jn = xh[4 + c] * L.ga[4 + c] + L.be[4 + c];
+            const float fn = xh[8 + c] * L.ga[8 + c] + L.be[8 + c];
+            const float si = sigmoidf_(in_), tj = tanhf_(jn), sf = sigmoidf_(fn + p.forget_bias);
+            const float cpre = cp[c] * sf + si * tj;
+            const float x2 = (cpre - L.mu2[c]) * L.rs2[c];
+            const float dcpre = L.g2[c] * L.rs2[c] * (dz[c] - r2a[c] * inv - x2 * r2b[c] * inv);
+            dcp[c] = dcpre * sf;
+            dg[c] = dcpre * tj * si * (1.f - si);
+            dg[4 + c] = dcpre * si * (1.f - tj * tj);
+            dg[8 + c] = dcpre * cp[c] * sf * (1.f - sf);
+            dg[12 + c] = don[c];
+        }
+        if (p.dc_prev) st4(p.dc_prev + ((long long)n * p.HW + px) * F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+        st4(gq, make_float4(dg[0], dg[1], dg[2], dg[3]));
+        st4(gq + F, make_float4(dg[4], dg[5], dg[6], dg[7]));
+        st4(gq + 2 * F, make_float4(dg[8], dg[9], dg[10], dg[11]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { r1[i] += dg[i]; r1[16 + i] += dg[i] * xh[i]; }
+    }
+    // sh[prow][which][q*F + c]
+    float* d = sh + prow * 8 * F;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { d[q * F + c0 + c] = r1[q * 4 + c]; d[4 * F + q * F + c0 + c] = r1[16 + q * 4 + c]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * F; i += NT) {
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += sh[r * 8 * F + i];
+        const int which = i / (4 * F), ch = i % (4 * F);
+        unsafeAtomicAdd(w.r1 + ((long long)n * 4 * F + ch) * 2 + which, t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int chunk) {
+    const int n = blockIdx.y, F = p.F, F4 = F / 4;
+    const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
+    const int c0 = fq * 4;
+    const float inv = 1.f / (float)p.HW;
+    float mu[16], rs[16], ga[16], s1[16], s2[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long o = (long long)n * 4 * F + q * F + c0 + c;
+            mu[q * 4 + c] = p.mean1[o]; rs[q * 4 + c] = p.rstd1[o]; ga[q * 4 + c] = p.g1[q * F + c0 + c];
+            s1[q * 4 + c] = w.r1[o * 2]; s2[q * 4 + c] = w.r1[o * 2 + 1];
+        }
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsafeAtomicAdd(p.db1 + q * F + c0 + c, s1[q * 4 + c]);
+                unsafeAtomicAdd(p.dg1 + q * F + c0 + c, s2[q * 4 + c]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1[i] *= inv; s2[i] *= inv; }
+    const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
+    for (int px = p0 + prow; px < p1; px += rows) {
+        const float* q = p.gates + ((long long)n * p.HW + px) * 4 * F + c0;
+        float* gq = p.dgates + ((long long)n * p.HW + px) * 4 * F + c0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 raw = ld4(q + g * F), dgv = ld4(gq + g * F);
+            const float rv[4] = {raw.x, raw.y, raw.z, raw.w}, dv[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = g * 4 + c;
+                const float xh = (rv[c] - mu[i]) * rs[i];
+                o[c] = ga[i] * rs[i] * (dv[c] - s1[i] - xh * s2[i]);
+            }
+            st4(gq + g * F, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
 static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
-    if (!a || a->F % 4 || a->HW > MAXPPT * NT || a->HW < 1) return SAVP_EINVAL;
+    if (!a || a->F % 4 || a->HW < 1) return SAVP_EINVAL;
     p.N = a->N; p.HW = a->HW; p.F = a->F;
     p.gates = a->gates;
     p.c_prev = (const float*)a->c_prev.p; p.cp_sn = a->c_prev.sn; p.cp_sp = a->c_prev.sp;
@@ -652,11 +976,45 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     return SAVP_OK;
 }
 
+// workspace floats of the coalesced forward: ws1 [N][4F][2] + ws2 [N][F][2] + k2 [N][F] + sigmoid(o) [N][HW][F]
+static long long lstm_ws_floats(const SavpLstmArgs* a) { return (long long)a->N * a->F * (11 + (long long)a->HW); }
+static bool lstm_coalesced_ok(const SavpLstmArgs* a) {
+    const int F = a->F;
+    return a->ws && a->ws_floats >= lstm_ws_floats(a) && F >= 16 && F <= 256 && (F & (F - 1)) == 0 && a->HW >= 16;
+}
+
 extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (lstm_coalesced_ok(a)) {
+        const int N = a->N, F = a->F, HW = a->HW;
+        LstmWs w;
+        w.s1 = a->ws; w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = w.s2 + (size_t)N * F * 2; w.so = w.k2 + (size_t)N * F;
+        hipMemsetAsync(a->ws, 0, (size_t)N * F * 10 * sizeof(float), st);
+        // pass 1: shifted sums of the gate tensor, the instance-norm statistics kernel with C = 4F
+        InormP q;
+        q.N = N; q.HW = HW; q.C = 4 * F;
+        q.x = a->gates; q.x_sn = (long long)HW * 4 * F; q.x_sp = 4 * F;
+        const int rows1 = NT / F;                                   // C/4 = F float4 per pixel
+        long long c1 = ((long long)HW * N + 511) / 512;
+        if (c1 < rows1) c1 = rows1;
+        if (c1 > 256) c1 = 256;
+        q.chunk = (int)c1;
+        hipLaunchKernelGGL(inorm_stats_kernel, dim3((HW + q.chunk - 1) / q.chunk, N), dim3(NT), (size_t)rows1 * 2 * 4 * F * sizeof(float), st,
+                           q, w.s1);
+        const int rows2 = NT / (F / 4);
+        long long c2 = ((long long)HW * N + 511) / 512;
+        if (c2 < rows2) c2 = rows2;
+        if (c2 > 256) c2 = 256;
+        dim3 grid((HW + (int)c2 - 1) / (int)c2, N);
+        hipLaunchKernelGGL(lstm_cell_kernel, grid, dim3(NT), (size_t)rows2 * 2 * F * sizeof(float), st, p, w, (int)c2);
+        hipLaunchKernelGGL(lstm_out_kernel, grid, dim3(NT), 0, st, p, w, (int)c2);
+        return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    }
+    if (a->HW > MAXPPT * NT) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, st, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }
 
@@ -664,6 +1022,23 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
+    if (lstm_coalesced_ok(a)) {
+        hipStream_t st = (hipStream_t)stream;
+        const int N = a->N, F = a->F, HW = a->HW;
+        LstmBws w;
+        w.r2 = a->ws; w.r1 = w.r2 + (size_t)N * F * 2; w.dz2 = w.r1 + (size_t)N * 4 * F * 2;
+        hipMemsetAsync(a->ws, 0, (size_t)N * F * 10 * sizeof(float), st);
+        const int rows = NT / (F / 4);
+        long long c = ((long long)HW * N + 511) / 512;
+        if (c < rows) c = rows;
+        if (c > 256) c = 256;
+        dim3 grid((HW + (int)c - 1) / (int)c, N);
+        hipLaunchKernelGGL(lstm_bwd1_kernel, grid, dim3(NT), (size_t)rows * 2 * F * sizeof(float), st, p, w, (int)c);
+        hipLaunchKernelGGL(lstm_bwd2_kernel, grid, dim3(NT), (size_t)rows * 8 * F * sizeof(float), st, p, w, (int)c);
+        hipLaunchKernelGGL(lstm_bwd3_kernel, grid, dim3(NT), 0, st, p, w, (int)c);
+        return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    }
+    if (a->HW > MAXPPT * NT) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }

@@ -272,17 +272,28 @@ def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
     return a
 
 
-def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0):
+def lstm_ws_floats(N, HW, F):
+    """Workspace size (floats) that selects the coalesced three-pass ConvLSTM forward (include/savp_hip.h)."""
+    return N * F * (11 + HW)
+
+
+def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None):
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     a.c_new = c_new.data_ptr()
+    if ws is not None:
+        lib.require_device(ws)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     a.nh = len(hs)
     _set_views(a.h, hs)
     lib.check(lib.get().savp_convlstm_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_fwd')
 
 
 def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates, dc_prev, dparams, eps=1e-6,
-                       forget_bias=1.0):
+                       forget_bias=1.0, ws=None):
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
+    if ws is not None:
+        lib.require_device(ws)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     a.ndh = len(dhs)
     _set_views(a.dh, dhs)
     a.dc_new = dc_new.data_ptr() if dc_new is not None else None

@@ -125,6 +125,7 @@ class SavpLstmArgs(ctypes.Structure):
         ('mean1', c_vp), ('rstd1', c_vp), ('mean2', c_vp), ('rstd2', c_vp),
         ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
+        ('ws', c_vp), ('ws_floats', ctypes.c_int64),
     ]
 
 

@@ -313,7 +313,7 @@ class SAVPGenerator(object):
                     n1, n2 = L['n1'], L['n2']
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
-                                         eps=EPS_IN)
+                                         eps=EPS_IN, ws=self._lstm_ws(L))
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
@@ -351,6 +351,15 @@ class SAVPGenerator(object):
         return self.gen.v
 
     # ---------------------------------------------------------------------------------------------------------
+    def _lstm_ws(self, L):
+        """Scratch of the coalesced ConvLSTM gate kernels (one buffer shared by all layers: the launches are serial)."""
+        h, w = L['hw']
+        need = K.lstm_ws_floats(self.N, h * w, L['f'])
+        ws = getattr(self, '_lstm_ws_buf', None)
+        if ws is None or ws.numel() < need:
+            ws = self._lstm_ws_buf = torch.empty(max(need, K.lstm_ws_floats(self.N, self.H * self.W // 4, 32)), device=L["gates"].v.device)
+        return ws
+
     def backward(self):
         """BPTT.  Expects self.gen.g (zero-initialised each step by the caller) to hold dL/dgen_images.
         Accumulates every generator-cell weight gradient into the store and returns dL/dzs [T1, N, nz] (or None)."""
@@ -423,7 +432,7 @@ class SAVPGenerator(object):
                     dc_prev = L['dc'][t & 1] if t > 0 else None
                     K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
-                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN)
+                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L))
                     L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
                                        [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
