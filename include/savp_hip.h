@@ -148,7 +148,8 @@ int savp_axpby(void* stream, int64_t n, float a, const float* x, float b, const 
 int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW, int32_t C, float value);
 /* tf.train.AdamOptimizer on a flat arena (base_model.py:486-487); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
 int savp_adam(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2,
-              float eps, float gscale);
+              float eps, float gscale, const float* lr_t_dev);   /* lr_t_dev != NULL: lr_t is read from device memory
+                                                                    (hipGraph replays of the step with a changing rate) */
 
 /* ------------------------------------------------------------------------------------------------------------
  * CDNA head + mask compositing (cdna_composite.hip): savp_model.py:551-559, 893-923, 634-646.
@@ -195,7 +196,7 @@ int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* 
 int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
                      float* z, float* kl_out);
 int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
-                     const float* dz, float klw, float* dmu, float* dls_raw);
+                     const float* dz, float klw, float* dmu, float* dls_raw, const float* klw_dev);   /* klw_dev: as lr_t_dev */
 int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride, int32_t p2,
                  const float* pred, const float* target, float weight, float* loss_out, float* dpred);
 /* type 0 LSGAN, 1 GAN (sigmoid cross-entropy), 2 SNGAN (softplus hinge-free form), losses.py:29-54 */

@@ -159,7 +159,8 @@ __global__ void reparam_fwd_kernel(long long n, int rows, const float* mu, const
 }
 
 __global__ void reparam_bwd_kernel(long long n, int rows, const float* mu, const float* ls_raw, const float* eps, const float* dz,
-                                   float klw, float* dmu, float* dls_raw) {
+                                   float klw_host, float* dmu, float* dls_raw, const float* klw_dev) {
+    const float klw = klw_dev ? *klw_dev : klw_host;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float lr = ls_raw[i];
         float l = fminf(fmaxf(lr, -10.f), 10.f);
@@ -181,12 +182,12 @@ extern "C" int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const flo
 }
 
 extern "C" int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
-                                const float* dz, float klw, float* dmu, float* dls_raw) {
+                                const float* dz, float klw, float* dmu, float* dls_raw, const float* klw_dev) {
     if (!mu || !ls_raw || !eps || !dmu || !dls_raw) return SAVP_EINVAL;
     unsigned nb = (unsigned)((n + NT - 1) / NT);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, rows, mu, ls_raw, eps, dz,
-                       klw, dmu, dls_raw);
+                       klw, dmu, dls_raw, klw_dev);
     return LAUNCH_OK();
 }
 

@@ -231,7 +231,8 @@ extern "C" int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW,
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p -= lr_t * m / (sqrt(v) + eps)       (epsilon outside the sqrt)
 // gscale multiplies the gradient first (1/world_size after a sum all-reduce).
 __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float lr_t, float b1, float b2, float eps, float gscale) {
+                            float* __restrict__ v, float lr_host, float b1, float b2, float eps, float gscale, const float* lr_dev) {
+    const float lr_t = lr_dev ? *lr_dev : lr_host;
     long long n4 = n / 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
@@ -259,13 +260,13 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __r
 }
 
 extern "C" int savp_adam(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1,
-                         float beta2, float eps, float gscale) {
+                         float beta2, float eps, float gscale, const float* lr_t_dev) {
     if (!p || !g || !m || !v || n < 1) return SAVP_EINVAL;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return SAVP_EINVAL;
     unsigned nb = nblocks(n / 4 + 1);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, lr_t, beta1, beta2,
-                       eps, gscale);
+                       eps, gscale, lr_t_dev);
     return LAUNCH_OK();
 }
 

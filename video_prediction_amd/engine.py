@@ -83,11 +83,16 @@ class ParamGroup(object):
     def zero_grad(self):
         self.g.zero_()
 
-    def adam_step(self, lr, beta1, beta2, gscale=1.0, eps=1e-8):
-        """tf.train.AdamOptimizer (base_model.py:486-487): lr_t = lr*sqrt(1-b2^t)/(1-b1^t)."""
+    def next_lr_t(self, lr, beta1, beta2):
+        """Advance the step count; returns tf.train.AdamOptimizer's lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (base_model.py:486-487)."""
         self.t += 1
-        lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
-        K.adam(self.p, self.g, self.m, self.v, lr_t, beta1, beta2, eps=eps, gscale=gscale)
+        return lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
+
+    def adam_apply(self, lr_t, beta1, beta2, gscale=1.0, eps=1e-8, lr_t_dev=None):
+        K.adam(self.p, self.g, self.m, self.v, lr_t, beta1, beta2, eps=eps, gscale=gscale, lr_t_dev=lr_t_dev)
+
+    def adam_step(self, lr, beta1, beta2, gscale=1.0, eps=1e-8):
+        self.adam_apply(self.next_lr_t(lr, beta1, beta2), beta1, beta2, gscale=gscale, eps=eps)
 
 
 class ParamStore(object):

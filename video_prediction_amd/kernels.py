@@ -379,9 +379,10 @@ def fill_view(out, value=0.0):
     lib.check(_L().savp_fill_view(lib.stream(), view(out), out.shape[0], _hw(out), out.shape[-1], float(value)), 'savp_fill_view')
 
 
-def adam(p, g, m, v, lr_t, beta1, beta2, eps=1e-8, gscale=1.0):
+def adam(p, g, m, v, lr_t, beta1, beta2, eps=1e-8, gscale=1.0, lr_t_dev=None):
+    """lr_t_dev: optional 1-element device tensor that overrides lr_t (graph replays with a changing rate)."""
     lib.check(_L().savp_adam(lib.stream(), p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr_t), float(beta1), float(beta2),
-                             float(eps), float(gscale)), 'savp_adam')
+                             float(eps), float(gscale), _p(lr_t_dev) if lr_t_dev is not None else None), 'savp_adam')
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -474,10 +475,10 @@ def reparam_fwd(mu, ls_raw, eps, ls, z, kl_out=None):
               'savp_reparam_fwd')
 
 
-def reparam_bwd(mu, ls_raw, eps, dz, klw, dmu, dls_raw):
+def reparam_bwd(mu, ls_raw, eps, dz, klw, dmu, dls_raw, klw_dev=None):
     rows = mu.numel() // mu.shape[-1]
     lib.check(_L().savp_reparam_bwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(dz), float(klw), _p(dmu),
-                                    _p(dls_raw)), 'savp_reparam_bwd')
+                                    _p(dls_raw), _p(klw_dev) if klw_dev is not None else None), 'savp_reparam_bwd')
 
 
 def lp_loss(pred, target, weight, loss_out=None, dpred=None, p2=False):

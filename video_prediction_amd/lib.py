@@ -160,7 +160,7 @@ register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i6
 register('savp_sigmoid_bwd', [c_vp, SavpView, SavpView, c_vp, c_i64, c_i32, c_i32])
 register('savp_axpby', [c_vp, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp])
 register('savp_fill_view', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32])
-register('savp_adam', [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32])
+register('savp_adam', [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp])
 register('savp_cdna_kernels_fwd', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_cdna_kernels_bwd', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_cdna_apply_fwd', [c_vp, ctypes.POINTER(SavpCdnaArgs)])
@@ -170,7 +170,7 @@ register('savp_composite_bwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
 register('savp_lstm_z_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
-register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp])
+register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp])
 register('savp_lp_loss', [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])
 register('savp_lsgan_loss', [c_vp, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])

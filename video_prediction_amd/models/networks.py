@@ -92,10 +92,11 @@ class PosteriorEncoder(object):
         K.reparam_fwd(self.mu, self.ls_raw, eps, self.ls, self.z, self.kl)                  # savp_model.py:45-49,712
         return self.z
 
-    def backward(self, dz, kl_weight):
-        """dz [T1,B,nz] = dL/dz_posterior (may be None); adds the KL term's gradient with weight kl_weight."""
+    def backward(self, dz, kl_weight, kl_weight_dev=None):
+        """dz [T1,B,nz] = dL/dz_posterior (may be None); adds the KL term's gradient with weight kl_weight (read from the
+        1-element device tensor kl_weight_dev if given)."""
         M = self.M
-        K.reparam_bwd(self.mu, self.ls_raw, self.eps, dz, kl_weight or 0.0, self.dmu, self.dls)
+        K.reparam_bwd(self.mu, self.ls_raw, self.eps, dz, kl_weight or 0.0, self.dmu, self.dls, klw_dev=kl_weight_dev)
         dmu2, dls2 = self.dmu.reshape(M, -1), self.dls.reshape(M, -1)
         self.mu_fc.backward_data(dmu2, self.dpooled, beta=0)
         self.ls_fc.backward_data(dls2, self.dpooled, beta=1)

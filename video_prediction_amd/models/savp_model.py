@@ -11,6 +11,8 @@ given), and one ``train_step`` call is one ``sess.run(train_op)``.
 import collections
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 
@@ -25,6 +27,9 @@ from .savp_cell import SAVPGenerator
 
 def _image_shape(images):
     return tuple(images.shape[2:])
+
+
+IDX_KEYS = ('enc_real', 'enc_fake', 'real', 'fake')
 
 
 class SAVPEngine(object):
@@ -83,6 +88,18 @@ class SAVPEngine(object):
         self.step = 0
         self.world = 1
         self.dist = None
+        # per-step inputs drawn on the host are staged into these persistent device buffers BEFORE the kernels of the step
+        # are launched, so that the launch sequence itself has no host input and can be captured into a hipGraph
+        dev = self.device
+        self.d_gt = torch.zeros(self.T1, N, dtype=torch.int32, device=dev)
+        self.d_eps = torch.zeros(self.T1, B, self.nz, device=dev) if self.nz else None
+        self.d_prior = torch.zeros(self.T - hp.context_frames, B, self.nz, device=dev) if self.nz else None
+        self.d_idx = torch.zeros(2, len(IDX_KEYS), 2, B, dtype=torch.int32, device=dev)    # [pre/post][key][t_sample/t_start][B]
+        self.d_scal = torch.zeros(4, device=dev)                                           # lr_t(D), lr_t(G), kl weight
+        self.graph = None
+        self.graph_info = None
+        self.use_graph = self.train and os.environ.get('SAVP_GRAPH', '1') == '1'
+        self.eager_steps = 0
 
     # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
     def attach_process_group(self, dist_module):
@@ -149,7 +166,7 @@ class SAVPEngine(object):
         return 0.0
 
     def _gt_mask(self, noise):
-        """self.ground_truth of savp_model.py:333-334 for the 2B-batched unroll -> int32 [T1, N] on device."""
+        """self.ground_truth of savp_model.py:333-334 for the 2B-batched unroll -> int32 [T1, N] (host)."""
         hp, B, T1 = self.hp, self.B, self.T1
         ns = T1 - hp.context_frames
         halves = []
@@ -160,7 +177,22 @@ class SAVPEngine(object):
                 s = torch.zeros(ns, B, dtype=torch.bool)
             m = torch.cat([torch.ones(hp.context_frames, B, dtype=torch.bool), torch.as_tensor(s, dtype=torch.bool)], dim=0)
             halves.append(m)
-        return torch.cat(halves, dim=1).to(torch.int32).to(self.device)
+        return torch.cat(halves, dim=1).to(torch.int32)
+
+    def _stage_noise(self, noise):
+        """Host -> device copies of the step's random inputs (the only host inputs of the launch sequence)."""
+        self.d_gt.copy_(self._gt_mask(noise))
+        if self.nz:
+            self.d_eps.copy_(torch.as_tensor(noise['eps'], dtype=torch.float32))
+            self.d_prior.copy_(torch.as_tensor(noise['prior'], dtype=torch.float32))
+        if self.train and 'd_indices_pre' in noise:
+            idx = np.zeros((2, len(IDX_KEYS), 2, self.B), dtype=np.int32)
+            for pi, ph in enumerate(('d_indices_pre', 'd_indices_post')):
+                for ki, k in enumerate(IDX_KEYS):
+                    if k in noise[ph]:
+                        for which in (0, 1):
+                            idx[pi, ki, which] = np.asarray(noise[ph][k][which])
+            self.d_idx.copy_(torch.from_numpy(idx))
 
     # -- forward ---------------------------------------------------------------------------------------------------------
     def prep_generator_weights(self):
@@ -171,9 +203,11 @@ class SAVPEngine(object):
     def forward_generator(self, noise, collect_masks=False):
         """generator_fn (savp_model.py:699-768).  Returns gen [T1, N, H, W, C]: [:, :B] posterior ('_enc'), [:, B:] prior."""
         hp, B, T1 = self.hp, self.B, self.T1
-        gt = self._gt_mask(noise)
+        if noise is not None:
+            self._stage_noise(noise)
+        gt = self.d_gt
         if self.nz:
-            eps = noise['eps'].to(self.device, torch.float32)
+            eps = self.d_eps
             z_post = self.enc.forward(self.images_tm, eps)
             nzv = self.nz
             # zs (2B): posterior half, prior half = [posterior z for the first context_frames-1 steps ; N(0,1)]  (:724-725)
@@ -181,39 +215,78 @@ class SAVPEngine(object):
             c1 = hp.context_frames - 1
             if c1 > 0:
                 copy_view(z_post[:c1], [self.zs_all[:c1, B:]])
-            prior = noise['prior'].to(self.device, torch.float32)
-            copy_view(prior, [self.zs_all[c1:, B:]])
+            copy_view(self.d_prior, [self.zs_all[c1:, B:]])
             return self.gen.forward(self.images_n, self.zs_all, gt, collect_masks=collect_masks)
         return self.gen.forward(self.images_n, None, gt, collect_masks=collect_masks)
 
     # -- one sess.run(train_op) --------------------------------------------------------------------------------------------
-    def _d_clips(self, D, idx_real, idx_fake, fake_half, lo_real, lo_fake):
+    def _d_clips(self, D, phase, key_real, key_fake, fake_half, lo_real, lo_fake):
         """discriminator_given_video_fn's frame / clip gather (savp_model.py:93-102) into D.clip[lo_real:...] and
-        D.clip[lo_fake:...].  idx = (t_sample[B], t_start[B]); the image discriminator uses t_sample, the others t_start."""
+        D.clip[lo_fake:...].  Staged indices d_idx[phase][key] = (t_sample[B], t_start[B]); the image discriminator uses
+        t_sample, the others t_start.  key_real None: only the fake clips."""
         B = self.B
-        dev = self.device
         which = 0 if D.kind == 'image' else 1
         real_src = self.images_tm[1:self.T]                                       # inputs['images'][1:]
-        if idx_real is not None:
-            ts = torch.as_tensor(np.asarray(idx_real[which]), dtype=torch.int32).to(dev)
-            K.gather_clips(real_src, D.clip[lo_real:lo_real + B], ts)
-        ts_f = torch.as_tensor(np.asarray(idx_fake[which]), dtype=torch.int32).to(dev)
+        if key_real is not None:
+            K.gather_clips(real_src, D.clip[lo_real:lo_real + B], self.d_idx[phase, IDX_KEYS.index(key_real), which])
+        ts_f = self.d_idx[phase, IDX_KEYS.index(key_fake), which]
         K.gather_clips(fake_half, D.clip[lo_fake:lo_fake + B], ts_f)
         return ts_f
 
     def train_step(self, noise=None, return_grads=False):
         """D Adam update, then G(+E) Adam update against the updated D (base_model.py:486-510).  Returns a dict of
-        device scalars (losses) -- nothing is synchronised unless the caller reads them."""
-        hp, B, T1 = self.hp, self.B, self.T1
+        device scalars (losses) -- nothing is synchronised unless the caller reads them.
+
+        The step = (a) host part: draw / stage the random inputs and the step-dependent scalars into device buffers,
+        (b) the launch sequence _step_body(), which has no host input.  On one GPU (b) is captured into a hipGraph after
+        the first eager steps and replayed afterwards (SAVP_GRAPH=0 keeps it eager): ~3.5k launches per step otherwise
+        cost more host time than the GPU needs for the small per-timestep kernels."""
+        hp = self.hp
         if noise is None:
             noise = self.default_noise()
         lr = learning_rate(hp, self.step)
         klw = kl_weight(hp, self.step)
         store = self.store
+        self._stage_noise(noise)
+        lr_d = store.groups['d'].next_lr_t(lr, hp.beta1, hp.beta2) if self.discs else 0.0
+        lr_g = store.groups['g'].next_lr_t(lr, hp.beta1, hp.beta2)
+        self.d_scal.copy_(torch.tensor([lr_d, lr_g, klw or 0.0, 0.0], dtype=torch.float32))
+        graph_ok = self.use_graph and self.world == 1 and not return_grads
+        if graph_ok and self.graph is not None:
+            self.graph.replay()
+            info = self.graph_info
+        elif graph_ok and self.eager_steps >= 1:
+            # capture: every conv problem has been tuned and every kernel launched once by the eager step(s)
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    info = self._step_body(klw, False)
+                self.graph, self.graph_info = g, info
+            except Exception as ex:        # capture refused (e.g. an untuned conv problem wanted to time itself): stay eager
+                import warnings
+                warnings.warn('hipGraph capture of the train step failed (%r); continuing eagerly' % (ex,))
+                self.use_graph, self.graph = False, None
+                torch.cuda.synchronize()
+                info = self._step_body(klw, False)
+            else:
+                g.replay()
+        else:
+            info = self._step_body(klw, return_grads)
+            self.eager_steps += 1
+        for D in {id(d['D']): d['D'] for d in self.discs}.values():
+            D.commit_u_host() if hasattr(D, 'commit_u_host') else None
+        info = OrderedDict(info)
+        return info
+
+    def _step_body(self, klw, return_grads):
+        """The launch sequence of one train step (no host inputs: see train_step)."""
+        hp, B, T1 = self.hp, self.B, self.T1
+        store = self.store
         lb = self.loss_buf
         lb.zero_()
         self.prep_generator_weights()
-        gen = self.forward_generator(noise)
+        gen = self.forward_generator(None)
         gen_enc, gen_prior = (gen[:, :B], gen[:, B:]) if self.nz else (None, gen)
         info = OrderedDict()
         discs = self.discs
@@ -222,7 +295,6 @@ class SAVPEngine(object):
         # ---------------- discriminator step ---------------------------------------------------------------------------------
         if discs:
             store.groups['d'].zero_grad()
-            ipre = noise['d_indices_pre']
             prepped = set()
             for d in discs:
                 D, w, slot = d['D'], d['w'], d['slot']
@@ -231,7 +303,7 @@ class SAVPEngine(object):
                     prepped.add(id(D))
                 if not w:
                     continue
-                self._d_clips(D, ipre[d['kr']], ipre[d['kf']], d['fake'], 0, B)
+                self._d_clips(D, 0, d['kr'], d['kf'], d['fake'], 0, B)
                 D.forward()
                 r0, r1 = D.rows(0, B)
                 f0, f1 = D.rows(B, 2 * B)
@@ -243,12 +315,11 @@ class SAVPEngine(object):
             if return_grads:
                 info['d_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'd'}
             self._allreduce('d')
-            store.groups['d'].adam_step(lr, hp.beta1, hp.beta2, gscale=1.0 / self.world)
+            store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
         # ---------------- generator (+ encoder) step --------------------------------------------------------------------------
         store.groups['g'].zero_grad()
         self.gen.gen.g.zero_()
         if discs:
-            ipost = noise['d_indices_post']
             prepped = set()
             for d in discs:
                 D, w, slot, is_vae = d['D'], d['w'], d['slot'], d['enc']
@@ -260,7 +331,7 @@ class SAVPEngine(object):
                 wf_cd = hp.vae_gan_feature_cdist_weight if is_vae else hp.gan_feature_cdist_weight
                 wf_l2 = hp.vae_gan_feature_l2_weight if is_vae else hp.gan_feature_l2_weight
                 if wf_cd or wf_l2:
-                    ts_f = self._d_clips(D, ipost[d['kr']], ipost[d['kf']], d['fake'], 0, B)
+                    ts_f = self._d_clips(D, 1, d['kr'], d['kf'], d['fake'], 0, B)
                     D.forward()
                     lo, hi = B, 2 * B
                     r0, r1 = D.rows(0, B)
@@ -273,7 +344,7 @@ class SAVPEngine(object):
                         if wf_l2:       # losses.l2_loss between fake and real features (base_model.py:790-793,817-820)
                             K.lp_loss(L['y'][f0:f1], L['y'][r0:r1], wf_l2, lb[slot + 4:slot + 5], L['dy'][f0:f1], p2=True)
                 else:
-                    ts_f = self._d_clips(D, None, ipost[d['kf']], d['fake'], 0, 0)
+                    ts_f = self._d_clips(D, 1, None, d['kf'], d['fake'], 0, 0)
                     D.forward(n=B)
                     lo, hi = 0, B
                     f0, f1 = D.rows(lo, hi)
@@ -294,14 +365,13 @@ class SAVPEngine(object):
             copy_view(dzs[:, :B], [self.dz_post])
             if c1 > 0:
                 add_views([dzs[:c1, B:]], self.dz_post[:c1])
-            self.enc.backward(self.dz_post, klw)
+            self.enc.backward(self.dz_post, klw, kl_weight_dev=self.d_scal[2:3])
         if return_grads:
             info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
         self._allreduce('g')
-        store.groups['g'].adam_step(lr, hp.beta1, hp.beta2, gscale=1.0 / self.world)
+        store.groups['g'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[1:2])
         for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
-        self.step += 1
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
         d_losses, g_losses = OrderedDict(), OrderedDict()
         for d in discs:
@@ -324,8 +394,8 @@ class SAVPEngine(object):
             g_losses['gen_kl_loss'] = (self.enc.kl[0], klw)
         info['d_losses'], info['g_losses'] = d_losses, g_losses
         info['d_loss'] = sum(l * w for l, w in d_losses.values()) if d_losses else torch.zeros((), device=self.device)
-        info['g_loss'] = sum(l * w for l, w in g_losses.values())
-        info['learning_rate'] = lr
+        # the annealed KL weight is a device scalar here (the graph is replayed with the weight of the current step)
+        info['g_loss'] = sum(l * (self.d_scal[2] if k == 'gen_kl_loss' else w) for k, (l, w) in g_losses.items())
         return info
 
     # -- inference (scripts/generate.py:166: model.outputs['gen_images']) ------------------------------------------------------
@@ -406,14 +476,14 @@ def discriminator_fn(inputs, outputs, mode, hparams, engine=None, noise=None):
         return OrderedDict()
     if noise is None:
         noise = eng.default_noise()
-    idx = noise['d_indices_pre']
+    eng._stage_noise(noise)
     B = eng.B
     out = OrderedDict()
     for d in eng.discs:
         D, sfx = d['D'], ('_enc' if d['enc'] else '')
         fake = outputs['gen_images_enc'] if d['enc'] else outputs['gen_images']
         D.prep_weights(update_u=False)
-        eng._d_clips(D, idx[d['kr']], idx[d['kf']], fake, 0, B)
+        eng._d_clips(D, 0, d['kr'], d['kf'], fake, 0, B)
         D.forward()
         for part, lo in (('real', 0), ('fake', B)):
             r0, r1 = D.rows(lo, lo + B)
