@@ -90,7 +90,9 @@ typedef struct SavpInormArgs {
     int32_t ndy; SavpView dy[4];
     SavpView dx; int32_t dx_beta;
     float* dgamma; float* dbeta;
-    float* ws;                     /* optional scratch [N*C*2]; when given and HW >= 2048 the coalesced two-kernel path is used */
+    float* ws;                     /* optional scratch [N*C*2]: selects the coalesced two-kernel path for planes of >= 256 pixels */
+    int32_t ws_clean;              /* 1: the caller guarantees ws is all zero (e.g. a slice of an arena cleared once per step),
+                                      0: the library clears it with a memset per call */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);
@@ -117,8 +119,11 @@ typedef struct SavpLstmArgs {
     float* dgates;
     float* dc_prev;
     float *dgamma1, *dbeta1, *dgamma2, *dbeta2;
-    float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(11 + HW) floats: selects the coalesced three-pass forward
-                                      (F a power of two in [16, 256]); NULL = single fused kernel (HW <= 1024) */
+    float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(11 + HW) floats (N*F*HW if ws_stats is given): selects the
+                                      coalesced three-pass kernels (F a power of two in [16, 256]); NULL = single fused
+                                      kernel (HW <= 1024) */
+    float* ws_stats;               /* optional separate reduction workspace, N*F*11 floats */
+    int32_t ws_stats_clean;        /* 1: the caller guarantees ws_stats is all zero (see SavpInormArgs.ws_clean) */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);

@@ -332,7 +332,7 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     p.mean = a->mean; p.rstd = a->rstd;
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
@@ -358,7 +358,7 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
     p.dgamma = a->dgamma; p.dbeta = a->dbeta;
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
@@ -977,7 +977,7 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
 }
 
 // workspace floats of the coalesced forward: ws1 [N][4F][2] + ws2 [N][F][2] + k2 [N][F] + sigmoid(o) [N][HW][F]
-static long long lstm_ws_floats(const SavpLstmArgs* a) { return (long long)a->N * a->F * (11 + (long long)a->HW); }
+static long long lstm_ws_floats(const SavpLstmArgs* a) { return (long long)a->N * a->F * ((a->ws_stats ? 0 : 11) + (long long)a->HW); }
 static bool lstm_coalesced_ok(const SavpLstmArgs* a) {
     const int F = a->F;
     return a->ws && a->ws_floats >= lstm_ws_floats(a) && F >= 16 && F <= 256 && (F & (F - 1)) == 0 && a->HW >= 16;
@@ -991,8 +991,10 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     if (lstm_coalesced_ok(a)) {
         const int N = a->N, F = a->F, HW = a->HW;
         LstmWs w;
-        w.s1 = a->ws; w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = w.s2 + (size_t)N * F * 2; w.so = w.k2 + (size_t)N * F;
-        hipMemsetAsync(a->ws, 0, (size_t)N * F * 10 * sizeof(float), st);
+        w.s1 = a->ws_stats ? a->ws_stats : a->ws;
+        w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = w.s2 + (size_t)N * F * 2;
+        w.so = a->ws_stats ? a->ws : w.k2 + (size_t)N * F;
+        if (!(a->ws_stats && a->ws_stats_clean)) hipMemsetAsync(w.s1, 0, (size_t)N * F * 10 * sizeof(float), st);
         // pass 1: shifted sums of the gate tensor, the instance-norm statistics kernel with C = 4F
         InormP q;
         q.N = N; q.HW = HW; q.C = 4 * F;
@@ -1026,8 +1028,10 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
         hipStream_t st = (hipStream_t)stream;
         const int N = a->N, F = a->F, HW = a->HW;
         LstmBws w;
-        w.r2 = a->ws; w.r1 = w.r2 + (size_t)N * F * 2; w.dz2 = w.r1 + (size_t)N * 4 * F * 2;
-        hipMemsetAsync(a->ws, 0, (size_t)N * F * 10 * sizeof(float), st);
+        w.r2 = a->ws_stats ? a->ws_stats : a->ws;
+        w.r1 = w.r2 + (size_t)N * F * 2;
+        w.dz2 = a->ws_stats ? a->ws : w.r1 + (size_t)N * 4 * F * 2;
+        if (!(a->ws_stats && a->ws_stats_clean)) hipMemsetAsync(w.r2, 0, (size_t)N * F * 10 * sizeof(float), st);
         const int rows = NT / (F / 4);
         long long c = ((long long)HW * N + 511) / 512;
         if (c < rows) c = rows;

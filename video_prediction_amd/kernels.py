@@ -212,21 +212,48 @@ def _set_views(arr, tensors):
         arr[i] = view(t)
 
 
-_INORM_WS = {}
+class ZeroArena(object):
+    """Pre-zeroed scratch for the atomically accumulated per-(sample, channel) reductions of the coalesced norm / ConvLSTM
+    kernels: every call takes a fresh all-zero slice, the whole arena is cleared by ONE memset when it is reset (the train
+    step resets it once at its start) instead of one memset per call (~700 per SAVP step, each a launch of its own)."""
+
+    def __init__(self, device, floats=16 << 20):
+        self.buf = torch.zeros(floats, device=device)
+        self.off = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, n):
+        n = (int(n) + 63) & ~63
+        if self.off + n > self.buf.numel():
+            if n > self.buf.numel():
+                raise ValueError('zero arena too small for %d floats' % n)
+            self.reset()
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+_ARENAS = {}
+
+
+def zero_arena(device):
+    key = str(device)
+    a = _ARENAS.get(key)
+    if a is None:
+        a = _ARENAS[key] = ZeroArena(device)
+    return a
 
 
 def _inorm_ws(x):
-    n = x.shape[0] * x.shape[-1] * 2
-    key = (str(x.device), n)
-    t = _INORM_WS.get(key)
-    if t is None:
-        t = _INORM_WS[key] = torch.zeros(n, device=x.device)
-    return t
+    return zero_arena(x.device).take(x.shape[0] * x.shape[-1] * 2)
 
 
 def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6):
     a = lib.SavpInormArgs()
-    a.ws = _inorm_ws(x).data_ptr()
+    a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)
@@ -240,7 +267,7 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
 def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, dx_beta=0, act='relu', alpha=0.0,
                      eps=1e-6):
     a = lib.SavpInormArgs()
-    a.ws = _inorm_ws(x).data_ptr()
+    a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)
@@ -273,16 +300,22 @@ def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
 
 
 def lstm_ws_floats(N, HW, F):
-    """Workspace size (floats) that selects the coalesced three-pass ConvLSTM forward (include/savp_hip.h)."""
-    return N * F * (11 + HW)
+    """Scratch size (floats) that selects the coalesced three-pass ConvLSTM kernels (include/savp_hip.h); the small
+    reduction workspace comes from the zero arena."""
+    return N * F * HW
+
+
+def _lstm_ws(a, gates, ws):
+    lib.require_device(ws)
+    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    a.ws_stats, a.ws_stats_clean = zero_arena(gates.device).take(a.N * a.F * 11).data_ptr(), 1
 
 
 def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None):
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     a.c_new = c_new.data_ptr()
     if ws is not None:
-        lib.require_device(ws)
-        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+        _lstm_ws(a, gates, ws)
     a.nh = len(hs)
     _set_views(a.h, hs)
     lib.check(lib.get().savp_convlstm_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_fwd')
@@ -292,8 +325,7 @@ def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates
                        forget_bias=1.0, ws=None):
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     if ws is not None:
-        lib.require_device(ws)
-        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+        _lstm_ws(a, gates, ws)
     a.ndh = len(dhs)
     _set_views(a.dh, dhs)
     a.dc_new = dc_new.data_ptr() if dc_new is not None else None

@@ -112,7 +112,7 @@ class SavpInormArgs(ctypes.Structure):
         ('x', SavpView), ('gamma', c_vp), ('beta', c_vp),
         ('nout', c_i32), ('out', SavpView * 4), ('mean', c_vp), ('rstd', c_vp),
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
-        ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp),
+        ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
     ]
 
 
@@ -125,7 +125,7 @@ class SavpLstmArgs(ctypes.Structure):
         ('mean1', c_vp), ('rstd1', c_vp), ('mean2', c_vp), ('rstd2', c_vp),
         ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
-        ('ws', c_vp), ('ws_floats', ctypes.c_int64),
+        ('ws', c_vp), ('ws_floats', ctypes.c_int64), ('ws_stats', c_vp), ('ws_stats_clean', c_i32),
     ]
 
 

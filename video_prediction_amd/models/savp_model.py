@@ -285,6 +285,7 @@ class SAVPEngine(object):
         store = self.store
         lb = self.loss_buf
         lb.zero_()
+        K.zero_arena(self.device).reset()          # one memset for every reduction workspace of the step
         self.prep_generator_weights()
         gen = self.forward_generator(None)
         gen_enc, gen_prior = (gen[:, :B], gen[:, B:]) if self.nz else (None, gen)
