@@ -108,3 +108,28 @@ def test_variable_inventory_matches_survey_counts():
     assert abs(sum(int(np.prod(s)) for _, s in d) / 1e6 - 10.29) < 0.01
     assert specs['generator/rnn/savp_cell/lstm_h2/basic_conv2dlstm_cell/kernel'][0] == (5, 5, 264, 512)
     assert specs['discriminator/encoder/video/sn_fc4/dense/kernel'][0] == (65536, 1)
+
+
+def test_tuning_table_round_trip(tmp_path):
+    """The shipped conv tuning tables parse, and save/load reproduces the cache (keys are reprs of the problem tuples)."""
+    import glob
+    import os
+    from video_prediction_amd import kernels as K
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved = dict(K.AUTOTUNE['cache'])
+    try:
+        for path in glob.glob(os.path.join(root, 'video_prediction_amd', 'tuning_gfx950_*.json')):
+            K.AUTOTUNE['cache'].clear()
+            n = K.load_tuning(path)
+            assert n == len(K.AUTOTUNE['cache']) and n > 20
+            for key, (tile, sk) in K.AUTOTUNE['cache'].items():
+                assert isinstance(key, tuple) and key[0] in (0, 1, 2) and 0 <= tile < 0x1000 and 0 <= sk <= 64
+            out = str(tmp_path / 'table.json')
+            K.save_tuning(out)
+            before = dict(K.AUTOTUNE['cache'])
+            K.AUTOTUNE['cache'].clear()
+            K.load_tuning(out)
+            assert K.AUTOTUNE['cache'] == before
+    finally:
+        K.AUTOTUNE['cache'].clear()
+        K.AUTOTUNE['cache'].update(saved)

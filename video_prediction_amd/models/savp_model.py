@@ -274,9 +274,9 @@ class SAVPEngine(object):
         else:
             info = self._step_body(klw, return_grads)
             self.eager_steps += 1
-        for D in {id(d['D']): d['D'] for d in self.discs}.values():
-            D.commit_u_host() if hasattr(D, 'commit_u_host') else None
+        self.step += 1
         info = OrderedDict(info)
+        info['learning_rate'] = lr
         return info
 
     def _step_body(self, klw, return_grads):
