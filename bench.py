@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16',
                     help='conv multiply precision: bf16 operands / fp32 accumulate (BASELINE configs[1]) or exact fp32')
     ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (no per-kernel HIP-event '
+                    'instrumentation inside the timed region -> the roofline object carries no live numbers)')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
     args = ap.parse_args()
@@ -146,6 +148,9 @@ def main():
     engine = SAVPEngine(hp, (H, W, C), args.batch, mode='train', seed=4, device=str(device))
     if dist is not None:
         engine.attach_process_group(dist)
+    # The roofline numbers come from HIP events around the ConvLSTM gate-conv launches of the timed steps; events cannot be timed
+    # inside a graph replay, so the default run keeps the step eager (measured cost of eager launches: ~0.5 ms of an 84 ms step)
+    engine.use_graph = bool(args.graph) and world == 1
     engine.set_images(synthetic_batch(args.batch, 1234 + rank, device))      # inputs resident in HBM before timing
 
     def sync():
@@ -156,7 +161,7 @@ def main():
 
     for _ in range(args.warmup):
         engine.train_step()
-    inst = convlstm_flops(engine)
+    inst = convlstm_flops(engine) if not engine.use_graph else []
     for layer, _ in inst:
         layer.prof = []
     sync()
@@ -177,7 +182,7 @@ def main():
             tot_flops += fl
             launches += 1
         layer.prof = None
-    achieved = tot_flops / tot_s / 1e12 if tot_s > 0 else 0.0
+    achieved = tot_flops / tot_s / 1e12 if tot_s > 0 else None
     # HBM traffic of the same kernel/shapes from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md); bench.py cannot collect counters itself.
     traffic = None
@@ -198,7 +203,7 @@ def main():
                    'global_batch': world * args.batch, 'seq_len': SEQ, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_TFLOPS[args.precision], 'traffic': traffic,
+                     'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic,
                      'traffic_unit': 'bytes per launch, mean of the 5 layers (PMC, profiles/r01_convlstm_fprop_pmc_*.json); algorithmic 19.1 MB',
                      'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_patch_kernel (LDS patch, bf16 MFMA)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None},
