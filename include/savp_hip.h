@@ -54,7 +54,8 @@ typedef struct SavpConvArgs {
     float alpha;
     int32_t splitk;                /* WGRAD: number of K splits (>=1); 0 = pick automatically */
     int32_t tile;                  /* 0 = auto; low byte (WM<<4)|WN with tile = 64*WM x 64*WN; bits 8-9 pick the FPROP/DGRAD
-                                      algorithm: 0 auto, 1 generic gather kernel, 2 LDS patch kernel (EINVAL if not applicable) */
+                                      algorithm: 0 auto, 1 generic gather kernel, 2 LDS patch kernel (EINVAL if not applicable); bit 10: patch
+                                      kernel with 8 waves; bits 12-13: its LDS budget (0 = 160 KB, 1 = 64 KB, 2 = 96 KB) */
     int32_t precision;             /* SAVP_PREC_F32: exact fp32 MFMA; SAVP_PREC_BF16: operands rounded to bf16 in LDS */
     void* x; int64_t x_sn, x_sd, x_sh, x_sw;
     void* y; int64_t y_sn, y_sd, y_sh, y_sw;

@@ -123,7 +123,7 @@ def test_tuning_table_round_trip(tmp_path):
             n = K.load_tuning(path)
             assert n == len(K.AUTOTUNE['cache']) and n > 20
             for key, (tile, sk) in K.AUTOTUNE['cache'].items():
-                assert isinstance(key, tuple) and key[0] in (0, 1, 2) and 0 <= tile < 0x1000 and 0 <= sk <= 64
+                assert isinstance(key, tuple) and key[0] in (0, 1, 2) and 0 <= tile < 0x4000 and 0 <= sk <= 64
             out = str(tmp_path / 'table.json')
             K.save_tuning(out)
             before = dict(K.AUTOTUNE['cache'])

@@ -31,9 +31,9 @@ struct ConvP {
     int tm, tn;          // tile counts (1-D XCD-aware launch grids)
     unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
     // patch kernel (conv_patch.hip): LDS geometry chosen by the launcher
-    int s1_cp, s1_pitch, s1_nch;              // patch pixel stride / row pitch (bf16 elements), weight slabs per tap
-    int s1_ph, s1_pw, s1_th, s1_tw;           // patch rows / columns, tiles per image (rows, columns)
-    unsigned long long s1_magC4, s1_magPW;    // fastdiv by (padded channels / 4) and by the patch width
+    int s1_pitch, s1_nch, s1_spp;             // patch row pitch (bf16 elements), channel slabs, slabs per patch group
+    int s1_ph, s1_pw, s1_th, s1_tw, s1_tih;   // patch rows / columns per image, tiles per image (rows, columns), tile rows per image
+    unsigned long long s1_magPI, s1_magPW, s1_magC4;   // fastdiv by the float4 count of one image's patch, the patch width, float4 per pixel
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {

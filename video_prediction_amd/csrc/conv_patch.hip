@@ -21,10 +21,15 @@
 
 
 // NW waves per workgroup in an (NW/2) x 2 grid, each wave owns a 32 WM x 32 WN block of the BM x BN tile.
+// The BM = 16 NW WM tile rows are NI images x TIH rows x 8 columns of output pixels (TIH = s1_tih, a power of two >= 4 chosen by
+// the launcher: 8x8 planes put several images into one tile so that the weight stream is shared by more rows).
+// The reduction channels are cut into slabs of CKB = 16 NKS; the LDS patch holds a GROUP of s1_spp slabs (all of them when they
+// fit -> one staging pass; fewer for wide layers, e.g. 512-channel DGRADs, whose patch is then re-staged per group).  Inside a
+// group the (tap, slab) weight slabs stream through the double-buffered LDS stage.
 template <int NW, int WM, int WN, int NKS>
 __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     constexpr int NT = 64 * NW;
-    constexpr int BM = 16 * NW * WM, BN = 64 * WN, TW = 8, TH = BM / TW;
+    constexpr int BM = 16 * NW * WM, BN = 64 * WN, TW = 8;
     constexpr int CKB = 16 * NKS, BROW = CKB + 8;
     constexpr int SLOTS = BN * 2 * NKS;                    // 16-byte slots of one weight slab
     constexpr int Q = (SLOTS + NT - 1) / NT;
@@ -40,35 +45,42 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     const int Cred = dgrad ? p.Cy : p.Cx;
     const int Nout = dgrad ? p.Cx : p.Cy;
     const int kh = gh.nt, kw = gw.nt;                      // (reduced) taps of this phase
+    const int ntaps = kh * kw;
     const int ldb = p.kh * p.kw * Cred;
     const int Hm = gh.Mdim, Wm = gw.Mdim;
     const int tW = p.s1_tw, tH = p.s1_th;                  // tiles per image (of the largest phase)
-    const int PW = p.s1_pw;                                // patch columns: (TW-1)*mstep + (nt-1)*|jstep| + 1 (max over phases)
-    const int PH = p.s1_ph;
-    const int nch = p.s1_nch, CP = p.s1_cp, pitch = p.s1_pitch;
-    const int Cpad = nch * CKB;
-    __bf16* patch = reinterpret_cast<__bf16*>(smem);
-    __bf16* Bs = patch + PH * pitch;                       // [2][BN][BROW]
+    const int PW = p.s1_pw, PH = p.s1_ph;                  // patch extent of ONE image (max over phases)
+    const int tih = p.s1_tih;                              // tile rows per image
+    const int ni = (BM / TW) / tih;                        // images per tile
+    const int rpi = tih * TW;                              // tile rows (GEMM rows) per image: a multiple of 32
+    const int nch = p.s1_nch, pitch = p.s1_pitch;
+    const int spp = p.s1_spp;                              // slabs per patch group
+    const int CP = spp * CKB + 8;                          // patch pixel stride (16 B x odd)
+    const int pimg = PH * pitch;                           // LDS elements of one image's patch
+    __bf16* patch = reinterpret_cast<__bf16*>(smem);       // [ni][PH][pitch]
+    __bf16* Bs = patch + ni * pimg;                        // [2][BN][BROW]
 
     if (ABL(16)) return;
     const int split = blockIdx.z;
     const int tlog = xcd_logical(blockIdx.x, p.tm * p.tn);
     const int mt = tlog % p.tm;
     const int n0 = (tlog / p.tm) * BN;
-    const int img = mt / (tH * tW);
-    const int trem = mt - img * (tH * tW);
-    const int oy0 = (trem / tW) * TH, ox0 = (trem % tW) * TW;
+    const int ig = mt / (tH * tW);                         // image group
+    const int trem = mt - ig * (tH * tW);
+    const int oy0 = (trem / tW) * tih, ox0 = (trem % tW) * TW;
+    const int img0 = ig * ni;
     if (oy0 >= Hm || ox0 >= Wm || kh <= 0 || kw <= 0) return;     // smaller phase / phase without taps (uniform)
     // patch origin in source coordinates: smallest tap displacement
     const int org_h = gh.base + oy0 * gh.mstep + (gh.jstep > 0 ? 0 : (kh - 1) * gh.jstep);
     const int org_w = gw.base + ox0 * gw.mstep + (gw.jstep > 0 ? 0 : (kw - 1) * gw.jstep);
 
-    const float* __restrict__ src = (dgrad ? p.y : p.x) + (long long)img * (dgrad ? p.y_sn : p.x_sn);
+    const float* __restrict__ src = dgrad ? p.y : p.x;
+    const long long s_sn = dgrad ? p.y_sn : p.x_sn;
     const int s_sh = (int)(dgrad ? p.y_sh : p.x_sh), s_sw = (int)(dgrad ? p.y_sw : p.x_sw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- split-K range over the (tap, slab) iteration list ----------------------------------------------------
-    const int it_all = kh * kw * nch;
+    // ---- split-K range over the (group, tap, slab-in-group) iteration list ---------------------------------------------
+    const int it_all = ntaps * nch;
     const int it_per = (it_all + p.splitk - 1) / p.splitk;
     const int it_begin = split * it_per;
     const int it_end = ABL(32) ? it_begin : min(it_all, it_begin + it_per);
@@ -82,16 +94,16 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         const int slot = tid + NT * q;
         const int r = slot / (2 * NKS), k8 = slot % (2 * NKS);
         const int row = min(n0 + r, Nout - 1);             // columns >= Nout are computed on valid data, never stored
-        okL[q] = (nch - 1) * CKB + k8 * 8 < Cred;          // channel padding exists only in the last slab of a tap
+        okL[q] = (nch - 1) * CKB + k8 * 8 < Cred;          // channel padding exists only in the last slab
         goffF[q] = (unsigned)(row * ldb + k8 * 8);
         goffL[q] = (unsigned)(row * ldb + (okL[q] ? k8 * 8 : 0));
         loff[q] = (ALLIN || slot < SLOTS) ? r * BROW + k8 * 8 : -1;
     }
     uint4 rb[Q];
-    int f_cc = it_begin % nch;
-    int f_jh = (it_begin / nch) / kw, f_jw = (it_begin / nch) % kw;
+    int f_cc = 0, f_sl = 0, f_jh = 0, f_jw = 0, g_slabs = 1, g_first = 0;      // set per group
     auto fetch = [&]() {
         const int f_tap = (gh.t0 + f_jh * gh.tstep) * p.kw + (gw.t0 + f_jw * gw.tstep);    // full weight tap
+        f_cc = g_first + f_sl;
         const unsigned short* wp = p.w16 + (f_tap * Cred + f_cc * CKB);
         if (ABL(1)) return;
         if (f_cc == nch - 1) {
@@ -104,8 +116,8 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) rb[q] = *reinterpret_cast<const uint4*>(wp + goffF[q]);
         }
-        if (++f_cc == nch) {
-            f_cc = 0;
+        if (++f_sl == g_slabs) {
+            f_sl = 0;
             if (++f_jw == kw) { f_jw = 0; ++f_jh; }
         }
     };
@@ -116,26 +128,28 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
             if (ALLIN || loff[q] >= 0) *reinterpret_cast<uint4*>(Bs + cur * BN * BROW + loff[q]) = rb[q];
     };
 
-    if (it_begin < it_end) fetch();                        // first slab in flight while the patch is staged
-
-    // ---- stage the input patch (all channels; zero outside the image and in the channel padding) ---------------
-    {
-        const int c4n = Cpad >> 2;
-        const int total = PH * PW * c4n;
-#pragma unroll 16
+    // ---- input patch of one channel slab (zero outside the image, beyond Cred and for images >= N) ---------------
+    auto stage_patch = [&](int cfirst) {                   // channels [cfirst*CKB, (cfirst + spp)*CKB)
+        const int c4n = (spp * CKB) >> 2;
+        const int per_img = PH * PW * c4n;
+        const int total = ni * per_img;
+#pragma unroll 8
         for (int idx = tid; idx < (ABL(4) ? 0 : total); idx += NT) {
-            const int pix = (int)fastdiv((unsigned)idx, p.s1_magC4);
-            const int c = (idx - pix * c4n) << 2;
+            const int im = (int)fastdiv((unsigned)idx, p.s1_magPI);
+            const int rem = idx - im * per_img;
+            const int pix = (int)fastdiv((unsigned)rem, p.s1_magC4);
+            const int c = (rem - pix * c4n) << 2;
             const int pyy = (int)fastdiv((unsigned)pix, p.s1_magPW);
             const int pxx = pix - pyy * PW;
             const int iy = org_h + pyy, ix = org_w + pxx;
-            const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && c < Cred;
-            float4 v = ldg4(src + (ok ? iy * s_sh + ix * s_sw + c : 0));
+            const int cg = cfirst * CKB + c;
+            const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && img0 + im < p.N;
+            float4 v = ldg4(src + (ok ? (long long)(img0 + im) * s_sn + iy * s_sh + ix * s_sw + cg : 0ll));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-            *reinterpret_cast<bf16x4*>(patch + pyy * pitch + pxx * CP + c) = o;
+            *reinterpret_cast<bf16x4*>(patch + im * pimg + pyy * pitch + pxx * CP + c) = o;
         }
-    }
+    };
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -151,17 +165,17 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int row = wm0 + i * 32 + l31;
-        arow[i] = (row >> 3) * gh.mstep * pitch + (row & 7) * gw.mstep * CP + khalf * 8;
+        const int im = row / rpi, rr = row - im * rpi;
+        arow[i] = im * pimg + (rr >> 3) * gh.mstep * pitch + (rr & 7) * gw.mstep * CP + khalf * 8;
     }
     const int brow0 = (wn0 + l31) * BROW + khalf * 8;
 
-    int c_cc = it_begin % nch, c_tap = it_begin / nch;
-    int c_jh = c_tap / kw, c_jw = c_tap - (c_tap / kw) * kw;
+    int c_jh = 0, c_jw = 0, c_sl = 0;
     auto compute = [&](auto curc) {
         constexpr int cur = decltype(curc)::value;
         const int pu = gh.jstep > 0 ? c_jh * gh.jstep : (kh - 1 - c_jh) * -gh.jstep;
         const int pv = gw.jstep > 0 ? c_jw * gw.jstep : (kw - 1 - c_jw) * -gw.jstep;
-        const __bf16* a = patch + (pu * pitch + pv * CP + c_cc * CKB);
+        const __bf16* a = patch + (pu * pitch + pv * CP + c_sl * CKB);
         const __bf16* b = Bs + cur * BN * BROW + brow0;
         bf16x8 af[NKS][WM], bf[NKS][WN];
 #pragma unroll
@@ -178,72 +192,85 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
-        if (++c_cc == nch) {
-            c_cc = 0;
+        if (++c_sl == g_slabs) {
+            c_sl = 0;
             if (++c_jw == kw) { c_jw = 0; ++c_jh; }
         }
     };
 
-    if (it_begin < it_end) {
+    // ---- group-outer loop; inside a group the weight slabs of its (tap, slab) entries run through a two-stage software
+    // pipeline (LDS holds entry e, registers hold entry e+1 whose global loads were issued one whole iteration earlier), unrolled
+    // by two so that the LDS buffer parity is a compile-time constant ------------------------------------------------------
+    const int gsz = ntaps * spp;                           // entries of a full group
+    for (int g = it_begin / gsz; g * gsz < it_end; ++g) {
+        g_first = g * spp;
+        g_slabs = min(spp, nch - g_first);
+        const int e_lo = g * gsz;
+        const int t_begin = max(it_begin, e_lo) - e_lo;
+        const int t_end = min(min(it_end, e_lo + ntaps * g_slabs), it_all) - e_lo;
+        if (t_begin >= t_end) continue;
+        const int tap0 = t_begin / g_slabs;
+        f_sl = t_begin - tap0 * g_slabs; f_jh = tap0 / kw; f_jw = tap0 - f_jh * kw;
+        c_sl = f_sl; c_jh = f_jh; c_jw = f_jw;
+        fetch();                                           // first weight slab in flight while the patch is staged
+        __syncthreads();                                   // every wave is done with the previous group's patch and weights
+        stage_patch(g_first);
         stage(std::integral_constant<int, 0>{});
-        if (it_begin + 1 < it_end) fetch();
-    }
-    __syncthreads();
-
-    // software pipeline, unrolled by two so that the LDS buffer parity is a compile-time constant: LDS holds slab `it`,
-    // the registers hold slab it+1 (its global loads were issued one whole iteration earlier).  Pairs first, odd tail
-    // after the loop (a break inside the pair makes the compiler shuffle all accumulators between two AGPR sets).
-    int it = it_begin;
-    for (; it + 1 < it_end; it += 2) {
-        compute(std::integral_constant<int, 0>{});
-        stage(std::integral_constant<int, 1>{});
-        if (it + 2 < it_end) fetch();
+        if (t_begin + 1 < t_end) fetch();
         __syncthreads();
-        compute(std::integral_constant<int, 1>{});
-        if (it + 2 < it_end) {
-            stage(std::integral_constant<int, 0>{});
-            if (it + 3 < it_end) fetch();
+        int it = t_begin;
+        for (; it + 1 < t_end; it += 2) {
+            compute(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            if (it + 2 < t_end) fetch();
+            __syncthreads();
+            compute(std::integral_constant<int, 1>{});
+            if (it + 2 < t_end) {
+                stage(std::integral_constant<int, 0>{});
+                if (it + 3 < t_end) fetch();
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (it < t_end) compute(std::integral_constant<int, 0>{});
     }
-    if (it < it_end) compute(std::integral_constant<int, 0>{});
 
-    // ---- epilogue: accumulator (i, j, r) of lane (l31, khalf) is pixel row wm0 + 32 i + (r&3) + 8 (r>>2) + 4 khalf of
-    // the tile, i.e. tile pixel (py, px) = (wm0/8 + 4 i + (r>>2), (r&3) + 4 khalf), column n0 + wn0 + 32 j + l31 ---------
+    // ---- epilogue: accumulator (i, j, r) of lane (l31, khalf) is tile row wm0 + 32 i + (r&3) + 8 (r>>2) + 4 khalf; every
+    // 32-row block lies inside one image (rows per image are a multiple of 32) --------------------------------------------
     if (ABL(8) && acc[0][0][0] != 123.f) return;
     const long long d_sn = dgrad ? p.x_sn : p.y_sn;
     const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
-    const int py0 = oy0 + (wm0 >> 3), px0 = ox0 + 4 * khalf;       // M-grid coordinates of this lane's first pixel
-    const int col0 = n0 + wn0 + l31;
-    float* __restrict__ dst = p.out + (long long)img * d_sn + (long long)(gh.ob + py0 * gh.os) * d_sh +
-                              (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
     const int e_sh = d_sh * gh.os, e_sw = d_sw * gw.os;            // destination strides of one M-grid step
-    const bool full = (oy0 + TH <= Hm) && (ox0 + TW <= Wm);
+    const int col0 = n0 + wn0 + l31;
+    const int px0 = ox0 + 4 * khalf;
     const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
-    if (plain && full) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int rowb = wm0 + i * 32;
+        const int im = rowb / rpi;
+        const int py0 = oy0 + ((rowb - im * rpi) >> 3);            // M-grid row of this block's first pixel row
+        if (img0 + im >= p.N) continue;
+        float* __restrict__ dst = p.out + (long long)(img0 + im) * d_sn + (long long)(gh.ob + py0 * gh.os) * d_sh +
+                                  (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
+        const bool full = (py0 + 4 <= Hm) && (ox0 + TW <= Wm);
+        if (plain && full) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (col0 + 32 * j >= Nout) continue;
+                const float bias = p.bias ? p.bias[col0 + 32 * j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
+            }
+            continue;
+        }
+        const float* __restrict__ aux = p.aux ? p.aux + (dst - p.out) : nullptr;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (col0 + 32 * j >= Nout) continue;
-            const float bias = p.bias ? p.bias[col0 + 32 * j] : 0.f;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dst[(4 * i + (r >> 2)) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
-        }
-        return;
-    }
-    const float* __restrict__ aux = p.aux ? p.aux + (dst - p.out) : nullptr;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        if (col0 + 32 * j >= Nout) continue;
-        const float bias = (p.bias && split == 0) ? p.bias[col0 + 32 * j] : 0.f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
+            const float bias = (p.bias && split == 0) ? p.bias[col0 + 32 * j] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (!full && (py0 + 4 * i + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
-                const int off = (4 * i + (r >> 2)) * e_sh + (r & 3) * e_sw + 32 * j;
+                if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
+                const int off = (r >> 2) * e_sh + (r & 3) * e_sw + 32 * j;
                 float v = acc[i][j][r] + bias;
                 if (p.splitk > 1) {
                     unsafeAtomicAdd(dst + off, v);
@@ -312,6 +339,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     // 32-bit in-image offsets (source and destination) and weight offsets
     if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)Nout * a->kh * a->kw * Cred >= (1ll << 31))
         return false;
+    if ((long long)Hm * Wm < 16) return false;                   // dense-like problems: the generic kernel
     const int tW = (Wm + 7) / 8;
     if (!wm) {
         wn = Nout > 64 ? 2 : 1;
@@ -319,7 +347,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         wm = (t16 >= 256 && Hm >= 16) ? 2 : 1;
         nw = 4;
     }
-    // channel chunking: nch slabs of NKS*16 channels per tap, minimising (k-steps + per-iteration overhead)
+    // channel slabs: nch slabs of NKS*16 channels, minimising (k-steps + per-iteration overhead)
     const int Cp16 = (Cred + 15) & ~15;
     int nch = 0, nks = 0;
     double best = 1e30;
@@ -330,22 +358,38 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         if (cost < best) { best = cost; nch = c; nks = k; }
     }
     if (!nch) return false;
-    const int Cpad = nch * nks * 16;
+    // tile rows: TH = BM/8 rows of 8 pixels, split into NI images x TIH rows (TIH a power of two, 4 <= TIH <= TH): small planes
+    // put several images into one tile
+    const int TH = 2 * nw * wm;
+    int tih = 4;
+    while (tih < TH && tih < Hm) tih *= 2;
+    const int ni = TH / tih;
     // patch extent per dim: (tile-1)*mstep + (taps-1)*|jstep| + 1 ; FPROP: mstep = stride, jstep = 1 ; DGRAD: mstep = 1,
     // taps = ceil(k / stride) per phase, jstep = -1
-    const int TH = 2 * nw * wm;
-    const int PH = dg ? TH + (a->kh + a->sh - 1) / a->sh - 1 : (TH - 1) * a->sh + a->kh;
+    const int PH = dg ? tih + (a->kh + a->sh - 1) / a->sh - 1 : (tih - 1) * a->sh + a->kh;
     const int PW = dg ? 8 + (a->kw + a->sw - 1) / a->sw - 1 : 7 * a->sw + a->kw;
-    p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + TH - 1) / TH; p.s1_tw = tW;
-    const int CP = Cpad + 8;
-    const int x = (8 - (PW * (CP / 8)) % 16 + 16) % 16;          // row pitch = 8 (mod 16) 16-byte slots
-    const int pitch = PW * CP + 8 * x;
-    const size_t lds = (size_t)PH * pitch * 2 + (size_t)2 * 64 * wn * (nks * 16 + 8) * 2;
-    if (lds > 160 * 1024) return false;
-    p.s1_cp = CP; p.s1_pitch = pitch; p.s1_nch = nch;
-    p.s1_magC4 = magic40(Cpad / 4); p.s1_magPW = magic40(PW);
+    // slabs per patch group: all of them if the patch fits into LDS beside the weight stage (one staging pass), otherwise as
+    // many as fit (every further group costs a barrier + an exposed patch load)
+    // (bits 12-13 of `tile` cap the LDS budget at 64 / 96 KB instead: more workgroups per CU can beat fewer staging passes; the
+    // autotuner tries all three)
+    const int cls = (a->tile >> 12) & 3;
+    const size_t budget = cls == 1 ? 64 * 1024 : (cls == 2 ? 96 * 1024 : 160 * 1024);
+    int spp = nch, pitch = 0;
+    size_t lds = 0;
+    for (; spp >= 1; --spp) {
+        const int CP = spp * nks * 16 + 8;
+        const int x = (8 - (PW * (CP / 8)) % 16 + 16) % 16;      // row pitch = 8 (mod 16) 16-byte slots
+        pitch = PW * CP + 8 * x;
+        lds = (size_t)ni * PH * pitch * 2 + (size_t)2 * 64 * wn * (nks * 16 + 8) * 2;
+        if (lds <= budget || (spp == 1 && lds <= 160 * 1024)) break;
+    }
+    if (spp < 1) return false;
+    p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
+    p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
+    p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
+    if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
     const int BN = 64 * wn;
-    p.tm = a->N * ((Hm + TH - 1) / TH) * tW; p.tn = (Nout + BN - 1) / BN;
+    p.tm = ((a->N + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
     const long long tiles = (long long)p.tm * p.tn;
     const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch;
     int splitk = a->splitk;

@@ -119,8 +119,8 @@ def _tune(a, mode, dst, w):
     else:
         splits = (1, 2, 4, 8) if a.act == 0 else (1,)
         # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
-        # (0x6xx = patch kernel with 8 waves per workgroup)
-        cands = [(alg | t, sk) for alg in (0x100, 0x200, 0x600) for t in tiles for sk in splits]
+        # (0x6xx = patch kernel with 8 waves per workgroup; 0x1000 / 0x2000 = its LDS budget capped at 64 / 96 KB)
+        cands = [(alg | t, sk) for alg in (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600) for t in tiles for sk in splits]
         real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
         scratch = None
         if a.beta:                       # never accumulate tuning runs into the real destination
