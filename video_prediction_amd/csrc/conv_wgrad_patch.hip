@@ -16,6 +16,7 @@
 // share of the pixel tiles; the result is added to dW with fp32 atomics.  LDS pixel strides are 64 (mod 256) bytes so
 // that the 8 row segments of a 32-lane transpose read fall into distinct bank groups.
 #include "conv_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
 #define LDS_AS __attribute__((address_space(3)))
@@ -241,10 +242,18 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.G16 = (a->Cx + 15) / 16;
     q.PH = 7 * a->sh + a->kh; q.PW = 7 * a->sw + a->kw;           // input rows / columns under an 8x8 output tile
     if (q.PH > 31 || q.PW > 31) return false;                    // packed staging map: 5 bits per coordinate
-    // workgroup shape: 8 waves x 8 row tiles (64 tiles = 128 row groups) for the big layers, 4 x 8 / 4 x 4 for small ones
+    // workgroup shape
     const int groups_all = q.taps * q.G16;
     int nw, mtw;
-    if (groups_all <= 32) { nw = 4; mtw = 4; } else if (groups_all <= 64) { nw = 4; mtw = 8; } else { nw = 8; mtw = 8; }
+    // 8 waves; the fewest row tiles per wave that still cover every (tap, channel group) row block in one chunk (measured on
+    // the 3x3 heads: 8x2 305 us, 8x4 424 us, 4x4 476 us, 4x8 831 us -- fewer tiles per wave = better balance and occupancy)
+    nw = 8;
+    mtw = groups_all <= 32 ? 2 : (groups_all <= 64 ? 4 : 8);
+    {   // developer override: SAVP_WGP_CFG=<nw><mtw> (e.g. 84)
+        static int ov = -1;
+        if (ov < 0) { const char* e = getenv("SAVP_WGP_CFG"); ov = e ? atoi(e) : 0; }
+        if (ov) { nw = ov / 10; mtw = ov % 10; if (2 * nw * mtw < groups_all && 2 * nw * mtw < q.taps) return false; }
+    }
     const int nthreads = 64 * nw;
     const int npf_max = (nw == 8) ? 8 : 16;
     const int cg_pf = (npf_max * nthreads) / (4 * q.PH * q.PW);  // prefetch-register bound on the channel groups
@@ -275,7 +284,9 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     const int npf = (q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
     dim3 grid((unsigned)q.S, (unsigned)NB, (unsigned)MC);
     hipError_t err;
-    if (nw == 8) err = (npf <= 4) ? launch_wgp<8, 8, 4>(q, grid, lds, st) : launch_wgp<8, 8, 8>(q, grid, lds, st);
+    if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp<8, 4, 4>(q, grid, lds, st) : launch_wgp<8, 4, 8>(q, grid, lds, st);
+    else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp<8, 2, 4>(q, grid, lds, st) : launch_wgp<8, 2, 8>(q, grid, lds, st);
+    else if (nw == 8) err = (npf <= 4) ? launch_wgp<8, 8, 4>(q, grid, lds, st) : launch_wgp<8, 8, 8>(q, grid, lds, st);
     else if (mtw == 8) err = (npf <= 8) ? launch_wgp<4, 8, 8>(q, grid, lds, st) : launch_wgp<4, 8, 16>(q, grid, lds, st);
     else err = (npf <= 8) ? launch_wgp<4, 4, 8>(q, grid, lds, st) : launch_wgp<4, 4, 16>(q, grid, lds, st);
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
