@@ -132,7 +132,7 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
             tag = name + ('' if tile == 0 else '_t%x' % tile)
             xd, wd_, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
             if tile & 0x200:          # LDS patch kernel forced: 2-D stride-1, channels % 8, bf16 weight copy only
-                if not (precision == 1 and dhw[0] == 1 and k[0] == 1 and s[0] == 1 and k[1] >= s[1] and k[2] >= s[2] and
+                if not (precision == 1 and s[0] == 1 and k[1] >= s[1] and k[2] >= s[2] and
                         Cx % 8 == 0 and Cy % 8 == 0 and y.shape[2] * y.shape[3] >= 16):
                     continue
                 # the kernel parks a (8*WM+kh-1) x (8+kw-1) pixel patch of ALL reduction channels in LDS; shapes whose patch

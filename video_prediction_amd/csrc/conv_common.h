@@ -33,6 +33,7 @@ struct ConvP {
     // patch kernel (conv_patch.hip): LDS geometry chosen by the launcher
     int s1_pitch, s1_nch, s1_spp;             // patch row pitch (bf16 elements), channel slabs, slabs per patch group
     int s1_ph, s1_pw, s1_th, s1_tw, s1_tih;   // patch rows / columns per image, tiles per image (rows, columns), tile rows per image
+    unsigned long long s1_magDm;              // fastdiv by the depth of the output grid
     unsigned long long s1_magPI, s1_magPW, s1_magC4;   // fastdiv by the float4 count of one image's patch, the patch width, float4 per pixel
 };
 

@@ -40,14 +40,16 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     // blockIdx.y = output phase of a strided DGRAD (conv2d_transpose): each phase is a dense stride-1 problem over its
     // own taps t0 + j*s, so no MAC is spent on the zeros of the transposed convolution
     const int fh = dgrad ? (int)blockIdx.y / p.sw : 0, fw = dgrad ? (int)blockIdx.y % p.sw : 0;
+    const DimGeom gd = make_geom(dgrad, 0, p.D, p.Do, p.kd, 1, p.pd);      // depth: stride 1 only (3-D discriminator convs)
     const DimGeom gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
     const DimGeom gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
     const int Cred = dgrad ? p.Cy : p.Cx;
     const int Nout = dgrad ? p.Cx : p.Cy;
     const int kh = gh.nt, kw = gw.nt;                      // (reduced) taps of this phase
     const int ntaps = kh * kw;
-    const int ldb = p.kh * p.kw * Cred;
-    const int Hm = gh.Mdim, Wm = gw.Mdim;
+    const int ldb = p.kd * p.kh * p.kw * Cred;
+    const int Hm = gh.Mdim, Wm = gw.Mdim, Dm = gd.Mdim;
+    const int nimg = p.N * Dm;                             // "images" = (sample, output depth) pairs
     const int tW = p.s1_tw, tH = p.s1_th;                  // tiles per image (of the largest phase)
     const int PW = p.s1_pw, PH = p.s1_ph;                  // patch extent of ONE image (max over phases)
     const int tih = p.s1_tih;                              // tile rows per image
@@ -75,12 +77,13 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     const int org_w = gw.base + ox0 * gw.mstep + (gw.jstep > 0 ? 0 : (kw - 1) * gw.jstep);
 
     const float* __restrict__ src = dgrad ? p.y : p.x;
-    const long long s_sn = dgrad ? p.y_sn : p.x_sn;
+    const long long s_sn = dgrad ? p.y_sn : p.x_sn, s_sd = dgrad ? p.y_sd : p.x_sd;
     const int s_sh = (int)(dgrad ? p.y_sh : p.x_sh), s_sw = (int)(dgrad ? p.y_sw : p.x_sw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- split-K range over the (group, tap, slab-in-group) iteration list ---------------------------------------------
-    const int it_all = ntaps * nch;
+    const int it_dep = ntaps * nch;                        // entries of one depth tap
+    const int it_all = gd.nt * it_dep;
     const int it_per = (it_all + p.splitk - 1) / p.splitk;
     const int it_begin = split * it_per;
     const int it_end = ABL(32) ? it_begin : min(it_all, it_begin + it_per);
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         loff[q] = (ALLIN || slot < SLOTS) ? r * BROW + k8 * 8 : -1;
     }
     uint4 rb[Q];
-    int f_cc = 0, f_sl = 0, f_jh = 0, f_jw = 0, g_slabs = 1, g_first = 0;      // set per group
+    int f_cc = 0, f_sl = 0, f_jh = 0, f_jw = 0, g_slabs = 1, g_first = 0, g_jd = 0;      // set per group
     auto fetch = [&]() {
-        const int f_tap = (gh.t0 + f_jh * gh.tstep) * p.kw + (gw.t0 + f_jw * gw.tstep);    // full weight tap
+        const int f_tap = ((gd.t0 + g_jd * gd.tstep) * p.kh + (gh.t0 + f_jh * gh.tstep)) * p.kw + (gw.t0 + f_jw * gw.tstep);   // full weight tap
         f_cc = g_first + f_sl;
         const unsigned short* wp = p.w16 + (f_tap * Cred + f_cc * CKB);
         if (ABL(1)) return;
@@ -143,8 +146,12 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
             const int pxx = pix - pyy * PW;
             const int iy = org_h + pyy, ix = org_w + pxx;
             const int cg = cfirst * CKB + c;
-            const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && img0 + im < p.N;
-            float4 v = ldg4(src + (ok ? (long long)(img0 + im) * s_sn + iy * s_sh + ix * s_sw + cg : 0ll));
+            const int gi = img0 + im;                          // (sample, depth) index
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;      // source plane of this depth tap
+            const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
+                            (unsigned)dz < (unsigned)gd.srcN;
+            float4 v = ldg4(src + (ok ? (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg : 0ll));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
             *reinterpret_cast<bf16x4*>(patch + im * pimg + pyy * pitch + pxx * CP + c) = o;
@@ -201,13 +208,17 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     // ---- group-outer loop; inside a group the weight slabs of its (tap, slab) entries run through a two-stage software
     // pipeline (LDS holds entry e, registers hold entry e+1 whose global loads were issued one whole iteration earlier), unrolled
     // by two so that the LDS buffer parity is a compile-time constant ------------------------------------------------------
-    const int gsz = ntaps * spp;                           // entries of a full group
-    for (int g = it_begin / gsz; g * gsz < it_end; ++g) {
+    const int gsz = ntaps * spp;                           // entries of a full slab group
+    const int ngs = (nch + spp - 1) / spp;                 // slab groups per depth tap
+    for (int gg = (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
+        g_jd = gg / ngs;
+        const int g = gg - g_jd * ngs;
         g_first = g * spp;
         g_slabs = min(spp, nch - g_first);
-        const int e_lo = g * gsz;
+        const int e_lo = g_jd * it_dep + g * gsz;
+        if (e_lo >= it_end) break;
         const int t_begin = max(it_begin, e_lo) - e_lo;
-        const int t_end = min(min(it_end, e_lo + ntaps * g_slabs), it_all) - e_lo;
+        const int t_end = min(it_end, e_lo + ntaps * g_slabs) - e_lo;
         if (t_begin >= t_end) continue;
         const int tap0 = t_begin / g_slabs;
         f_sl = t_begin - tap0 * g_slabs; f_jh = tap0 / kw; f_jw = tap0 - f_jh * kw;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     // ---- epilogue: accumulator (i, j, r) of lane (l31, khalf) is tile row wm0 + 32 i + (r&3) + 8 (r>>2) + 4 khalf; every
     // 32-row block lies inside one image (rows per image are a multiple of 32) --------------------------------------------
     if (ABL(8) && acc[0][0][0] != 123.f) return;
-    const long long d_sn = dgrad ? p.x_sn : p.y_sn;
+    const long long d_sn = dgrad ? p.x_sn : p.y_sn, d_sd = dgrad ? p.x_sd : p.y_sd;
     const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
     const int e_sh = d_sh * gh.os, e_sw = d_sw * gw.os;            // destination strides of one M-grid step
     const int col0 = n0 + wn0 + l31;
@@ -248,8 +259,11 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         const int rowb = wm0 + i * 32;
         const int im = rowb / rpi;
         const int py0 = oy0 + ((rowb - im * rpi) >> 3);            // M-grid row of this block's first pixel row
-        if (img0 + im >= p.N) continue;
-        float* __restrict__ dst = p.out + (long long)(img0 + im) * d_sn + (long long)(gh.ob + py0 * gh.os) * d_sh +
+        const int gi = img0 + im;
+        if (gi >= nimg) continue;
+        const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+        float* __restrict__ dst = p.out + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
+                                  (long long)(gh.ob + py0 * gh.os) * d_sh +
                                   (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
         const bool full = (py0 + 4 <= Hm) && (ox0 + TW <= Wm);
         if (plain && full) {
@@ -328,14 +342,17 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     const long long ssn = dg ? a->y_sn : a->x_sn, ssh = dg ? a->y_sh : a->x_sh, ssw = dg ? a->y_sw : a->x_sw;
     const void* sptr = dg ? a->y : a->x;
     const bool src4 = (ssn % 4 == 0) && (ssh % 4 == 0) && (ssw % 4 == 0) && aligned16(sptr);
-    if (!(p.bf16 && p.w16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh <= 4 && a->sw <= 4 &&
-          a->kh >= a->sh && a->kw >= a->sw && (Cred % 8 == 0) && src4))
+    const long long ssd = dg ? a->y_sd : a->x_sd;
+    if (!(p.bf16 && p.w16 && a->sd == 1 && a->sh <= 4 && a->sw <= 4 && a->kh >= a->sh && a->kw >= a->sw && (Cred % 8 == 0) &&
+          src4 && ssd % 4 == 0))
         return false;
+    const int Dm = dg ? a->D : a->Do;                           // depth of the output grid (1 for 2-D problems)
     // M-grid of the (largest) output phase; strided DGRAD runs sh*sw phases as blockIdx.y
     const int phases = dg ? a->sh * a->sw : 1;
     const int Hm = dg ? (a->H + a->sh - 1) / a->sh : a->Ho, Wm = dg ? (a->W + a->sw - 1) / a->sw : a->Wo;
-    const long long dH = Hm, dW_ = Wm;
+    const long long dH = dg ? a->H : a->Ho, dW_ = dg ? a->W : a->Wo;      // full destination extents (all phases)
     const long long d_sn = dg ? a->x_sn : a->y_sn, d_sh = dg ? a->x_sh : a->y_sh, d_sw = dg ? a->x_sw : a->y_sw;
+    const long long d_sd = dg ? a->x_sd : a->y_sd;
     // 32-bit in-image offsets (source and destination) and weight offsets
     if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)Nout * a->kh * a->kw * Cred >= (1ll << 31))
         return false;
@@ -387,11 +404,13 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
     p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
     p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
+    p.s1_magDm = magic40(Dm);
+    if ((long long)a->N * Dm >= (1 << 24)) return false;
     if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
     const int BN = 64 * wn;
-    p.tm = ((a->N + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
+    p.tm = (int)(((long long)a->N * Dm + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
     const long long tiles = (long long)p.tm * p.tn;
-    const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch;
+    const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
     int splitk = a->splitk;
     if (a->act != SAVP_ACT_NONE) splitk = 1;
     else if (splitk <= 0) {
@@ -405,8 +424,10 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
     }
     if (splitk > iters) splitk = (int)iters;
     if (splitk > 1 && !a->beta) {
-        const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (d_sn == dH * dW_ * Nout);
-        if (dense) hipMemsetAsync(p.out, 0, (size_t)a->N * dH * dW_ * Nout * sizeof(float), st);
+        const long long dD = Dm;
+        const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (dD == 1 || d_sd == dH * dW_ * Nout) &&
+                           (d_sn == dD * dH * dW_ * Nout);
+        if (dense) hipMemsetAsync(p.out, 0, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
         else splitk = 1;
     }
     p.splitk = splitk;
