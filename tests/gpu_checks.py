@@ -731,6 +731,8 @@ def failures(results):
 def smoke():
     """One small hot-path invocation on cuda:0 checked against the oracle (used by __graft_entry__.smoke)."""
     res = check_conv(cases=('lstm5x5_32',)) + check_lstm()[:3]
+    # the bench datapath: bf16 LDS-patch FPROP / DGRAD / WGRAD kernels on the ConvLSTM gate-conv shape
+    res += [('bf16/' + n, e, t) for (n, e, t) in check_conv(cases=('lstm5x5_32',), precision=1, tol=1e-2)]
     bad = failures(res)
     if bad:
         raise AssertionError('smoke parity failures: %r' % bad)
