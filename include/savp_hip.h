@@ -285,6 +285,24 @@ int savp_convgru_out_fwd(void* stream, const SavpGruArgs* a);
 int savp_convgru_out_bwd(void* stream, const SavpGruArgs* a);
 int savp_convgru_gates_bwd(void* stream, const SavpGruArgs* a);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Evaluation metrics and the best-of-N sampling fold (metrics.hip).  Time-major [T, B, ...] tensors with
+ * explicit element strides (x_st = time, x_sb = batch); frames are contiguous (H*W*C floats).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* metrics.py:5-10: mse[t,b] = mean((a-b)^2), psnr[t,b] = -10 log10(mse) (tf.image.psnr, max_val 1); either output may be NULL */
+int savp_frame_mse_psnr(void* stream, const float* a, int64_t a_st, int64_t a_sb, const float* b, int64_t b_st, int64_t b_sb,
+                        int32_t T, int32_t B, int32_t inner, float* mse, float* psnr);
+/* metrics.py:13-14: tf.image.ssim(a, b, 1.0) per frame -> out[t,b] (11x11 Gaussian sigma 1.5, k1 .01, k2 .03, VALID) */
+int savp_frame_ssim(void* stream, const float* a, int64_t a_st, int64_t a_sb, const float* b, int64_t b_st, int64_t b_sb,
+                    int32_t T, int32_t B, int32_t H, int32_t W, int32_t C, float* out);
+/* base_model.py:176-190: per batch element, if mean_t(metric) < mean_t(vmin): vmin <- metric (cond_min = 1); likewise max;
+ * vsum += metric.  All [T, B] contiguous. */
+int savp_eval_accumulate(void* stream, const float* metric, float* vmin, float* vsum, float* vmax, int32_t* cond_min,
+                         int32_t* cond_max, int32_t T, int32_t B);
+/* base_model.py:170-171: mode 0: out[t,b,:] = cond[b] ? x[t,b,:] : out[t,b,:] ; mode 1: out[t,b,:] += x[t,b,:] */
+int savp_select_batch(void* stream, const int32_t* cond, const float* x, int64_t x_st, int64_t x_sb, float* out, int64_t o_st,
+                      int64_t o_sb, int32_t T, int32_t B, int32_t inner, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -737,3 +737,57 @@ def smoke():
     if bad:
         raise AssertionError('smoke parity failures: %r' % bad)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evaluation metrics (csrc/metrics.hip) vs oracle/metrics.py
+# ---------------------------------------------------------------------------------------------------------------
+def check_metrics(seed=11):
+    from oracle import metrics as OM
+    out = []
+    rng = np.random.default_rng(seed)
+    for (T, B, H, W, C) in [(3, 2, 64, 64, 3), (2, 3, 24, 20, 1), (4, 2, 32, 32, 3)]:
+        tgt = torch.tensor(rng.random((T, B, H, W, C)))
+        big = torch.tensor(rng.random((T, 2 * B, H, W, C)))                  # the generator's [T, 2B, ...] buffer
+        big[:, B:] = (tgt + 0.1 * torch.tensor(rng.standard_normal((T, B, H, W, C)))).clamp(0, 1)
+        pred = big[:, B:]
+        td, bd = dev(tgt), dev(big)
+        pd = bd[:, B:]                                                       # strided batch half, used in place
+        tag = 'metrics_%dx%dx%d' % (H, W, C)
+        mse = torch.empty(T, B, device=DEV); psnr = torch.empty(T, B, device=DEV); ssim = torch.empty(T, B, device=DEV)
+        K.frame_mse_psnr(td, pd, mse=mse, psnr=psnr)
+        K.frame_ssim(td, pd, ssim)
+        out.append((tag + '/mse', rel_err(mse, OM.mse(tgt, pred)), 1e-5))
+        out.append((tag + '/psnr', rel_err(psnr, OM.psnr(tgt, pred)), 1e-5))
+        out.append((tag + '/ssim', rel_err(ssim, OM.ssim(tgt, pred)), 2e-5))
+        K.frame_ssim(td, td, ssim)
+        out.append((tag + '/ssim_identity', float((ssim - 1).abs().max()), 1e-5))
+    # the sampling fold (base_model.py:170-198) on random metrics / images
+    T, B = 4, 5
+    shape = (T + 2, B, 8, 8, 3)
+    vmin = torch.full((T, B), float('inf'), device=DEV); vmax = torch.full((T, B), float('-inf'), device=DEV)
+    vsum = torch.zeros(T, B, device=DEV)
+    gmin = torch.zeros(shape, device=DEV); gmax = torch.zeros(shape, device=DEV); gsum = torch.zeros(shape, device=DEV)
+    cmin = torch.zeros(B, dtype=torch.int32, device=DEV); cmax = torch.zeros(B, dtype=torch.int32, device=DEV)
+    r_min = torch.full((T, B), float('inf'), dtype=torch.float64); r_max = torch.full((T, B), float('-inf'), dtype=torch.float64)
+    r_sum = torch.zeros(T, B, dtype=torch.float64)
+    rg = {k: torch.zeros(shape, dtype=torch.float64) for k in ('min', 'max', 'sum')}
+    for s in range(6):
+        m = torch.tensor(rng.standard_normal((T, B)))
+        g = torch.tensor(rng.random(shape))
+        lo = m.mean(0) < r_min.mean(0); hi = m.mean(0) > r_max.mean(0)
+        r_min = torch.where(lo[None], m, r_min); r_max = torch.where(hi[None], m, r_max); r_sum = r_sum + m
+        sel = lambda c, x, y: torch.where(c.reshape(1, -1, 1, 1, 1), x, y)
+        rg['min'] = sel(lo, g, rg['min']); rg['max'] = sel(hi, g, rg['max']); rg['sum'] = rg['sum'] + g
+        gd = dev(g)
+        K.eval_accumulate(dev(m), vmin, vsum, vmax, cmin, cmax)
+        K.select_batch(cmin, gd, gmin); K.select_batch(cmax, gd, gmax); K.select_batch(None, gd, gsum, mode=1)
+    out.append(('fold/min', rel_err(vmin, r_min), 1e-6)); out.append(('fold/max', rel_err(vmax, r_max), 1e-6))
+    out.append(('fold/sum', rel_err(vsum, r_sum), 1e-6))
+    out.append(('fold/gmin', rel_err(gmin, rg['min']), 1e-6)); out.append(('fold/gmax', rel_err(gmax, rg['max']), 1e-6))
+    out.append(('fold/gsum', rel_err(gsum, rg['sum']), 1e-6))
+    torch.cuda.synchronize()
+    return out
+
+
+ALL_CHECKS.append(('metrics', check_metrics))

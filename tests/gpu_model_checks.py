@@ -239,3 +239,38 @@ def check_model_bf16():
     finally:
         K.set_conv_precision('f32')
     return out
+
+
+def check_eval_best_of_n(B=2, T=6, H=32, W=32, C=3, num_samples=4):
+    """eval_outputs_and_metrics_fn (base_model.py:132-227) vs the oracle: best / mean / worst of num_samples prior samples."""
+    from oracle import metrics as OM
+    hp = make_hparams(context_frames=2, sequence_length=T, nz=8, schedule_sampling='none')
+    specs = V.variable_specs(hp, (H, W, C), mode='test')
+    vals = V.init_variables(specs, seed=4)
+    rng = np.random.default_rng(5)
+    for k in vals:                                     # make the latent matter at init scale
+        if 'rnn_z' in k or k.endswith('gamma'):
+            vals[k] = (vals[k] + 0.3 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+    images = synth(hp, B, H, W, C, 3)
+    noises = [make_noise(hp, B, seed=20 + i, sampling=False) for i in range(num_samples)]
+    P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
+    gens = []
+    with torch.no_grad():
+        for n in noises:
+            gens.append(OS.generator_fn(OS.Scope(P).sub('generator'), {'images': images}, 'test', hp, n)['gen_images'])
+    r_out, r_met = OM.eval_outputs_and_metrics(images, gens, hp.context_frames)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, device=DEV)
+    eng.set_images(images.float().to(DEV), time_major=True)
+    outs, mets = eng.eval_outputs_and_metrics(num_samples, noises)
+    torch.cuda.synchronize()
+    res = []
+    for k in r_met:
+        res.append(('eval/' + k, rel(mets[k], r_met[k]), 2e-3))
+    for k in r_out:
+        res.append(('eval/' + k, rel(outs[k], r_out[k]), 2e-3))
+    # metrics_fn (base_model.py:113-130) on the first sample
+    m = eng.metrics(eng.generate(noises[0]))
+    r = OM.metrics_fn(images, gens[0], hp.context_frames)
+    for k in r:
+        res.append(('metrics_fn/' + k, rel(m[k], r[k]), 2e-3))
+    return res

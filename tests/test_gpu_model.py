@@ -172,3 +172,9 @@ def test_bf16_patch_kernels_match_generic_kernels_on_a_train_step(monkeypatch):
     assert abs(lp[0][0] - lg[0][0]) <= 1e-3 * max(1.0, abs(lp[0][0])), (lp, lg)
     for (d0, g0), (d1, g1) in zip(lp, lg):
         assert abs(d0 - d1) <= 5e-2 * max(1.0, abs(d0)) and abs(g0 - g1) <= 5e-2 * max(1.0, abs(g0)), (lp, lg)
+
+
+def test_best_of_n_sampling_eval_vs_oracle():
+    """eval_outputs_and_metrics_fn (base_model.py:132-227): psnr / mse / ssim, per-sequence best / mean / worst over samples."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_eval_best_of_n())

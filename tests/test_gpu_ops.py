@@ -59,3 +59,8 @@ def test_conv_bf16_mode():
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)
+
+
+def test_eval_metrics_and_sampling_fold():
+    from tests import gpu_checks
+    _run(gpu_checks.check_metrics)

@@ -685,3 +685,56 @@ def gan_loss(logits, label, weight, gan_loss_type='LSGAN', loss_out=None, dlogit
     """losses.gan_loss (losses.py:29-54): value accumulated into loss_out, weighted gradient into dlogits."""
     lib.check(_L().savp_gan_loss(lib.stream(), logits.numel(), GAN_TYPES[gan_loss_type], _p(logits), float(label), float(weight),
                                  _p(loss_out), _p(dlogits), int(beta)), 'savp_gan_loss')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evaluation metrics / best-of-N sampling fold (csrc/metrics.hip; SURVEY.md 8(f1))
+# ---------------------------------------------------------------------------------------------------------------
+def _tb(x):
+    """(time stride, batch stride, frame length) of a time-major [T, B, ...] tensor with contiguous frames."""
+    if x.dim() < 3 or not x[0, 0].is_contiguous():
+        raise ValueError('expected a time-major [T, B, ...] tensor with contiguous frames')
+    return x.stride(0), x.stride(1), x[0, 0].numel()
+
+
+def _require_i32(*tensors):
+    for t in tensors:
+        if t is not None and (not t.is_cuda or t.dtype != torch.int32):
+            raise RuntimeError('expected an int32 device tensor, got %s on %s' % (t.dtype, t.device))
+
+
+def frame_mse_psnr(a, b, mse=None, psnr=None):
+    """metrics.py:5-10 per frame: mse / psnr [T, B] (either may be None)."""
+    lib.require_device(a, b, mse, psnr)
+    a_st, a_sb, inner = _tb(a)
+    b_st, b_sb, _ = _tb(b)
+    lib.check(_L().savp_frame_mse_psnr(lib.stream(), _p(a), a_st, a_sb, _p(b), b_st, b_sb, a.shape[0], a.shape[1], inner, _p(mse),
+                                       _p(psnr)), 'savp_frame_mse_psnr')
+
+
+def frame_ssim(a, b, out):
+    """metrics.py:13-14 (tf.image.ssim, max_val 1) per frame of [T, B, H, W, C] tensors -> out [T, B]."""
+    lib.require_device(a, b, out)
+    a_st, a_sb, _ = _tb(a)
+    b_st, b_sb, _ = _tb(b)
+    T, B, H, W, C = a.shape
+    lib.check(_L().savp_frame_ssim(lib.stream(), _p(a), a_st, a_sb, _p(b), b_st, b_sb, T, B, H, W, C, _p(out)), 'savp_frame_ssim')
+
+
+def eval_accumulate(metric, vmin, vsum, vmax, cond_min, cond_max):
+    """base_model.py:176-190 on contiguous [T, B] tensors; cond_* int32 [B] receive the per-sequence decisions."""
+    lib.require_device(metric, vmin, vsum, vmax)
+    _require_i32(cond_min, cond_max)
+    T, B = metric.shape
+    lib.check(_L().savp_eval_accumulate(lib.stream(), _p(metric), _p(vmin), _p(vsum), _p(vmax), _p(cond_min), _p(cond_max), T, B),
+              'savp_eval_accumulate')
+
+
+def select_batch(cond, x, out, mode=0):
+    """mode 0: out[t,b] = x[t,b] where cond[b] (base_model.py:170-171); mode 1: out += x."""
+    lib.require_device(x, out)
+    _require_i32(cond)
+    x_st, x_sb, inner = _tb(x)
+    o_st, o_sb, _ = _tb(out)
+    lib.check(_L().savp_select_batch(lib.stream(), _p(cond), _p(x), x_st, x_sb, _p(out), o_st, o_sb, x.shape[0], x.shape[1], inner,
+                                     int(mode)), 'savp_select_batch')

@@ -407,6 +407,77 @@ class SAVPEngine(object):
         gen = self.forward_generator(noise, collect_masks=collect_masks)
         return gen
 
+    # -- evaluation: metrics_fn / eval_outputs_and_metrics_fn (base_model.py:113-227) ------------------------
+    METRICS = ('psnr', 'mse', 'ssim')            # base_model.py:119-124 without lpips (external AlexNet weights)
+
+    def _frame_metrics(self, pred, buf):
+        """psnr / mse / ssim [T_future, B] of the future frames of pred [T1, B, H, W, C] against the staged images."""
+        hp = self.hp
+        fut = self.T - hp.context_frames
+        target = self.images_tm[self.T - fut:]
+        p = pred[self.T1 - fut:]
+        K.frame_mse_psnr(target, p, mse=buf['mse'], psnr=buf['psnr'])
+        K.frame_ssim(target, p, buf['ssim'])
+        return buf
+
+    def metrics(self, gen=None):
+        """metrics_fn (base_model.py:113-130): mean psnr / mse / ssim over the future frames of the prior unroll."""
+        gen = self.generate() if gen is None else gen
+        fut = self.T - self.hp.context_frames
+        buf = {k: torch.empty(fut, self.B, device=self.device) for k in self.METRICS}
+        self._frame_metrics(gen[:, self.B:] if self.nz else gen, buf)
+        return OrderedDict((k, buf[k].mean()) for k in self.METRICS)
+
+    def eval_outputs_and_metrics(self, num_samples=100, noises=None):
+        """eval_outputs_and_metrics_fn (base_model.py:132-227): draw num_samples prior unrolls; per metric keep, for every
+        sequence, the sample whose time-mean is smallest / largest, and the running mean.  noises: optional list of noise dicts
+        (one per sample; default = fresh draws).  Returns (eval_outputs, eval_metrics) with the reference's keys, time-major;
+        the lpips / eval_diversity entries need external network weights and are not produced."""
+        hp, B, dev = self.hp, self.B, self.device
+        fut = self.T - hp.context_frames
+        outs, mets = OrderedDict(), OrderedDict()
+        outs['eval_images'] = self.images_tm
+        buf = {k: torch.empty(fut, B, device=dev) for k in self.METRICS}
+        if not self.nz:                                               # deterministic model (:163-168)
+            gen = self.generate(noises[0] if noises else None)
+            self._frame_metrics(gen, buf)
+            for k in self.METRICS:
+                for sfx in ('min', 'avg', 'max'):
+                    mets['eval_%s/%s' % (k, sfx)] = buf[k]
+            outs['eval_gen_images'] = gen
+            return outs, mets
+        shape = (self.T1, B) + tuple(self.image_shape)
+        st = {}
+        for k in self.METRICS:                                         # initializer (:201-210)
+            st[k] = dict(min=torch.full((fut, B), float('inf'), device=dev), sum=torch.zeros(fut, B, device=dev),
+                         max=torch.full((fut, B), float('-inf'), device=dev), gmin=torch.zeros(shape, device=dev),
+                         gsum=torch.zeros(shape, device=dev), gmax=torch.zeros(shape, device=dev))
+        cmin = torch.zeros(B, dtype=torch.int32, device=dev)
+        cmax = torch.zeros(B, dtype=torch.int32, device=dev)
+        for s_i in range(num_samples):                                 # accum_gen_images_and_metrics_fn (:176-198)
+            gen = self.generate(noises[s_i] if noises else self.default_noise(
+                torch.Generator().manual_seed(7919 * (self.step + 1) + s_i)))
+            prior = gen[:, B:]                                         # the prior unroll ('gen_images')
+            self._frame_metrics(prior, buf)
+            for k in self.METRICS:
+                a = st[k]
+                K.eval_accumulate(buf[k], a['min'], a['sum'], a['max'], cmin, cmax)
+                K.select_batch(cmin, prior, a['gmin'])
+                K.select_batch(cmax, prior, a['gmax'])
+                K.select_batch(None, prior, a['gsum'], mode=1)
+        inv = 1.0 / float(num_samples)
+        for k in self.METRICS:                                         # (:215-221)
+            a = st[k]
+            K.axpby(inv, a['gsum'].reshape(-1), 0.0, a['gsum'].reshape(-1), a['gsum'].reshape(-1))
+            K.axpby(inv, a['sum'].reshape(-1), 0.0, a['sum'].reshape(-1), a['sum'].reshape(-1))
+            outs['eval_gen_images_%s/min' % k] = a['gmin']
+            outs['eval_gen_images_%s/avg' % k] = a['gsum']
+            outs['eval_gen_images_%s/max' % k] = a['gmax']
+            mets['eval_%s/min' % k] = a['min']
+            mets['eval_%s/avg' % k] = a['sum']
+            mets['eval_%s/max' % k] = a['max']
+        return outs, mets
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # plug-in functions with the reference's signatures
@@ -551,6 +622,23 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         if self.engine.nz:
             self.outputs['gen_images_enc'] = gen[:, :self.engine.B].transpose(0, 1)
         return self.outputs
+
+    def metrics_fn(self, inputs=None, outputs=None):
+        """base_model.py:113-130 on the current inputs (psnr / mse / ssim; lpips needs external weights)."""
+        if inputs is not None:
+            self.inputs = inputs
+            self.engine.set_images(self.inputs['images'])
+        self.metrics = self.engine.metrics()
+        return self.metrics
+
+    def eval_outputs_and_metrics_fn(self, inputs=None, outputs=None, num_samples=None, num_samples_for_diversity=None,
+                                    parallel_iterations=None, noises=None):
+        """base_model.py:132-227: best / mean / worst of num_samples prior samples per sequence (time-major tensors)."""
+        if inputs is not None:
+            self.inputs = inputs
+            self.engine.set_images(self.inputs['images'])
+        self.eval_outputs, self.eval_metrics = self.engine.eval_outputs_and_metrics(num_samples or self.eval_num_samples, noises)
+        return self.eval_outputs, self.eval_metrics
 
     def restore(self, values):
         self.engine.store.load(values)
