@@ -285,6 +285,10 @@ int savp_convgru_out_fwd(void* stream, const SavpGruArgs* a);
 int savp_convgru_out_bwd(void* stream, const SavpGruArgs* a);
 int savp_convgru_gates_bwd(void* stream, const SavpGruArgs* a);
 
+/* uint8 frames [B, T, frame] -> float32 time-major [T, B, frame] * (1/255): tf.image.convert_image_dtype (base_dataset.py:187)
+ * + transpose_batch_time (tf_utils.py:118-122) for batches delivered by libsavp_io.so (include/savp_io.h); frame % 4 == 0 */
+int savp_u8_frames_to_f32(void* stream, const uint8_t* in, float* out, int32_t B, int32_t T, int64_t frame);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Evaluation metrics and the best-of-N sampling fold (metrics.hip).  Time-major [T, B, ...] tensors with
  * explicit element strides (x_st = time, x_sb = batch); frames are contiguous (H*W*C floats).

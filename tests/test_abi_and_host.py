@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.savp_version().startswith(b'savp_hip')
 
 
+def test_io_library_exports_every_declared_symbol():
+    """libsavp_io.so (host C++ input pipeline) exports everything include/savp_io.h declares."""
+    from video_prediction_amd import io as sio
+    txt = open(os.path.join(ROOT, 'include', 'savp_io.h')).read()
+    syms = sorted(set(re.findall(r'\b(savp_[a-z0-9_]+)\s*\(', txt)))
+    assert len(syms) >= 11
+    sio.get()
+    raw = ctypes.CDLL(sio.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), 'libsavp_io.so does not export %s' % s
+
+
 def test_ops_fail_loudly_without_device():
     import torch
     from video_prediction_amd import kernels as K, lib
@@ -39,7 +51,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'video_prediction_amd')
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h'):
+            if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h') or f.endswith('.cpp'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), '%s imports the oracle' % f
 

@@ -64,3 +64,31 @@ def test_flow_warp_and_dna():
 def test_eval_metrics_and_sampling_fold():
     from tests import gpu_checks
     _run(gpu_checks.check_metrics)
+
+
+def test_input_pipeline_to_device(tmp_path):
+    """TFRecords (written by the oracle) -> C++ pipeline -> uint8 over PCIe -> savp_u8_frames_to_f32: float32 images in [0,1],
+    bit-equal to tf.image.convert_image_dtype's x * (1/255) (base_dataset.py:187)."""
+    import numpy as np
+    import torch
+    from oracle import tfrecord as R
+    from video_prediction_amd import kernels as K
+    from video_prediction_amd.datasets import get_dataset_class
+    rng = np.random.default_rng(0)
+    d = tmp_path / 'test'
+    d.mkdir()
+    frames = rng.integers(0, 256, (6, 30, 64, 64, 3), dtype=np.uint8)
+    R.write_records(str(d / 'traj_0_to_5.tfrecords'),
+                    [R.encode_example({'%d/image_aux1/encoded' % t: frames[i, t].tobytes() for t in range(30)}) for i in range(6)])
+    u8 = torch.from_numpy(frames[:4, :12]).cuda().contiguous()
+    out = torch.empty(12, 4, 64, 64, 3, device='cuda')
+    K.u8_frames_to_f32(u8, out)
+    want = (frames[:4, :12].astype(np.float32) * np.float32(1.0 / 255.0)).transpose(1, 0, 2, 3, 4)
+    assert np.array_equal(out.cpu().numpy(), want)
+    ds = get_dataset_class('bair')(str(tmp_path), mode='test', num_epochs=1, hparams='sequence_length=12')
+    it = ds.make_batch(4)
+    batch = next(it)
+    assert batch['images'].shape == (4, 12, 64, 64, 3)
+    assert np.array_equal(batch['images'].cpu().numpy(), frames[:4, :12].astype(np.float32) * np.float32(1.0 / 255.0))
+    with pytest.raises(StopIteration):                      # 6 examples, batch 4, drop_remainder
+        next(it)

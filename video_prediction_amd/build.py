@@ -48,7 +48,23 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(OUT) or force:
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    build_io(force=force, verbose=verbose)
     return OUT
+
+
+def build_io(force=False, verbose=False):
+    """libsavp_io.so: the host-side C++ input pipeline (include/savp_io.h), plain g++."""
+    src = os.path.join(HERE, 'csrc_host', 'tfrecord_pipeline.cpp')
+    out = os.path.join(HERE, 'libsavp_io.so')
+    hdr = os.path.join(INCLUDE, 'savp_io.h')
+    if force or _newer(src, out, (hdr,)):
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-I' + INCLUDE, src, '-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('g++ failed:\n' + r.stdout)
+    return out
 
 
 if __name__ == '__main__':

@@ -375,3 +375,32 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
                        (long long)K, C, W, bias, scale, out, nsub);
     return LAUNCH_OK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// uint8 frames [B, T, F] (batch-major, as the input pipeline delivers them) -> float32 [T, B, F] * (1/255):
+// tf.image.convert_image_dtype(uint8 -> float32) (base_dataset.py:187) fused with transpose_batch_time
+// (base_model.py:283 / tf_utils.py:118-122).  4 bytes per thread per step.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void u8_frames_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int T, long long F) {
+    const int t = blockIdx.y, b = blockIdx.z;
+    const uint8_t* src = in + ((long long)b * T + t) * F;
+    float* dst = out + ((long long)t * B + b) * F;
+    const float scale = (float)(1.0 / 255.0);
+    const long long F4 = F / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < F4; i += (long long)gridDim.x * blockDim.x) {
+        const uchar4 v = reinterpret_cast<const uchar4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+    for (long long i = F4 * 4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < F; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i] * scale;
+}
+
+extern "C" int savp_u8_frames_to_f32(void* stream, const uint8_t* in, float* out, int32_t B, int32_t T, int64_t frame) {
+    // frame = H*W*C values per frame; requires frame % 4 == 0 and 4- / 16-byte aligned buffers (true for every dataset shape)
+    if (!in || !out || B < 1 || T < 1 || frame < 4 || (frame % 4) != 0) return SAVP_EINVAL;
+    if ((((uintptr_t)in) & 3) != 0 || (((uintptr_t)out) & 15) != 0) return SAVP_EINVAL;
+    unsigned gx = (unsigned)((frame / 4 + NT - 1) / NT);
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(u8_frames_kernel, dim3(gx, (unsigned)T, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, in, out, B, T, (long long)frame);
+    return LAUNCH_OK();
+}

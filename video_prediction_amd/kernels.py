@@ -738,3 +738,13 @@ def select_batch(cond, x, out, mode=0):
     o_st, o_sb, _ = _tb(out)
     lib.check(_L().savp_select_batch(lib.stream(), _p(cond), _p(x), x_st, x_sb, _p(out), o_st, o_sb, x.shape[0], x.shape[1], inner,
                                      int(mode)), 'savp_select_batch')
+
+
+def u8_frames_to_f32(frames_u8, out_tm):
+    """uint8 [B, T, H, W, C] -> float32 time-major [T, B, H, W, C] / 255 (base_dataset.py:187 + transpose_batch_time)."""
+    if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()):
+        raise RuntimeError('expected a contiguous uint8 device tensor')
+    lib.require_device(out_tm)
+    B, T = frames_u8.shape[:2]
+    frame = frames_u8[0, 0].numel()
+    lib.check(_L().savp_u8_frames_to_f32(lib.stream(), frames_u8.data_ptr(), out_tm.data_ptr(), B, T, frame), 'savp_u8_frames_to_f32')

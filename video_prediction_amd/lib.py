@@ -160,6 +160,7 @@ register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i6
 register('savp_sigmoid_bwd', [c_vp, SavpView, SavpView, c_vp, c_i64, c_i32, c_i32])
 register('savp_axpby', [c_vp, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp])
 register('savp_fill_view', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32])
+register('savp_u8_frames_to_f32', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64])
 register('savp_frame_mse_psnr', [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp])
 register('savp_frame_ssim', [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp])
 register('savp_eval_accumulate', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32])
