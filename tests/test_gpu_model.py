@@ -178,3 +178,29 @@ def test_best_of_n_sampling_eval_vs_oracle():
     """eval_outputs_and_metrics_fn (base_model.py:132-227): psnr / mse / ssim, per-sequence best / mean / worst over samples."""
     from tests import gpu_model_checks as G
     _assert_ok(G.check_eval_best_of_n())
+
+
+def test_checkpoint_save_restore_round_trip(tmp_path):
+    """model.save -> TensorFlow V2 checkpoint files -> model.restore into a differently initialised model: identical variables,
+    global_step and generated frames (tf_utils.py:528-559, savp_model.py:848-855)."""
+    from tests.gpu_model_checks import make_hparams
+    from video_prediction_amd.models import get_model_class
+    Model = get_model_class('savp')
+    hp = dict(context_frames=2, sequence_length=5, nz=8)
+    images = torch.rand(2, 5, 64, 64, 3).cuda()
+    a = Model(mode='test', hparams_dict=hp)
+    a.build_graph({'images': images})
+    a.engine.step = 321
+    a.save(str(tmp_path / 'model-321'))
+    b = Model(mode='test', hparams_dict=hp)
+    b.build_graph({'images': images})
+    for n in b.engine.store.names():                      # scramble
+        b.engine.store[n].mul_(0.5)
+    b.restore(str(tmp_path))                              # directory -> latest checkpoint
+    assert b.engine.step == 321
+    for n in a.engine.store.names():
+        assert torch.equal(a.engine.store[n], b.engine.store[n]), n
+    noise = a.engine.default_noise()
+    ga = a.engine.generate(noise).clone()
+    gb = b.engine.generate(noise)
+    assert float((ga - gb).abs().max()) <= 1e-5          # same weights; the norm statistics are summed atomically

@@ -145,6 +145,8 @@ class SAVPEngine(object):
                 noise[key] = (torch.rand(ns, B, generator=g) < prob) if prob >= 0.001 else torch.zeros(ns, B, dtype=torch.bool)
         L = T1
         idx = {}
+        if not self.train or L - hp.clip_length + 1 <= 0:      # no discriminator clips to draw (inference / too short a sequence)
+            return noise
         for phase in ('pre', 'post'):
             idx[phase] = {k: (torch.randint(0, L, (B,), generator=g), torch.randint(0, L - hp.clip_length + 1, (B,), generator=g))
                           for k in ('enc_real', 'enc_fake', 'real', 'fake')}
@@ -640,5 +642,32 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         self.eval_outputs, self.eval_metrics = self.engine.eval_outputs_and_metrics(num_samples or self.eval_num_samples, noises)
         return self.eval_outputs, self.eval_metrics
 
-    def restore(self, values):
-        self.engine.store.load(values)
+    def restore(self, checkpoints, restore_to_checkpoint_mapping=None):
+        """savp_model.py:848-855 / base_model.py:229-247: `checkpoints` is a TensorFlow V2 checkpoint directory or prefix (or a
+        list of them, each holding a subset of the variables), read by video_prediction_amd.checkpoint without TensorFlow; a
+        {variable name: array} dict is accepted as well.  Names fall back from `savp_cell` to `dna_cell` like the reference."""
+        if isinstance(checkpoints, dict):
+            self.engine.store.load(checkpoints)
+            return
+        from .. import checkpoint as CK
+
+        def mapping(name, names):
+            name = name.split(':')[0]
+            if name not in names:
+                name = name.replace('savp_cell', 'dna_cell')
+            return name
+        log = lambda head, items: print(head + '\n' + '\n'.join('     ' + i for i in items))
+        wanted = self.engine.store.names() + ['global_step']
+        vals = CK.restore_values(checkpoints, wanted, restore_to_checkpoint_mapping or mapping, log=log)
+        step = vals.pop('global_step', None)
+        self.engine.store.load(vals)
+        if step is not None:
+            self.engine.step = int(step)
+            VideoPredictionModel.global_step = int(step)
+
+    def save(self, prefix):
+        """tf.train.Saver.save equivalent: all variables (TF names) + global_step as a V2 checkpoint at `prefix`."""
+        from .. import checkpoint as CK
+        vals = self.engine.store.to_numpy()
+        vals['global_step'] = np.asarray(self.engine.step, dtype=np.int64)
+        CK.write_checkpoint(prefix, vals)
