@@ -26,10 +26,12 @@ struct WgP {
     long long x_sn, y_sn;
     int x_sh, x_sw, y_sh, y_sw;
     int H, W, Ho, Wo, Cx, Cy, ph, pw, kw, sh, sw;
+    int D, Do, kd, pd, khw;            // depth (3-D convs, depth stride 1): input / output planes, depth taps, pad, kh*kw
+    long long x_sd, y_sd;
     int taps, G16, CG, S;              // taps, 16-channel groups of Cx, groups per chunk, pixel splits
     int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
     int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
-    unsigned long long magC4, magPW, magTaps, magTHW, magTW;
+    unsigned long long magC4, magPW, magTaps, magTHW, magTW, magPP, magDo, magKHW;
 };
 
 // NW waves x MTW row tiles (32 rows of dW each) per workgroup.  NPF = float4 prefetch registers per thread for the patch.
@@ -44,8 +46,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int cgc = min(q.CG, q.G16 - ca);                     // groups in this chunk
     const int ngroups = cgc * q.taps;                          // (cx16, tap) row groups of this workgroup
     const int cy0 = nb * 32;
-    const int patch_elems = q.PH * q.pitch;
-    __bf16* patch = reinterpret_cast<__bf16*>(smem);           // [2][PH * pitch]
+    const int pplane = q.PH * q.pitch;                         // one depth plane of the patch
+    const int patch_elems = q.kd * pplane;                     // the kd input planes under one output plane
+    __bf16* patch = reinterpret_cast<__bf16*>(smem);           // [2][kd][PH * pitch]
     __bf16* dyt = patch + 2 * patch_elems;                     // [2][64 * 32]
 
     // pixel tiles of this split
@@ -53,21 +56,24 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int t_begin = sp * per, t_end = min(q.PT, t_begin + per);
     if (t_begin >= t_end) return;
 
-    // ---- staging maps, packed into one register per slot: LDS offset | c4 << 15 | py << 21 | px << 26 | valid << 31 ----
-    unsigned pinfo[NPF];
+    // ---- staging maps, two packed registers per slot: LDS offset | valid << 31 ; c4 | py << 8 | px << 16 | plane << 24 -------
+    unsigned pinfo[NPF], pcoord[NPF];
     {
         const int c4n = q.CG * 4;
-        const int ptotal = q.PH * q.PW * c4n;
+        const int per_plane = q.PH * q.PW * c4n;
+        const int ptotal = q.kd * per_plane;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + NT * i;
-            const int pix = (int)fastdiv((unsigned)idx, q.magC4);
-            const int c4 = idx - pix * c4n;
+            const int plane = (int)fastdiv((unsigned)idx, q.magPP);
+            const int rem = idx - plane * per_plane;
+            const int pix = (int)fastdiv((unsigned)rem, q.magC4);
+            const int c4 = rem - pix * c4n;
             const int pyy = (int)fastdiv((unsigned)pix, q.magPW);
             const int pxx = pix - pyy * q.PW;
             const bool ok = idx < ptotal;
-            pinfo[i] = ok ? ((unsigned)(pyy * q.pitch + pxx * q.CP + c4 * 4) | ((unsigned)c4 << 15) | ((unsigned)pyy << 21) |
-                             ((unsigned)pxx << 26) | (1u << 31)) : 0u;
+            pinfo[i] = ok ? ((unsigned)(plane * pplane + pyy * q.pitch + pxx * q.CP + c4 * 4) | (1u << 31)) : 0u;
+            pcoord[i] = (unsigned)c4 | ((unsigned)pyy << 8) | ((unsigned)pxx << 16) | ((unsigned)plane << 24);
         }
     }
     float4 pf[NPF], pd[NPD];
@@ -75,24 +81,28 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const bool do_db = (q.db != nullptr) && (mc == 0);
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int t) {
-        const int img = (int)fastdiv((unsigned)t, q.magTHW);
-        const int r = t - img * q.tHW;
+        const int gi = (int)fastdiv((unsigned)t, q.magTHW);          // (sample, output plane)
+        const int r = t - gi * q.tHW;
+        const int img = (int)fastdiv((unsigned)gi, q.magDo);
+        const int dout = gi - img * q.Do;
         const int ty = (int)fastdiv((unsigned)r, q.magTW);
         const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
         const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw;       // patch origin in the input plane
         const float* __restrict__ xs = q.x + (long long)img * q.x_sn + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw + ca * 16;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            unsigned inf = pinfo[i];
-            asm volatile("" : "+v"(inf));                      // keep the unpacking inside the loop (register pressure)
-            const int c = (int)((inf >> 15) & 63u) << 2, pyy = (int)((inf >> 21) & 31u), pxx = (int)((inf >> 26) & 31u);
+            unsigned inf = pinfo[i], co = pcoord[i];
+            asm volatile("" : "+v"(inf), "+v"(co));            // keep the unpacking inside the loop (register pressure)
+            const int c = (int)(co & 255u) << 2, pyy = (int)((co >> 8) & 255u), pxx = (int)((co >> 16) & 255u);
+            const int dz = dout - q.pd + (int)(co >> 24);      // input plane of this patch plane (depth stride 1)
             const bool ok = (inf >> 31) && (unsigned)(iy0 + pyy) < (unsigned)q.H && (unsigned)(ix0 + pxx) < (unsigned)q.W &&
-                            ca * 16 + c < q.Cx;
+                            ca * 16 + c < q.Cx && (unsigned)dz < (unsigned)q.D;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = ldg4(xs + pyy * q.x_sh + pxx * q.x_sw + c);
+            if (ok) v = ldg4(xs + (long long)dz * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c);
             pf[i] = v;
         }
-        const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw + cy0;
+        const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh +
+                                       (long long)ox0 * q.y_sw + cy0;
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
             const int idx = tid + NT * i;                      // 64 pixels x 8 float4
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             asm volatile("" : "+v"(inf));
             if (inf >> 31) {
                 bf16x4 o = {(__bf16)pf[i].x, (__bf16)pf[i].y, (__bf16)pf[i].z, (__bf16)pf[i].w};
-                *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffu)) = o;
+                *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffffffu)) = o;
             }
         }
         __bf16* pb = dyt + buf * 64 * 32;
@@ -140,8 +150,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         const int lgc = min(lg, ngroups - 1);
         const int cl = (int)fastdiv((unsigned)lgc, q.magTaps);
         const int tap = lgc - cl * q.taps;
-        const int u = tap / q.kw, v = tap - u * q.kw;
-        a_tile[i] = (a_lane + u * q.pitch + v * q.CP + cl * 16) * 2;   // bytes
+        const int jd = (int)fastdiv((unsigned)tap, q.magKHW);
+        const int t2 = tap - jd * q.khw;
+        const int u = t2 / q.kw, v = t2 - u * q.kw;
+        a_tile[i] = (a_lane + jd * pplane + u * q.pitch + v * q.CP + cl * 16) * 2;   // bytes
     }
 
     f32x16 acc[MTW];
@@ -229,7 +241,7 @@ static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
-    if (!(p.bf16 && a->D == 1 && a->Do == 1 && a->kd == 1 && a->sd == 1 && a->sh <= 2 && a->sw <= 2 && a->Cx % 4 == 0 &&
+    if (!(p.bf16 && a->sd == 1 && a->x_sd % 4 == 0 && a->y_sd % 4 == 0 && a->sh <= 2 && a->sw <= 2 && a->Cx % 4 == 0 &&
           a->Cy % 4 == 0 && xs4 && ys4 && a->kh <= 8 && a->kw <= 8 && a->Ho * a->Wo >= 64))
         return false;
     if (a->x_sh * (long long)(a->H + 8) >= (1ll << 31) || a->y_sh * (long long)(a->Ho + 8) >= (1ll << 31)) return false;
@@ -238,10 +250,10 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.x_sn = a->x_sn; q.y_sn = a->y_sn;
     q.x_sh = (int)a->x_sh; q.x_sw = (int)a->x_sw; q.y_sh = (int)a->y_sh; q.y_sw = (int)a->y_sw;
     q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw; q.sh = a->sh; q.sw = a->sw;
-    q.taps = a->kh * a->kw;
+    q.D = a->D; q.Do = a->Do; q.kd = a->kd; q.pd = a->pd; q.khw = a->kh * a->kw; q.x_sd = a->x_sd; q.y_sd = a->y_sd;
+    q.taps = a->kd * a->kh * a->kw;
     q.G16 = (a->Cx + 15) / 16;
     q.PH = 7 * a->sh + a->kh; q.PW = 7 * a->sw + a->kw;           // input rows / columns under an 8x8 output tile
-    if (q.PH > 31 || q.PW > 31) return false;                    // packed staging map: 5 bits per coordinate
     // workgroup shape
     const int groups_all = q.taps * q.G16;
     int nw, mtw;
@@ -256,7 +268,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     }
     const int nthreads = 64 * nw;
     const int npf_max = (nw == 8) ? 8 : 16;
-    const int cg_pf = (npf_max * nthreads) / (4 * q.PH * q.PW);  // prefetch-register bound on the channel groups
+    const int cg_pf = (npf_max * nthreads) / (4 * a->kd * q.PH * q.PW);  // prefetch-register bound on the channel groups
     int cg = (2 * nw * mtw) / q.taps;                            // row groups per workgroup / taps
     if (cg > q.G16) cg = q.G16;
     if (cg > cg_pf) cg = cg_pf;
@@ -268,20 +280,21 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     while ((cpu % 8) != 2 && (cpu % 8) != 6) ++cpu;
     q.CP = cpu * 16;
     q.pitch = q.PW * q.CP;
-    if (q.PH * q.pitch >= 32768) return false;                   // packed LDS offsets are 15 bits
+    if (q.PH > 255 || q.PW > 255 || cg * 4 > 255 || a->kd > 127) return false;   // packed staging coordinates are 8 bits each
     const int tH = (a->Ho + 7) / 8;
     q.tW = (a->Wo + 7) / 8; q.tHW = tH * q.tW;
-    q.PT = a->N * q.tHW;
+    q.PT = a->N * a->Do * q.tHW;
     long long s = 768 / ((long long)NB * MC);
     if (s < 1) s = 1;
     if (s > q.PT) s = q.PT;
     q.S = (int)s;
     q.magC4 = magic40(cg * 4); q.magPW = magic40(q.PW); q.magTaps = magic40(q.taps);
     q.magTHW = magic40(q.tHW); q.magTW = magic40(q.tW);
+    q.magPP = magic40(q.PH * q.PW * cg * 4); q.magDo = magic40(a->Do); q.magKHW = magic40(q.khw);
     if ((double)q.PT * q.tHW >= 1099511627776.0) return false;
-    const size_t lds = (size_t)2 * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
+    const size_t lds = (size_t)2 * a->kd * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
     if (lds > 160 * 1024) return false;
-    const int npf = (q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
+    const int npf = (a->kd * q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
     dim3 grid((unsigned)q.S, (unsigned)NB, (unsigned)MC);
     hipError_t err;
     if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp<8, 4, 4>(q, grid, lds, st) : launch_wgp<8, 4, 8>(q, grid, lds, st);
