@@ -572,19 +572,68 @@ def image_sn_discriminator(vs, images, ndf=64, sn_state=None):
 # --------------------------------------------------------------------------------------------
 # posterior / discriminator / generator fns
 # --------------------------------------------------------------------------------------------
+def basic_lstm_unroll(kernel, bias, xs, forget_bias=1.0):
+    """tf.contrib.rnn.BasicLSTMCell(num_units) under tf.nn.dynamic_rnn (tf_utils.unroll_rnn, tf_utils.py:134-141), zero
+    initial state.  kernel [in + units, 4*units], gate order i, j, f, o (rnn_cell_impl.BasicLSTMCell.call):
+      c' = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o).   xs [T, B, in] -> hs [T, B, units]."""
+    units = kernel.shape[1] // 4
+    T, B = xs.shape[:2]
+    c = torch.zeros(B, units, dtype=xs.dtype)
+    h = torch.zeros(B, units, dtype=xs.dtype)
+    out = []
+    for t in range(T):
+        gates = torch.cat([xs[t], h], dim=-1) @ kernel + bias
+        i, j, f, o = torch.chunk(gates, 4, dim=-1)
+        c = c * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * torch.tanh(j)
+        h = torch.tanh(c) * torch.sigmoid(o)
+        out.append(h)
+    return torch.stack(out)
+
+
+def _e_rnn(vs, h, hp):
+    """savp_model.py:32-43 / :66-76: dense to nef*4 under scope layer_{n_layers+1}, then the `rnn` cell over time under scope
+    hparams.rnn (dynamic_rnn's default scope 'rnn' -> variables '<rnn>/rnn/basic_lstm_cell/{kernel,bias}').  h [T, B, F]."""
+    T, B = h.shape[:2]
+    s = vs.sub('layer_%d' % (hp.n_layers + 1))
+    h = ops.dense(h.reshape(T * B, -1), s['dense/kernel'], s['dense/bias']).reshape(T, B, -1)
+    if hp.rnn != 'lstm':
+        raise NotImplementedError('rnn=%s (GRUCell) is not restated' % hp.rnn)
+    r = vs.sub(hp.rnn)
+    return basic_lstm_unroll(r['rnn/basic_lstm_cell/kernel'], r['rnn/basic_lstm_cell/bias'], h)
+
+
+def _z_heads(vs, h):
+    T, B = h.shape[:2]
+    flat = h.reshape(T * B, -1)
+    z_mu = ops.dense(flat, vs['z_mu/dense/kernel'], vs['z_mu/dense/bias']).reshape(T, B, -1)
+    z_ls = ops.dense(flat, vs['z_log_sigma_sq/dense/kernel'], vs['z_log_sigma_sq/dense/bias'])
+    return {'zs_mu': z_mu, 'zs_log_sigma_sq': torch.clamp(z_ls, -10, 10).reshape(T, B, -1)}
+
+
 def posterior_fn(vs, inputs, hp):
-    """savp_model.py:21-51 (use_e_rnn=False, no actions)."""
+    """savp_model.py:21-51 (no actions)."""
     images = inputs['images']
     image_pairs = torch.cat([images[:-1], images[1:]], dim=-1)
     T1, B = image_pairs.shape[:2]
     flat = image_pairs.reshape((T1 * B,) + tuple(image_pairs.shape[2:]))
-    h = encoder(vs, flat, nef=hp.nef, n_layers=hp.n_layers, norm_layer=hp.norm_layer)
+    h = encoder(vs, flat, nef=hp.nef, n_layers=hp.n_layers, norm_layer=hp.norm_layer).reshape(T1, B, -1)
     if hp.use_e_rnn:
-        raise NotImplementedError('use_e_rnn')
-    z_mu = ops.dense(h, vs['z_mu/dense/kernel'], vs['z_mu/dense/bias']).reshape(T1, B, -1)
-    z_ls = ops.dense(h, vs['z_log_sigma_sq/dense/kernel'], vs['z_log_sigma_sq/dense/bias'])
-    z_ls = torch.clamp(z_ls, -10, 10).reshape(T1, B, -1)
-    return {'zs_mu': z_mu, 'zs_log_sigma_sq': z_ls}
+        h = _e_rnn(vs, h, hp)
+    return _z_heads(vs, h)
+
+
+def prior_fn(vs, inputs, hp):
+    """savp_model.py:54-85: encoder on the context_frames-1 context pairs, zero features for the remaining
+    sequence_length - context_frames steps, dense + rnn over all T-1 steps, the two heads."""
+    images = inputs['images']
+    c = hp.context_frames
+    image_pairs = torch.cat([images[:c - 1], images[1:c]], dim=-1)
+    Tc, B = image_pairs.shape[:2]
+    flat = image_pairs.reshape((Tc * B,) + tuple(image_pairs.shape[2:]))
+    h = encoder(vs, flat, nef=hp.nef, n_layers=hp.n_layers, norm_layer=hp.norm_layer).reshape(Tc, B, -1)
+    h = torch.cat([h, torch.zeros((hp.sequence_length - c,) + tuple(h.shape[1:]), dtype=h.dtype)], dim=0)
+    h = _e_rnn(vs, h, hp)
+    return _z_heads(vs, h)
 
 
 def discriminator_given_video_fn(vs, targets, hp, t_sample, t_start, sn_state=None):
@@ -643,8 +692,8 @@ def discriminator_fn(vs, inputs, outputs, mode, hp, indices, sn_state=None):
 
 
 def generator_fn(vs, inputs, mode, hp, noise=None):
-    """savp_model.py:699-768 (learn_prior=False; the gen_images_samples visualisation unroll :745-767 is
-    not on the train path and is omitted).
+    """savp_model.py:699-768 (the gen_images_samples visualisation unroll :745-767 is not on the train path and is
+    omitted).
 
     noise: {'eps': [T-1,B,nz], 'prior': [T-context,B,nz], 'ground_truth_sampling': bool [T-1-context,B],
             'ground_truth_sampling_enc': same for the posterior unroll}  (each unroll builds its own
@@ -653,12 +702,15 @@ def generator_fn(vs, inputs, mode, hp, noise=None):
     noise = noise or {}
     if hp.nz == 0:
         return generator_given_z_fn(vs, inputs, mode, hp, noise.get('ground_truth_sampling'))
-    if hp.learn_prior:
-        raise NotImplementedError('learn_prior')
     outputs_posterior = posterior_fn(vs.sub('encoder'), inputs, hp)
     eps = noise['eps']
     zs_posterior = outputs_posterior['zs_mu'] + torch.sqrt(torch.exp(outputs_posterior['zs_log_sigma_sq'])) * eps
-    zs_prior = torch.cat([zs_posterior[:hp.context_frames - 1], noise['prior']], dim=0)     # :724-725
+    if hp.learn_prior:                                                                      # :717-721 (noise['prior_eps'] [T-1,B,nz])
+        outputs_prior = prior_fn(vs.sub('prior'), inputs, hp)
+        zs_prior = outputs_prior['zs_mu'] + torch.sqrt(torch.exp(outputs_prior['zs_log_sigma_sq'])) * noise['prior_eps']
+    else:
+        outputs_prior = {}
+        zs_prior = torch.cat([zs_posterior[:hp.context_frames - 1], noise['prior']], dim=0)     # :724-725
     inputs_posterior = dict(inputs)
     inputs_posterior['zs'] = zs_posterior
     inputs_prior = dict(inputs)
@@ -668,6 +720,8 @@ def generator_fn(vs, inputs, mode, hp, noise=None):
     outputs = OrderedDict()
     for k, v in gen_prior.items():
         outputs[k] = v
+    for k, v in outputs_prior.items():
+        outputs[k + '_prior'] = v                                                           # :735-739
     for k, v in outputs_posterior.items():
         outputs[k + '_enc'] = v
     for k, v in gen_post.items():

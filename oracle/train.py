@@ -45,9 +45,13 @@ def gan_loss(logits, labels, gan_loss_type):
     raise ValueError('Unknown GAN loss type %s' % gan_loss_type)
 
 
-def kl_loss(mu, log_sigma_sq):
-    sigma_sq = torch.exp(log_sigma_sq)
-    return -0.5 * (1 + log_sigma_sq - mu ** 2 - sigma_sq).sum(dim=-1).mean()   # losses.py:57-60
+def kl_loss(mu, log_sigma_sq, mu2=None, log_sigma2_sq=None):
+    """losses.py:57-67: KL(N(mu, s) || N(0, I)), or against a second diagonal Gaussian (the learned prior, base_model.py:825-828)."""
+    if mu2 is None and log_sigma2_sq is None:
+        sigma_sq = torch.exp(log_sigma_sq)
+        return -0.5 * (1 + log_sigma_sq - mu ** 2 - sigma_sq).sum(dim=-1).mean()   # losses.py:57-60
+    return ((log_sigma2_sq - log_sigma_sq) / 2 + (torch.exp(log_sigma_sq) + (mu - mu2) ** 2) / (2 * torch.exp(log_sigma2_sq))
+            - 0.5).sum(dim=-1).mean()                                              # losses.py:62-67
 
 
 # ---- schedules (base_model.py:286-319) ---------------------------------------------------------
@@ -117,7 +121,8 @@ def generator_loss_fn(hp, inputs, outputs, kl_w):
                 losses['gen%s_%s_feature_cdist_loss' % (infix, nm)] = (
                     sum(cosine_distance(f, r) for f, r in zip(fk, rl)), wf_cd)
     if hp.kl_weight:
-        losses['gen_kl_loss'] = (kl_loss(outputs['zs_mu_enc'], outputs['zs_log_sigma_sq_enc']), kl_w)
+        losses['gen_kl_loss'] = (kl_loss(outputs['zs_mu_enc'], outputs['zs_log_sigma_sq_enc'], outputs.get('zs_mu_prior'),
+                                         outputs.get('zs_log_sigma_sq_prior')), kl_w)       # base_model.py:825-828
     return losses
 
 

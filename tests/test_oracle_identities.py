@@ -125,3 +125,81 @@ def test_instance_norm_is_per_sample_per_channel_biased():
     mu = x.mean(dim=(1, 2), keepdim=True)
     var = ((x - mu) ** 2).mean(dim=(1, 2), keepdim=True)
     assert np.allclose(y.numpy(), ((x - mu) / torch.sqrt(var + 1e-6) * g + b).numpy(), atol=1e-10)
+
+
+def test_basic_lstm_unroll_matches_an_independent_lstm_cell():
+    """oracle.savp.basic_lstm_unroll (BasicLSTMCell: gate order i, j, f, o, forget_bias 1 added before the sigmoid) against
+    torch.nn.LSTMCell (gate order i, f, g, o, no forget bias) with the weights re-mapped."""
+    import torch
+    from oracle import savp as OS
+    torch.manual_seed(0)
+    T, B, nin, units = 5, 3, 7, 6
+    kernel = torch.randn(nin + units, 4 * units, dtype=torch.float64) * 0.3
+    bias = torch.randn(4 * units, dtype=torch.float64) * 0.1
+    xs = torch.randn(T, B, nin, dtype=torch.float64)
+    hs = OS.basic_lstm_unroll(kernel, bias, xs)
+    cell = torch.nn.LSTMCell(nin, units).double()
+    i, j, f, o = [kernel[:, k * units:(k + 1) * units] for k in range(4)]
+    bi, bj, bf, bo = [bias[k * units:(k + 1) * units] for k in range(4)]
+    w = torch.cat([i, f, j, o], dim=1)                                     # torch order: i, f, g(=j), o
+    with torch.no_grad():
+        cell.weight_ih.copy_(w[:nin].t()); cell.weight_hh.copy_(w[nin:].t())
+        cell.bias_ih.copy_(torch.cat([bi, bf + 1.0, bj, bo])); cell.bias_hh.zero_()
+        h = torch.zeros(B, units, dtype=torch.float64); c = torch.zeros_like(h)
+        ref = []
+        for t in range(T):
+            h, c = cell(xs[t], (h, c))
+            ref.append(h)
+    assert float((hs - torch.stack(ref)).abs().max()) < 1e-12
+
+
+def test_kl_between_gaussians_reduces_to_the_standard_normal_case():
+    import torch
+    from oracle import train as OT
+    torch.manual_seed(1)
+    mu, ls = torch.randn(4, 3, 8, dtype=torch.float64), torch.randn(4, 3, 8, dtype=torch.float64)
+    z = torch.zeros_like(mu)
+    assert abs(float(OT.kl_loss(mu, ls) - OT.kl_loss(mu, ls, z, z))) < 1e-12           # losses.py:57-67
+    assert abs(float(OT.kl_loss(mu, ls, mu, ls))) < 1e-12                               # KL(p || p) = 0
+    mu2, ls2 = torch.randn_like(mu), torch.randn_like(ls)
+    p = torch.distributions.Normal(mu, torch.exp(0.5 * ls)); q = torch.distributions.Normal(mu2, torch.exp(0.5 * ls2))
+    ref = torch.distributions.kl_divergence(p, q).sum(-1).mean()
+    assert abs(float(OT.kl_loss(mu, ls, mu2, ls2) - ref)) < 1e-10
+
+
+def test_prior_fn_and_e_rnn_shapes_and_context_dependence():
+    """savp_model.py:54-85: the learned prior sees only the context frames; later frames cannot influence it."""
+    import numpy as np
+    import torch
+    from oracle import savp as OS
+    rng = np.random.default_rng(0)
+    T, B, H, nz, nef = 6, 2, 16, 4, 8
+
+    class HP(object):
+        nef = 8; n_layers = 3; norm_layer = 'instance'; use_e_rnn = True; rnn = 'lstm'; context_frames = 2; sequence_length = T
+    P = {}
+    cin = 6
+    for i, cout in enumerate((nef, 2 * nef, 4 * nef)):
+        P['layer_%d/conv2d/kernel' % (i + 1)] = rng.standard_normal((4, 4, cin, cout)) * 0.1
+        P['layer_%d/conv2d/bias' % (i + 1)] = np.zeros(cout)
+        if i:
+            P['layer_%d/InstanceNorm/gamma' % (i + 1)] = np.ones(cout); P['layer_%d/InstanceNorm/beta' % (i + 1)] = np.zeros(cout)
+        cin = cout
+    P['layer_4/dense/kernel'] = rng.standard_normal((4 * nef, 4 * nef)) * 0.2; P['layer_4/dense/bias'] = np.zeros(4 * nef)
+    P['lstm/rnn/basic_lstm_cell/kernel'] = rng.standard_normal((8 * nef, 16 * nef)) * 0.2
+    P['lstm/rnn/basic_lstm_cell/bias'] = np.zeros(16 * nef)
+    for head in ('z_mu', 'z_log_sigma_sq'):
+        P[head + '/dense/kernel'] = rng.standard_normal((4 * nef, nz)) * 0.2; P[head + '/dense/bias'] = np.zeros(nz)
+    vs = OS.Scope({k: torch.tensor(v, dtype=torch.float64) for k, v in P.items()})
+    images = torch.tensor(rng.random((T, B, H, H, 3)))
+    try:
+        out = OS.prior_fn(vs, {'images': images}, HP)
+    except KeyError as ex:                                   # encoder variable naming differs: report, do not hide
+        raise AssertionError('oracle encoder expects other variable names: %s' % ex)
+    assert out['zs_mu'].shape == (T - 1, B, nz) and out['zs_log_sigma_sq'].shape == (T - 1, B, nz)
+    images2 = images.clone(); images2[2:] = torch.rand_like(images2[2:])
+    out2 = OS.prior_fn(vs, {'images': images2}, HP)
+    assert torch.equal(out['zs_mu'], out2['zs_mu'])          # frames beyond the context do not enter
+    post = OS.posterior_fn(vs, {'images': images}, HP)
+    post2 = OS.posterior_fn(vs, {'images': images2}, HP)
+    assert torch.equal(post['zs_mu'][0], post2['zs_mu'][0]) and not torch.equal(post['zs_mu'][-1], post2['zs_mu'][-1])
