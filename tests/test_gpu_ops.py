@@ -92,3 +92,19 @@ def test_input_pipeline_to_device(tmp_path):
     assert np.array_equal(batch['images'].cpu().numpy(), frames[:4, :12].astype(np.float32) * np.float32(1.0 / 255.0))
     with pytest.raises(StopIteration):                      # 6 examples, batch 4, drop_remainder
         next(it)
+
+
+def test_metric_kernels_against_committed_golden():
+    """HIP psnr / mse / ssim vs tests/golden/metrics_golden.npz (fp64 oracle values committed with their generating script)."""
+    import os
+    import numpy as np
+    import torch
+    from video_prediction_amd import kernels as K
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'metrics_golden.npz'))
+    a, b = torch.tensor(d['a']).cuda(), torch.tensor(d['b']).cuda()
+    T, B = a.shape[:2]
+    mse = torch.empty(T, B, device='cuda'); psnr = torch.empty(T, B, device='cuda'); ssim = torch.empty(T, B, device='cuda')
+    K.frame_mse_psnr(a, b, mse=mse, psnr=psnr)
+    K.frame_ssim(a, b, ssim)
+    for name, got in (('mse', mse), ('psnr', psnr), ('ssim', ssim)):
+        assert np.allclose(got.cpu().numpy(), d[name], rtol=2e-5, atol=0), name
