@@ -159,7 +159,8 @@ def is_trainable(name):
 
 
 def train_step(params, opt_state, inputs, hp, noise, d_indices_pre, d_indices_post, step, mode='train'):
-    """One sess.run(train_op): D Adam update, then G Adam update against the *updated* D.
+    """One sess.run(train_op): D Adam update, then G Adam update against the *updated* D (against the pre-update D when
+    hp.joint_gan_optimization: no control dependency / read replacement, base_model.py:498-505).
 
     params: dict name -> tensor (leaf, requires_grad irrelevant; copied).  opt_state: dict with 'm','v' dicts and
     't_d','t_g' counters (Adam's own beta-power accumulators, one optimizer per network).
@@ -204,8 +205,9 @@ def train_step(params, opt_state, inputs, hp, noise, d_indices_pre, d_indices_po
         info['d_grads'] = {k: g for k, g in zip(d_names, grads) if g is not None}
         # post-update discriminator on the (attached) generator outputs, pre-assign u
         P2 = dict(P)
-        for k in d_names:
-            P2[k] = new_params[k]
+        if not hp.joint_gan_optimization:          # base_model.py:498-501: replace_read_ops(g_loss_post, d_vars) only when sequential
+            for k in d_names:
+                P2[k] = new_params[k]
         d_out_post = savp.discriminator_fn(savp.Scope(P2).sub('discriminator'), inputs, gen_outputs, mode, hp,
                                            d_indices_post, sn_state=None)
         outputs_post = OrderedDict(list(gen_outputs.items()) + list(d_out_post.items()))

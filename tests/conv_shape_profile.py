@@ -10,7 +10,9 @@ def run():
     from tests.gpu_model_checks import make_hparams
     from video_prediction_amd.models.savp_model import SAVPEngine
     from video_prediction_amd import kernels as K
+    os.environ['SAVP_GRAPH'] = '0'
     K.set_conv_precision('bf16'); K.enable_autotune(True)
+    K.load_tuning(os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
     B, T = 16, 30
     hp = make_hparams(context_frames=2, sequence_length=T, batch_size=B, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,

@@ -37,6 +37,8 @@ def golden_generator(nz, name, T=4, B=1, H=32, W=32, C=3):
         out = OS.generator_fn(OS.Scope(P).sub('generator'), {'images': torch.tensor(images)}, 'test', hp, noise)
     save = {'images': images.astype(np.float32), 'gen_images': out['gen_images'].numpy(),
             'masks_argmax': out['masks'].squeeze(-2).argmax(-1).numpy().astype(np.int8)}
+    top2 = out['masks'].squeeze(-2).topk(2, dim=-1).values
+    save['masks_margin'] = (top2[..., 0] - top2[..., 1]).numpy().astype(np.float32)     # argmax is only asked where this is > 1e-5
     if nz:
         save['gen_images_enc'] = out['gen_images_enc'].numpy()
         save['eps'] = noise['eps'].numpy()

@@ -56,7 +56,9 @@ def make_noise(hp, B, seed=1, sampling=True):
 
 
 def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, **over):
-    hp = make_hparams(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid', **over)
+    hpd = dict(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid')
+    hpd.update(over)
+    hp = make_hparams(**hpd)
     specs = V.variable_specs(hp, (H, W, C), mode='test')
     vals = V.init_variables(specs, seed=4)
     # perturb norm params / biases so that they matter
@@ -191,6 +193,101 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
                 cnt += d.numel()
             out.append((t + '/param_mean_abs_diff_over_lr', tot / cnt / lr, 0.05))
     return out
+
+
+def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
+    """One train step at the recipe's sequence / clip lengths (hparams/bair_action_free/ours_savp/model_hparams.json: T=30,
+    clip_length=10, nz=8) with B scaled down, run on BOTH datapaths from the same variables / inputs / noise and compared with ONE
+    fp64 oracle step.  fp32 mode: same yardstick as check_train_step.  bf16 mode (bench default: conv operands rounded to bf16,
+    fp32 accumulate): losses within 2e-2 of max(|ref|, 0.05) (the LSGAN generator terms (D-1)^2 sit at ~1e-3 after the D update, so
+    a plain relative error would only measure cancellation), the generated frames within 5e-2 absolute, per-variable gradients
+    within 0.25 relative L2 = cosine >= 0.97 (measured on MI355X: 0.11 worst for D, 0.19 worst for G against the fp32 datapath;
+    the spread comes from ReLU / LeakyReLU masks that flip under the 4e-3 operand rounding, the fp32 CPU oracle shows the same
+    effect at 1e-2)."""
+    from video_prediction_amd import kernels as K
+    hp = make_hparams(context_frames=2, sequence_length=T, clip_length=10, nz=8, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
+                      l2_weight=0.0, kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
+                      vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
+    specs = V.variable_specs(hp, (H, W, C), mode='train')
+    vals = V.init_variables(specs, seed=4)
+    rng = np.random.default_rng(9)
+    for k in vals:
+        if k.endswith('gamma'):
+            vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('bias'):
+            vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('kernel') and k.startswith('generator'):
+            vals[k] = (vals[k] * 3).astype(np.float32)
+    images = synth(hp, B, H, W, C, seed)
+    noise = make_noise(hp, B, seed=100, sampling=True)
+    P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
+    P_new, _, ref = OT.train_step(P, OT.init_opt_state(P), {'images': images}, hp, noise, noise['d_indices_pre'],
+                                  noise['d_indices_post'], step=0)
+    P32 = {k: v.float() for k, v in P.items()}
+    n32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in noise.items()}
+    _, _, ref32 = OT.train_step(P32, OT.init_opt_state(P32), {'images': images.float()}, hp, n32, noise['d_indices_pre'],
+                                noise['d_indices_post'], step=0)
+    out = []
+    for prec in ('f32', 'bf16'):
+        K.set_conv_precision(prec)
+        try:
+            eng = SAVPEngine(hp, (H, W, C), B, mode='train', values=vals, device=DEV)
+            eng.set_images(images.float().to(DEV), time_major=True)
+            info = eng.train_step(noise, return_grads=True)
+            torch.cuda.synchronize()
+        finally:
+            K.set_conv_precision('f32')
+        t = 'recipe_T%d_clip10/%s' % (T, prec)
+        ltol = 1e-3 if prec == 'f32' else 2e-2
+        floor = 0.0 if prec == 'f32' else 0.05
+
+        def lrel(got, want):
+            return abs(float(got) - float(want)) / max(abs(float(want)), floor, 1e-30)
+        out.append((t + '/d_loss', lrel(info['d_loss'], ref['d_loss']), ltol))
+        out.append((t + '/g_loss', lrel(info['g_loss'], ref['g_loss']), ltol))
+        for nm, (l, w) in info['g_losses'].items():
+            out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm]), 2 * ltol))
+        gen = eng.gen.gen.v
+        out.append((t + '/gen_images_enc_abs', float((gen[:, :B].double().cpu() - ref['gen_images_enc']).abs().max()),
+                    1e-3 if prec == 'f32' else 5e-2))
+        out.append((t + '/gen_images_abs', float((gen[:, B:].double().cpu() - ref['gen_images']).abs().max()),
+                    1e-3 if prec == 'f32' else 5e-2))
+        for grp, key in (('d', 'd_grads'), ('g', 'g_grads')):
+            gmax = max(float(v.abs().max()) for v in ref[key].values())
+            worst, wname = 0.0, ''
+            for name, gref in ref[key].items():
+                got = info[key][name]
+                if float(gref.abs().max()) < 1e-9 * gmax:
+                    e, tol = float(got.abs().max()) / gmax, (1e-4 if prec == 'f32' else 1e-2)
+                else:
+                    e = _l2rel(got, gref)
+                    tol = max(20.0 * _l2rel(ref32[key][name], gref), 2e-3) if prec == 'f32' else 0.25
+                    aerr = float((got.detach().double().cpu() - gref).abs().max())
+                    if aerr <= (2e-5 if prec == 'f32' else 2e-3) * gmax:        # heavily cancelling sums: absolute yardstick
+                        e = min(e, tol)
+                if e / tol > worst:
+                    worst, wname = e / tol, name
+            out.append((t + '/%s_grads_worst_err_over_tol[%s]' % (grp, wname.split('/', 1)[-1][-36:]), worst, 1.0))
+        if prec == 'f32':
+            tot, cnt = 0.0, 0
+            for name, pref in P_new.items():
+                d = (eng.store[name].detach().double().cpu() - pref).abs()
+                tot += float(d.sum())
+                cnt += d.numel()
+            out.append((t + '/param_mean_abs_diff_over_lr', tot / cnt / hp.lr, 0.05))
+    return out
+
+
+def check_config_c4():
+    res = check_generator_forward(nz=32, B=2, T=12, C=1, tag='c4_kth_fwd', context_frames=10)
+    res += check_train_step(B=1, T=12, C=1, nz=32, steps=1, tag='c4_kth_train', context_frames=10, clip_length=10, kl_weight=0.01)
+    return res
+
+
+def check_config_c5():
+    res = check_generator_forward(nz=8, B=1, T=4, H=128, W=128, tag='c5_128_fwd')
+    res += check_train_step(B=1, T=5, H=128, W=128, nz=8, steps=1, tag='c5_128_train', clip_length=4)
+    return res
 
 
 def check_model_small():

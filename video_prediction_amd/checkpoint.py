@@ -296,10 +296,11 @@ def write_checkpoint(prefix, tensors, update_state=True):
             f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
 
 
-def restore_values(checkpoints, wanted, mapping=None, skip_global_step=None, log=None):
+def restore_values(checkpoints, wanted, mapping=None, skip_global_step=None, log=None, optional=()):
     """get_checkpoint_restore_saver semantics (tf_utils.py:528-559): for every wanted variable name look up mapping(name, names
     in the checkpoint); restore what both sides have, report the rest.  Several checkpoints may each hold a subset
-    (base_model.py:231-236; global_step is skipped automatically then).  Returns {name: array}."""
+    (base_model.py:231-236; global_step is skipped automatically then).  Names in `optional` (optimizer slots) are not reported
+    when absent.  Returns {name: array}."""
     if not isinstance(checkpoints, (list, tuple)):
         checkpoints = [checkpoints]
     skip_global_step = len(checkpoints) > 1 if skip_global_step is None else skip_global_step
@@ -315,7 +316,7 @@ def restore_values(checkpoints, wanted, mapping=None, skip_global_step=None, log
         vals = read_checkpoint(ck, set(both))
         for k, w in both.items():
             out[w] = vals[k]
-        missing = sorted(w for k, w in lookup.items() if k not in names)
+        missing = sorted(w for k, w in lookup.items() if k not in names and w not in optional)
         unused = sorted(n for n in names if n not in lookup and not (skip_global_step and n == 'global_step'))
         if missing:
             log('variables that were not restored because they are not in the checkpoint:', missing)

@@ -273,7 +273,6 @@ __global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, float* ws
         for (int rr = 0; rr < rows; ++rr) t += sh[rr * 2 * C + i];
         const int c = i % C, which = i / C;
         unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, t);
-        unsafeAtomicAdd((which ? p.dgamma : p.dbeta) + c, t);
     }
 }
 
@@ -288,8 +287,16 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         m[e] = p.mean[(long long)n * C + c4 * 4 + e]; r[e] = p.rstd[(long long)n * C + c4 * 4 + e];
-        s1[e] = ws[((long long)n * C + c4 * 4 + e) * 2] * inv; s2[e] = ws[((long long)n * C + c4 * 4 + e) * 2 + 1] * inv;
+        s1[e] = ws[((long long)n * C + c4 * 4 + e) * 2]; s2[e] = ws[((long long)n * C + c4 * 4 + e) * 2 + 1];
     }
+    // dbeta / dgamma = the per-sample sums added up over samples: one atomic per (sample, channel) here instead of one per
+    // (workgroup, channel) in the statistics pass (512 workgroups hammering C addresses made that pass latency-bound)
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(p.dbeta + c4 * 4 + e, s1[e]); unsafeAtomicAdd(p.dgamma + c4 * 4 + e, s2[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] *= inv; s2[e] *= inv; }
     const float4 g = ld4(p.gamma + c4 * 4);
     float* dx = p.dx + (long long)n * p.dx_sn + c4 * 4;
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);

@@ -369,7 +369,11 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
     if (M > 64 || C > 256) return SAVP_EINVAL;
     size_t lds = (size_t)(M * DKC + DKC * C + M * C) * sizeof(float);
     const long long chunks = (K + DKC - 1) / DKC;
-    int nsub = (int)((chunks + 255) / 256);                    // at most ~256 workgroups (fewer atomics for very long K)
+    // every workgroup ends with M*C float atomics on the same M*C words (measured ~7 per ns chip-wide): bound their number to
+    // ~64k per call (CDNA head, M=32, C=100: 19 workgroups of 7 chunks instead of 128 of 1 -- the atomics were 80 % of its 62 us)
+    int nsub = (int)((chunks * (long long)M * C + 65535) / 65536);
+    const int nsub_min = (int)((chunks + 255) / 256);          // at most ~256 workgroups
+    if (nsub < nsub_min) nsub = nsub_min;
     if (nsub < 1) nsub = 1;
     hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((chunks + nsub - 1) / nsub)), dim3(NT), lds, st, x, (long long)x_row_stride, M,
                        (long long)K, C, W, bias, scale, out, nsub);

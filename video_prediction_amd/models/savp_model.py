@@ -36,8 +36,16 @@ class SAVPEngine(object):
     """All device state of one SAVP replica: variables, generator unroll (batch 2B: posterior + prior), posterior
     encoder, the two video discriminators; implements one training step and inference."""
 
-    def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0'):
+    # loss terms of base_model.py:733-829 that need inputs / networks outside the SAVP hot path (VGG features, robot states,
+    # auto-encoder outputs): accepting them silently would train a different model than the recipe asks for
+    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'state_weight', 'tv_weight', 'z_l1_weight')
+
+    def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0', base_seed=0, rank=0):
         self.hp, self.mode, self.B = hp, mode, batch_size
+        bad = [k for k in self.UNSUPPORTED_WEIGHTS if getattr(hp, k, 0)]
+        if bad and mode == 'train':
+            raise NotImplementedError('loss weights not covered by the HIP path: %s' % ', '.join(bad))
+        self.base_seed, self.rank = int(base_seed), int(rank)
         self.image_shape = tuple(image_shape)
         self.device = torch.device(device)
         self.train = mode == 'train'
@@ -57,6 +65,12 @@ class SAVPEngine(object):
         self.zs_all = torch.zeros(self.T1, N, self.nz, device=self.device) if self.nz else None
         self.dz_post = torch.zeros(self.T1, B, self.nz, device=self.device) if (self.nz and self.train) else None
         self.has_d = self.train and V.uses_discriminator(hp)
+        if self.has_d and self.T1 < hp.clip_length:
+            # tf.random_uniform(maxval <= minval) raises in the reference (savp_model.py:97); a silent pass would gather clips
+            # beyond the sequence
+            raise ValueError('clip_length=%d needs sequence_length >= %d (got %d)' % (hp.clip_length, hp.clip_length + 1, self.T))
+        if self.nz and hp.learn_prior:
+            raise NotImplementedError('learn_prior=True (prior_fn, savp_model.py:54-85) is not on the HIP path yet')
         # (discriminator, loss weight, loss-name infix, operates on the posterior ('_enc') unroll?, clip index keys)
         self.discs = []
         if self.has_d:
@@ -108,6 +122,7 @@ class SAVPEngine(object):
         self.replicas = ReplicaGroup(self.store, dist_module)
         self.dist = dist_module
         self.world = self.replicas.world
+        self.rank = self.replicas.rank          # independent noise per replica (default_noise)
 
     def _allreduce(self, group):
         if self.world > 1:
@@ -130,9 +145,17 @@ class SAVPEngine(object):
             copy_view(src, [self.images_n[:, :B].reshape(T, B * HW, C)])
             copy_view(src, [self.images_n[:, B:].reshape(T, B * HW, C)])
 
+    def _noise_seed(self, step, stream=0):
+        """Seed of the host-side draws of one step: every (base_seed, rank, step, stream) gets its own sequence -- the reference's
+        random ops are independent per tower (base_model.py:523-560) and per run."""
+        x = (self.base_seed * 0x9E3779B97F4A7C15 + self.rank * 0xBF58476D1CE4E5B9 + (step + 1) * 0x94D049BB133111EB +
+             stream * 0xD6E8FEB86659FD93) & ((1 << 63) - 1)
+        x ^= x >> 31
+        return (x * 0x2545F4914F6CDD1D) & ((1 << 63) - 1)
+
     def default_noise(self, generator=None):
         """Draw the step's random tensors (eps, prior z, scheduled-sampling masks, clip indices) on the host."""
-        g = generator or torch.Generator().manual_seed(1000 + self.step)
+        g = generator or torch.Generator().manual_seed(self._noise_seed(self.step))
         hp, B, T1 = self.hp, self.B, self.T1
         noise = {}
         if self.nz:
@@ -145,7 +168,7 @@ class SAVPEngine(object):
                 noise[key] = (torch.rand(ns, B, generator=g) < prob) if prob >= 0.001 else torch.zeros(ns, B, dtype=torch.bool)
         L = T1
         idx = {}
-        if not self.train or L - hp.clip_length + 1 <= 0:      # no discriminator clips to draw (inference / too short a sequence)
+        if not self.has_d:                                     # no discriminator clips to draw
             return noise
         for phase in ('pre', 'post'):
             idx[phase] = {k: (torch.randint(0, L, (B,), generator=g), torch.randint(0, L - hp.clip_length + 1, (B,), generator=g))
@@ -256,7 +279,7 @@ class SAVPEngine(object):
         graph_ok = self.use_graph and self.world == 1 and not return_grads
         if graph_ok and self.graph is not None:
             self.graph.replay()
-            info = self.graph_info
+            info = self._fresh_info(self.graph_info, klw)
         elif graph_ok and self.eager_steps >= 1:
             # capture: every conv problem has been tuned and every kernel launched once by the eager step(s)
             torch.cuda.synchronize()
@@ -280,6 +303,18 @@ class SAVPEngine(object):
         info = OrderedDict(info)
         info['learning_rate'] = lr
         return info
+
+    @staticmethod
+    def _fresh_info(info, klw):
+        """The dict returned for a graph replay: same device scalars (they are rewritten by every replay: clone them to keep
+        a value across steps), host-side weights of the CURRENT step (the annealed KL weight changes between replays)."""
+        out = OrderedDict(info)
+        g = OrderedDict(info['g_losses'])
+        if 'gen_kl_loss' in g:
+            g['gen_kl_loss'] = (g['gen_kl_loss'][0], klw)
+        out['g_losses'] = g
+        out['d_losses'] = OrderedDict(info['d_losses'])
+        return out
 
     def _step_body(self, klw, return_grads):
         """The launch sequence of one train step (no host inputs: see train_step)."""
@@ -318,7 +353,10 @@ class SAVPEngine(object):
             if return_grads:
                 info['d_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'd'}
             self._allreduce('d')
-            store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
+            if not hp.joint_gan_optimization:
+                store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
+            # joint_gan_optimization (base_model.py:498-505): no control dependency on the D update and no replace_read_ops, i.e. the
+            # generator loss is taken against the PRE-update discriminator; D's Adam is applied after the generator step below
         # ---------------- generator (+ encoder) step --------------------------------------------------------------------------
         store.groups['g'].zero_grad()
         self.gen.gen.g.zero_()
@@ -373,6 +411,8 @@ class SAVPEngine(object):
             info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
         self._allreduce('g')
         store.groups['g'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[1:2])
+        if discs and hp.joint_gan_optimization:
+            store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
         for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
@@ -458,7 +498,7 @@ class SAVPEngine(object):
         cmax = torch.zeros(B, dtype=torch.int32, device=dev)
         for s_i in range(num_samples):                                 # accum_gen_images_and_metrics_fn (:176-198)
             gen = self.generate(noises[s_i] if noises else self.default_noise(
-                torch.Generator().manual_seed(7919 * (self.step + 1) + s_i)))
+                torch.Generator().manual_seed(self._noise_seed(self.step, stream=1 + s_i))))
             prior = gen[:, B:]                                         # the prior unroll ('gen_images')
             self._frame_metrics(prior, buf)
             for k in self.METRICS:
@@ -657,17 +697,81 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
                 name = name.replace('savp_cell', 'dna_cell')
             return name
         log = lambda head, items: print(head + '\n' + '\n'.join('     ' + i for i in items))
-        wanted = self.engine.store.names() + ['global_step']
-        vals = CK.restore_values(checkpoints, wanted, restore_to_checkpoint_mapping or mapping, log=log)
+        store = self.engine.store
+        slot_names = self._optimizer_slot_names()
+        wanted = store.names() + ['global_step'] + list(slot_names)
+        vals = CK.restore_values(checkpoints, wanted, restore_to_checkpoint_mapping or mapping, log=log, optional=set(slot_names))
         step = vals.pop('global_step', None)
-        self.engine.store.load(vals)
+        slots = {k: vals.pop(k) for k in list(vals) if k in slot_names}
+        store.load(vals)
         if step is not None:
             self.engine.step = int(step)
-            VideoPredictionModel.global_step = int(step)
+        self._load_optimizer_slots(slots, step)
+
+    # -- optimizer state (base_model.py:229-247,512-515: saveable_variables include the Adam slots and beta powers) -----------
+    def _optimizer_slot_names(self):
+        """{checkpoint name: (group, kind, variable name)} in tf.train.AdamOptimizer's naming: slots '<var>/Adam' (m) and
+        '<var>/Adam_1' (v); the non-slot accumulators 'beta1_power' / 'beta2_power' of the optimizer whose apply_gradients is
+        built first (D when there is one, base_model.py:489-496) and 'beta1_power_1' / 'beta2_power_1' of the second (G).
+        (Names inferred from TF's slot creator; unverifiable offline -- restore treats every one of them as optional.)"""
+        store = self.engine.store
+        out = OrderedDict()
+        for n in store.names():
+            grp = store.group_of[n]
+            if grp == 'aux':
+                continue
+            out[n + '/Adam'] = (grp, 'm', n)
+            out[n + '/Adam_1'] = (grp, 'v', n)
+        order = (['d'] if self.engine.discs else []) + ['g']
+        for i, grp in enumerate(order):
+            sfx = '' if i == 0 else '_%d' % i
+            out['beta1_power' + sfx] = (grp, 'b1', None)
+            out['beta2_power' + sfx] = (grp, 'b2', None)
+        return out
+
+    def _load_optimizer_slots(self, slots, step):
+        import math
+        import warnings
+        store, hp = self.engine.store, self.hparams
+        names = self._optimizer_slot_names()
+        seen = {'d': 0, 'g': 0}
+        t_from_power = {}
+        for k, val in slots.items():
+            grp, kind, var = names[k]
+            G = store.groups[grp]
+            if kind in ('m', 'v'):
+                dst = G.arena.view_of(G.m if kind == 'm' else G.v, var)
+                dst.copy_(torch.as_tensor(np.asarray(val, dtype=np.float32)).reshape(dst.shape))
+                seen[grp] += 1
+            elif kind == 'b1' and 0.0 < float(val) < 1.0 and 0.0 < hp.beta1 < 1.0:
+                t_from_power[grp] = int(round(math.log(float(val)) / math.log(hp.beta1))) - 1      # power = beta^(t+1) after t steps
+        for grp in ('d', 'g'):
+            G = store.groups[grp]
+            ntrain = sum(1 for n in store.names() if store.group_of[n] == grp)
+            if not ntrain or self.mode != 'train':
+                continue
+            if seen[grp] == 2 * ntrain:
+                G.t = max(t_from_power.get(grp, int(step) if step is not None else 0), 0)
+            else:
+                warnings.warn('checkpoint holds %d of %d Adam slots of group %r: optimizer state RESET (moments zero, bias '
+                              'correction restarts)' % (seen[grp], 2 * ntrain, grp))
+                G.m.zero_()
+                G.v.zero_()
+                G.t = 0
 
     def save(self, prefix):
-        """tf.train.Saver.save equivalent: all variables (TF names) + global_step as a V2 checkpoint at `prefix`."""
+        """tf.train.Saver.save equivalent: all variables (TF names), global_step and the optimizer state (Adam slots + beta
+        powers of both optimizers) as a V2 checkpoint at `prefix`."""
         from .. import checkpoint as CK
-        vals = self.engine.store.to_numpy()
+        store, hp = self.engine.store, self.hparams
+        vals = store.to_numpy()
         vals['global_step'] = np.asarray(self.engine.step, dtype=np.int64)
+        if self.mode == 'train':
+            for k, (grp, kind, var) in self._optimizer_slot_names().items():
+                G = store.groups[grp]
+                if kind in ('m', 'v'):
+                    vals[k] = G.arena.view_of(G.m if kind == 'm' else G.v, var).detach().cpu().numpy().copy()
+                else:
+                    beta = hp.beta1 if kind == 'b1' else hp.beta2
+                    vals[k] = np.asarray(beta ** (G.t + 1), dtype=np.float32)       # TF: initial value beta, multiplied per step
         CK.write_checkpoint(prefix, vals)
