@@ -54,8 +54,9 @@ typedef struct SavpConvArgs {
     float alpha;
     int32_t splitk;                /* WGRAD: number of K splits (>=1); 0 = pick automatically */
     int32_t tile;                  /* 0 = auto; low byte (WM<<4)|WN with tile = 64*WM x 64*WN; bits 8-9 pick the FPROP/DGRAD
-                                      algorithm: 0 auto, 1 generic gather kernel, 2 LDS patch kernel (EINVAL if not applicable); bit 10: patch
-                                      kernel with 8 waves; bits 12-13: its LDS budget (0 = 160 KB, 1 = 64 KB, 2 = 96 KB) */
+                                      algorithm: 0 auto, 1 generic gather kernel, 2 LDS patch kernel, 3 LDS-DMA ring kernel (EINVAL if
+                                      not applicable); bit 10: patch / ring kernel with 8 waves; bits 12-13: LDS budget of the patch
+                                      kernel (0 = 160 KB, 1 = 64 KB, 2 = 96 KB) */
     int32_t precision;             /* SAVP_PREC_F32: exact fp32 MFMA; SAVP_PREC_BF16: operands rounded to bf16 in LDS */
     void* x; int64_t x_sn, x_sd, x_sh, x_sw;
     void* y; int64_t y_sn, y_sd, y_sh, y_sw;
@@ -64,6 +65,14 @@ typedef struct SavpConvArgs {
                                       accumulated as well: bias[c] += sum over all pixels of y[..., c] (y pixel-contiguous) */
     const float* aux;              /* act==3: saved activation, addressed like the destination */
     const void* w_bf16;            /* optional bf16 copy of w (FPROP/DGRAD, SAVP_PREC_BF16): halves the weight stream */
+    /* bf16 activations (SAVP_PREC_BF16, FPROP/DGRAD, ring kernel; EINVAL where it does not apply -- no silent fp32 fallback): */
+    int32_t src_bf16;              /* the source tensor (x for FPROP, y for DGRAD) holds bf16; its strides count bf16 elements */
+    int32_t out_bf16;              /* the destination receives bf16 (strides in bf16 elements; no bias / act / beta / split-K).
+                                      This is the ConvLSTM gate convolution (rnn_ops.py:121): the gate tensor makes its round trip to
+                                      the gate kernels in half the bytes */
+    float* stats;                  /* with out_bf16: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
+                                      of every (sample, channel) of the destination, taken from the fp32 accumulators before rounding
+                                      = the statistics of the instance norm that follows (rnn_ops.py:148-149); caller zeroes; may be NULL */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
@@ -109,7 +118,7 @@ int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);
 typedef struct SavpLstmArgs {
     int32_t N, HW, F;
     float eps, forget_bias;
-    const float* gates;
+    const void* gates;
     SavpView c_prev;
     const float *gamma1, *beta1, *gamma2, *beta2;
     float* c_new;
@@ -125,6 +134,10 @@ typedef struct SavpLstmArgs {
                                       kernel (HW <= 1024) */
     float* ws_stats;               /* optional separate reduction workspace, N*F*11 floats */
     int32_t ws_stats_clean;        /* 1: the caller guarantees ws_stats is all zero (see SavpInormArgs.ws_clean) */
+    int32_t gates_bf16;            /* `gates` holds bf16 (written by savp_conv with out_bf16); coalesced kernels only */
+    int32_t stats1_ready;          /* fwd: the first N*4F*2 floats of ws_stats already hold the per-(sample, gate channel) sum / sum of
+                                      squares of the gate tensor (savp_conv's `stats` epilogue; the remaining N*F*3 floats zero): the
+                                      statistics pass over the gates is skipped -> conv + 2 launches per ConvLSTM cell */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);

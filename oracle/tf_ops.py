@@ -41,7 +41,7 @@ def conv2d(x, w, strides=(1, 1), padding='SAME'):
         xc = F.pad(xc, (pl, pr, pt, pb))
     elif padding != 'VALID':
         raise ValueError(padding)
-    y = F.conv2d(xc, w.permute(3, 2, 0, 1), stride=(sh, sw))
+    y = F.conv2d(xc, w.permute(3, 2, 0, 1).contiguous(), stride=(sh, sw))
     return _nchw_to_nhwc(y)
 
 
@@ -51,7 +51,7 @@ def conv2d_transpose(x, w, output_shape, strides, padding='SAME'):
     kh, kw = w.shape[0], w.shape[1]
     sh, sw = strides
     H, W = output_shape[1], output_shape[2]
-    full = F.conv_transpose2d(_nhwc_to_nchw(x), w.permute(3, 2, 0, 1), stride=(sh, sw))
+    full = F.conv_transpose2d(_nhwc_to_nchw(x), w.permute(3, 2, 0, 1).contiguous(), stride=(sh, sw))
     if padding == 'SAME':
         pt, _ = same_pad(H, kh, sh)
         pl, _ = same_pad(W, kw, sw)
@@ -79,7 +79,7 @@ def conv3d(x, w, strides=(1, 1, 1), padding='VALID'):
         xc = F.pad(xc, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
     elif padding != 'VALID':
         raise ValueError(padding)
-    y = F.conv3d(xc, w.permute(4, 3, 0, 1, 2), stride=tuple(strides))
+    y = F.conv3d(xc, w.permute(4, 3, 0, 1, 2).contiguous(), stride=tuple(strides))
     return y.permute(0, 2, 3, 4, 1)
 
 

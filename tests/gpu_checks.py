@@ -131,6 +131,23 @@ def check_conv(cases=None, seed=0, tiles=(0,), precision=0, tol=None):
         for tile in tiles:
             tag = name + ('' if tile == 0 else '_t%x' % tile)
             xd, wd_, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+            if (tile & 0x300) == 0x300:          # LDS-DMA ring kernel forced (conv_ring.hip); a refused shape raises -> skipped
+                if not (precision == 1 and s[0] == 1 and k[1] >= s[1] and k[2] >= s[2] and Cx % 8 == 0 and Cy % 8 == 0):
+                    continue
+                wtp, wdp = dev(pack_wt(w.detach())), dev(pack_wd(w.detach()))
+                try:
+                    yd2 = torch.empty(y.shape, device=DEV, dtype=torch.float32)
+                    K.conv(lib.CONV_FPROP, geom, xd, yd2, wtp, bias=bd, tile=tile, precision=1, w16=wtp.to(torch.bfloat16))
+                    out.append((tag + '/fprop_ring', rel_err(yd2, y), tol))
+                except RuntimeError:
+                    pass
+                try:
+                    dx2 = torch.full(x.shape, float('nan'), device=DEV, dtype=torch.float32)
+                    K.conv(lib.CONV_DGRAD, geom, dx2, dyd, wdp, tile=tile, precision=1, w16=wdp.to(torch.bfloat16))
+                    out.append((tag + '/dgrad_ring', rel_err(dx2, x.grad), tol))
+                except RuntimeError:
+                    pass
+                continue
             if tile & 0x200:          # LDS patch kernel forced: 2-D stride-1, channels % 8, bf16 weight copy only
                 if not (precision == 1 and s[0] == 1 and k[1] >= s[1] and k[2] >= s[2] and
                         Cx % 8 == 0 and Cy % 8 == 0 and y.shape[2] * y.shape[3] >= 16):
@@ -715,11 +732,73 @@ def check_warp_dna(seed=8):
 
 def check_conv_bf16():
     """bf16-operand / fp32-accumulate mode of the implicit-GEMM kernel: per-op rel <= 1e-2."""
-    res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11, 0x212, 0x221, 0x122, 0x612, 0x621, 0x611))   # 0x2xx: LDS patch kernel (0x6xx: 8 waves), 0x1xx: generic
+    res = check_conv(precision=1, tol=1e-2, tiles=(0, 0x22, 0x11, 0x212, 0x221, 0x122, 0x612, 0x621, 0x611,
+                                                   0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721, 0x722))
+    # 0x2xx: LDS patch kernel (0x6xx: 8 waves), 0x1xx: generic, 0x3xx / 0x7xx: LDS-DMA ring kernel (4 / 8 waves)
     return [('bf16/' + n, e, t) for (n, e, t) in res]
 
 
-ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
+def check_conv_cell(seed=21):
+    """The fused ConvLSTM cell of the bf16 datapath (csrc/conv_ring.hip + the coalesced gate kernels): gate convolution with the
+    bf16 / statistics epilogue, then IN(4F) + gates + IN(F) + h from the bf16 gate tensor and the epilogue's sums, against the
+    fp64 oracle of the whole cell (rnn_ops.py:137-171).  Also a bf16 SOURCE tensor."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for (N, H, W, Cx, F) in [(2, 32, 32, 72, 32), (4, 16, 16, 136, 64), (4, 8, 8, 264, 128), (2, 16, 24, 40, 16)]:
+        x = rnd(rng, N, H, W, Cx)
+        w = rnd(rng, 5, 5, Cx, 4 * F) * 0.05
+        c = rnd(rng, N, H, W, F)
+        g1, b1 = rnd(rng, 4 * F) * 0.3 + 1, rnd(rng, 4 * F) * 0.3
+        g2, b2 = rnd(rng, F) * 0.3 + 1, rnd(rng, F) * 0.3
+        gates = TF.conv2d(x, w, (1, 1), 'SAME')
+        cn, hn = _ref_lstm_gates(gates, c, g1, b1, g2, b2)
+        tag = 'cell_%dx%dx%d' % (H, W, F)
+        geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
+        wt = dev(pack_wt(w))
+        for src16 in (False, True):
+            t2 = tag + ('_src16' if src16 else '')
+            xd = dev(x).to(torch.bfloat16) if src16 else dev(x)
+            yd = torch.empty(N, H, W, 4 * F, device=DEV, dtype=torch.bfloat16)
+            ws, s1 = K.lstm_stats_ws(torch.device(DEV), N, F)
+            ws.zero_()
+            K.conv(lib.CONV_FPROP, geom, xd, yd, wt, precision=1, w16=wt.to(torch.bfloat16), stats=s1)
+            out.append((t2 + '/gates_bf16', rel_err(yd.float(), gates), 1e-2))
+            ref_s = torch.stack([gates.sum(dim=(1, 2)), (gates ** 2).sum(dim=(1, 2))], dim=-1)         # [N, 4F, 2]
+            out.append((t2 + '/stats_sum', rel_err(s1[..., 0], ref_s[..., 0]), 1e-2))
+            out.append((t2 + '/stats_sumsq', rel_err(s1[..., 1], ref_s[..., 1]), 1e-2))
+            p = [dev(t) for t in (g1, b1, g2, b2)]
+            c_new = torch.empty(N, H, W, F, device=DEV)
+            h1 = torch.empty(N, H, W, F, device=DEV)
+            stats = [torch.empty(N, 4 * F, device=DEV), torch.empty(N, 4 * F, device=DEV), torch.empty(N, F, device=DEV),
+                     torch.empty(N, F, device=DEV)]
+            lws = torch.empty(K.lstm_ws_floats(N, H * W, F), device=DEV)
+            K.convlstm_gates_fwd(yd, dev(c), p[0], p[1], p[2], p[3], c_new, [h1], stats, ws=lws, stats1=ws)
+            out.append((t2 + '/c', rel_err(c_new, cn), 2e-2))
+            out.append((t2 + '/h', rel_err(h1, hn), 2e-2))
+        # the gate kernels alone, exact: bf16 gate tensor + exact unshifted sums vs the oracle run on the SAME rounded tensor
+        gq = gates.float().to(torch.bfloat16)
+        gq64 = gq.double().requires_grad_(True)
+        c64 = c.clone().requires_grad_(True)
+        cn2, hn2 = _ref_lstm_gates(gq64, c64, g1, b1, g2, b2)
+        dh, dcn = rnd(rng, *hn2.shape), rnd(rng, *cn2.shape)
+        ((hn2 * dh).sum() + (cn2 * dcn).sum()).backward()
+        ws, s1 = K.lstm_stats_ws(torch.device(DEV), N, F)
+        s1.copy_(torch.stack([gq64.detach().sum(dim=(1, 2)), (gq64.detach() ** 2).sum(dim=(1, 2))], dim=-1).float().to(DEV))
+        K.convlstm_gates_fwd(gq.to(DEV), dev(c), p[0], p[1], p[2], p[3], c_new, [h1], stats, ws=lws, stats1=ws)
+        out.append((tag + '/gate_kernels_bf16in/c', rel_err(c_new, cn2), 2e-4))
+        out.append((tag + '/gate_kernels_bf16in/h', rel_err(h1, hn2), 2e-4))
+        dgates = torch.empty(N, H, W, 4 * F, device=DEV)
+        dcp = torch.empty(N, H, W, F, device=DEV)
+        dpar = [torch.zeros(4 * F, device=DEV), torch.zeros(4 * F, device=DEV), torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)]
+        K.convlstm_gates_bwd(gq.to(DEV), dev(c), p[0], p[1], p[2], p[3], stats, [dev(dh)], dev(dcn), dgates, dcp, dpar, ws=lws)
+        out.append((tag + '/gate_kernels_bf16in/dgates', rel_err(dgates, gq64.grad), 1e-3))
+        out.append((tag + '/gate_kernels_bf16in/dc_prev', rel_err(dcp, c64.grad), 1e-3))
+    torch.cuda.synchronize()
+    return out
+
+
+ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_cell', check_conv_cell),
+              ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
               ('lstm', check_lstm), ('util', check_util), ('cdna_composite', check_cdna_composite),
               ('small', check_small), ('weight_prep', check_weight_prep), ('warp_dna', check_warp_dna)]
 

@@ -56,6 +56,11 @@ def test_conv_bf16_mode():
     _run(gpu_checks.check_conv_bf16)
 
 
+def test_fused_convlstm_cell_bf16():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv_cell)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

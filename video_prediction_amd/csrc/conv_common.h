@@ -35,6 +35,10 @@ struct ConvP {
     int s1_ph, s1_pw, s1_th, s1_tw, s1_tih;   // patch rows / columns per image, tiles per image (rows, columns), tile rows per image
     unsigned long long s1_magDm;              // fastdiv by the depth of the output grid
     unsigned long long s1_magPI, s1_magPW, s1_magC4;   // fastdiv by the float4 count of one image's patch, the patch width, float4 per pixel
+    // ring kernel (conv_ring.hip)
+    int src16;                                // source activations are bf16 (strides in elements)
+    int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
+    float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
@@ -108,3 +112,5 @@ static inline void ablate_init() {}
 bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced, hipStream_t st, int* rc);
 // conv_wgrad_patch.hip: LDS patch WGRAD (2-D stride-1, bf16); same contract.
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc);
+// conv_ring.hip: LDS patch + LDS-DMA weight ring (+ fused bf16 / statistics epilogue); same contract.
+bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc);

@@ -23,6 +23,7 @@
 #include "savp_hip.h"
 
 #include "conv_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------------
 // FPROP / DGRAD kernel.  GEMM: C[M = grid pixels][N = dst channels] = A[M][K=(taps,Cred)] * B[K][N]
@@ -746,6 +747,13 @@ static void pick_tile(long long M, long long N, int& wm, int& wn) {
     }
 }
 
+// auto algorithm choice between the two LDS-patch kernels when the caller gives no tile: SAVP_CONV_RING=1 prefers conv_ring.hip
+static bool ring_default() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SAVP_CONV_RING"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     if (!a || !a->x || !a->y || !a->w) return SAVP_EINVAL;
     if (a->sd < 1 || a->sh < 1 || a->sw < 1 || a->kd < 1 || a->kh < 1 || a->kw < 1) return SAVP_EINVAL;
@@ -763,10 +771,11 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.w16 = nullptr;
     p.bias = a->bias; p.aux = a->aux;
     p.splitk = 1; p.tm = p.tn = 1;
+    p.src16 = a->src_bf16 ? 1 : 0; p.cell = 0; p.stats = nullptr;
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
-    const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel
+    const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel, 3 = LDS-DMA ring kernel
     if (a->tile & 0xff) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return SAVP_EINVAL; }
     hipError_t err;
     ablate_init();
@@ -789,6 +798,12 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         }
         if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
         // ---- LDS patch kernel (conv_patch.hip): 2-D stride-1 convs in bf16 with pre-packed bf16 weights --------------
+        const bool needs_ring = a->out_bf16 || a->src_bf16 || a->stats;       // only the ring kernel reads / writes bf16 activations
+        if (algo == 3 || needs_ring || (algo == 0 && ring_default())) {
+            int rc = SAVP_OK;
+            if (conv_ring_try(p, a, wm, wn, st, &rc)) return rc;
+            if (algo == 3 || needs_ring) return SAVP_EINVAL;
+        }
         if (algo != 1) {
             int rc = SAVP_OK;
             if (conv_patch_try(p, a, wm, wn, algo == 2, st, &rc)) return rc;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
     const int CP = spp * CKB + 8;                          // patch pixel stride (16 B x odd)
     const int pimg = PH * pitch;                           // LDS elements of one image's patch
     __bf16* patch = reinterpret_cast<__bf16*>(smem);       // [ni][PH][pitch]
-    __bf16* Bs = patch + ni * pimg;                        // [2][BN][BROW]
+    __bf16* Bs = patch + ni * pimg + 8;                    // [2][BN][BROW] (8 elements behind the patch = stage_patch's dummy slot)
 
     if (ABL(16)) return;
     const int split = blockIdx.z;
@@ -136,25 +136,40 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         const int c4n = (spp * CKB) >> 2;
         const int per_img = PH * PW * c4n;
         const int total = ni * per_img;
-#pragma unroll 8
-        for (int idx = tid; idx < (ABL(4) ? 0 : total); idx += NT) {
-            const int im = (int)fastdiv((unsigned)idx, p.s1_magPI);
-            const int rem = idx - im * per_img;
-            const int pix = (int)fastdiv((unsigned)rem, p.s1_magC4);
-            const int c = (rem - pix * c4n) << 2;
-            const int pyy = (int)fastdiv((unsigned)pix, p.s1_magPW);
-            const int pxx = pix - pyy * PW;
-            const int iy = org_h + pyy, ix = org_w + pxx;
-            const int cg = cfirst * CKB + c;
-            const int gi = img0 + im;                          // (sample, depth) index
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-            const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;      // source plane of this depth tap
-            const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
-                            (unsigned)dz < (unsigned)gd.srcN;
-            float4 v = ldg4(src + (ok ? (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg : 0ll));
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-            *reinterpret_cast<bf16x4*>(patch + im * pimg + pyy * pitch + pxx * CP + c) = o;
+        // batches of U loads per thread, all issued before the first is consumed (one guarded load per loop trip made hipcc wait
+        // vmcnt(0) after each: ~10 serial HBM round trips per workgroup, the "patch staging 6 us" of the r01 ablation); trips past
+        // the end are redirected to a dummy slot behind the patch so that no load is left unconsumed
+        constexpr int U = 8;
+        for (int base = tid; base < (ABL(4) ? 0 : total); base += NT * U) {
+            float4 v[U];
+            int dsto[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = min(base + u * NT, total - 1);
+                const int im = (int)fastdiv((unsigned)idx, p.s1_magPI);
+                const int rem = idx - im * per_img;
+                const int pix = (int)fastdiv((unsigned)rem, p.s1_magC4);
+                const int c = (rem - pix * c4n) << 2;
+                const int pyy = (int)fastdiv((unsigned)pix, p.s1_magPW);
+                const int pxx = pix - pyy * PW;
+                const int iy = org_h + pyy, ix = org_w + pxx;
+                const int cg = cfirst * CKB + c;
+                const int gi = img0 + im;                          // (sample, depth) index
+                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;      // source plane of this depth tap
+                const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
+                                (unsigned)dz < (unsigned)gd.srcN;
+                v[u] = ldg4(src + (ok ? (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg : 0ll));
+                const int d = im * pimg + pyy * pitch + pxx * CP + c;
+                dsto[u] = (base + u * NT < total) ? (ok ? d : (d | (int)0x40000000)) : (ni * pimg) | (int)0x40000000;   // bit 30: zeros
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 t = v[u];
+                if (dsto[u] & 0x40000000) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                bf16x4 o = {(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+                *reinterpret_cast<bf16x4*>(patch + (dsto[u] & 0x3fffffff)) = o;
+            }
         }
     };
 
@@ -397,7 +412,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         const int CP = spp * nks * 16 + 8;
         const int x = (8 - (PW * (CP / 8)) % 16 + 16) % 16;      // row pitch = 8 (mod 16) 16-byte slots
         pitch = PW * CP + 8 * x;
-        lds = (size_t)ni * PH * pitch * 2 + (size_t)2 * 64 * wn * (nks * 16 + 8) * 2;
+        lds = (size_t)ni * PH * pitch * 2 + 16 + (size_t)2 * 64 * wn * (nks * 16 + 8) * 2;
         if (lds <= budget || (spp == 1 && lds <= 160 * 1024)) break;
     }
     if (spp < 1) return false;

@@ -1,0 +1,617 @@
+// conv_ring.hip -- LDS-patch convolution with an LDS-DMA weight ring and a fused "cell" epilogue, gfx950, bf16 MFMA.
+//
+// Same tiling idea as conv_patch.hip (a workgroup owns NI images x TIH rows x 8 columns of output pixels, the input patch of a
+// group of channel slabs is parked in LDS once, every tap's A fragment is that patch read at a tap-shifted address) with the two
+// parts of that kernel that its own ablation found on the critical path rebuilt:
+//
+//   * weight stream: the (tap, slab) weight slabs no longer travel global -> VGPR -> ds_write behind a barrier per slab.  Every
+//     wave issues `global_load_lds_dwordx4` (LDS-DMA, inline asm so that hipcc neither counts nor drains it) straight into a
+//     FOUR-deep LDS ring; slabs i+2 and i+3 are in flight while slab i is multiplied, the loop waits with a counted `s_waitcnt vmcnt(LW)`
+//     and a raw `s_barrier` (DMA requests stay in flight across it).  The LDS image keeps the conflict-free row pitch of
+//     conv_patch.hip (16 B x odd): the DMA destination is lane-linear, so the pad slot of every row is simply one more 16-byte
+//     lane whose source address is a duplicate.  No VGPRs, no ds_write, no exposed L2 latency per slab.
+//   * epilogue "cell" mode (the ConvLSTM gate convolution, rnn_ops.py:121,148-149): the accumulators are (a) reduced to the
+//     per-(sample, channel) sum / sum of squares the instance norm over the 4F gate pre-activations needs (registers -> LDS ->
+//     ONE global atomic per (image, channel) per workgroup; the separate statistics pass over the gate tensor disappears) and
+//     (b) rounded to bf16, transposed through LDS and stored as full 16-byte pieces of contiguous pixel rows (the fp32 epilogue
+//     of conv_patch.hip stores 16 strided dwords per lane).  The gate tensor makes its HBM round trip in half the bytes.
+//
+// Applies to stride-1 and strided 2-D / 3-D FPROP and DGRAD problems in SAVP_PREC_BF16 exactly like conv_patch.hip (same ConvP
+// geometry fields, filled by conv_ring_try); the plain fp32 epilogue (bias / LeakyReLU / sigmoid / beta / split-K) is kept.
+#include "conv_common.h"
+#include <type_traits>
+
+// one LDS-DMA instruction: lane l copies 16 bytes from its own global address to LDS byte address lds_dst + 16 l
+// (MI355X guide 5.7: M0 is written in the same statement that reads it; hipcc does not count this load)
+__device__ __forceinline__ void ring_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float dpp_xor1(float v) {        // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int NW, int WM, int WN, int NKS>
+__global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
+    constexpr int NT = 64 * NW;
+    constexpr int BM = 16 * NW * WM, BN = 64 * WN, TW = 8;
+    constexpr int CKB = 16 * NKS;
+    constexpr int RS = 2 * NKS + 1;                        // 16-byte slots per weight row (last one = pad)
+    constexpr int BROW = RS * 8;                           // row pitch in elements
+    constexpr int SLOTS = BN * RS;
+    constexpr int LW = (SLOTS + NT - 1) / NT;              // DMA instructions per wave and slab
+    constexpr int SLABB = LW * NT * 16;                    // bytes of one ring buffer
+    constexpr int RING = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
+    const int fh = dgrad ? (int)blockIdx.y / p.sw : 0, fw = dgrad ? (int)blockIdx.y % p.sw : 0;
+    const DimGeom gd = make_geom(dgrad, 0, p.D, p.Do, p.kd, 1, p.pd);
+    const DimGeom gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
+    const DimGeom gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
+    const int Cred = dgrad ? p.Cy : p.Cx;
+    const int Nout = dgrad ? p.Cx : p.Cy;
+    const int kh = gh.nt, kw = gw.nt;
+    const int ntaps = kh * kw;
+    const int ldb = p.kd * p.kh * p.kw * Cred;
+    const int Hm = gh.Mdim, Wm = gw.Mdim, Dm = gd.Mdim;
+    const int nimg = p.N * Dm;
+    const int tW = p.s1_tw, tH = p.s1_th;
+    const int PW = p.s1_pw, PH = p.s1_ph;
+    const int tih = p.s1_tih;
+    const int ni = (BM / TW) / tih;
+    const int rpi = tih * TW;
+    const int nch = p.s1_nch, pitch = p.s1_pitch;
+    const int spp = p.s1_spp;
+    const int CP = spp * CKB + 8;
+    const int pimg = PH * pitch;
+    unsigned char* ring = reinterpret_cast<unsigned char*>(smem);                     // [RING][SLABB]
+    __bf16* patch = reinterpret_cast<__bf16*>(ring + RING * SLABB);                    // [ni][PH][pitch]
+    const unsigned ring_lds = (unsigned)(uintptr_t)ring;                               // LDS byte address of the ring
+
+    if (ABL(16)) return;
+    const int split = blockIdx.z;
+    const int tlog = xcd_logical(blockIdx.x, p.tm * p.tn);
+    const int mt = tlog % p.tm;
+    const int n0 = (tlog / p.tm) * BN;
+    const int ig = mt / (tH * tW);
+    const int trem = mt - ig * (tH * tW);
+    const int oy0 = (trem / tW) * tih, ox0 = (trem % tW) * TW;
+    const int img0 = ig * ni;
+    if (oy0 >= Hm || ox0 >= Wm || kh <= 0 || kw <= 0) return;
+    const int org_h = gh.base + oy0 * gh.mstep + (gh.jstep > 0 ? 0 : (kh - 1) * gh.jstep);
+    const int org_w = gw.base + ox0 * gw.mstep + (gw.jstep > 0 ? 0 : (kw - 1) * gw.jstep);
+
+    const long long s_sn = dgrad ? p.y_sn : p.x_sn, s_sd = dgrad ? p.y_sd : p.x_sd;
+    const int s_sh = (int)(dgrad ? p.y_sh : p.x_sh), s_sw = (int)(dgrad ? p.y_sw : p.x_sw);
+    const float* __restrict__ src = dgrad ? p.y : p.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int it_dep = ntaps * nch;
+    const int it_all = gd.nt * it_dep;
+    const int it_per = (it_all + p.splitk - 1) / p.splitk;
+    const int it_begin = split * it_per;
+    const int it_end = min(it_all, it_begin + it_per);
+
+    // ---- weight slab DMA: per-lane source offsets (bytes) computed once --------------------------------------------------
+    unsigned goffF[LW], goffL[LW];
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+        const int slot = (wave * LW + q) * 64 + lane;
+        const int r = min(slot / RS, BN - 1);                  // slots >= SLOTS land in the buffer's tail, never read
+        int j = slot % RS;
+        if (j == 2 * NKS) j = 0;                               // pad slot of the row: any valid address
+        const int row = min(n0 + r, Nout - 1);                 // columns >= Nout are computed on valid data, never stored
+        const bool okL = (nch - 1) * CKB + j * 8 < Cred;       // beyond Cred the patch holds zeros: any FINITE weights do
+        goffF[q] = (unsigned)(row * ldb + j * 8) * 2u;
+        goffL[q] = (unsigned)(row * ldb + (okL ? j * 8 : 0)) * 2u;
+    }
+    int g_slabs = 1, g_first = 0, g_jd = 0;
+    // Per-entry offsets come from a small LDS table filled once per group (below): the walk over (tap, slab) entries then costs
+    // no scalar arithmetic.  (The CU has ONE scalar unit for all its waves: the tap / slab state machine of conv_patch.hip, run
+    // by 8 waves, was ~40 % of that kernel's main loop.)
+    uint2* etab = reinterpret_cast<uint2*>(ring + RING * SLABB + (size_t)ni * pimg * 2 + 16);      // [entries] {weight byte offset | last-slab flag, patch byte offset}
+    const unsigned dma_lds = ring_lds + (unsigned)(wave * LW) * 1024u;
+    auto issue = [&](uint2 te, auto bufc) {                    // DMA of one (tap, slab) entry into ring buffer BUF
+        constexpr int BUF = decltype(bufc)::value;
+        if (ABL(1)) return;
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.w16) + (te.x & 0x7fffffffu);
+        const bool last = (te.x >> 31) != 0;
+#pragma unroll
+        for (int q = 0; q < LW; ++q) ring_dma16(wp + (last ? goffL[q] : goffF[q]), dma_lds + (unsigned)(BUF * SLABB + q * 1024));
+    };
+
+    // ---- input patch of one slab group (fp32 or bf16 source; zero outside the image, beyond Cred and for images >= N) ----
+    auto stage_patch = [&](int cfirst, auto s16c) {
+        constexpr bool S16 = decltype(s16c)::value;        // compile-time: a runtime branch inside the loop serialises the loads
+        const int c4n = (spp * CKB) >> 2;
+        const int per_img = PH * PW * c4n;
+        const int total = ni * per_img;
+        // batches of U loads per thread: every load of a batch is issued before the first one is consumed (a loop with one guarded
+        // load per trip makes hipcc wait vmcnt(0) after each -- ten serial HBM round trips per workgroup in conv_patch.hip)
+        constexpr int U = 8;
+        for (int base = tid; base < (ABL(4) ? 0 : total); base += NT * U) {
+            float4 v[U];
+            uint2 w[U];
+            int dsto[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = min(base + u * NT, total - 1);
+                const int im = (int)fastdiv((unsigned)idx, p.s1_magPI);
+                const int rem = idx - im * per_img;
+                const int pix = (int)fastdiv((unsigned)rem, p.s1_magC4);
+                const int c = (rem - pix * c4n) << 2;
+                const int pyy = (int)fastdiv((unsigned)pix, p.s1_magPW);
+                const int pxx = pix - pyy * PW;
+                const int iy = org_h + pyy, ix = org_w + pxx;
+                const int cg = cfirst * CKB + c;
+                const int gi = img0 + im;
+                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
+                const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
+                                (unsigned)dz < (unsigned)gd.srcN;
+                const long long off = ok ? (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg : 0ll;
+                if constexpr (S16) w[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(src) + off);
+                else v[u] = ldg4(src + off);
+                const int d = im * pimg + pyy * pitch + pxx * CP + c;
+                // bit 30: store zeros.  Trips past the end write zeros to a dummy slot behind the patch: EVERY load is consumed
+                // unconditionally, so hipcc's scoreboard is empty when the DMA loop starts (a skipped consumer leaves the load
+                // "pending" and the compiler then drains vmcnt -- and with it the DMA ring -- inside the main loop)
+                dsto[u] = (base + u * NT < total) ? (ok ? d : (d | (int)0x40000000)) : (ni * pimg) | (int)0x40000000;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool zero = (dsto[u] & 0x40000000) != 0;
+                bf16x4 o;
+                if constexpr (S16) {
+                    uint2 t = w[u];
+                    if (zero) t = make_uint2(0u, 0u);
+                    o = __builtin_bit_cast(bf16x4, t);
+                } else {
+                    float4 t = v[u];
+                    if (zero) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o = bf16x4{(__bf16)t.x, (__bf16)t.y, (__bf16)t.z, (__bf16)t.w};
+                }
+                *reinterpret_cast<bf16x4*>(patch + (dsto[u] & 0x3fffffff)) = o;
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    int arow[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wm0 + i * 32 + l31;
+        const int im = row / rpi, rr = row - im * rpi;
+        arow[i] = im * pimg + (rr >> 3) * gh.mstep * pitch + (rr & 7) * gw.mstep * CP + khalf * 8;
+    }
+    const int brow0 = (wn0 + l31) * BROW + khalf * 8;
+
+    // ---- fragments of one (tap, slab) entry; two register sets: the ds_reads of entry e+1 are issued BEFORE the MFMAs of entry e --
+    struct Frags { bf16x8 a[NKS][WM]; bf16x8 b[NKS][WN]; };
+    const unsigned char* patch_b = reinterpret_cast<const unsigned char*>(patch);
+    int arow_b[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) arow_b[i] = arow[i] * 2;
+    auto load_a = [&](Frags& f, uint2 te) {
+        const unsigned char* a = patch_b + te.y;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) f.a[ks][i] = *reinterpret_cast<const bf16x8*>(a + arow_b[i] + ks * 32);
+    };
+    auto load_b = [&](Frags& f, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const __bf16* b = reinterpret_cast<const __bf16*>(ring + BUF * SLABB) + brow0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) f.b[ks][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * BROW + ks * 16);
+    };
+    auto mma = [&](const Frags& f, int k0, int k1) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks < k0 || ks >= k1) continue;
+            if (ABL(2)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) asm volatile("" :: "v"(f.a[ks][i]));
+#pragma unroll
+                for (int j = 0; j < WN; ++j) asm volatile("" :: "v"(f.b[ks][j]));
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- group-outer loop; inside a group the weight slabs stream through the four-deep DMA ring -----------------------------
+    // entry e: its slab is DMAed three iterations ahead, its fragments are read one iteration ahead, its MFMAs run in iteration e.
+    const int gsz = ntaps * spp;
+    const int ngs = (nch + spp - 1) / spp;
+    Frags F0, F1;
+    using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
+    for (int gg = (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
+        g_jd = gg / ngs;
+        const int g = gg - g_jd * ngs;
+        g_first = g * spp;
+        g_slabs = min(spp, nch - g_first);
+        const int e_lo = g_jd * it_dep + g * gsz;
+        if (e_lo >= it_end) break;
+        const int t_begin = max(it_begin, e_lo) - e_lo;
+        const int t_end = ABL(32) ? 0 : min(it_end, e_lo + ntaps * g_slabs) - e_lo;
+        if (t_begin >= t_end) continue;
+        const int len = t_end - t_begin;
+        __syncthreads();                                   // previous group's patch, ring and table are dead (no DMA in flight here)
+        for (int e = tid; e < len; e += NT) {              // entry table of this group
+            const int ent = t_begin + e;
+            const int tap = ent / g_slabs, sl = ent - tap * g_slabs;
+            const int jh = tap / kw, jw = tap - jh * kw;
+            const int f_tap = ((gd.t0 + g_jd * gd.tstep) * p.kh + (gh.t0 + jh * gh.tstep)) * p.kw + (gw.t0 + jw * gw.tstep);
+            const int f_cc = g_first + sl;
+            const int pu = gh.jstep > 0 ? jh * gh.jstep : (kh - 1 - jh) * -gh.jstep;
+            const int pv = gw.jstep > 0 ? jw * gw.jstep : (kw - 1 - jw) * -gw.jstep;
+            etab[e] = make_uint2((unsigned)((f_tap * Cred + f_cc * CKB) * 2) | (f_cc == nch - 1 ? 0x80000000u : 0u),
+                                 (unsigned)((pu * pitch + pv * CP + sl * CKB) * 2));
+        }
+        if (p.src16) stage_patch(g_first, std::true_type{}); else stage_patch(g_first, std::false_type{});
+        __syncthreads();                                   // table + patch visible
+        issue(etab[0], B0{});
+        if (len > 1) issue(etab[1], B1{});
+        if (len > 2) issue(etab[2], B2{});
+        // slab 0 of every wave has landed (up to two more stay in flight)
+        if (len > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LW) : "memory");
+        else if (len > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_a(F0, etab[0]);
+        load_b(F0, B0{});
+        // step e (cur holds the fragments of entry e): wait for slab e+1, barrier, DMA slab e+3 into the buffer slab e-1 just left,
+        // read the fragments of entry e+1, then the MFMAs of entry e
+        // The reads of entry e+1 are issued in two batches around the first MFMAs of entry e (pinned with sched_barrier): with all
+        // of them ahead of the MFMAs more than 15 LDS operations are outstanding, lgkmcnt cannot count that far and hipcc falls
+        // back to lgkmcnt(0) in front of the second MFMA -- the serialisation the second register set is there to remove.
+        constexpr int KH = (NKS + 1) / 2;
+        // `steady`: entries e+1 .. e+3 exist -- no branch in the step (a conditional load / DMA merges hipcc's wait-count states
+        // at the join and it falls back to lgkmcnt(0) in front of the MFMAs again)
+        auto step = [&](int e, Frags& cur, Frags& nxt, auto bn, auto bd, auto steadyc) {
+            constexpr bool STEADY = decltype(steadyc)::value;
+            const bool more = STEADY || e + 1 < len;
+            if (more) {
+                const uint2 tn = etab[e + 1];
+                uint2 td = tn;
+                if (STEADY || e + 3 < len) td = etab[e + 3];
+                if (STEADY || e + 2 < len) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (STEADY || e + 3 < len) issue(td, bd);
+                load_a(nxt, tn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur, 0, KH);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_b(nxt, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur, KH, NKS);
+        };
+        int e = 0;
+        for (; e + 6 < len; e += 4) {
+            step(e, F0, F1, B1{}, B3{}, std::true_type{});
+            step(e + 1, F1, F0, B2{}, B0{}, std::true_type{});
+            step(e + 2, F0, F1, B3{}, B1{}, std::true_type{});
+            step(e + 3, F1, F0, B0{}, B2{}, std::true_type{});
+        }
+        for (; e < len; e += 4) {
+            step(e, F0, F1, B1{}, B3{}, std::false_type{});
+            if (e + 1 < len) step(e + 1, F1, F0, B2{}, B0{}, std::false_type{});
+            if (e + 2 < len) step(e + 2, F0, F1, B3{}, B1{}, std::false_type{});
+            if (e + 3 < len) step(e + 3, F1, F0, B0{}, B2{}, std::false_type{});
+        }
+    }
+
+    const long long d_sn = dgrad ? p.x_sn : p.y_sn, d_sd = dgrad ? p.x_sd : p.y_sd;
+    const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
+
+    if (ABL(8) && acc[0][0][0] != 123.f) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (p.cell) {
+        // ---- "cell" epilogue: per-(image, channel) sum / sum of squares + bf16 rows through LDS ---------------------------------
+        // (launcher guarantees: full tiles, Nout % BN == 0, nimg % ni == 0, split-K 1, no bias / activation / beta)
+        constexpr int TP = BN / 2 + 4;                        // dwords per tile row (bf16 pairs; 16-byte aligned rows)
+        unsigned* T = reinterpret_cast<unsigned*>(smem);      // [BM][TP]
+        float* stat = reinterpret_cast<float*>(T + BM * TP);  // [ni][BN][2]
+        __syncthreads();                                      // ring and patch are dead
+        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
+        __syncthreads();
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int rowb = wm0 + i * 32;
+            const int im = rowb / rpi;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
+                s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                if (khalf == 0) {
+                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
+                    atomicAdd(d, s); atomicAdd(d + 1, q);
+                }
+                const int cp = (wn0 + 32 * j + (l31 & ~1)) >> 1;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float e = acc[i][j][2 * m], o = acc[i][j][2 * m + 1];
+                    const float en = dpp_xor1(e), on = dpp_xor1(o);
+                    // even lane: row of register 2m, columns (own, neighbour); odd lane: row of register 2m+1, (neighbour, own)
+                    const int r = 2 * m + (odd ? 1 : 0);
+                    const int row = rowb + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    T[row * TP + cp] = odd ? pack_bf16x2(on, o) : pack_bf16x2(e, en);
+                }
+            }
+        }
+        __syncthreads();
+        unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
+        constexpr int CH = BN / 8;                            // 16-byte pieces per tile row
+        for (int idx = tid; idx < BM * CH; idx += NT) {
+            const int row = idx / CH, c8 = idx - row * CH;
+            const int im = row / rpi, rr = row - im * rpi;
+            const int gi = img0 + im;
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int py = oy0 + (rr >> 3), px = ox0 + (rr & 7);
+            const uint4 v = *reinterpret_cast<const uint4*>(T + row * TP + c8 * 4);
+            unsigned short* dst = out16 + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
+                                  (long long)(gh.ob + py * gh.os) * d_sh + (long long)(gw.ob + px * gw.os) * d_sw + n0 + c8 * 8;
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+        if (p.stats) {
+            for (int i = tid; i < ni * BN * 2; i += NT) {
+                const int im = i / (BN * 2), rem = i - im * (BN * 2);
+                const int gi = img0 + im;
+                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
+            }
+        }
+        return;
+    }
+
+    // ---- plain epilogue (as conv_patch.hip) -------------------------------------------------------------------------------------
+    const int e_sh = d_sh * gh.os, e_sw = d_sw * gw.os;
+    const int col0 = n0 + wn0 + l31;
+    const int px0 = ox0 + 4 * khalf;
+    const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int rowb = wm0 + i * 32;
+        const int im = rowb / rpi;
+        const int py0 = oy0 + ((rowb - im * rpi) >> 3);
+        const int gi = img0 + im;
+        if (gi >= nimg) continue;
+        const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+        float* __restrict__ dst = p.out + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
+                                  (long long)(gh.ob + py0 * gh.os) * d_sh +
+                                  (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
+        const bool full = (py0 + 4 <= Hm) && (ox0 + TW <= Wm);
+        if (plain && full) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (col0 + 32 * j >= Nout) continue;
+                const float bias = p.bias ? p.bias[col0 + 32 * j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
+            }
+            continue;
+        }
+        const float* __restrict__ aux = p.aux ? p.aux + (dst - p.out) : nullptr;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (col0 + 32 * j >= Nout) continue;
+            const float bias = (p.bias && split == 0) ? p.bias[col0 + 32 * j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
+                const int off = (r >> 2) * e_sh + (r & 3) * e_sw + 32 * j;
+                float v = acc[i][j][r] + bias;
+                if (p.splitk > 1) {
+                    unsafeAtomicAdd(dst + off, v);
+                    continue;
+                }
+                if (p.beta) v += dst[off];
+                if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
+                else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                else if (p.act == SAVP_ACT_DLRELU_FROM_OUT) v *= (aux[off] > 0.f ? 1.f : p.alpha);
+                dst[off] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+template <int NW, int WM, int WN, int NKS>
+static hipError_t launch_ring(const ConvP& p, dim3 grid, size_t lds, hipStream_t st) {
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipFuncSetAttribute((const void*)conv_ring_kernel<NW, WM, WN, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((conv_ring_kernel<NW, WM, WN, NKS>), grid, dim3(64 * NW), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int NW, int WM, int WN>
+static hipError_t launch_ring_nks(const ConvP& p, int nks, dim3 grid, size_t lds, hipStream_t st) {
+    switch (nks) {
+        case 1: return launch_ring<NW, WM, WN, 1>(p, grid, lds, st);
+        case 2: return launch_ring<NW, WM, WN, 2>(p, grid, lds, st);
+        case 3: return launch_ring<NW, WM, WN, 3>(p, grid, lds, st);
+        case 4: return launch_ring<NW, WM, WN, 4>(p, grid, lds, st);
+        case 5: return launch_ring<NW, WM, WN, 5>(p, grid, lds, st);
+        default: return launch_ring<NW, WM, WN, 6>(p, grid, lds, st);
+    }
+}
+
+template <int NW>
+static hipError_t launch_ring_tile(const ConvP& p, int wm, int wn, int nks, dim3 grid, size_t lds, hipStream_t st) {
+    if (wm == 2 && wn == 2) return launch_ring_nks<NW, 2, 2>(p, nks, grid, lds, st);
+    if (wm == 2 && wn == 1) return launch_ring_nks<NW, 2, 1>(p, nks, grid, lds, st);
+    if (wm == 1 && wn == 2) return launch_ring_nks<NW, 1, 2>(p, nks, grid, lds, st);
+    return launch_ring_nks<NW, 1, 1>(p, nks, grid, lds, st);
+}
+
+struct RingPlan { int nw, wm, wn, nks; size_t lds; dim3 grid; };
+
+// Geometry of one (nw, wm, wn) choice; false = this choice cannot run the problem (LDS, cell-mode tiling constraints, ...).
+static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, RingPlan& pl) {
+    const bool dg = a->mode == SAVP_CONV_DGRAD;
+    const int Cred = dg ? a->Cy : a->Cx, Nout = dg ? a->Cx : a->Cy;
+    const int Dm = dg ? a->D : a->Do;
+    const int phases = dg ? a->sh * a->sw : 1;
+    const int Hm = dg ? (a->H + a->sh - 1) / a->sh : a->Ho, Wm = dg ? (a->W + a->sw - 1) / a->sw : a->Wo;
+    const long long dH = dg ? a->H : a->Ho, dW_ = dg ? a->W : a->Wo;
+    const long long d_sn = dg ? a->x_sn : a->y_sn, d_sh = dg ? a->x_sh : a->y_sh, d_sw = dg ? a->x_sw : a->y_sw;
+    const long long d_sd = dg ? a->x_sd : a->y_sd;
+    const int tW = (Wm + 7) / 8;
+    // channel slabs: with the DMA ring a slab costs (k-steps + ~0.5), so exact fits beat fewer, wider slabs
+    const int Cp16 = (Cred + 15) & ~15;
+    int nch = 0, nks = 0;
+    double best = 1e30;
+    for (int c = (Cp16 + 95) / 96; c <= (Cp16 + 95) / 96 + 3; ++c) {
+        const int k = (Cp16 / 16 + c - 1) / c;
+        if (k < 1 || k > 6) continue;
+        const double cost = c * (k + 0.5);
+        if (cost < best) { best = cost; nch = c; nks = k; }
+    }
+    if (!nch) return false;
+    const int TH = 2 * nw * wm;
+    int tih = 4;
+    while (tih < TH && tih < Hm) tih *= 2;
+    const int ni = TH / tih;
+    const int PH = dg ? tih + (a->kh + a->sh - 1) / a->sh - 1 : (tih - 1) * a->sh + a->kh;
+    const int PW = dg ? 8 + (a->kw + a->sw - 1) / a->sw - 1 : 7 * a->sw + a->kw;
+    const int BM = 16 * nw * wm, BN = 64 * wn, NT = 64 * nw;
+    const int RS = 2 * nks + 1;
+    const int LW = (BN * RS + NT - 1) / NT;
+    const size_t ringb = (size_t)4 * LW * NT * 16;
+    const size_t budget = 160 * 1024;
+    int spp = nch, pitch = 0;
+    size_t lds = 0;
+    for (; spp >= 1; --spp) {
+        const int CP = spp * nks * 16 + 8;
+        const int x = (8 - (PW * (CP / 8)) % 16 + 16) % 16;
+        pitch = PW * CP + 8 * x;
+        // + dummy slot of stage_patch + entry table of one group (8 bytes per (tap, slab) entry)
+        lds = ringb + (size_t)ni * PH * pitch * 2 + 16 + (size_t)8 * (dg ? ((a->kh + a->sh - 1) / a->sh) * ((a->kw + a->sw - 1) / a->sw) : a->kh * a->kw) * spp;
+        if (lds <= budget) break;
+    }
+    if (spp < 1) return false;
+    const bool cell = a->out_bf16 != 0;
+    if (cell) {
+        const size_t epi = (size_t)BM * (BN / 2 + 4) * 4 + (size_t)ni * BN * 2 * 4;
+        if (epi > lds) lds = epi;
+        if (lds > budget) return false;
+        const long long nimg = (long long)a->N * Dm;
+        if (a->bias || a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || Nout % BN || nimg % ni || (d_sw % 8) || (d_sh % 8) ||
+            (d_sn % 8) || (d_sd % 8) || ((((uintptr_t)(dg ? a->x : a->y)) & 15) != 0) || phases != 1)
+            return false;
+    }
+    if ((long long)a->N * Dm >= (1 << 24)) return false;
+    if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
+    p.cell = cell ? 1 : 0;
+    p.stats = cell ? (float*)a->stats : nullptr;
+    p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
+    p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
+    p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
+    p.s1_magDm = magic40(Dm);
+    p.tm = (int)(((long long)a->N * Dm + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
+    const long long tiles = (long long)p.tm * p.tn;
+    const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
+    int splitk = a->splitk;
+    if (a->act != SAVP_ACT_NONE || cell) splitk = 1;
+    else if (splitk <= 0) {
+        splitk = 1;
+        if (tiles <= 192 && iters >= 16) {
+            long long s1 = 512 / tiles, s2 = iters / 8;
+            splitk = (int)(s1 < s2 ? s1 : s2);
+            if (splitk < 1) splitk = 1;
+            if (splitk > 16) splitk = 16;
+        }
+    }
+    if (splitk > iters) splitk = (int)iters;
+    if (splitk > 1 && !a->beta) {
+        const long long dD = Dm;
+        const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (dD == 1 || d_sd == dH * dW_ * Nout) &&
+                           (d_sn == dD * dH * dW_ * Nout);
+        if (!dense) splitk = 1;
+    }
+    p.splitk = splitk;
+    pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
+    pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
+    return true;
+}
+
+// Returns true when the ring kernel handled the call (*rc = status); false = not applicable (the caller falls back).
+// SavpConvArgs.out_bf16 selects the cell epilogue: bf16 destination + optional statistics; with an automatic tile the first
+// (waves, tile) choice whose tiling can honour it is taken, a forced tile that cannot is refused (false).
+bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc) {
+    const bool dg = a->mode == SAVP_CONV_DGRAD;
+    const int Cred = dg ? a->Cy : a->Cx, Nout = dg ? a->Cx : a->Cy;
+    const long long ssn = dg ? a->y_sn : a->x_sn, ssh = dg ? a->y_sh : a->x_sh, ssw = dg ? a->y_sw : a->x_sw;
+    const void* sptr = dg ? a->y : a->x;
+    const int sal = p.src16 ? 8 : 4;                             // source alignment in elements (8 / 16 bytes per load)
+    const bool src_al = (ssn % sal == 0) && (ssh % sal == 0) && (ssw % sal == 0) && ((((uintptr_t)sptr) & (p.src16 ? 7 : 15)) == 0);
+    const long long ssd = dg ? a->y_sd : a->x_sd;
+    if (!(p.bf16 && p.w16 && a->sd == 1 && a->sh <= 4 && a->sw <= 4 && a->kh >= a->sh && a->kw >= a->sw && (Cred % 8 == 0) &&
+          src_al && ssd % sal == 0))
+        return false;
+    const int Hm = dg ? (a->H + a->sh - 1) / a->sh : a->Ho, Wm = dg ? (a->W + a->sw - 1) / a->sw : a->Wo;
+    const long long dH = dg ? a->H : a->Ho;
+    const long long d_sh = dg ? a->x_sh : a->y_sh;
+    if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)Nout * a->kh * a->kw * a->kd * Cred >= (1ll << 30))
+        return false;
+    if ((long long)Hm * Wm < 16) return false;
+    RingPlan pl;
+    bool ok = false;
+    if (wm) {
+        ok = ring_plan(p, a, (a->tile & 0x400) ? 8 : 4, wm, wn, pl);
+    } else {
+        const int tW = (Wm + 7) / 8;
+        const int wn0 = Nout > 64 ? 2 : 1;
+        const long long t16 = (long long)a->N * ((Hm + 15) / 16) * tW * ((Nout + 64 * wn0 - 1) / (64 * wn0));
+        const int wm0 = (t16 >= 256 && Hm >= 16) ? 2 : 1;
+        const int cand[5][3] = {{8, wm0, wn0}, {8, 1, wn0}, {4, 1, wn0}, {8, 1, 1}, {4, 1, 1}};
+        for (int i = 0; i < 5 && !ok; ++i) ok = ring_plan(p, a, cand[i][0], cand[i][1], cand[i][2], pl);
+    }
+    if (!ok) return false;
+    if (p.splitk > 1 && !a->beta) {
+        const int Dm = dg ? a->D : a->Do;
+        const long long dW_ = dg ? a->W : a->Wo;
+        hipMemsetAsync(p.out, 0, (size_t)a->N * Dm * dH * dW_ * Nout * sizeof(float), st);
+    }
+    ablate_init();
+    hipError_t err = (pl.nw == 8) ? launch_ring_tile<8>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st)
+                                  : launch_ring_tile<4>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st);
+    *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
+    return true;
+}

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     // bias gradient = column sums of dy, taken from the tiles as they stream by (fp32, before the bf16 rounding); one M chunk only
     const bool do_db = (q.db != nullptr) && (mc == 0);
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned fmask = 0u, dmask = 0u;                           // validity of the elements held in pf / pd
     auto fetch = [&](int t) {
+        fmask = 0u; dmask = 0u;
         const int gi = (int)fastdiv((unsigned)t, q.magTHW);          // (sample, output plane)
         const int r = t - gi * q.tHW;
         const int img = (int)fastdiv((unsigned)gi, q.magDo);
@@ -97,9 +99,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             const int dz = dout - q.pd + (int)(co >> 24);      // input plane of this patch plane (depth stride 1)
             const bool ok = (inf >> 31) && (unsigned)(iy0 + pyy) < (unsigned)q.H && (unsigned)(ix0 + pxx) < (unsigned)q.W &&
                             ca * 16 + c < q.Cx && (unsigned)dz < (unsigned)q.D;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = ldg4(xs + (long long)dz * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c);
-            pf[i] = v;
+            // unconditional load from a clamped address, zeroed at stage() time through the mask: a branch around the load (or
+            // a select right behind it) makes hipcc wait for every element here instead of behind the MFMAs of the current tile
+            pf[i] = ldg4(ok ? xs + (long long)dz * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c : q.x);
+            fmask |= (ok ? 1u : 0u) << i;
         }
         const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh +
                                        (long long)ox0 * q.y_sw + cy0;
@@ -108,10 +111,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             const int idx = tid + NT * i;                      // 64 pixels x 8 float4
             const int px = idx >> 3, c = (idx & 7) << 2;
             const bool ok = idx < 512 && oy0 + (px >> 3) < q.Ho && ox0 + (px & 7) < q.Wo && cy0 + c < q.Cy;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = ldg4(ys + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c);
-            pd[i] = v;
-            if (do_db) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+            pd[i] = ldg4(ok ? ys + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c : q.y);
+            dmask |= (ok ? 1u : 0u) << i;
         }
     };
     auto stage = [&](int buf) {
@@ -121,7 +122,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             unsigned inf = pinfo[i];
             asm volatile("" : "+v"(inf));
             if (inf >> 31) {
-                bf16x4 o = {(__bf16)pf[i].x, (__bf16)pf[i].y, (__bf16)pf[i].z, (__bf16)pf[i].w};
+                float4 v = pf[i];
+                if (!((fmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                 *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffffffu)) = o;
             }
         }
@@ -130,7 +133,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         for (int i = 0; i < NPD; ++i) {
             const int idx = tid + NT * i;
             if (idx < 512) {
-                bf16x4 o = {(__bf16)pd[i].x, (__bf16)pd[i].y, (__bf16)pd[i].z, (__bf16)pd[i].w};
+                float4 v = pd[i];
+                if (!((dmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (do_db) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                 *reinterpret_cast<bf16x4*>(pb + (idx >> 3) * 32 + ((idx & 7) << 2)) = o;
             }
         }

@@ -43,6 +43,15 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// four consecutive elements at element index idx of a tensor that holds fp32 or (is16) bf16
+__device__ __forceinline__ float4 ld4x(const float* base, long long idx, int is16) {
+    if (is16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    return ld4(base + idx);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
@@ -384,7 +393,8 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
 #define MAXPPT 4
 struct LstmP {
     int N, HW, F;
-    const float* gates;
+    const float* gates;                                   // fp32, or bf16 when gates16 (coalesced kernels only)
+    int gates16, stats1_ready;                            // stats1_ready: ws s1 holds UNSHIFTED sums (conv epilogue), pass 1 is skipped
     const float* c_prev; long long cp_sn, cp_sp;          // may be null (zero state)
     const float *g1, *b1, *g2, *b2;
     float eps, forget_bias;
@@ -658,12 +668,13 @@ __global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int ch
     const int n = blockIdx.y, F = p.F, F4 = F / 4;
     const int fq = threadIdx.x % F4, prow = threadIdx.x / F4, rows = NT / F4;
     const int c0 = fq * 4;
-    const float* g0 = p.gates + (long long)n * p.HW * 4 * F;
+    const long long g0 = (long long)n * p.HW * 4 * F;     // element index of this sample's gates
     const float inv = 1.f / (float)p.HW;
     float mu[16], rs[16], ga[16], be[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 k = ld4(g0 + q * F + c0);            // shift of pass 1 = pixel 0
+        float4 k = make_float4(0.f, 0.f, 0.f, 0.f);       // shift of pass 1 = pixel 0 (none for the conv epilogue's sums)
+        if (!p.stats1_ready) k = ld4x(p.gates, g0 + q * F + c0, p.gates16);
         const float kk[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -682,8 +693,9 @@ __global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int ch
         }
     }
     auto cell = [&](int px, float (&cn)[4], float (&so)[4]) {
-        const float* q = g0 + (long long)px * 4 * F + c0;
-        const float4 gi = ld4(q), gj = ld4(q + F), gf = ld4(q + 2 * F), go = ld4(q + 3 * F);
+        const long long q = g0 + (long long)px * 4 * F + c0;
+        const float4 gi = ld4x(p.gates, q, p.gates16), gj = ld4x(p.gates, q + F, p.gates16), gf = ld4x(p.gates, q + 2 * F, p.gates16),
+                     go = ld4x(p.gates, q + 3 * F, p.gates16);
         float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)px * p.cp_sp + c0);
         const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, jv[4] = {gj.x, gj.y, gj.z, gj.w};
@@ -794,8 +806,9 @@ __device__ __forceinline__ void lstm_lane_load(const LstmP& p, int n, int c0, Ls
 // normalised gates xh[16] and previous cell state of pixel px
 __device__ __forceinline__ void lstm_load_px(const LstmP& p, const LstmLane& L, int n, int px, int c0, float (&xh)[16], float (&cp)[4]) {
     const int F = p.F;
-    const float* q = p.gates + ((long long)n * p.HW + px) * 4 * F + c0;
-    const float4 a0 = ld4(q), a1 = ld4(q + F), a2 = ld4(q + 2 * F), a3 = ld4(q + 3 * F);
+    const long long q = ((long long)n * p.HW + px) * 4 * F + c0;
+    const float4 a0 = ld4x(p.gates, q, p.gates16), a1 = ld4x(p.gates, q + F, p.gates16), a2 = ld4x(p.gates, q + 2 * F, p.gates16),
+                 a3 = ld4x(p.gates, q + 3 * F, p.gates16);
     const float raw[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
 #pragma unroll
     for (int i = 0; i < 16; ++i) xh[i] = (raw[i] - L.mu[i]) * L.rs[i];
@@ -946,11 +959,11 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
     for (int i = 0; i < 16; ++i) { s1[i] *= inv; s2[i] *= inv; }
     const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
     for (int px = p0 + prow; px < p1; px += rows) {
-        const float* q = p.gates + ((long long)n * p.HW + px) * 4 * F + c0;
+        const long long q = ((long long)n * p.HW + px) * 4 * F + c0;
         float* gq = p.dgates + ((long long)n * p.HW + px) * 4 * F + c0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 raw = ld4(q + g * F), dgv = ld4(gq + g * F);
+            const float4 raw = ld4x(p.gates, q + g * F, p.gates16), dgv = ld4(gq + g * F);
             const float rv[4] = {raw.x, raw.y, raw.z, raw.w}, dv[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
             float o[4];
 #pragma unroll
@@ -967,7 +980,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
 static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     if (!a || a->F % 4 || a->HW < 1) return SAVP_EINVAL;
     p.N = a->N; p.HW = a->HW; p.F = a->F;
-    p.gates = a->gates;
+    p.gates = (const float*)a->gates; p.gates16 = a->gates_bf16 ? 1 : 0; p.stats1_ready = a->stats1_ready ? 1 : 0;
     p.c_prev = (const float*)a->c_prev.p; p.cp_sn = a->c_prev.sn; p.cp_sp = a->c_prev.sp;
     p.g1 = a->gamma1; p.b1 = a->beta1; p.g2 = a->gamma2; p.b2 = a->beta2;
     p.eps = a->eps; p.forget_bias = a->forget_bias;
@@ -1001,11 +1014,14 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
         w.s1 = a->ws_stats ? a->ws_stats : a->ws;
         w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = w.s2 + (size_t)N * F * 2;
         w.so = a->ws_stats ? a->ws : w.k2 + (size_t)N * F;
+        if (a->stats1_ready && !a->ws_stats) return SAVP_EINVAL;
+        if (!a->stats1_ready) {
         if (!(a->ws_stats && a->ws_stats_clean)) hipMemsetAsync(w.s1, 0, (size_t)N * F * 10 * sizeof(float), st);
+        if (a->gates_bf16) return SAVP_EINVAL;             // bf16 gates come with their statistics from the conv epilogue
         // pass 1: shifted sums of the gate tensor, the instance-norm statistics kernel with C = 4F
         InormP q;
         q.N = N; q.HW = HW; q.C = 4 * F;
-        q.x = a->gates; q.x_sn = (long long)HW * 4 * F; q.x_sp = 4 * F;
+        q.x = (const float*)a->gates; q.x_sn = (long long)HW * 4 * F; q.x_sp = 4 * F;
         const int rows1 = NT / F;                                   // C/4 = F float4 per pixel
         long long c1 = ((long long)HW * N + 511) / 512;
         if (c1 < rows1) c1 = rows1;
@@ -1013,6 +1029,7 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
         q.chunk = (int)c1;
         hipLaunchKernelGGL(inorm_stats_kernel, dim3((HW + q.chunk - 1) / q.chunk, N), dim3(NT), (size_t)rows1 * 2 * 4 * F * sizeof(float), st,
                            q, w.s1);
+        }
         const int rows2 = NT / (F / 4);
         long long c2 = ((long long)HW * N + 511) / 512;
         if (c2 < rows2) c2 = rows2;
@@ -1022,7 +1039,7 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
         hipLaunchKernelGGL(lstm_out_kernel, grid, dim3(NT), 0, st, p, w, (int)c2);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
-    if (a->HW > MAXPPT * NT) return SAVP_EINVAL;
+    if (a->HW > MAXPPT * NT || a->gates_bf16 || a->stats1_ready) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, st, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }
@@ -1049,7 +1066,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
         hipLaunchKernelGGL(lstm_bwd3_kernel, grid, dim3(NT), 0, st, p, w, (int)c);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
-    if (a->HW > MAXPPT * NT) return SAVP_EINVAL;
+    if (a->HW > MAXPPT * NT || a->gates_bf16) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }

@@ -256,7 +256,8 @@ class ConvLayer(object):
             self.u.copy_(self.u_next)
 
     # -- execution ----------------------------------------------------------------------------------------------
-    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True):
+    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True, stats=None):
+        """stats: see kernels.conv (bf16 destination only: the fused ConvLSTM gate convolution)."""
         b = self.bias if use_bias else None
         if self.kind == 'conv' and x.dim() == 2 and x.shape[0] <= 64 and not act and not beta and y.is_contiguous():
             # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
@@ -268,7 +269,7 @@ class ConvLayer(object):
         if self.kind == 'up':
             K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16)
         else:
-            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16)
+            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats)
         if self.prof is not None:
             e1.record()
             self.prof.append((e0, e1))

@@ -76,7 +76,7 @@ def enable_autotune(flag=True):
     AUTOTUNE['enabled'] = bool(flag)
 
 
-def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None):
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -94,6 +94,11 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     a.bias = bias.data_ptr() if bias is not None else None
     a.aux = aux.data_ptr() if aux is not None else None
     a.w_bf16 = w16.data_ptr() if w16 is not None else None
+    # bf16 activations (ring kernel): the source / destination tensor's dtype says so; strides are in elements of that dtype
+    src, dst = (y, x) if mode == lib.CONV_DGRAD else (x, y)
+    a.src_bf16 = int(src.dtype == torch.bfloat16)
+    a.out_bf16 = int(dst.dtype == torch.bfloat16) if mode != lib.CONV_WGRAD else 0
+    a.stats = stats.data_ptr() if stats is not None else None
     taps = geom.k[0] * geom.k[1] * geom.k[2]
     if w.numel() != taps * Cx * Cy:
         raise ValueError('weight has %d elements, expected %d' % (w.numel(), taps * Cx * Cy))
@@ -120,9 +125,17 @@ def _tune(a, mode, dst, w):
         splits = (1, 2, 4, 8) if a.act == 0 else (1,)
         # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
         # (0x6xx = patch kernel with 8 waves per workgroup; 0x1000 / 0x2000 = its LDS budget capped at 64 / 96 KB)
-        cands = [(alg | t, sk) for alg in (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600) for t in tiles for sk in splits]
+        # 0x3xx / 0x7xx = LDS-DMA ring kernel with 4 / 8 waves (the only one for bf16 activations / the cell epilogue)
+        algs = (0x300, 0x700) if (a.src_bf16 or a.out_bf16) else (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600, 0x300, 0x700)
+        if a.out_bf16:
+            splits = (1,)
+        cands = [(alg | t, sk) for alg in algs for t in tiles for sk in splits]
         real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
         scratch = None
+        real_stats = a.stats
+        if a.stats:                      # tuning runs must not accumulate into the real statistics
+            stats_scratch = torch.zeros(a.N * (a.Cx if mode == lib.CONV_DGRAD else a.Cy) * 2, device=dst.device)
+            a.stats = stats_scratch.data_ptr()
         if a.beta:                       # never accumulate tuning runs into the real destination
             scratch = torch.empty_like(dst)
             if scratch.stride() != dst.stride():
@@ -152,6 +165,7 @@ def _tune(a, mode, dst, w):
         a.w, a.bias = real_w, real_bias
     else:
         a.beta = real_beta
+        a.stats = real_stats
         if mode == lib.CONV_DGRAD:
             a.x = real_dst
         else:
@@ -159,13 +173,16 @@ def _tune(a, mode, dst, w):
     return best or (0, 0)
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None):
-    """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h."""
-    lib.require_device(x, y, w, bias, aux)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16)
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None):
+    """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
+    destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] fp32 (zeroed by the caller)
+    receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only)."""
+    lib.require_device(w, bias, aux, stats)
+    lib.require_device_any(x, y)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats)
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
-               a.x_sw, a.y_sw, bias is not None, w16 is not None)
+               a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
@@ -292,6 +309,7 @@ def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
     if not gates.is_contiguous():
         raise ValueError('gates must be contiguous')
     a.gates = gates.data_ptr()
+    a.gates_bf16 = int(gates.dtype == torch.bfloat16)
     if c_prev is not None:
         a.c_prev = view(c_prev)
     a.gamma1, a.beta1, a.gamma2, a.beta2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
@@ -305,17 +323,29 @@ def lstm_ws_floats(N, HW, F):
     return N * F * HW
 
 
-def _lstm_ws(a, gates, ws):
+def _lstm_ws(a, gates, ws, ws_stats=None):
     lib.require_device(ws)
     a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
-    a.ws_stats, a.ws_stats_clean = zero_arena(gates.device).take(a.N * a.F * 11).data_ptr(), 1
+    if ws_stats is None:
+        ws_stats = zero_arena(gates.device).take(a.N * a.F * 11)
+    a.ws_stats, a.ws_stats_clean = ws_stats.data_ptr(), 1
 
 
-def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None):
+def lstm_stats_ws(device, N, F):
+    """An all-zero reduction workspace [N*F*11] of the coalesced ConvLSTM gate kernels from the step's zero arena; its first
+    N*4F*2 floats, viewed [N, 4F, 2], are what savp_conv's `stats` epilogue fills for convlstm_gates_fwd(stats1=...)."""
+    ws = zero_arena(device).take(N * F * 11)
+    return ws, ws[:N * 4 * F * 2].view(N, 4 * F, 2)
+
+
+def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None, stats1=None):
+    """stats1: the workspace returned by lstm_stats_ws whose head the gate convolution's epilogue has already filled (the
+    statistics pass over the gate tensor is skipped); needed for bf16 gates."""
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     a.c_new = c_new.data_ptr()
     if ws is not None:
-        _lstm_ws(a, gates, ws)
+        _lstm_ws(a, gates, ws, stats1)
+        a.stats1_ready = int(stats1 is not None)
     a.nh = len(hs)
     _set_views(a.h, hs)
     lib.check(lib.get().savp_convlstm_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_fwd')

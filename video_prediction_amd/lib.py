@@ -30,6 +30,7 @@ class SavpConvArgs(ctypes.Structure):
         ('x', c_vp), ('x_sn', c_i64), ('x_sd', c_i64), ('x_sh', c_i64), ('x_sw', c_i64),
         ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
         ('w', c_vp), ('bias', c_vp), ('aux', c_vp), ('w_bf16', c_vp),
+        ('src_bf16', c_i32), ('out_bf16', c_i32), ('stats', c_vp),
     ]
 
 
@@ -102,6 +103,17 @@ def require_device(*tensors):
             raise RuntimeError('expected float32, got %s' % t.dtype)
 
 
+def require_device_any(*tensors):
+    """Activations that may be fp32 or bf16 (ring conv kernel)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('video_prediction_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError('expected float32 or bfloat16, got %s' % t.dtype)
+
+
 class SavpView(ctypes.Structure):
     _fields_ = [('p', c_vp), ('sn', c_i64), ('sp', c_i64)]
 
@@ -126,6 +138,7 @@ class SavpLstmArgs(ctypes.Structure):
         ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
         ('ws', c_vp), ('ws_floats', ctypes.c_int64), ('ws_stats', c_vp), ('ws_stats_clean', c_i32),
+        ('gates_bf16', c_i32), ('stats1_ready', c_i32),
     ]
 
 

@@ -13,6 +13,8 @@ MI355X-first layout decisions:
     concat buffer, gradients are read back from the same slices;
   * the posterior and prior unrolls share weights, so they run as ONE unroll of batch 2B (all ops are per-sample).
 """
+import os
+
 import torch
 
 from .. import kernels as K
@@ -30,8 +32,8 @@ def ceil4(n):
 class Act(object):
     """Time-major activation buffer with an optional gradient twin."""
 
-    def __init__(self, shape, device, grad=True, zero_grad=False):
-        self.v = torch.zeros(shape, device=device, dtype=torch.float32)
+    def __init__(self, shape, device, grad=True, zero_grad=False, dtype=torch.float32):
+        self.v = torch.zeros(shape, device=device, dtype=dtype)            # the gradient twin is always fp32
         self.g = None
         if grad:
             self.g = torch.zeros(shape, device=device, dtype=torch.float32) if zero_grad else \
@@ -127,7 +129,11 @@ class SAVPGenerator(object):
             elif use_rnn:
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
                 L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g)
-                L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g)
+                # fused ConvLSTM cell of the bf16 datapath: the gate convolution's epilogue produces the statistics of the first
+                # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
+                L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
+                              h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0)
+                L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32)
                 L['c'] = Act((T1, N, h_, w_, f), dev, grad=False)
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
                 L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
@@ -306,14 +312,17 @@ class SAVPGenerator(object):
                     a = L['a']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
-                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False)
+                    stats1 = s1 = None
+                    if L['fused']:
+                        stats1, s1 = K.lstm_stats_ws(self.dev, N, f)
+                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                     outs = self._out_views(L, t)
                     if t + 1 < T1:
                         outs.append(a.v[t + 1][..., f + nz:f + nz + f])
                     n1, n2 = L['n1'], L['n2']
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
-                                         eps=EPS_IN, ws=self._lstm_ws(L))
+                                         eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
