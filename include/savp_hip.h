@@ -160,9 +160,10 @@ int savp_gather_clips(void* stream, float* src, float* dst, const int32_t* t_sta
                       int64_t src_t_stride, int32_t adjoint);
 /* out = dy * y * (1-y) (contiguous out): backward of the sigmoid fused into a conv epilogue (savp_model.py:572) */
 int savp_sigmoid_bwd(void* stream, SavpView dy, SavpView y, float* out, int64_t N, int32_t HW, int32_t C);
-/* ops.dense for few rows (M <= 64), split over K: out[M,C] = scale*x[M,K] W[K,C] + bias (out contiguous) */
+/* ops.dense for few rows (M <= 64), split over K: out[M,C] = scale*x[M,K] W[K,C] + bias (out contiguous).
+ * ws (optional, ws_floats >= M*C; best 64*M*C): per-slice partial sums + a reduction launch instead of float atomics on `out` */
 int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,
-                   const float* bias, const float* scale, float* out);
+                   const float* bias, const float* scale, float* out, float* ws, int64_t ws_floats);
 int savp_axpby(void* stream, int64_t n, float a, const float* x, float b, const float* y, float* out);
 int savp_fill_view(void* stream, SavpView out, int64_t R, int32_t HW, int32_t C, float value);
 /* tf.train.AdamOptimizer on a flat arena (base_model.py:486-487); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */

@@ -1,5 +1,4 @@
-for sh in lstm_h0 lstm_h1; do
-for tile in 0x712 0x621; do
-for a in 0 4 8 12 32 36 40 44 2 1 3; do
-  SHAPE=$sh MODE=fprop TILE=$tile SAVP_ABLATE=$a ITERS=20 python tests/micro_one.py 2>&1 | tail -1
-done; done; done
+for cfg in "lstm_h0 0x712" "lstm_h1 0x711" "lstm_h2 0x311"; do set -- $cfg
+for a in 0 4 8 32 44 2 1 3; do
+  SHAPE=$1 MODE=fprop TILE=$2 SAVP_ABLATE=$a ITERS=20 python tests/micro_one.py 2>&1 | tail -1
+done; done

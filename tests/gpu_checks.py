@@ -363,6 +363,24 @@ def check_lstm(seed=3):
 # ---------------------------------------------------------------------------------------------------------------
 # util ops
 # ---------------------------------------------------------------------------------------------------------------
+def check_dense(seed=14):
+    """ops.dense for few rows (ops.py:5-16): the K-sliced kernel + reduction launch, incl. spectral-norm scale and row strides."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for (M, Kd, C, strided) in [(32, 8192, 100, False), (4, 65536, 1, False), (2, 4096, 1, True), (7, 1000, 36, False), (64, 520, 256, False)]:
+        xb = rnd(rng, M, Kd + 8)
+        x = xb[:, :Kd] if strided else xb[:, :Kd].contiguous()
+        W, b = rnd(rng, Kd, C) * 0.05, rnd(rng, C)
+        sc = 0.37
+        ref = sc * (x @ W) + b
+        xd = dev(xb)[:, :Kd] if strided else dev(x)
+        o = torch.full((M, C), float('nan'), device=DEV)
+        K.dense_fwd(xd, dev(W), dev(b), o, scale=torch.tensor([sc], device=DEV))
+        out.append(('dense_%dx%dx%d%s' % (M, Kd, C, '_strided' if strided else ''), rel_err(o, ref), TOL_OP))
+    torch.cuda.synchronize()
+    return out
+
+
 def check_util(seed=4):
     out = []
     rng = np.random.default_rng(seed)
@@ -799,7 +817,7 @@ def check_conv_cell(seed=21):
 
 ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_cell', check_conv_cell),
               ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
-              ('lstm', check_lstm), ('util', check_util), ('cdna_composite', check_cdna_composite),
+              ('lstm', check_lstm), ('util', check_util), ('dense', check_dense), ('cdna_composite', check_cdna_composite),
               ('small', check_small), ('weight_prep', check_weight_prep), ('warp_dna', check_warp_dna)]
 
 

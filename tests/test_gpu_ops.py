@@ -36,6 +36,11 @@ def test_util_ops():
     _run(gpu_checks.check_util)
 
 
+def test_dense_few_rows():
+    from tests import gpu_checks
+    _run(gpu_checks.check_dense)
+
+
 def test_cdna_and_composite():
     from tests import gpu_checks
     _run(gpu_checks.check_cdna_composite)

@@ -39,8 +39,32 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// Issue order of one pipeline step: the R ds_reads of the NEXT entry's fragments are spread between the M MFMAs of the current
+// one (both waves of a SIMD share its matrix pipe and all waves leave the barrier together: with the reads issued as a block every
+// wave reads while the matrix pipe idles, then every wave multiplies while the LDS idles).
+template <int R, int M, int I>
+__device__ __forceinline__ void sched_interleave() {
+    if constexpr (I < M) {
+        constexpr int r = (R * (I + 1)) / M - (R * I) / M;     // reads in front of MFMA I
+        if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        sched_interleave<R, M, I + 1>();
+    }
+}
+
+#ifdef SAVP_CONV_ABLATE
+__device__ unsigned long long g_ring_t[16];       // developer build: s_memtime stamps of workgroup 0, wave 0 (savp_debug_ring_times)
+#define RT(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_ring_t[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int savp_debug_ring_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_t), sizeof(g_ring_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define RT(i) do {} while (0)
+#endif
+
 template <int NW, int WM, int WN, int NKS>
 __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
+    RT(0);
     constexpr int NT = 64 * NW;
     constexpr int BM = 16 * NW * WM, BN = 64 * WN, TW = 8;
     constexpr int CKB = 16 * NKS;
@@ -275,8 +299,10 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             etab[e] = make_uint2((unsigned)((f_tap * Cred + f_cc * CKB) * 2) | (f_cc == nch - 1 ? 0x80000000u : 0u),
                                  (unsigned)((pu * pitch + pv * CP + sl * CKB) * 2));
         }
+        RT(1);
         if (p.src16) stage_patch(g_first, std::true_type{}); else stage_patch(g_first, std::false_type{});
         __syncthreads();                                   // table + patch visible
+        RT(2);
         issue(etab[0], B0{});
         if (len > 1) issue(etab[1], B1{});
         if (len > 2) issue(etab[2], B2{});
@@ -308,13 +334,20 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 if (STEADY || e + 3 < len) issue(td, bd);
                 load_a(nxt, tn);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(cur, 0, KH);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b(nxt, bn);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(cur, KH, NKS);
+            if constexpr (STEADY) {
+                load_b(nxt, bn);
+                mma(cur, 0, NKS);
+                sched_interleave<NKS * (WM + WN), NKS * WM * WN, 0>();
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                mma(cur, 0, KH);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) load_b(nxt, bn);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(cur, KH, NKS);
+            }
         };
+        RT(3);
         int e = 0;
         for (; e + 6 < len; e += 4) {
             step(e, F0, F1, B1{}, B3{}, std::true_type{});
@@ -328,11 +361,13 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             if (e + 2 < len) step(e + 2, F0, F1, B3{}, B1{}, std::false_type{});
             if (e + 3 < len) step(e + 3, F1, F0, B0{}, B2{}, std::false_type{});
         }
+        RT(4);
     }
 
     const long long d_sn = dgrad ? p.x_sn : p.y_sn, d_sd = dgrad ? p.x_sd : p.y_sd;
     const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
 
+    RT(5);
     if (ABL(8) && acc[0][0][0] != 123.f) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     if (p.cell) {
         // ---- "cell" epilogue: per-(image, channel) sum / sum of squares + bf16 rows through LDS ---------------------------------
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
                 if (khalf == 0) {
                     float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
-                    atomicAdd(d, s); atomicAdd(d + 1, q);
+                    unsafeAtomicAdd(d, s); unsafeAtomicAdd(d + 1, q);      // ds_add_f32 (plain atomicAdd on LDS floats is a CAS loop)
                 }
                 const int cp = (wn0 + 32 * j + (l31 & ~1)) >> 1;
 #pragma unroll
@@ -392,6 +427,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
             }
         }
+        RT(6);
         return;
     }
 
@@ -444,6 +480,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             }
         }
     }
+    RT(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------

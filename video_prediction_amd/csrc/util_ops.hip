@@ -361,19 +361,133 @@ __global__ __launch_bounds__(NT) void dense_smallm_kernel(const float* __restric
     }
 }
 
+// Two-launch form used when the caller provides a workspace: partial products of S K-slices written with plain stores, then one
+// small reduction kernel (scale, bias).  The atomic form above ends every workgroup with M*C device-scope float atomics on the
+// same M*C words (~7 per ns chip-wide: 80 % of its 62 us on the CDNA head 8192 -> 100 at M = 32).
+// Thread (c4, kq): 4 output columns x all rows of a 32-row block, k rows kq, kq + KQ, ... of the slice; x is staged transposed in
+// LDS ([k][m], rows padded to 36 floats) and read as broadcast float4.
+#define DP_KT 64
+template <bool VEC>          // C % 4 == 0 (compile time: a runtime branch around the row loads serialises them)
+__global__ __launch_bounds__(NT) void dense_partial_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
+                                                           const float* __restrict__ W, float* __restrict__ part, long long kslice) {
+    __shared__ __attribute__((aligned(16))) float xl[DP_KT * 36];
+    const int C4 = (C + 3) >> 2;
+    const int KQ = NT / C4;
+    const int c4 = threadIdx.x % C4, kq = threadIdx.x / C4;
+    const bool active = kq < KQ;
+    const long long k_lo = (long long)blockIdx.x * kslice, k_hi = min(Kd, k_lo + kslice);
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int mb = min(32, M - m0);
+        float acc[32][4];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) { acc[m][0] = 0.f; acc[m][1] = 0.f; acc[m][2] = 0.f; acc[m][3] = 0.f; }
+        for (long long k0 = k_lo; k0 < k_hi; k0 += DP_KT) {
+            const int kn = (int)min((long long)DP_KT, k_hi - k0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < 32 * DP_KT; i += NT) {
+                const int m = i / DP_KT, kk = i - m * DP_KT;
+                xl[kk * 36 + m] = (m < mb && kk < kn) ? x[(long long)(m0 + m) * xs + k0 + kk] : 0.f;
+            }
+            __syncthreads();
+            if (active) {
+                // all weight rows of this sub-chunk are requested before the first is used (W is streamed from HBM once per call:
+                // one load per loop trip would expose a full memory round trip per row)
+                constexpr int RMAX = DP_KT / 4;                      // KQ >= 4 (C <= 256)
+                float4 wv[RMAX];
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const int kk = kq + r * KQ;
+                    const float* wr = W + (k0 + min(kk, kn - 1)) * C + c4 * 4;
+                    if constexpr (VEC) wv[r] = *reinterpret_cast<const float4*>(wr);
+                    else {
+                        wv[r].x = wr[0];
+                        wv[r].y = c4 * 4 + 1 < C ? wr[1] : 0.f; wv[r].z = c4 * 4 + 2 < C ? wr[2] : 0.f; wv[r].w = c4 * 4 + 3 < C ? wr[3] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const int kk = kq + r * KQ;
+                    if (kk >= kn) break;
+                    const float4 w = wv[r];
+                    const float4* xr = reinterpret_cast<const float4*>(xl + kk * 36);
+#pragma unroll
+                    for (int mq = 0; mq < 8; ++mq) {
+                        const float4 xv = xr[mq];
+                        const float xm[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[mq * 4 + j][0] += xm[j] * w.x; acc[mq * 4 + j][1] += xm[j] * w.y;
+                            acc[mq * 4 + j][2] += xm[j] * w.z; acc[mq * 4 + j][3] += xm[j] * w.w;
+                        }
+                    }
+                }
+            }
+        }
+        // reduce the KQ partial sums of this workgroup through LDS (one [32][4 C4] block), then one plain store per output
+        __syncthreads();
+        float* red = xl;                                   // needs 32 * 4 * C4 floats <= DP_KT * 36 (C <= 64 ... handled in passes)
+        const int cols = C4 * 4;
+        for (int pass = 0; pass * 8 < 32; ++pass) {        // 8 rows per pass: 8 * cols <= 8 * 256 = 2048 floats < 2304
+            for (int i = threadIdx.x; i < 8 * cols; i += NT) red[i] = 0.f;
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(&red[r * cols + c4 * 4 + j], acc[pass * 8 + r][j]);   // ds_add_f32
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 8 * cols; i += NT) {
+                const int r = i / cols, c = i - r * cols, m = pass * 8 + r;
+                if (m < mb && c < C) part[((long long)blockIdx.x * M + m0 + m) * C + c] = red[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// 32 outputs x 8 slice groups per workgroup: lane = 8 * output + group; every thread adds S/8 partials, then a shuffle tree
+__global__ __launch_bounds__(NT) void dense_reduce_kernel(const float* __restrict__ part, int S, int MC, int C, const float* bias,
+                                                          const float* scale, float* __restrict__ out) {
+    const int g = threadIdx.x & 7;
+    const int i = blockIdx.x * (NT / 8) + (threadIdx.x >> 3);
+    float s = 0.f;
+    if (i < MC) {
+#pragma unroll 8
+        for (int k = g; k < S; k += 8) s += part[(long long)k * MC + i];
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (i >= MC || g) return;
+    s *= scale ? *scale : 1.f;
+    if (bias) s += bias[i % C];
+    out[i] = s;
+}
+
 extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,
-                              const float* bias, const float* scale, float* out) {
+                              const float* bias, const float* scale, float* out, float* ws, int64_t ws_floats) {
     if (!x || !W || !out || M < 1 || K < 1 || C < 1) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
     if (M > 64 || C > 256) return SAVP_EINVAL;
+    if (ws && ws_floats >= (int64_t)M * C) {
+        // K slices: multiples of DP_KT rows, as many as the workspace holds, at most 64 (the reduction kernel reads them all)
+        long long S = ws_floats / ((long long)M * C);
+        if (S > 64) S = 64;
+        long long kslice = ((K + S - 1) / S + DP_KT - 1) / DP_KT * DP_KT;
+        S = (K + kslice - 1) / kslice;
+        if ((C & 3) == 0 && ((uintptr_t)W & 15) == 0)
+            hipLaunchKernelGGL(dense_partial_kernel<true>, dim3((unsigned)S), dim3(NT), 0, st, x, (long long)x_row_stride, M, (long long)K, C,
+                               W, ws, kslice);
+        else
+            hipLaunchKernelGGL(dense_partial_kernel<false>, dim3((unsigned)S), dim3(NT), 0, st, x, (long long)x_row_stride, M, (long long)K, C,
+                               W, ws, kslice);
+        hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((M * C + NT / 8 - 1) / (NT / 8))), dim3(NT), 0, st, ws, (int)S, M * C, C, bias, scale,
+                           out);
+        return LAUNCH_OK();
+    }
+    hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
     size_t lds = (size_t)(M * DKC + DKC * C + M * C) * sizeof(float);
     const long long chunks = (K + DKC - 1) / DKC;
-    // every workgroup ends with M*C float atomics on the same M*C words (measured ~7 per ns chip-wide): bound their number to
-    // ~64k per call (CDNA head, M=32, C=100: 19 workgroups of 7 chunks instead of 128 of 1 -- the atomics were 80 % of its 62 us)
-    int nsub = (int)((chunks * (long long)M * C + 65535) / 65536);
-    const int nsub_min = (int)((chunks + 255) / 256);          // at most ~256 workgroups
-    if (nsub < nsub_min) nsub = nsub_min;
+    int nsub = (int)((chunks + 255) / 256);                    // at most ~256 workgroups (fewer atomics for very long K)
     if (nsub < 1) nsub = 1;
     hipLaunchKernelGGL(dense_smallm_kernel, dim3((unsigned)((chunks + nsub - 1) / nsub)), dim3(NT), lds, st, x, (long long)x_row_stride, M,
                        (long long)K, C, W, bias, scale, out, nsub);

@@ -10,6 +10,7 @@ Everything numerical is a HIP kernel launched through ``kernels``; this file onl
   timesteps and samples (the time axis is folded into the GEMM's K dimension).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np

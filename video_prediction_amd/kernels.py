@@ -603,12 +603,21 @@ def sn_bwd(W, u, ws, G, dW, beta=0):
     lib.check(_L().savp_sn_bwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(G), _p(dW), int(beta)), 'savp_sn_bwd')
 
 
+_DENSE_WS = {}
+
+
 def dense_fwd(x, W, bias, out, scale=None):
-    """out[M,C] = scale * x[M,K] @ W[K,C] + bias for few rows (split-K GEMV-like kernel); out contiguous."""
+    """out[M,C] = scale * x[M,K] @ W[K,C] + bias for few rows (K-sliced partial sums + a reduction launch); out contiguous."""
     M, Kd = x.shape
     C = W.shape[-1]
     assert out.is_contiguous() and x.stride(1) == 1 and W.is_contiguous()
-    lib.check(_L().savp_dense_fwd(lib.stream(), _p(x), x.stride(0), M, Kd, C, _p(W), _p(bias), _p(scale), _p(out)), 'savp_dense_fwd')
+    key = str(x.device)
+    ws = _DENSE_WS.get(key)
+    need = 64 * M * C
+    if ws is None or ws.numel() < need:
+        ws = _DENSE_WS[key] = torch.empty(max(need, 64 * 64 * 128), device=x.device)      # launches are stream-ordered: one buffer
+    lib.check(_L().savp_dense_fwd(lib.stream(), _p(x), x.stride(0), M, Kd, C, _p(W), _p(bias), _p(scale), _p(out), _p(ws), ws.numel()),
+              'savp_dense_fwd')
 
 
 # ---------------------------------------------------------------------------------------------------------------

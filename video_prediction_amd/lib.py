@@ -197,7 +197,7 @@ register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
 register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
 register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
 register('savp_sn_bwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32])
-register('savp_dense_fwd', [c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp])
+register('savp_dense_fwd', [c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64])
 
 
 class SavpWarpArgs(ctypes.Structure):
