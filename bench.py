@@ -119,11 +119,27 @@ def main():
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the SAVP hot path has no CPU fallback')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run (the driver's own
+        # launch line), rank 0 prints the JSON line
+        import socket
+        import subprocess
+        if args.gpus > torch.cuda.device_count():
+            raise SystemExit('bench.py --gpus %d: this node has %d GPU(s)' % (args.gpus, torch.cuda.device_count()))
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the SAVP hot path has no CPU fallback')
+    if args.gpus != world and rank == 0:
+        print('bench.py: --gpus %d but launched with WORLD_SIZE=%d; reporting n_gpus=%d' % (args.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None

@@ -213,6 +213,18 @@ int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* 
                     int32_t T, int32_t B, int32_t nz, float forget_bias);
 int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
                     const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias);
+/* BasicLSTMCell over all timesteps (recurrent encoder of posterior_fn / prior_fn, savp_model.py:31-43,66-76).
+ * A [T,B,I+U]: x_t in columns [0,I) (caller), h_{t-1} in [I,I+U) (written by fwd); W [I+U,4U], gate order i,j,f,o.
+ * bwd produces dG [T,B,4U] and dA [T,B,I+U] (first I columns = dL/dx); dW = A^T dG and db = colsum(dG) are the caller's GEMM. */
+int savp_lstm_seq_fwd(void* stream, float* A, const float* W, const float* bias, float* hout, float* gates, float* cs,
+                      int32_t T, int32_t B, int32_t I, int32_t U, float forget_bias);
+int savp_lstm_seq_bwd(void* stream, const float* A, const float* W, const float* gates, const float* cs, const float* dh_out,
+                      float* dG, float* dA, int32_t T, int32_t B, int32_t I, int32_t U, float forget_bias);
+/* KL between two diagonal Gaussians (losses.py:61-67; learn_prior): value into *kl_out (optional), klw-weighted gradient ADDED
+ * to dmu1 / dls1 / dmu2 / dls2 (all four or none); ls*_raw are the unclipped log-variances. */
+int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,
+                  const float* ls2_raw, float* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
+                  float* dls2);
 int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
                      float* z, float* kl_out);
 int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,

@@ -44,6 +44,8 @@ def make_noise(hp, B, seed=1, sampling=True):
     if hp.nz:
         noise['eps'] = torch.tensor(rng.standard_normal((T1, B, hp.nz)))
         noise['prior'] = torch.tensor(rng.standard_normal((hp.sequence_length - hp.context_frames, B, hp.nz)))
+        if hp.learn_prior:
+            noise['prior_eps'] = torch.tensor(rng.standard_normal((T1, B, hp.nz)))
     ns = T1 - hp.context_frames
     if sampling:
         noise['ground_truth_sampling'] = torch.tensor(rng.random((ns, B)) < 0.5)
@@ -107,6 +109,9 @@ def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, *
         out.append((tag + '/gen_images_enc', rel(gen[:, :B], ref['gen_images_enc']), 1e-3))
         out.append((tag + '/zs_mu', rel(eng.enc.mu, ref['zs_mu_enc']), 1e-4))
         out.append((tag + '/zs_log_sigma_sq', rel(eng.enc.ls, ref['zs_log_sigma_sq_enc']), 1e-4))
+    if nz and hp.learn_prior:
+        out.append((tag + '/zs_mu_prior', rel(eng.prior.mu, ref['zs_mu_prior']), 1e-4))
+        out.append((tag + '/zs_log_sigma_sq_prior', rel(eng.prior.ls, ref['zs_log_sigma_sq_prior']), 1e-4))
     return out
 
 
@@ -246,7 +251,9 @@ def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
         out.append((t + '/d_loss', lrel(info['d_loss'], ref['d_loss']), ltol))
         out.append((t + '/g_loss', lrel(info['g_loss'], ref['g_loss']), ltol))
         for nm, (l, w) in info['g_losses'].items():
-            out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm]), 2 * ltol))
+            # bf16 datapath: 3 * ltol = 6e-2 of max(|ref|, 0.05) per term -- besides the operand rounding, the ConvLSTM gate
+            # pre-activations make their HBM round trip in bf16 (fused cell epilogue), measured 4.7e-2 on the LSGAN generator term
+            out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm]), 2 * ltol if prec == 'f32' else 3 * ltol))
         gen = eng.gen.gen.v
         out.append((t + '/gen_images_enc_abs', float((gen[:, :B].double().cpu() - ref['gen_images_enc']).abs().max()),
                     1e-3 if prec == 'f32' else 5e-2))

@@ -64,7 +64,12 @@ def _worker(rank, world, port, q):
     g = store.groups['g']
     for n, gr in grads.items():
         store.grad(n).copy_(gr.float())
-    rg.allreduce_grads('g')
+    # chunked exchange as SAVPEngine issues it: one network's contiguous chunk first, the rest of the arena at finish
+    lo, hi = store.chunk_of('g', 'generator/rnn/savp_cell/lstm_h2/')
+    assert 0 <= lo < hi <= g.g.numel()
+    rg.begin_allreduce('g', lo, hi)
+    rg.finish_allreduce('g')
+    assert rg.stats['chunks'] == 3 and rg.stats['elements'] == g.g.numel(), rg.stats      # [0,lo) [lo,hi) [hi,n): every element once
     avg = g.g * rg.grad_scale
     p, m, v = TF.adam_update(g.p, avg, g.m, g.v, 1e-3, 0.9, 0.999, 1)
     g.p.copy_(p)

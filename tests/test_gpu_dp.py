@@ -1,0 +1,122 @@
+"""Data-parallel train step on the GPU (pytest -m gpu): two replica processes share cuda:0 and exchange gradients over gloo
+(the box has one GPU; gloo all-reduces device tensors) through SAVPEngine.train_step -- the chunked side-stream exchange of
+video_prediction_amd.parallel.ReplicaGroup, 1/K in Adam, rank-0 broadcast.  Reference: the same global batch in ONE process.
+
+Checked: (1) the averaged shard gradients equal the single-process gradients of the global batch (every op is per-sample, losses
+are batch means: base_model.py:523-527 tf.split, tf_utils.py:470-475 average=True); (2) the replicas hold bit-identical variables
+after the step (checksum_identical); (3) the updated variables equal the single-process update."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B_GLOBAL, T, HW, C = 4, 6, 64, 3
+HP = dict(context_frames=2, sequence_length=T, clip_length=4, nz=8, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
+          kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
+          vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_noise(noise, lo, hi):
+    """Slice every random input of the step along its batch axis (tf.split of the towers' inputs)."""
+    out = {}
+    for k, v in noise.items():
+        if isinstance(v, dict):
+            out[k] = {kk: (a[lo:hi], b[lo:hi]) for kk, (a, b) in v.items()}
+        else:
+            out[k] = v[:, lo:hi]
+    return out
+
+
+def _setup(joint=False):
+    from tests import gpu_model_checks as G
+    from video_prediction_amd import variables as V
+    hp = G.make_hparams(**dict(HP, joint_gan_optimization=bool(joint)))
+    specs = V.variable_specs(hp, (HW, HW, C), mode='train')
+    vals = V.init_variables(specs, seed=4)
+    images = G.synth(hp, B_GLOBAL, HW, HW, C, 0).float()
+    noise = G.make_noise(hp, B_GLOBAL, seed=100, sampling=True)
+    return hp, vals, images, noise
+
+
+def _worker(rank, world, port, q, joint):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from video_prediction_amd.models.savp_model import SAVPEngine
+        hp, vals, images, noise = _setup(joint)
+        per = B_GLOBAL // world
+        lo, hi = rank * per, (rank + 1) * per
+        if rank != 0:       # replicas start different on purpose: attach_process_group must broadcast rank 0's variables
+            vals = {k: (v + 0.01).astype(np.float32) for k, v in vals.items()}
+        eng = SAVPEngine(hp, (HW, HW, C), per, mode='train', values=vals, device='cuda:0')
+        eng.attach_process_group(dist)
+        eng.set_images(images[:, lo:hi].to('cuda:0'), time_major=True)
+        eng.train_step(_shard_noise(noise, lo, hi))
+        torch.cuda.synchronize()
+        same = eng.replicas.checksum_identical()
+        res = {'rank': rank, 'same': same, 'chunks': eng.replicas.stats['chunks'], 'overlap': eng.replicas.comm_stream is not None}
+        if rank == 0:
+            store = eng.store
+            res['avg_grads'] = {n: (store.grad(n) / world).cpu().numpy() for n in store.names() if store.group_of[n] != 'aux'}
+            res['params'] = store.to_numpy()
+        q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('joint', [False, True])
+def test_two_replicas_on_one_gpu_match_the_global_batch_step(joint):
+    import multiprocessing
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, joint)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r['same'] for r in results), 'replicas diverged'
+    assert all(r['overlap'] for r in results), 'the exchange did not run on the side stream'
+    # D step: one chunk per discriminator; G step: generator cell + the rest (encoder)
+    assert all(r['chunks'] == 4 for r in results), [r['chunks'] for r in results]
+    r0 = [r for r in results if r['rank'] == 0][0]
+    # single-process reference on the global batch
+    hp, vals, images, noise = _setup(joint)
+    eng = SAVPEngine(hp, (HW, HW, C), B_GLOBAL, mode='train', values=vals, device='cuda:0')
+    eng.set_images(images.to('cuda:0'), time_major=True)
+    info = eng.train_step(noise, return_grads=True)
+    torch.cuda.synchronize()
+    for grp, key in (('d', 'd_grads'), ('g', 'g_grads')):
+        gmax = max(float(v.abs().max()) for v in info[key].values())
+        for name, gref in info[key].items():
+            err = float((torch.tensor(r0['avg_grads'][name]).double() - gref.double().cpu()).abs().max())
+            # fp32 sums in a different order (per-shard batch means, then the average; other conv tiles at half the batch) and
+            # the occasional ReLU / LeakyReLU mask flipping under that rounding: 2e-3 of the group's largest gradient
+            assert err <= 2e-3 * gmax + 1e-12, (name, err, gmax)
+    tot = cnt = 0.0
+    for name, p in eng.store.to_numpy().items():
+        d = np.abs(p.astype(np.float64) - r0['params'][name])
+        tot += float(d.sum())
+        cnt += d.size
+    assert tot / cnt <= 0.05 * hp.lr, tot / cnt      # Adam's first step is sign-like: compare in units of lr

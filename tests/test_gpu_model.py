@@ -42,6 +42,16 @@ def test_train_step_joint_gan_optimization_vs_oracle():
     _assert_ok(G.check_train_step(B=2, T=6, nz=8, steps=2, tag='train_joint_gan', joint_gan_optimization=True))
 
 
+def test_learned_prior_and_recurrent_encoder_vs_oracle():
+    """learn_prior=True + use_e_rnn=True (savp_model.py:31-43,54-85,717-721; KL between the two Gaussians losses.py:61-67,
+    base_model.py:825-828): forward at the default width (nef=64 -> 256-unit BasicLSTMCell, 1024-thread workgroups) with context 3
+    (two encoded context pairs + zero rows), then a train step (losses, per-variable gradients incl. generator/prior/*, Adam)."""
+    from tests import gpu_model_checks as G
+    res = G.check_generator_forward(nz=8, B=2, T=6, tag='gen_fwd_learn_prior', learn_prior=True, use_e_rnn=True, context_frames=3)
+    res += G.check_train_step(B=2, T=6, nz=8, steps=1, tag='train_learn_prior', learn_prior=True, use_e_rnn=True, nef=16)
+    _assert_ok(res)
+
+
 def test_config_c4_kth_forward_and_train_vs_oracle():
     """BASELINE configs[3] shapes scaled in batch/time: KTH 64x64x1, nz=32, context 10 (datasets/kth_dataset.py:26-36,
     hparams/kth/ours_savp/model_hparams.json)."""

@@ -139,6 +139,167 @@ extern "C" int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// lstm_seq: tf.contrib.rnn.BasicLSTMCell under dynamic_rnn for ALL timesteps in one launch -- the recurrent encoder of
+// posterior_fn (use_e_rnn, savp_model.py:31-43) and prior_fn (:66-76).  A [T,B,I+U]: columns [0,I) hold the inputs x_t
+// (filled by the caller), columns [I,I+U) receive h_{t-1} (written here; zeros at t = 0), so that afterwards A is exactly
+// the matrix whose transpose times dG is the kernel gradient.  W [I+U,4U] (rows: x then h; gate order i,j,f,o), bias [4U].
+// One workgroup per batch row, 4U threads: thread j owns gate column j.  Saves the pre-activation gates [T,B,4U] and the
+// cell states [T,B,U].
+// bwd: dh_out [T,B,U] -> dG [T,B,4U] (gradient of the pre-activation gates) and dA [T,B,I+U] whose first I columns are
+// dL/dx_t (the last U columns are scratch: dL/dh_{t-1} before the carry).  Weight / bias gradients are a GEMM over all
+// (t,b) rows afterwards (A^T dG, column sums of dG): the caller runs them as one WGRAD launch.
+// ---------------------------------------------------------------------------------------------------------------
+#define MAXU 256
+__global__ void lstm_seq_fwd_kernel(float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                    float* __restrict__ hout, float* __restrict__ gates, float* __restrict__ cs, int T, int B,
+                                    int I, int U, float forget_bias) {
+    extern __shared__ float sh_seq[];
+    const int K = I + U, G = 4 * U;
+    float* sh_a = sh_seq;              // [K]  current [x_t | h_{t-1}]
+    float* sh_g = sh_seq + K;          // [G]
+    const int b = blockIdx.x, j = threadIdx.x;
+    float c = 0.f;
+    for (int i = j; i < U; i += G) sh_a[I + i] = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const long long o = (long long)t * B + b;
+        for (int i = j; i < I; i += G) sh_a[i] = A[o * K + i];
+        __syncthreads();
+        float g0 = bias[j], g1 = 0.f, g2 = 0.f, g3 = 0.f;
+        int i = 0;
+        for (; i + 4 <= K; i += 4) {
+            g0 += sh_a[i] * W[(long long)i * G + j];
+            g1 += sh_a[i + 1] * W[(long long)(i + 1) * G + j];
+            g2 += sh_a[i + 2] * W[(long long)(i + 2) * G + j];
+            g3 += sh_a[i + 3] * W[(long long)(i + 3) * G + j];
+        }
+        for (; i < K; ++i) g0 += sh_a[i] * W[(long long)i * G + j];
+        const float g = (g0 + g1) + (g2 + g3);
+        sh_g[j] = g;
+        gates[o * G + j] = g;
+        __syncthreads();
+        if (j < U) {
+            const float gi = sh_g[j], gj = sh_g[U + j], gf = sh_g[2 * U + j], go = sh_g[3 * U + j];
+            c = sigm(gf + forget_bias) * c + sigm(gi) * tanh_(gj);
+            const float h = sigm(go) * tanh_(c);
+            cs[o * U + j] = c;
+            hout[o * U + j] = h;
+            A[o * K + I + j] = sh_a[I + j];            // h_{t-1}: the recurrent half of row t
+            sh_a[I + j] = h;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void lstm_seq_bwd_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ gates,
+                                    const float* __restrict__ cs, const float* __restrict__ dh_out, float* __restrict__ dG,
+                                    float* __restrict__ dA, int T, int B, int I, int U, float forget_bias) {
+    extern __shared__ float sh_seq[];
+    const int K = I + U, G = 4 * U;
+    float* sh_dg = sh_seq;             // [G]
+    float* sh_dh = sh_seq + G;         // [U]  dL/dh_t carried from step t+1
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int lane = j & 63, wave = j >> 6, nwaves = G >> 6;
+    float dc_next = 0.f;
+    if (j < U) sh_dh[j] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const long long o = (long long)t * B + b;
+        if (j < U) {
+            const float gi = gates[o * G + j], gj = gates[o * G + U + j], gf = gates[o * G + 2 * U + j], go = gates[o * G + 3 * U + j];
+            const float c = cs[o * U + j];
+            const float cprev = t > 0 ? cs[(o - B) * U + j] : 0.f;
+            const float dh = dh_out[o * U + j] + sh_dh[j];
+            const float so = sigm(go), tc = tanh_(c);
+            const float dc = dh * so * (1.f - tc * tc) + dc_next;
+            const float si = sigm(gi), tj = tanh_(gj), sf = sigm(gf + forget_bias);
+            const float d0 = dc * tj * si * (1.f - si), d1 = dc * si * (1.f - tj * tj), d2 = dc * cprev * sf * (1.f - sf),
+                        d3 = dh * tc * so * (1.f - so);
+            sh_dg[j] = d0; sh_dg[U + j] = d1; sh_dg[2 * U + j] = d2; sh_dg[3 * U + j] = d3;
+            dG[o * G + j] = d0; dG[o * G + U + j] = d1; dG[o * G + 2 * U + j] = d2; dG[o * G + 3 * U + j] = d3;
+            dc_next = dc * sf;
+        }
+        __syncthreads();
+        // dA[i] = sum_q W[i][q] dg[q]: one wave per row i, lanes stride the 4U columns (coalesced), butterfly reduction
+        for (int i = wave; i < K; i += nwaves) {
+            float s = 0.f;
+            for (int q = lane; q < G; q += 64) s += W[(long long)i * G + q] * sh_dg[q];
+            s = wsum(s);
+            if (lane == 0) {
+                dA[o * K + i] = s;
+                if (i >= I) sh_dh[i - I] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int savp_lstm_seq_fwd(void* stream, float* A, const float* W, const float* bias, float* hout, float* gates, float* cs,
+                                 int32_t T, int32_t B, int32_t I, int32_t U, float forget_bias) {
+    if (!A || !W || !bias || !hout || !gates || !cs || U < 16 || U > MAXU || (U & 15) || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B), dim3(4 * U), (size_t)(I + U + 4 * U) * sizeof(float), (hipStream_t)stream, A, W,
+                       bias, hout, gates, cs, T, B, I, U, forget_bias);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_lstm_seq_bwd(void* stream, const float* A, const float* W, const float* gates, const float* cs,
+                                 const float* dh_out, float* dG, float* dA, int32_t T, int32_t B, int32_t I, int32_t U,
+                                 float forget_bias) {
+    if (!A || !W || !gates || !cs || !dh_out || !dG || !dA || U < 16 || U > MAXU || (U & 15) || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B), dim3(4 * U), (size_t)(5 * U) * sizeof(float), (hipStream_t)stream, A, W, gates,
+                       cs, dh_out, dG, dA, T, B, I, U, forget_bias);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// KL between two diagonal Gaussians (losses.py:61-67; learn_prior: posterior (1) against the learned prior (2)):
+//   kl = mean_rows sum_z [ (l2 - l1)/2 + (exp(l1) + (m1 - m2)^2) / (2 exp(l2)) - 1/2 ],   l = clip(ls_raw, -10, 10).
+// kl_out (optional) += value; with dmu1 != null the gradient, times klw (host value or *klw_dev), is ADDED to the four
+// gradient tensors (the clip passes no gradient outside [-10, 10], like tf.clip_by_value).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void kl_gauss_kernel(long long n, int rows, const float* mu1, const float* ls1_raw, const float* mu2, const float* ls2_raw,
+                                float* kl_out, float klw_host, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
+                                float* dls2) {
+    __shared__ float sh[4];
+    const float klw = klw_dev ? *klw_dev : klw_host;
+    const float inv = 1.f / (float)rows;
+    float acc = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float r1 = ls1_raw[i], r2 = ls2_raw[i];
+        const float l1 = fminf(fmaxf(r1, -10.f), 10.f), l2 = fminf(fmaxf(r2, -10.f), 10.f);
+        const float d = mu1[i] - mu2[i];
+        // with x = l1 - l2:  (l2-l1)/2 + (e^l1 + d^2) / (2 e^l2) - 1/2  =  [ (e^x - 1 - x) + d^2 e^-l2 ] / 2.  Early in training the two
+        // Gaussians nearly coincide (x ~ 1e-3): e^x - 1 - x is evaluated by its series there instead of by cancellation
+        const float x = l1 - l2, ie2 = __expf(-l2);
+        const float em1 = expm1f(x);
+        const float g = fabsf(x) < 0.5f
+            ? x * x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f + x * (1.f / 720.f + x * (1.f / 5040.f))))))
+            : em1 - x;
+        acc += 0.5f * (g + d * d * ie2);
+        if (dmu1) {
+            const float s = klw * inv;
+            dmu1[i] += s * d * ie2;
+            dmu2[i] -= s * d * ie2;
+            if (r1 >= -10.f && r1 <= 10.f) dls1[i] += s * 0.5f * em1;
+            if (r2 >= -10.f && r2 <= 10.f) dls2[i] -= s * 0.5f * (em1 + d * d * ie2);
+        }
+    }
+    const float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0 && kl_out) unsafeAtomicAdd(kl_out, t * inv);
+}
+
+extern "C" int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,
+                             const float* ls2_raw, float* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1,
+                             float* dmu2, float* dls2) {
+    if (!mu1 || !ls1_raw || !mu2 || !ls2_raw || rows < 1) return SAVP_EINVAL;
+    if (dmu1 && (!dls1 || !dmu2 || !dls2)) return SAVP_EINVAL;
+    unsigned nb = (unsigned)((n + NT - 1) / NT);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(kl_gauss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (long long)n, rows, mu1, ls1_raw, mu2, ls2_raw,
+                       kl_out, klw, klw_dev, dmu1, dls1, dmu2, dls2);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // reparameterisation + KL.  n = T*B*nz elements; rows = T*B (the KL mean is over rows).
 // fwd: ls = clip(ls_raw); z = mu + exp(0.5 ls)*eps; kl_out += -0.5*sum(1+ls-mu^2-exp(ls))/rows
 // bwd: dmu = dz + klw*mu/rows ; dls_raw = [ls_raw in [-10,10]] * (dz*eps*0.5*exp(0.5 ls) - 0.5*klw*(1-exp(ls))/rows)

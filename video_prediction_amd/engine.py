@@ -136,6 +136,26 @@ class ParamStore(object):
     def names(self):
         return list(self.group_of.keys())
 
+    def chunk_of(self, group, prefix):
+        """(lo, hi) element range, inside the flat arena of `group`, of the variables whose names start with `prefix`; they
+        must be laid out contiguously (they are: variable_specs lists one network after the other).  Used to exchange the
+        gradients of one network as soon as its backward pass has been issued (parallel.ReplicaGroup)."""
+        offs = self.groups[group].arena.offsets
+        lo = hi = None
+        inside = done = False
+        for name, (off, n, _) in offs.items():
+            if name.startswith(prefix):
+                if done:
+                    raise ValueError('variables under %r are not contiguous in group %r' % (prefix, group))
+                if not inside:
+                    lo, inside = off, True
+                hi = off + _align4(n)
+            elif inside:
+                inside, done = False, True
+        if lo is None:
+            return (0, 0)
+        return (lo, hi)
+
     def to_numpy(self):
         return OrderedDict((n, self[n].detach().cpu().numpy().copy()) for n in self.specs)
 

@@ -531,6 +531,34 @@ def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0):
                                    T, B, nz, float(forget_bias)), 'savp_lstm_z_bwd')
 
 
+def lstm_seq_fwd(A, W, b, hout, gates, cs, n_in, forget_bias=1.0):
+    """BasicLSTMCell over time (see include/savp_hip.h): A [T,B,I+U] with x in [..., :I]; fills A[..., I:], hout, gates, cs."""
+    T, B, K = A.shape
+    U = K - n_in
+    lib.require_device(A, W, b, hout, gates, cs)
+    lib.check(_L().savp_lstm_seq_fwd(lib.stream(), _p(A), _p(W), _p(b), _p(hout), _p(gates), _p(cs), T, B, n_in, U,
+                                     float(forget_bias)), 'savp_lstm_seq_fwd')
+
+
+def lstm_seq_bwd(A, W, gates, cs, dh_out, dG, dA, n_in, forget_bias=1.0):
+    T, B, K = A.shape
+    U = K - n_in
+    lib.require_device(A, W, gates, cs, dh_out, dG, dA)
+    lib.check(_L().savp_lstm_seq_bwd(lib.stream(), _p(A), _p(W), _p(gates), _p(cs), _p(dh_out), _p(dG), _p(dA), T, B, n_in, U,
+                                     float(forget_bias)), 'savp_lstm_seq_bwd')
+
+
+def kl_gauss(mu1, ls1_raw, mu2, ls2_raw, kl_out=None, klw=0.0, klw_dev=None, grads=None):
+    """losses.kl_loss between two Gaussians (losses.py:61-67).  grads = (dmu1, dls1_raw, dmu2, dls2_raw): accumulated into."""
+    rows = mu1.numel() // mu1.shape[-1]
+    g = grads or (None, None, None, None)
+    lib.require_device(mu1, ls1_raw, mu2, ls2_raw)
+    lib.check(_L().savp_kl_gauss(lib.stream(), mu1.numel(), rows, _p(mu1), _p(ls1_raw), _p(mu2), _p(ls2_raw),
+                                 _p(kl_out) if kl_out is not None else None, float(klw),
+                                 _p(klw_dev) if klw_dev is not None else None, *[(_p(t) if t is not None else None) for t in g]),
+              'savp_kl_gauss')
+
+
 def reparam_fwd(mu, ls_raw, eps, ls, z, kl_out=None):
     rows = mu.numel() // mu.shape[-1]
     lib.check(_L().savp_reparam_fwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(ls), _p(z), _p(kl_out)),

@@ -186,6 +186,9 @@ register('savp_cdna_apply_bwd', [c_vp, ctypes.POINTER(SavpCdnaArgs)])
 register('savp_composite_fwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
 register('savp_composite_bwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
 register('savp_lstm_z_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
+register('savp_lstm_seq_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32])
+register('savp_lstm_seq_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32])
+register('savp_kl_gauss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp])

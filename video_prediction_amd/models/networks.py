@@ -14,19 +14,28 @@ EPS_IN = 1e-6
 
 
 class PosteriorEncoder(object):
-    """posterior_fn: frame pairs -> (z_mu, z_log_sigma_sq), flat batch M = (T-1)*B."""
+    """posterior_fn (savp_model.py:21-51): frame pairs -> (z_mu, z_log_sigma_sq) for every step, flat batch M = (T-1)*B;
+    with use_e_rnn the features pass through dense(nef*4) + BasicLSTMCell over time before the heads (:31-43).
 
-    def __init__(self, store, hp, image_shape, B, train=True, prefix='generator/encoder/'):
+    prior=True builds prior_fn (:54-85) under its own scope: the convolutional encoder sees only the context_frames-1 context
+    pairs, the remaining sequence_length-context_frames feature rows are zeros, and the recurrent tail is always present."""
+
+    def __init__(self, store, hp, image_shape, B, train=True, prefix='generator/encoder/', prior=False):
         H, W, C = image_shape
         self.hp, self.store = hp, store
         self.T1 = T1 = hp.sequence_length - 1
-        self.B, self.M = B, T1 * B
-        M = self.M
+        self.prior = prior
+        self.Tc = Tc = (hp.context_frames - 1) if prior else T1           # steps whose frame pair is encoded
+        self.B, self.M, self.R = B, Tc * B, T1 * B
+        M, R = self.M, self.R
         dev = store.device
         self.dev = dev
-        if hp.use_e_rnn or hp.norm_layer != 'instance':
-            raise NotImplementedError('HIP encoder covers use_e_rnn=False, norm_layer=instance')
-        self.pairs = torch.zeros(M, H, W, 2 * C, device=dev)
+        if hp.norm_layer != 'instance':
+            raise NotImplementedError('HIP encoder covers norm_layer=instance')
+        self.recurrent = bool(prior or hp.use_e_rnn)
+        if self.recurrent and hp.rnn != 'lstm':
+            raise NotImplementedError('rnn=%r: only the BasicLSTMCell tail is on the HIP path' % (hp.rnn,))
+        self.pairs = torch.zeros(max(M, 1), H, W, 2 * C, device=dev)
         self.C = C
         self.layers = []
         cin, h, w = 2 * C, H, W
@@ -37,20 +46,41 @@ class PosteriorEncoder(object):
             L = {'conv': ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (4, 4), (2, 2), (1, 1)),
                  'x': x, 'normed': i > 0}
             h, w = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
-            L['y'] = torch.empty(M, h, w, cout, device=dev)            # layer output (after lrelu)
-            L['dy'] = torch.empty(M, h, w, cout, device=dev) if train else None
+            L['y'] = torch.empty(max(M, 1), h, w, cout, device=dev)            # layer output (after lrelu)
+            L['dy'] = torch.empty(max(M, 1), h, w, cout, device=dev) if train else None
             if i > 0:
-                L['pre'] = torch.empty(M, h, w, cout, device=dev)
-                L['dpre'] = torch.empty(M, h, w, cout, device=dev) if train else None
+                L['pre'] = torch.empty(max(M, 1), h, w, cout, device=dev)
+                L['dpre'] = torch.empty(max(M, 1), h, w, cout, device=dev) if train else None
                 L['gamma'], L['beta'] = store[s + 'InstanceNorm/gamma'], store[s + 'InstanceNorm/beta']
                 L['dgamma'], L['dbeta'] = store.grad(s + 'InstanceNorm/gamma'), store.grad(s + 'InstanceNorm/beta')
-                L['mean'], L['rstd'] = torch.empty(M, cout, device=dev), torch.empty(M, cout, device=dev)
+                L['mean'], L['rstd'] = torch.empty(max(M, 1), cout, device=dev), torch.empty(max(M, 1), cout, device=dev)
             self.layers.append(L)
             x = L['y']
             cin = cout
         self.hw = h * w
-        self.pooled = torch.zeros(M, cin, device=dev)
-        self.dpooled = torch.empty(M, cin, device=dev) if train else None
+        # pooled features of ALL T1 steps; rows >= M (prior: the steps after the context) stay zero (savp_model.py:63-64)
+        self.feat = torch.zeros(R, cin, device=dev)
+        self.dfeat = torch.zeros(R, cin, device=dev) if train else None
+        self.pooled = self.feat[:M]
+        self.dpooled = self.dfeat[:M] if train else None
+        hin = cin
+        if self.recurrent:
+            U = self.U = hp.nef * 4
+            s = prefix + 'layer_%d/' % (hp.n_layers + 1)
+            self.fc = ConvLayer(store, s + 'dense/kernel', s + 'dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
+            s = prefix + '%s/rnn/basic_lstm_cell/' % hp.rnn
+            # the cell's [2U,4U] kernel as a 1x1 layer object: only its WGRAD entry is used (dW = A^T dG over all (t,b) rows)
+            self.cell = ConvLayer(store, s + 'kernel', s + 'bias', 'conv', (1, 1), (1, 1), (0, 0))
+            self.cell.need_wt = self.cell.need_wd = False
+            self.A = torch.zeros(T1, B, 2 * U, device=dev)                  # [dense(feat)_t | h_{t-1}]
+            self.hout = torch.empty(T1, B, U, device=dev)
+            self.gates = torch.empty(T1, B, 4 * U, device=dev)
+            self.cs = torch.empty(T1, B, U, device=dev)
+            if train:
+                self.dh = torch.empty(T1, B, U, device=dev)
+                self.dG = torch.empty(T1, B, 4 * U, device=dev)
+                self.dA = torch.empty(T1, B, 2 * U, device=dev)
+            hin = U
         self.mu_fc = ConvLayer(store, prefix + 'z_mu/dense/kernel', prefix + 'z_mu/dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
         self.ls_fc = ConvLayer(store, prefix + 'z_log_sigma_sq/dense/kernel', prefix + 'z_log_sigma_sq/dense/bias', 'conv',
                                (1, 1), (1, 1), (0, 0))
@@ -62,63 +92,91 @@ class PosteriorEncoder(object):
         self.dmu = torch.empty(T1, B, nz, device=dev) if train else None
         self.dls = torch.empty(T1, B, nz, device=dev) if train else None
         self.kl = torch.zeros(1, device=dev)
-        self.convs = [L['conv'] for L in self.layers] + [self.mu_fc, self.ls_fc]
+        self.convs = [L['conv'] for L in self.layers] + ([self.fc] if self.recurrent else []) + [self.mu_fc, self.ls_fc]
 
     def prep_weights(self):
         for c in self.convs:
             c.prep()
 
-    def forward(self, images, eps):
-        """images [T,B,H,W,C] contiguous; eps [T1,B,nz].  Returns z_post [T1,B,nz] (and fills mu, ls, kl)."""
-        T1, B, C, M = self.T1, self.B, self.C, self.M
-        a = images[:T1].reshape((M,) + tuple(images.shape[2:]))
-        b = images[1:T1 + 1].reshape((M,) + tuple(images.shape[2:]))
-        copy_view(a, [self.pairs[..., 0:C]])                                   # image_pairs = concat([x_t, x_t+1])  :23
-        copy_view(b, [self.pairs[..., C:2 * C]])
-        for L in self.layers:
-            if not L['normed']:
-                L['conv'].forward(L['x'], L['y'], act=lib.ACT_LRELU, alpha=0.2)            # networks.py:18-19
-            else:
-                L['conv'].forward(L['x'], L['pre'])
-                K.instnorm_act_fwd(L['pre'], L['gamma'], L['beta'], [L['y']], L['mean'], L['rstd'], act='lrelu', alpha=0.2,
-                                   eps=EPS_IN)                                              # networks.py:25-27
-        last = self.layers[-1]['y']
-        self.pooled.zero_()
-        K.colsum(last, self.pooled, scale=1.0 / self.hw, per_row=True)                     # networks.py:30-31
-        self.mu_fc.forward(self.pooled, self.mu.reshape(M, -1))
-        self.ls_fc.forward(self.pooled, self.ls_raw.reshape(M, -1))
+    def _head_input(self):
+        return self.hout.reshape(self.R, -1) if self.recurrent else self.feat
+
+    def forward(self, images, eps, kl=True):
+        """images [T,B,H,W,C] contiguous; eps [T1,B,nz].  Returns z [T1,B,nz] = mu + sigma*eps (and fills mu, ls; kl=True also
+        accumulates KL(q || N(0,1)) into self.kl -- the learned-prior KL is taken by the caller with kernels.kl_gauss)."""
+        T1, B, C, M, R, Tc = self.T1, self.B, self.C, self.M, self.R, self.Tc
+        if M:
+            a = images[:Tc].reshape((M,) + tuple(images.shape[2:]))
+            b = images[1:Tc + 1].reshape((M,) + tuple(images.shape[2:]))
+            copy_view(a, [self.pairs[..., 0:C]])                                   # image_pairs = concat([x_t, x_t+1])  :23
+            copy_view(b, [self.pairs[..., C:2 * C]])
+            for L in self.layers:
+                if not L['normed']:
+                    L['conv'].forward(L['x'], L['y'], act=lib.ACT_LRELU, alpha=0.2)            # networks.py:18-19
+                else:
+                    L['conv'].forward(L['x'], L['pre'])
+                    K.instnorm_act_fwd(L['pre'], L['gamma'], L['beta'], [L['y']], L['mean'], L['rstd'], act='lrelu', alpha=0.2,
+                                       eps=EPS_IN)                                              # networks.py:25-27
+            last = self.layers[-1]['y']
+            self.pooled.zero_()
+            K.colsum(last, self.pooled, scale=1.0 / self.hw, per_row=True)                     # networks.py:30-31
+        if self.recurrent:
+            U = self.U
+            self.fc.forward(self.feat, self.A.reshape(R, 2 * U)[:, :U])                        # savp_model.py:32-33 / 66-67
+            K.lstm_seq_fwd(self.A, self.cell.W, self.cell.bias, self.hout, self.gates, self.cs, U)     # :35-43 / 69-76
+        hin = self._head_input()
+        self.mu_fc.forward(hin, self.mu.reshape(R, -1))
+        self.ls_fc.forward(hin, self.ls_raw.reshape(R, -1))
         self.eps = eps
         self.kl.zero_()
-        K.reparam_fwd(self.mu, self.ls_raw, eps, self.ls, self.z, self.kl)                  # savp_model.py:45-49,712
+        K.reparam_fwd(self.mu, self.ls_raw, eps, self.ls, self.z, self.kl if kl else None)  # savp_model.py:45-49,712
         return self.z
 
     def backward(self, dz, kl_weight, kl_weight_dev=None):
-        """dz [T1,B,nz] = dL/dz_posterior (may be None); adds the KL term's gradient with weight kl_weight (read from the
-        1-element device tensor kl_weight_dev if given)."""
-        M = self.M
+        """dz [T1,B,nz] = dL/dz (may be None); adds the gradient of kl_weight * KL(q || N(0,1)) (weight read from the 1-element
+        device tensor kl_weight_dev if given), then back-propagates through the network."""
+        self.reparam_backward(dz, kl_weight, kl_weight_dev)
+        self.backward_network()
+
+    def reparam_backward(self, dz, kl_weight=0.0, kl_weight_dev=None):
+        """dmu / dls <- gradient of z = mu + sigma*eps (and of the standard-normal KL when weighted in).  With a learned prior the
+        caller adds the Gaussian-vs-Gaussian KL terms of both networks (kernels.kl_gauss) before backward_network()."""
         K.reparam_bwd(self.mu, self.ls_raw, self.eps, dz, kl_weight or 0.0, self.dmu, self.dls, klw_dev=kl_weight_dev)
-        dmu2, dls2 = self.dmu.reshape(M, -1), self.dls.reshape(M, -1)
-        self.mu_fc.backward_data(dmu2, self.dpooled, beta=0)
-        self.ls_fc.backward_data(dls2, self.dpooled, beta=1)
-        self.mu_fc.backward_weights(self.pooled, dmu2)
-        self.ls_fc.backward_weights(self.pooled, dls2)
-        lastL = self.layers[-1]
-        K.tile_channels(self.dpooled, lastL['dy'], scale=1.0 / self.hw)
-        for i in range(len(self.layers) - 1, -1, -1):
-            L = self.layers[i]
-            if L['normed']:
-                K.instnorm_act_bwd(L['pre'], L['gamma'], L['beta'], L['y'], L['mean'], L['rstd'], [L['dy']], L['dpre'],
-                                   L['dgamma'], L['dbeta'], act='lrelu', alpha=0.2, eps=EPS_IN)
-                dpre = L['dpre']
-            else:
-                dpre = L['dy']       # already multiplied by lrelu' in the producing DGRAD epilogue
-            if i > 0:
-                below = self.layers[i - 1]
-                if below['normed']:
-                    L['conv'].backward_data(dpre, below['dy'], beta=0)
+
+    def backward_network(self):
+        M, R = self.M, self.R
+        dmu2, dls2 = self.dmu.reshape(R, -1), self.dls.reshape(R, -1)
+        hin = self._head_input()
+        dhin = self.dh.reshape(R, -1) if self.recurrent else self.dfeat
+        self.mu_fc.backward_data(dmu2, dhin, beta=0)
+        self.ls_fc.backward_data(dls2, dhin, beta=1)
+        self.mu_fc.backward_weights(hin, dmu2)
+        self.ls_fc.backward_weights(hin, dls2)
+        if self.recurrent:
+            U = self.U
+            K.lstm_seq_bwd(self.A, self.cell.W, self.gates, self.cs, self.dh, self.dG, self.dA, U)
+            self.cell.backward_weights(self.A.reshape(R, 2 * U), self.dG.reshape(R, 4 * U))         # dW = A^T dG, db = colsum(dG)
+            dx = self.dA.reshape(R, 2 * U)[:, :U]
+            self.fc.backward_data(dx, self.dfeat, beta=0)
+            self.fc.backward_weights(self.feat, dx)
+        if M:
+            lastL = self.layers[-1]
+            K.tile_channels(self.dpooled, lastL['dy'], scale=1.0 / self.hw)
+            for i in range(len(self.layers) - 1, -1, -1):
+                L = self.layers[i]
+                if L['normed']:
+                    K.instnorm_act_bwd(L['pre'], L['gamma'], L['beta'], L['y'], L['mean'], L['rstd'], [L['dy']], L['dpre'],
+                                       L['dgamma'], L['dbeta'], act='lrelu', alpha=0.2, eps=EPS_IN)
+                    dpre = L['dpre']
                 else:
-                    L['conv'].backward_data(dpre, below['dy'], beta=0, act=lib.ACT_DLRELU_FROM_OUT, alpha=0.2, aux=below['y'])
-            L['conv'].backward_weights(L['x'], dpre)
+                    dpre = L['dy']       # already multiplied by lrelu' in the producing DGRAD epilogue
+                if i > 0:
+                    below = self.layers[i - 1]
+                    if below['normed']:
+                        L['conv'].backward_data(dpre, below['dy'], beta=0)
+                    else:
+                        L['conv'].backward_data(dpre, below['dy'], beta=0, act=lib.ACT_DLRELU_FROM_OUT, alpha=0.2, aux=below['y'])
+                L['conv'].backward_weights(L['x'], dpre)
         for c in self.convs:
             c.finish_weight_grad()
 
@@ -133,6 +191,7 @@ class SNDiscriminator(object):
     def __init__(self, store, hp, image_shape, Nc, prefix, kind='video', train=True):
         H, W, C = image_shape
         self.hp, self.store, self.Nc, self.kind = hp, store, Nc, kind
+        self.prefix = prefix                       # variable scope of this network (= one chunk of the 'd' gradient arena)
         dev = store.device
         self.dev = dev
         self.frames = 1 if kind == 'image' else hp.clip_length

@@ -245,6 +245,8 @@ class SAVPGenerator(object):
                     r.append((self.hsmall, 0))
             L['routes'] = r
 
+    prefix_root = 'generator/rnn/'       # every variable of the generator cell lives under this scope (one gradient chunk)
+
     def weight_layers(self):
         return self.convs
 

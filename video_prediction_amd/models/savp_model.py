@@ -64,13 +64,16 @@ class SAVPEngine(object):
         self.images_n = torch.empty(self.T, N, H, W, C, device=self.device) if self.nz else self.images_tm
         self.zs_all = torch.zeros(self.T1, N, self.nz, device=self.device) if self.nz else None
         self.dz_post = torch.zeros(self.T1, B, self.nz, device=self.device) if (self.nz and self.train) else None
+        self.dz_prior = torch.zeros(self.T1, B, self.nz, device=self.device) if (self.nz and self.train and hp.learn_prior) else None
         self.has_d = self.train and V.uses_discriminator(hp)
         if self.has_d and self.T1 < hp.clip_length:
             # tf.random_uniform(maxval <= minval) raises in the reference (savp_model.py:97); a silent pass would gather clips
             # beyond the sequence
             raise ValueError('clip_length=%d needs sequence_length >= %d (got %d)' % (hp.clip_length, hp.clip_length + 1, self.T))
-        if self.nz and hp.learn_prior:
-            raise NotImplementedError('learn_prior=True (prior_fn, savp_model.py:54-85) is not on the HIP path yet')
+        # learned prior (prior_fn, savp_model.py:54-85,717-721): its own encoder + recurrent tail under scope generator/prior
+        self.learn_prior = bool(self.nz and hp.learn_prior)
+        self.prior = (PosteriorEncoder(self.store, hp, image_shape, B, train=self.train, prefix='generator/prior/', prior=True)
+                      if self.learn_prior else None)
         # (discriminator, loss weight, loss-name infix, operates on the posterior ('_enc') unroll?, clip index keys)
         self.discs = []
         if self.has_d:
@@ -108,6 +111,7 @@ class SAVPEngine(object):
         self.d_gt = torch.zeros(self.T1, N, dtype=torch.int32, device=dev)
         self.d_eps = torch.zeros(self.T1, B, self.nz, device=dev) if self.nz else None
         self.d_prior = torch.zeros(self.T - hp.context_frames, B, self.nz, device=dev) if self.nz else None
+        self.d_prior_eps = torch.zeros(self.T1, B, self.nz, device=dev) if self.learn_prior else None
         self.d_idx = torch.zeros(2, len(IDX_KEYS), 2, B, dtype=torch.int32, device=dev)    # [pre/post][key][t_sample/t_start][B]
         self.d_scal = torch.zeros(4, device=dev)                                           # lr_t(D), lr_t(G), kl weight
         self.graph = None
@@ -124,9 +128,19 @@ class SAVPEngine(object):
         self.world = self.replicas.world
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
 
-    def _allreduce(self, group):
+    def _begin_allreduce(self, group, prefix):
+        """Start the exchange of the gradients of the variables under `prefix` (one network = one contiguous chunk)."""
         if self.world > 1:
-            self.replicas.allreduce_grads(group)
+            try:
+                lo, hi = self.store.chunk_of(group, prefix)
+            except ValueError:          # scope not contiguous in the arena: left to finish_allreduce (exchanged at the end)
+                return
+            self.replicas.begin_allreduce(group, lo, hi)
+
+    def _allreduce(self, group):
+        """Complete the exchange of the group's gradient bucket (chunks not started yet are exchanged now)."""
+        if self.world > 1:
+            self.replicas.finish_allreduce(group)
 
     # -- input staging -------------------------------------------------------------------------------------------------
     def set_images(self, images, time_major=False):
@@ -160,7 +174,10 @@ class SAVPEngine(object):
         noise = {}
         if self.nz:
             noise['eps'] = torch.randn(T1, B, self.nz, generator=g)
-            noise['prior'] = torch.randn(self.T - hp.context_frames, B, self.nz, generator=g)
+            if self.learn_prior:
+                noise['prior_eps'] = torch.randn(T1, B, self.nz, generator=g)          # eps of the learned prior (:719-720)
+            else:
+                noise['prior'] = torch.randn(self.T - hp.context_frames, B, self.nz, generator=g)
         ns = T1 - hp.context_frames
         if self.train and hp.schedule_sampling != 'none':
             prob = self.schedule_sampling_prob()
@@ -209,7 +226,10 @@ class SAVPEngine(object):
         self.d_gt.copy_(self._gt_mask(noise))
         if self.nz:
             self.d_eps.copy_(torch.as_tensor(noise['eps'], dtype=torch.float32))
-            self.d_prior.copy_(torch.as_tensor(noise['prior'], dtype=torch.float32))
+            if self.learn_prior:
+                self.d_prior_eps.copy_(torch.as_tensor(noise['prior_eps'], dtype=torch.float32))
+            else:
+                self.d_prior.copy_(torch.as_tensor(noise['prior'], dtype=torch.float32))
         if self.train and 'd_indices_pre' in noise:
             idx = np.zeros((2, len(IDX_KEYS), 2, self.B), dtype=np.int32)
             for pi, ph in enumerate(('d_indices_pre', 'd_indices_post')):
@@ -224,6 +244,8 @@ class SAVPEngine(object):
         self.gen.prep_weights()
         if self.enc:
             self.enc.prep_weights()
+        if self.prior:
+            self.prior.prep_weights()
 
     def forward_generator(self, noise, collect_masks=False):
         """generator_fn (savp_model.py:699-768).  Returns gen [T1, N, H, W, C]: [:, :B] posterior ('_enc'), [:, B:] prior."""
@@ -233,14 +255,20 @@ class SAVPEngine(object):
         gt = self.d_gt
         if self.nz:
             eps = self.d_eps
-            z_post = self.enc.forward(self.images_tm, eps)
+            z_post = self.enc.forward(self.images_tm, eps, kl=not self.learn_prior)
             nzv = self.nz
-            # zs (2B): posterior half, prior half = [posterior z for the first context_frames-1 steps ; N(0,1)]  (:724-725)
             copy_view(z_post.reshape(T1, B, nzv), [self.zs_all[:, :B]])
-            c1 = hp.context_frames - 1
-            if c1 > 0:
-                copy_view(z_post[:c1], [self.zs_all[:c1, B:]])
-            copy_view(self.d_prior, [self.zs_all[c1:, B:]])
+            if self.learn_prior:
+                # zs_prior = mu_p + sigma_p * eps for ALL steps (:717-721); KL(posterior || learned prior) (base_model.py:825-828)
+                z_prior = self.prior.forward(self.images_tm, self.d_prior_eps, kl=False)
+                copy_view(z_prior, [self.zs_all[:, B:]])
+                K.kl_gauss(self.enc.mu, self.enc.ls_raw, self.prior.mu, self.prior.ls_raw, kl_out=self.enc.kl)
+            else:
+                # prior half = [posterior z for the first context_frames-1 steps ; N(0,1)]  (:724-725)
+                c1 = hp.context_frames - 1
+                if c1 > 0:
+                    copy_view(z_post[:c1], [self.zs_all[:c1, B:]])
+                copy_view(self.d_prior, [self.zs_all[c1:, B:]])
             return self.gen.forward(self.images_n, self.zs_all, gt, collect_masks=collect_masks)
         return self.gen.forward(self.images_n, None, gt, collect_masks=collect_masks)
 
@@ -334,32 +362,40 @@ class SAVPEngine(object):
         if discs:
             store.groups['d'].zero_grad()
             prepped = set()
-            for d in discs:
+            last_use = {id(d['D']): i for i, d in enumerate(discs)}
+            for i, d in enumerate(discs):
                 D, w, slot = d['D'], d['w'], d['slot']
                 if id(D) not in prepped:
                     D.prep_weights(update_u=True)
                     prepped.add(id(D))
-                if not w:
-                    continue
-                self._d_clips(D, 0, d['kr'], d['kf'], d['fake'], 0, B)
-                D.forward()
-                r0, r1 = D.rows(0, B)
-                f0, f1 = D.rows(B, 2 * B)
-                K.gan_loss(D.logits[r0:r1], 1.0, w, hp.gan_loss_type, lb[slot:slot + 1], D.dlogits[r0:r1])    # discrim_*_loss real
-                K.gan_loss(D.logits[f0:f1], 0.0, w, hp.gan_loss_type, lb[slot + 1:slot + 2], D.dlogits[f0:f1])  # ... fake
-                D.backward(0, 2 * B, weights=True, data=False)
-            for D in {id(d['D']): d['D'] for d in discs}.values():
-                D.finish_weight_grads()
+                if w:
+                    self._d_clips(D, 0, d['kr'], d['kf'], d['fake'], 0, B)
+                    D.forward()
+                    r0, r1 = D.rows(0, B)
+                    f0, f1 = D.rows(B, 2 * B)
+                    K.gan_loss(D.logits[r0:r1], 1.0, w, hp.gan_loss_type, lb[slot:slot + 1], D.dlogits[r0:r1])    # discrim_*_loss real
+                    K.gan_loss(D.logits[f0:f1], 0.0, w, hp.gan_loss_type, lb[slot + 1:slot + 2], D.dlogits[f0:f1])  # ... fake
+                    D.backward(0, 2 * B, weights=True, data=False)
+                if last_use[id(D)] == i:
+                    # this network's gradients are final: exchange them on the side stream while the next discriminator runs
+                    D.finish_weight_grads()
+                    if not return_grads:
+                        self._begin_allreduce('d', D.prefix)
             if return_grads:
                 info['d_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'd'}
-            self._allreduce('d')
+            # independent of the D update: clear the generator-side gradient buffers while the last D chunk is in flight
+            store.groups['g'].zero_grad()
+            self.gen.gen.g.zero_()
             if not hp.joint_gan_optimization:
+                self._allreduce('d')
                 store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
             # joint_gan_optimization (base_model.py:498-505): no control dependency on the D update and no replace_read_ops, i.e. the
             # generator loss is taken against the PRE-update discriminator; D's Adam is applied after the generator step below
+            # (its gradient exchange then overlaps the whole generator step)
+        else:
+            store.groups['g'].zero_grad()
+            self.gen.gen.g.zero_()
         # ---------------- generator (+ encoder) step --------------------------------------------------------------------------
-        store.groups['g'].zero_grad()
-        self.gen.gen.g.zero_()
         if discs:
             prepped = set()
             for d in discs:
@@ -401,17 +437,31 @@ class SAVPEngine(object):
         if hp.l2_weight:
             K.lp_loss(pred, target, hp.l2_weight, lb[-1:], dpred, p2=True)
         dzs = self.gen.backward()
+        if self.nz and not return_grads:
+            # the generator cell's gradients are final after BPTT: exchange them under the encoder's backward pass
+            self._begin_allreduce('g', self.gen.prefix_root)
         if self.nz:
             c1 = hp.context_frames - 1
             copy_view(dzs[:, :B], [self.dz_post])
-            if c1 > 0:
-                add_views([dzs[:c1, B:]], self.dz_post[:c1])
-            self.enc.backward(self.dz_post, klw, kl_weight_dev=self.d_scal[2:3])
+            if self.learn_prior:
+                copy_view(dzs[:, B:], [self.dz_prior])
+                self.enc.reparam_backward(self.dz_post)
+                self.prior.reparam_backward(self.dz_prior)
+                if hp.kl_weight:
+                    K.kl_gauss(self.enc.mu, self.enc.ls_raw, self.prior.mu, self.prior.ls_raw, klw=klw or 0.0, klw_dev=self.d_scal[2:3],
+                               grads=(self.enc.dmu, self.enc.dls, self.prior.dmu, self.prior.dls))
+                self.enc.backward_network()
+                self.prior.backward_network()
+            else:
+                if c1 > 0:
+                    add_views([dzs[:c1, B:]], self.dz_post[:c1])
+                self.enc.backward(self.dz_post, klw, kl_weight_dev=self.d_scal[2:3])
         if return_grads:
             info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
         self._allreduce('g')
         store.groups['g'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[1:2])
         if discs and hp.joint_gan_optimization:
+            self._allreduce('d')
             store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
         for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
@@ -553,6 +603,20 @@ def posterior_fn(inputs, hparams, engine=None, noise=None):
     return {'zs_mu': eng.enc.mu, 'zs_log_sigma_sq': eng.enc.ls}
 
 
+def prior_fn(inputs, hparams, engine=None, noise=None):
+    """savp_model.py:54-85 (learn_prior=True).  inputs['images'] time-major [T,B,H,W,C] on the device."""
+    if not hparams.learn_prior:
+        raise ValueError('prior_fn needs hparams.learn_prior=True (the prior network is not instantiated otherwise)')
+    eng = _engine_for(inputs, 'test', hparams, engine)
+    eng.set_images(inputs['images'], time_major=True)
+    eng.prior.prep_weights()
+    eps = (noise or {}).get('prior_eps')
+    if eps is None:
+        eps = torch.zeros(eng.T1, eng.B, hparams.nz)
+    eng.prior.forward(eng.images_tm, eps.to(eng.device, torch.float32), kl=False)
+    return {'zs_mu': eng.prior.mu, 'zs_log_sigma_sq': eng.prior.ls}
+
+
 def generator_fn(inputs, mode, hparams, engine=None, noise=None):
     """savp_model.py:699-768 (without the visualisation-only gen_images_samples unroll :745-767)."""
     eng = _engine_for(inputs, mode, hparams, engine)
@@ -572,6 +636,9 @@ def generator_fn(inputs, mode, hparams, engine=None, noise=None):
     outputs['masks'] = masks[:, lo:]
     gt = eng._gt_mask(noise)
     outputs['ground_truth_sampling_mean'] = gt[hparams.context_frames:, lo:].float().mean()
+    if eng.learn_prior:
+        outputs['zs_mu_prior'] = eng.prior.mu                    # savp_model.py:735 (keys get the '_prior' suffix)
+        outputs['zs_log_sigma_sq_prior'] = eng.prior.ls
     if eng.nz:
         outputs['zs_mu_enc'] = eng.enc.mu
         outputs['zs_log_sigma_sq_enc'] = eng.enc.ls

@@ -3,18 +3,39 @@
 The reference replicates the model in-graph per GPU and sums every gradient tensor separately with
 tf.contrib.nccl.all_sum, then scales by 1/K (/root/reference/video_prediction/utils/tf_utils.py:450-480, called at
 models/base_model.py:590-592 and :614-616); replicas are initialised by copying tower 0's variables (:640-646).
-Here each optimiser group (discriminator; generator+encoder) is ONE flat fp32 bucket (ParamGroup.g), so a step issues
-exactly two all-reduces (41.2 MB and 29.4 MB for BAIR SAVP) and the 1/K scale is folded into the Adam kernel.
-The time axis is a serial recurrence and is never sharded; the batch is.
+
+Here each optimiser group (discriminator; generator+encoder) is ONE flat fp32 arena (ParamGroup.g) whose variables are laid
+out network by network, so the gradients of one network are one contiguous chunk.  A chunk is all-reduced as soon as the
+backward pass that produces it has been ISSUED -- on a side HIP stream, chained to the compute stream with events:
+
+    compute stream : ... backward of network A | record(eA) | forward/backward of network B ...... | wait(dA) wait(dB) | Adam
+    comm stream    :                            wait(eA) | RCCL all-reduce(chunk A) | record(dA) ...
+
+so the reduction of chunk A overlaps the compute of network B (D step: the posterior-side discriminator's 20.6 MB under the
+prior-side discriminator's forward/backward; G step: the generator cell's 26 MB under the encoder's backward; with
+joint_gan_optimization the whole D bucket under the generator step).  The 1/K scale is folded into the Adam kernel.  The time
+axis is a serial recurrence and is never sharded; the batch is.
+
+Why torch.distributed is the boundary (SURVEY.md 8(b) lists `savp_allreduce_bucket(ncclComm_t, hipStream_t, void*, size_t)`):
+the communicator bootstrap (rendezvous, unique-id exchange, process-group lifetime) is exactly what torch.distributed provides
+around RCCL, bench.py is launched by torch.distributed.run, and ProcessGroupNCCL issues ncclAllReduce on the flat bucket
+pointer with no copy -- a C-ABI shim would call the same RCCL entry point with the same arguments.  See INTEGRATION.md.
 """
+import torch
 
 
 class ReplicaGroup(object):
-    def __init__(self, store, dist_module=None):
+    def __init__(self, store, dist_module=None, overlap=True):
         self.store = store
         self.dist = dist_module
         self.world = dist_module.get_world_size() if dist_module is not None else 1
         self.rank = dist_module.get_rank() if dist_module is not None else 0
+        dev = torch.device(store.device)
+        self.on_gpu = dev.type == 'cuda'
+        # side stream of the gradient exchange (None on the CPU: gloo reduces host tensors synchronously)
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and overlap and self.world > 1) else None
+        self.pending = {}          # group -> list of (lo, hi, done event | None)
+        self.stats = {'chunks': 0, 'elements': 0}
         if self.world > 1:
             for g in store.groups.values():            # post_init_ops: every replica starts from rank 0's variables
                 dist_module.broadcast(g.p, src=0)
@@ -23,10 +44,61 @@ class ReplicaGroup(object):
     def grad_scale(self):
         return 1.0 / self.world
 
+    # -- chunked, stream-overlapped exchange ---------------------------------------------------------------------------------
+    def begin_allreduce(self, group, lo=0, hi=None):
+        """Start summing elements lo:hi of the group's flat gradient arena over all replicas.  Everything launched on the
+        current stream so far (the backward pass that produced the chunk) is waited for by the side stream; later launches on
+        the current stream run concurrently with the exchange until finish_allreduce(group)."""
+        if self.world == 1:
+            return
+        g = self.store.groups[group].g
+        hi = g.numel() if hi is None else hi
+        if hi <= lo:
+            return
+        chunk = g[lo:hi]
+        done = None
+        if self.comm_stream is not None:
+            cur = torch.cuda.current_stream(g.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self.comm_stream.wait_event(ready)
+            with torch.cuda.stream(self.comm_stream):
+                self.dist.all_reduce(chunk)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+        else:
+            self.dist.all_reduce(chunk)
+        self.pending.setdefault(group, []).append((lo, hi, done))
+        self.stats['chunks'] += 1
+        self.stats['elements'] += hi - lo
+
+    def finish_allreduce(self, group):
+        """Exchange whatever part of the group's arena no begin_allreduce covered, then make the current stream wait for every
+        chunk: after this call the arena holds the sum over replicas (divide by world in Adam)."""
+        if self.world == 1:
+            return
+        n = self.store.groups[group].g.numel()
+        covered = sorted((lo, hi) for lo, hi, _ in self.pending.get(group, []))
+        pos = 0
+        gaps = []
+        for lo, hi in covered:
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < n:
+            gaps.append((pos, n))
+        for lo, hi in gaps:
+            self.begin_allreduce(group, lo, hi)
+        if self.comm_stream is not None:
+            cur = torch.cuda.current_stream(self.store.groups[group].g.device)
+            for _, _, done in self.pending.get(group, []):
+                cur.wait_event(done)
+        self.pending[group] = []
+
     def allreduce_grads(self, group, async_op=False):
-        """Sum the flat gradient bucket of one optimiser group over all replicas (average = grad_scale in Adam)."""
+        """Sum the whole flat gradient bucket of one optimiser group (blocking with respect to the current stream)."""
         if self.world > 1:
-            return self.dist.all_reduce(self.store.groups[group].g, async_op=async_op)
+            self.finish_allreduce(group)
         return None
 
     def shard(self, global_batch_tensor, dim=0):
@@ -41,7 +113,6 @@ class ReplicaGroup(object):
         """True iff every replica holds bit-identical variables (they must: identical averaged grads, identical Adam)."""
         if self.world == 1:
             return True
-        import torch
         ok = True
         for g in self.store.groups.values():
             s = g.p.double().sum().reshape(1).clone()

@@ -72,8 +72,9 @@ def generator_variable_specs(hp, image_shape):
     H, W, C = image_shape
     specs = OrderedDict()
     nz = hp.nz
-    if nz:
-        p = 'generator/encoder/'
+    def encoder_specs(p, recurrent):
+        """networks.encoder + the optional recurrent tail + the two heads under scope p (savp_model.py:21-51 posterior_fn with
+        use_e_rnn, :54-85 prior_fn which always has the tail)."""
         cin = 2 * C
         for i in range(hp.n_layers):
             cout = hp.nef * min(2 ** i, 4)
@@ -84,9 +85,27 @@ def generator_variable_specs(hp, image_shape):
                 specs[s + 'InstanceNorm/beta'] = ((cout,), 'zeros')
                 specs[s + 'InstanceNorm/gamma'] = ((cout,), 'ones')
             cin = cout
+        if recurrent:
+            if hp.rnn != 'lstm':
+                raise NotImplementedError('rnn=%r: only the BasicLSTMCell tail is built (savp_model.py:36-41)' % (hp.rnn,))
+            u = hp.nef * 4
+            s = p + 'layer_%d/' % (hp.n_layers + 1)
+            specs[s + 'dense/kernel'] = ((cin, u), 'tn0.02')
+            specs[s + 'dense/bias'] = ((u,), 'zeros')
+            # tf_utils.unroll_rnn = tf.nn.dynamic_rnn under scope hparams.rnn: '<rnn>/rnn/basic_lstm_cell/{kernel,bias}';
+            # BasicLSTMCell creates its kernel with get_variable's default initializer (glorot-uniform)
+            s = p + '%s/rnn/basic_lstm_cell/' % hp.rnn
+            specs[s + 'kernel'] = ((2 * u, 4 * u), 'glorot')
+            specs[s + 'bias'] = ((4 * u,), 'zeros')
+            cin = u
         for head in ('z_mu', 'z_log_sigma_sq'):
             specs[p + head + '/dense/kernel'] = ((cin, nz), 'tn0.02')
             specs[p + head + '/dense/bias'] = ((nz,), 'zeros')
+
+    if nz:
+        encoder_specs('generator/encoder/', bool(hp.use_e_rnn))
+        if hp.learn_prior:
+            encoder_specs('generator/prior/', True)
 
     p = 'generator/rnn/savp_cell/'
     if nz and hp.use_rnn_z:
