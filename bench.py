@@ -30,24 +30,34 @@ RECIPE = dict(  # hparams/bair_action_free/ours_savp/model_hparams.json of the r
     batch_size=16, lr=0.0002, beta1=0.5, beta2=0.999, l1_weight=100.0, l2_weight=0.0, kl_weight=1.0,
     video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0,
     state_weight=0.0)
-H, W, C = 64, 64, 3
-SEQ, CONTEXT = 30, 2      # BASELINE.json configs[1]: BAIR action-free, seq 30; context 2 (softmotion_dataset.py:46-54)
+# Workloads (BASELINE.json configs / SURVEY.md 8(d)); the headline metric is quoted on c2, the default.
+#   c2: configs[1] -- BAIR action-free 64x64x3, seq 30, context 2 (softmotion_dataset.py:46-54), batch 16 per GPU
+#   c4: configs[3] -- KTH 64x64x1, seq 40, context 10 (kth_dataset.py:26-36), nz 32 / kl 0.01 (hparams/kth/ours_savp), batch 16 per GPU
+#   c5: configs[4] -- synthetic 128x128x3, seq 30, context 2, batch 8 per GPU (the >= 128 layer table, savp_model.py:198-210)
+CONFIGS = {
+    'c2': dict(name='BAIR action-free 64x64x3', shape=(64, 64, 3), seq=30, context=2, batch=16, over={}),
+    'c4': dict(name='KTH 64x64x1', shape=(64, 64, 1), seq=40, context=10, batch=16, over=dict(nz=32, kl_weight=0.01)),
+    'c5': dict(name='synthetic 128x128x3', shape=(128, 128, 3), seq=30, context=2, batch=8, over={}),
+}
+H, W, C = CONFIGS['c2']['shape']
+SEQ, CONTEXT = CONFIGS['c2']['seq'], CONFIGS['c2']['context']
 CPU_SEQ = 12              # frames of the cpu_baseline sample (>= clip_length + 1 = 11 for the video discriminator)
 PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}  # MI355X_MICROARCH.md: fp32 MFMA / vector peak; dense bf16 MFMA peak
 
 
-def make_hparams(batch, seq=SEQ):
+def make_hparams(batch, seq=SEQ, context=CONTEXT, over=None):
     from video_prediction_amd.models import get_model_class
     d = dict(RECIPE)
-    d.update(context_frames=CONTEXT, sequence_length=seq, batch_size=batch)
+    d.update(over or {})
+    d.update(context_frames=context, sequence_length=seq, batch_size=batch)
     model = get_model_class('savp')(mode='train', hparams_dict=d)
     return model
 
 
-def synthetic_batch(batch, seed, device):
-    """Seeded synthetic BAIR-shaped video, uniform[0,1) like convert_image_dtype'd uint8 frames."""
+def synthetic_batch(batch, seed, device, seq=SEQ, shape=(H, W, C)):
+    """Seeded synthetic video of the workload's shape, uniform[0,1) like convert_image_dtype'd uint8 frames."""
     rng = np.random.default_rng(seed)
-    x = rng.random((batch, SEQ, H, W, C), dtype=np.float32)
+    x = rng.random((batch, seq) + tuple(shape), dtype=np.float32)
     return torch.from_numpy(x).to(device)
 
 
@@ -106,9 +116,10 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (BASELINE configs[1]: 16)')
+    ap.add_argument('--steps', type=int, default=120, help='timed steps (default: a timed region of ~10 s on the c2 workload)')
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2', help='workload (see CONFIGS); the headline metric is c2')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s: 16 for c2 / c4, 8 for c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16',
                     help='conv multiply precision: bf16 operands / fp32 accumulate (BASELINE configs[1]) or exact fp32')
@@ -159,15 +170,19 @@ def main():
     table = os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % args.precision)
     if not args.no_autotune and not args.retune and os.path.exists(table):
         K.load_tuning(table)
-    model = make_hparams(args.batch)
+    cfg = CONFIGS[args.config]
+    if not args.batch:
+        args.batch = cfg['batch']
+    shape, seq = cfg['shape'], cfg['seq']
+    model = make_hparams(args.batch, seq, cfg['context'], cfg['over'])
     hp = model.hparams
-    engine = SAVPEngine(hp, (H, W, C), args.batch, mode='train', seed=4, device=str(device))
+    engine = SAVPEngine(hp, shape, args.batch, mode='train', seed=4, device=str(device))
     if dist is not None:
         engine.attach_process_group(dist)
     # The roofline numbers come from HIP events around the ConvLSTM gate-conv launches of the timed steps; events cannot be timed
     # inside a graph replay, so the default run keeps the step eager (measured cost of eager launches: ~0.5 ms of an 84 ms step)
     engine.use_graph = bool(args.graph) and world == 1
-    engine.set_images(synthetic_batch(args.batch, 1234 + rank, device))      # inputs resident in HBM before timing
+    engine.set_images(synthetic_batch(args.batch, 1234 + rank, device, seq, shape))      # inputs resident in HBM before timing
 
     def sync():
         torch.cuda.synchronize()
@@ -203,32 +218,32 @@ def main():
     # separate runs, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md); bench.py cannot collect counters itself.
     traffic = None
     pmc_path = os.path.join(ROOT, 'profiles', 'r01_convlstm_fprop_pmc_%s.json' % args.precision)
-    if os.path.exists(pmc_path) and args.batch == 16:
+    if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
         try:
             traffic = json.load(open(pmc_path))['avg_hbm_bytes_per_launch_five_layers']
         except Exception:
             traffic = None
-    frames = world * args.batch * SEQ * args.steps
+    frames = world * args.batch * seq * args.steps
     result = {
         'metric': 'train frames/sec (whole node), BAIR 64x64 seq30 SAVP',
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': 'SAVP full VAE-GAN (ours_savp recipe), BAIR action-free 64x64x3, seq=30, context=2, '
-                               'batch=%d per GPU, D step + G/E step per train step' % args.batch,
-                   'global_batch': world * args.batch, 'seq_len': SEQ, 'parallelism': 'dp%d' % world,
+        'config': {'workload': '%s: SAVP full VAE-GAN (ours_savp recipe), %s, seq=%d, context=%d, nz=%d, '
+                               'batch=%d per GPU, D step + G/E step per train step' % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
+                   'global_batch': world * args.batch, 'seq_len': seq, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic,
                      'traffic_unit': 'bytes per launch, mean of the 5 layers (PMC, profiles/r01_convlstm_fprop_pmc_*.json); algorithmic 19.1 MB',
-                     'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_patch_kernel (LDS patch, bf16 MFMA)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
+                     'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
     if rank == 0 and args.save_tuning:
         K.save_tuning(args.save_tuning)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 'c2':     # the CPU sample has the c2 workload's shape
             try:
                 result['cpu_baseline'] = cpu_baseline()
             except Exception as ex:    # the oracle is only a reported baseline; never fail the bench on it

@@ -466,7 +466,8 @@ def check_util(seed=4):
 def check_cdna_composite(seed=5):
     out = []
     rng = np.random.default_rng(seed)
-    for (N, H, W, C, Kk) in [(3, 16, 16, 3, 4), (2, 8, 12, 1, 4)]:
+    # 16x16 = one LDS tile; 8x12 / 40x24 / 19x35 = partial tiles and several tiles per image (tiled 5x5 kernels)
+    for (N, H, W, C, Kk) in [(3, 16, 16, 3, 4), (2, 8, 12, 1, 4), (2, 40, 24, 3, 4), (2, 19, 35, 1, 4), (1, 64, 64, 3, 4)]:
         kh = kw = 5
         raw = (rnd(rng, N, kh, kw, Kk) * 0.3).requires_grad_(True)
         img = torch.tensor(rng.random((N, H, W, C)), dtype=torch.float64, requires_grad=True)
@@ -514,7 +515,7 @@ def check_cdna_composite(seed=5):
     K.cdna_apply_fwd(dev(img), kd, ov, 5, 5, Kk)
     out.append(('cdna_identity', rel_err(ov, torch.cat([img] * Kk, dim=-1)), 1e-6))
     # composite
-    for (N, H, W, C, M) in [(2, 16, 16, 3, 7), (2, 8, 8, 1, 7)]:
+    for (N, H, W, C, M) in [(2, 16, 16, 3, 7), (2, 8, 8, 1, 7), (3, 20, 23, 3, 7)]:
         logits = (rnd(rng, N, H, W, M) * 2).requires_grad_(True)
         timgs = torch.tensor(rng.random((N, H, W, M * C)), dtype=torch.float64, requires_grad=True)
         masks = torch.softmax(logits, dim=-1)
@@ -541,6 +542,17 @@ def check_cdna_composite(seed=5):
         dl = torch.full((N, H, W, 8), float('nan'), device=DEV)
         dbig = torch.full((N, H, W, 32 + M * C + 3), float('nan'), device=DEV)
         K.composite_bwd(l8, tv, dev(dgen), dl, dbig, 32, M=M)
+        # the generator's layout: value rows and gradient rows of the same width (coalesced LDS-transposed kernel)
+        rowc = (dbig.shape[-1] + 3) // 4 * 4
+        vwide = torch.zeros(N, H, W, rowc, device=DEV)
+        vwide[..., 32:32 + M * C] = tv
+        dl2 = torch.full((N, H, W, 8), float('nan'), device=DEV)
+        dbig2 = torch.full((N, H, W, rowc), float('nan'), device=DEV)
+        K.composite_bwd(l8, vwide[..., 32:32 + M * C], dev(dgen), dl2, dbig2, 32, M=M)
+        out.append((tag + '/tiled_dlogits', rel_err(dl2[..., :M], logits.grad), 5e-5))
+        out.append((tag + '/tiled_dlogits_pad_zero', float(dl2[..., M:].abs().max()), 0.0))
+        out.append((tag + '/tiled_dtimgs', rel_err(dbig2[..., 32:32 + M * C], timgs.grad), 5e-5))
+        out.append((tag + '/tiled_drow_rest_zero', float(dbig2[..., :32].abs().max() + dbig2[..., 32 + M * C:].abs().max()), 0.0))
         out.append((tag + '/dlogits', rel_err(dl[..., :M], logits.grad), 5e-5))
         out.append((tag + '/dlogits_pad_zero', float(dl[..., M:].abs().max()), 0.0))
         out.append((tag + '/dtimgs', rel_err(dbig[..., 32:32 + M * C], timgs.grad), 5e-5))
@@ -623,7 +635,7 @@ def check_small(seed=6):
     out.append(('lsgan/loss', rel_err(lo, l.reshape(1)), 1e-5))
     out.append(('lsgan/dlogits', rel_err(dl, lg.grad), 1e-5))
     # cosine distance
-    for Cc in (32, 256, 64):
+    for Cc in (32, 256, 64, 128, 48):           # 48: the one-wave-per-position fallback
         f0 = rnd(rng, 4, 2, 5, 5, Cc).requires_grad_(True)
         f1 = rnd(rng, 4, 2, 5, 5, Cc)
         l = OT.cosine_distance(f0, f1)

@@ -8,6 +8,7 @@
 //                          fused, so neither the masks nor the per-layer products touch HBM unless asked for.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "savp_hip.h"
 
 #define NT 256
@@ -342,6 +343,254 @@ __global__ __launch_bounds__(NT) void cdna_bwd_kern_fast_kernel(CdnaP p, int chu
         unsafeAtomicAdd(p.dkern + (long long)n * NV + i, sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i]);
 }
 
+// ---- LDS-tiled 5x5 kernels (compile-time K, C): a workgroup owns a 16x16 pixel tile --------------------------------------------
+// The one-thread-per-pixel kernels above read every tap straight from global memory: 75 scalar loads per thread at a pixel
+// stride of 64 B (forward; the image lives in the 16-channel input buffer of h0) or 75 float4 loads at a stride of 224 B
+// (backward; the gradient lives in the 56-channel mask-conv input row) -- a wave instruction touches 32-64 different 128-B
+// lines, so the kernels were bound by the texture-address path at ~10 x their HBM time.  Here the (tile + 2-pixel halo) of the
+// image (SYMMETRIC padding resolved while staging) or of the gradient is parked in LDS once per workgroup; taps are LDS reads.
+#define CT_TS 16
+#define CT_HS 20
+
+__device__ __forceinline__ int sym_clamped(int q, int n) { const int s = sym(q, n); return min(max(s, 0), n - 1); }
+
+// image halo tile -> LDS as one float4 per pixel (channels >= TC are 0)
+template <int TC>
+__device__ __forceinline__ void stage_img_halo(const CdnaP& p, int n, int ty0, int tx0, float* img) {
+    const float* im = p.img + (long long)n * p.i_sn;
+    for (int i = threadIdx.x; i < CT_HS * CT_HS; i += NT) {
+        const int yy = i / CT_HS, xx = i - yy * CT_HS;
+        const int sy = sym_clamped(ty0 + yy - 2, p.H), sx = sym_clamped(tx0 + xx - 2, p.W);
+        const float* q = im + (long long)(sy * p.W + sx) * p.i_sp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = q[0];
+        if (TC > 1) v.y = q[1];
+        if (TC > 2) v.z = q[2];
+        if (TC > 3) v.w = q[3];
+        *reinterpret_cast<float4*>(img + 4 * i) = v;
+    }
+}
+
+template <int TK, int TC>
+__global__ __launch_bounds__(NT) void cdna_apply_fwd_tiled_kernel(CdnaP p, int tiles_x, int vec) {
+    __shared__ __attribute__((aligned(16))) float img[CT_HS * CT_HS * 4];
+    __shared__ __attribute__((aligned(16))) float sk[25 * TK];
+    const int n = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_TS, tx0 = (blockIdx.x % tiles_x) * CT_TS;
+    for (int i = threadIdx.x; i < 25 * TK; i += NT) sk[i] = p.kern[(long long)n * 25 * TK + i];
+    stage_img_halo<TC>(p, n, ty0, tx0, img);
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = ty0 + ty, x = tx0 + tx;
+    if (y >= p.H || x >= p.W) return;
+    float acc[TK][TC];
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[k][c] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float4 pv = *reinterpret_cast<const float4*>(img + ((ty + u) * CT_HS + tx + v) * 4);
+            const float pix[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+            for (int k = 0; k < TK; ++k) {
+                const float w = sk[(u * 5 + v) * TK + k];
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc[k][c] += pix[c] * w;
+            }
+        }
+    float* o = p.out + (long long)n * p.o_sn + (long long)(y * p.W + x) * p.o_sp;
+    if (vec && (TK * TC) % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < TK * TC / 4; ++q) {
+            float4 t;
+            t.x = acc[(4 * q) / TC][(4 * q) % TC]; t.y = acc[(4 * q + 1) / TC][(4 * q + 1) % TC];
+            t.z = acc[(4 * q + 2) / TC][(4 * q + 2) % TC]; t.w = acc[(4 * q + 3) / TC][(4 * q + 3) % TC];
+            *reinterpret_cast<float4*>(o + 4 * q) = t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TK; ++k)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) o[k * TC + c] = acc[k][c];
+    }
+}
+
+// gradient (K*C floats per pixel) of the pixels (ty0 - 2 .. ty0 + 17) x (tx0 - 2 .. tx0 + 17) -> LDS; outside the image: zeros
+template <int TK, int TC>
+__device__ __forceinline__ void stage_dout_halo(const CdnaP& p, int n, int ty0, int tx0, int vec, float* dts) {
+    constexpr int KC = TK * TC;
+    const float* dout = p.dout + (long long)n * p.do_sn;
+    for (int i = threadIdx.x; i < CT_HS * CT_HS; i += NT) {
+        const int yy = i / CT_HS, xx = i - yy * CT_HS;
+        const int y = ty0 + yy - 2, x = tx0 + xx - 2;
+        const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const float* d = dout + (long long)((ok ? y : 0) * p.W + (ok ? x : 0)) * p.do_sp;
+        float* dst = dts + i * KC;
+        if (vec && KC % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(dst + 4 * q) = t;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KC; ++q) dst[q] = ok ? d[q] : 0.f;
+        }
+    }
+}
+
+template <int TK, int TC>
+__global__ __launch_bounds__(NT) void cdna_bwd_img_tiled_kernel(CdnaP p, int tiles_x, int vec) {
+    constexpr int KC = TK * TC, PT = 2, PL = 2, PB = 2, PR = 2;
+    __shared__ __attribute__((aligned(16))) float dts[CT_HS * CT_HS * KC];
+    __shared__ __attribute__((aligned(16))) float sk[25 * TK];
+    const int n = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_TS, tx0 = (blockIdx.x % tiles_x) * CT_TS;
+    for (int i = threadIdx.x; i < 25 * TK; i += NT) sk[i] = p.kern[(long long)n * 25 * TK + i];
+    stage_dout_halo<TK, TC>(p, n, ty0, tx0, vec, dts);
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int sy = ty0 + ty, sx = tx0 + tx;
+    if (sy >= p.H || sx >= p.W) return;
+    // padded positions (un-padded coordinates) that mirror onto (sy, sx): itself and, next to a border, its reflections
+    int qy[3], nqy = 0, qx[3], nqx = 0;
+    qy[nqy++] = sy;
+    if (-sy - 1 >= -PT) qy[nqy++] = -sy - 1;
+    if (2 * p.H - 1 - sy < p.H + PB && 2 * p.H - 1 - sy >= p.H) qy[nqy++] = 2 * p.H - 1 - sy;
+    qx[nqx++] = sx;
+    if (-sx - 1 >= -PL) qx[nqx++] = -sx - 1;
+    if (2 * p.W - 1 - sx < p.W + PR && 2 * p.W - 1 - sx >= p.W) qx[nqx++] = 2 * p.W - 1 - sx;
+    float acc[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[c] = 0.f;
+    for (int a = 0; a < nqy; ++a)
+        for (int b = 0; b < nqx; ++b) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int y = qy[a] - u + PT;
+                if (y < 0 || y >= p.H) continue;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const int x = qx[b] - v + PL;
+                    if (x < 0 || x >= p.W) continue;
+                    // every (y, x) reached here lies within 2 pixels of (sy, sx): inside the staged halo
+                    const float* d = dts + ((y - ty0 + 2) * CT_HS + (x - tx0 + 2)) * KC;
+                    float dv[KC];
+                    if (KC % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < KC / 4; ++q) {
+                            const float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                            dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < KC; ++q) dv[q] = d[q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        const float w = sk[(u * 5 + v) * TK + k];
+#pragma unroll
+                        for (int c = 0; c < TC; ++c) acc[c] += dv[k * TC + c] * w;
+                    }
+                }
+            }
+        }
+    float* di = p.dimg + (long long)n * p.di_sn + (long long)(sy * p.W + sx) * p.di_sp;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) di[c] = p.dimg_beta ? di[c] + acc[c] : acc[c];
+}
+
+// dkern[n, tap, k] += sum over a strip of tiles.  A workgroup walks `tiles_x` tiles of one tile row; wave w owns the taps
+// t_lo(w) .. (7 + 6 + 6 + 6 = 25), lane l the pixels l, l + 64, l + 128, l + 192 of the tile: 28 accumulators per thread
+// instead of 100, so the wave reduction at the end (one butterfly per accumulator) stays small against the tile work.
+template <int TK, int TC>
+__global__ __launch_bounds__(NT) void cdna_bwd_kern_tiled_kernel(CdnaP p, int tiles_x, int vec) {
+    constexpr int KC = TK * TC;
+    __shared__ __attribute__((aligned(16))) float img[CT_HS * CT_HS * 4];
+    __shared__ __attribute__((aligned(16))) float dts[NT * KC];
+    const int n = blockIdx.y;
+    const int ty0 = blockIdx.x * CT_TS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t_lo = wave == 0 ? 0 : 1 + 6 * wave, nt = wave == 0 ? 7 : 6;
+    float acc[7][TK];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int k = 0; k < TK; ++k) acc[t][k] = 0.f;
+    const float* dout = p.dout + (long long)n * p.do_sn;
+    for (int tile = 0; tile < tiles_x; ++tile) {
+        const int tx0 = tile * CT_TS;
+        __syncthreads();                                  // the previous tile's reads are done
+        stage_img_halo<TC>(p, n, ty0, tx0, img);
+        {
+            const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+            const int y = ty0 + ty, x = tx0 + tx;
+            const bool ok = y < p.H && x < p.W;
+            const float* d = dout + (long long)((ok ? y : 0) * p.W + (ok ? x : 0)) * p.do_sp;
+            float* dst = dts + threadIdx.x * KC;
+            if (vec && KC % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q) {
+                    float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(dst + 4 * q) = t;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KC; ++q) dst[q] = ok ? d[q] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pxl = lane + 64 * j;
+            const int ty = pxl >> 4, tx = pxl & 15;
+            float dv[KC];
+            if (KC % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(dts + pxl * KC + 4 * q);
+                    dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KC; ++q) dv[q] = dts[pxl * KC + q];
+            }
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                if (t < nt) {
+                    const int tap = t_lo + t;
+                    const int u = (tap * 13) >> 6, v = tap - 5 * u;          // tap / 5, tap % 5 for tap < 25
+                    const float4 pv = *reinterpret_cast<const float4*>(img + ((ty + u) * CT_HS + tx + v) * 4);
+                    const float pix[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int c = 0; c < TC; ++c) s += pix[c] * dv[k * TC + c];
+                        acc[t][k] += s;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int k = 0; k < TK; ++k) {
+                const float s = wsum(acc[t][k]);
+                if (lane == 0) unsafeAtomicAdd(p.dkern + ((long long)n * 25 + t_lo + t) * TK + k, s);
+            }
+        }
+    }
+}
+
 static int fill_cdna(CdnaP& p, const SavpCdnaArgs* a) {
     if (!a || a->kh * a->kw > MAXTAPS || a->K > MAXK || a->C > MAXC || a->K < 1 || a->C < 1) return SAVP_EINVAL;
     p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.K = a->K; p.kh = a->kh; p.kw = a->kw;
@@ -355,10 +604,31 @@ static int fill_cdna(CdnaP& p, const SavpCdnaArgs* a) {
     return SAVP_OK;
 }
 
+// SAVP_CDNA_LEGACY=1: the one-thread-per-pixel global-memory kernels (developer A/B switch)
+static bool cdna_legacy() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SAVP_CDNA_LEGACY"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+// 3 / 1: the tiled 5x5, K = 4 kernels for C = 3 / 1 apply; 0: generic
+static int cdna_tiled_kind(const SavpCdnaArgs* a) {
+    if (cdna_legacy() || a->kh != 5 || a->kw != 5 || a->K != 4 || a->H < 3 || a->W < 3) return 0;
+    return a->C == 3 ? 3 : (a->C == 1 ? 1 : 0);
+}
+
 extern "C" int savp_cdna_apply_fwd(void* stream, const SavpCdnaArgs* a) {
     CdnaP p;
     int rc = fill_cdna(p, a);
     if (rc) return rc;
+    const int kind = cdna_tiled_kind(a);
+    if (kind) {
+        const int tiles_x = (a->W + CT_TS - 1) / CT_TS, tiles_y = (a->H + CT_TS - 1) / CT_TS;
+        const int vec = ((uintptr_t)a->out.p % 16 == 0) && (a->out.sn % 4 == 0) && (a->out.sp % 4 == 0);
+        dim3 grid(tiles_x * tiles_y, a->N);
+        if (kind == 3) hipLaunchKernelGGL((cdna_apply_fwd_tiled_kernel<4, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p, tiles_x, vec);
+        else hipLaunchKernelGGL((cdna_apply_fwd_tiled_kernel<4, 1>), grid, dim3(NT), 0, (hipStream_t)stream, p, tiles_x, vec);
+        return LAUNCH_OK();
+    }
     hipLaunchKernelGGL(cdna_apply_fwd_kernel, dim3((a->H * a->W + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream, p);
     return LAUNCH_OK();
 }
@@ -369,6 +639,23 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool al = ((uintptr_t)a->dout.p % 16 == 0) && (a->dout.sn % 4 == 0) && (a->dout.sp % 4 == 0);
+    const int kind = cdna_tiled_kind(a);
+    if (kind) {
+        const int tiles_x = (a->W + CT_TS - 1) / CT_TS, tiles_y = (a->H + CT_TS - 1) / CT_TS;
+        const int vec = al ? 1 : 0;
+        if (p.dimg) {
+            dim3 grid(tiles_x * tiles_y, a->N);
+            if (kind == 3) hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
+            else hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
+        }
+        if (p.dkern) {
+            hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            dim3 grid(tiles_y, a->N);
+            if (kind == 3) hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
+            else hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
+        }
+        return LAUNCH_OK();
+    }
     const int fast = (a->kh == 5 && a->kw == 5 && a->K == 4 && a->C == 3 && al) ? 3 : ((a->kh == 5 && a->kw == 5 && a->K == 4 && a->C == 1 && al) ? 1 : 0);
     dim3 gimg((a->H * a->W + NT - 1) / NT, a->N);
     if (p.dimg) {
@@ -482,6 +769,85 @@ __global__ void composite_bwd_kernel(CompP p) {
     for (int k = M; k < p.ls; ++k) dl[k] = 0.f;
 }
 
+// Coalesced form of composite_bwd for rows that are contiguous over all pixels (the mask-conv input buffer [N,HW,rowc] and its
+// gradient twin): the thread-per-pixel kernel above stores its 56-float gradient row with 56 scalar stores at a lane stride of
+// 224 B (every wave instruction touches 64 lines) and gathers the 21 transformed-image channels the same way.  Here a workgroup
+// (256 pixels) moves both through LDS: 16-byte pieces are loaded / stored with consecutive lanes on consecutive addresses, each
+// thread picks up / deposits the pieces of its own pixel in between.  Requires toff % 4 == 0, rowc % 4 == 0, 16-byte aligned bases.
+template <int TM, int TC>
+__global__ __launch_bounds__(NT) void composite_bwd_tiled_kernel(CompP p) {
+    constexpr int MC = TM * TC;
+    constexpr int NPF = (MC + 3) / 4;                       // 16-byte pieces holding the transformed images of one pixel
+    __shared__ float4 tile[NT * NPF];
+    const long long tot = (long long)p.N * p.HW;
+    const long long i0 = blockIdx.x * (long long)NT;
+    const int tid = threadIdx.x;
+    // ---- transformed images of the 256 pixels -> LDS (timgs points at channel toff of the value buffer; rows contiguous) ----
+    for (int f = tid; f < NT * NPF; f += NT) {
+        const int pl = f / NPF, q = f - pl * NPF;
+        const long long gi = i0 + pl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi < tot) v = *reinterpret_cast<const float4*>(p.timgs + gi * p.t_sp + 4 * q);
+        tile[f] = v;
+    }
+    __syncthreads();
+    const long long i = i0 + tid;
+    if (i < tot) {
+        float t[NPF * 4];
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const float4 v = tile[tid * NPF + q];
+            t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+        }
+        const float* lg = p.logits + i * p.ls;
+        float m[TM], sk[TM];
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int k = 0; k < TM; ++k) { m[k] = lg[k]; mx = fmaxf(mx, m[k]); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < TM; ++k) { m[k] = __expf(m[k] - mx); s += m[k]; }
+        const float inv = 1.f / s;
+        const int n = (int)(i / p.HW), px = (int)(i - (long long)n * p.HW);
+        const float* dg = p.dgen + (long long)n * p.dg_sn + (long long)px * p.dg_sp;
+        float d[TC];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) d[c] = dg[c];
+        float o[NPF * 4];
+#pragma unroll
+        for (int j = 0; j < NPF * 4; ++j) o[j] = 0.f;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < TM; ++k) {
+            m[k] *= inv;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                a += d[c] * t[k * TC + c];
+                o[k * TC + c] = m[k] * d[c];
+            }
+            sk[k] = a;
+            dot += m[k] * a;
+        }
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) tile[tid * NPF + q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);   // own row only
+        float* dl = p.dlogits + i * p.ls;
+#pragma unroll
+        for (int k = 0; k < TM; ++k) dl[k] = m[k] * (sk[k] - dot);
+        for (int k = TM; k < p.ls; ++k) dl[k] = 0.f;
+    }
+    __syncthreads();
+    // ---- gradient rows out: rowc / 4 pieces per pixel, zeros outside [toff, toff + 4 NPF) ----
+    const int rp4 = p.rowc >> 2, q0 = p.toff >> 2;
+    const int npix = (int)min((long long)NT, tot - i0);
+    for (int f = tid; f < npix * rp4; f += NT) {
+        const int pl = f / rp4, q = f - pl * rp4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q >= q0 && q < q0 + NPF) v = tile[pl * NPF + q - q0];
+        *reinterpret_cast<float4*>(p.drow + (i0 + pl) * p.dr_sp + 4 * q) = v;
+    }
+}
+
 static int fill_comp(CompP& p, const SavpCompositeArgs* a) {
     if (!a || a->M > MAXM || a->C > MAXC || a->M < 1 || a->C < 1 || a->logits_stride < a->M) return SAVP_EINVAL;
     p.N = a->N; p.HW = a->HW; p.M = a->M; p.C = a->C;
@@ -515,7 +881,15 @@ extern "C" int savp_composite_bwd(void* stream, const SavpCompositeArgs* a) {
     if (!p.drow || !p.dlogits || a->timgs_offset + a->M * a->C > a->row_channels) return SAVP_EINVAL;
     long long tot = (long long)a->N * a->HW;
     dim3 grid((unsigned)((tot + NT - 1) / NT));
-    if (a->M == 7 && a->C == 3) hipLaunchKernelGGL((composite_bwd_kernel<7, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    // coalesced form: value rows (timgs) and gradient rows contiguous over all pixels, 16-byte pieces
+    const int npf4 = ((a->M * a->C + 3) / 4) * 4;
+    const bool tiled = !cdna_legacy() && a->M == 7 && (a->C == 3 || a->C == 1) && (a->timgs_offset % 4 == 0) && (a->row_channels % 4 == 0) &&
+                       a->timgs_offset + npf4 <= a->row_channels && p.dr_sp == a->row_channels && p.dr_sn == (long long)a->HW * p.dr_sp &&
+                       p.t_sp == a->row_channels && p.t_sn == (long long)a->HW * p.t_sp && ((uintptr_t)p.drow % 16 == 0) &&
+                       ((uintptr_t)p.timgs % 16 == 0);
+    if (tiled && a->C == 3) hipLaunchKernelGGL((composite_bwd_tiled_kernel<7, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else if (tiled && a->C == 1) hipLaunchKernelGGL((composite_bwd_tiled_kernel<7, 1>), grid, dim3(NT), 0, (hipStream_t)stream, p);
+    else if (a->M == 7 && a->C == 3) hipLaunchKernelGGL((composite_bwd_kernel<7, 3>), grid, dim3(NT), 0, (hipStream_t)stream, p);
     else if (a->M == 7 && a->C == 1) hipLaunchKernelGGL((composite_bwd_kernel<7, 1>), grid, dim3(NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((composite_bwd_kernel<0, 0>), grid, dim3(NT), 0, (hipStream_t)stream, p);
     return LAUNCH_OK();

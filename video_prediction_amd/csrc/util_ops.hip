@@ -11,6 +11,7 @@
 //   axpby / fill  : flat elementwise helpers (z concatenation savp_model.py:725, gradient accumulation).
 //   adam          : tf.train.AdamOptimizer update on a flat parameter arena (base_model.py:486-487).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "savp_hip.h"
 
@@ -446,6 +447,78 @@ __global__ __launch_bounds__(NT) void dense_partial_kernel(const float* __restri
     }
 }
 
+// MFMA form of the K-sliced partial products (the default): exact fp32 on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain per
+// output, MI355X guide 3).  A workgroup owns one K slice; its 8 waves take 32-row groups of the slice round-robin; a wave holds its
+// 32 x 32 k block of x in registers (lane (m, half): 16 consecutive k of row m) and streams the matching W rows straight from
+// global memory (per MFMA one coalesced 128-byte row piece per half-wave) -- no LDS staging, no barrier in the K loop.  MFMA i of a
+// group contracts k = base + 16*half + i: any bijection of the group's 32 k onto (instruction, half) is a valid order of the sum.
+// The waves' accumulators meet in LDS (ds_add_f32), one plain store per output of the slice.
+typedef float dm_f32x16 __attribute__((ext_vector_type(16)));
+template <int NTL>           // 32-column tiles: NTL * 32 >= C
+__global__ __launch_bounds__(512) void dense_mfma_partial_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
+                                                                 const float* __restrict__ W, float* __restrict__ part, long long kslice) {
+    __shared__ float red[32 * 32 * NTL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const long long k_lo = (long long)blockIdx.x * kslice, k_hi = min(Kd, k_lo + kslice);
+    const bool xvec = ((xs & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int mb = min(32, M - m0);
+        dm_f32x16 acc[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const float* xrow = x + (long long)(m0 + min(l31, mb - 1)) * xs;
+        for (long long k0 = k_lo + wave * 32; k0 < k_hi; k0 += 8 * 32) {
+            const long long kb = k0 + half * 16;
+            float a[16];
+            if (xvec && kb + 16 <= k_hi) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(xrow + kb + 4 * q);
+                    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = (kb + i < k_hi) ? xrow[kb + i] : 0.f;
+            }
+            float b[NTL][16];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const int col = min(t * 32 + l31, C - 1);          // columns >= C: computed on valid data, never stored
+#pragma unroll
+                for (int i = 0; i < 16; ++i) b[t][i] = W[min(kb + i, Kd - 1) * C + col];     // rows >= k_hi meet a == 0
+            }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][i], acc[t], 0, 0, 0);
+        }
+        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 512) red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;                            // C/D layout of the 32x32 MFMAs
+                unsafeAtomicAdd(&red[row * (32 * NTL) + t * 32 + l31], acc[t][r]);           // ds_add_f32
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 512) {
+            const int row = i / (32 * NTL), c = i - row * (32 * NTL);
+            if (row < mb && c < C) part[((long long)blockIdx.x * M + m0 + row) * C + c] = red[i];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NTL>
+static void launch_dense_mfma(hipStream_t st, unsigned S, const float* x, long long xs, int M, long long K, int C, const float* W, float* ws,
+                              long long kslice) {
+    hipLaunchKernelGGL(dense_mfma_partial_kernel<NTL>, dim3(S), dim3(512), 0, st, x, xs, M, K, C, W, ws, kslice);
+}
+
 // 32 outputs x 8 slice groups per workgroup: lane = 8 * output + group; every thread adds S/8 partials, then a shuffle tree
 __global__ __launch_bounds__(NT) void dense_reduce_kernel(const float* __restrict__ part, int S, int MC, int C, const float* bias,
                                                           const float* scale, float* __restrict__ out) {
@@ -463,18 +536,32 @@ __global__ __launch_bounds__(NT) void dense_reduce_kernel(const float* __restric
     out[i] = s;
 }
 
+// SAVP_DENSE_LEGACY=1: the VALU / LDS-broadcast partial kernel (developer A/B switch)
+static bool dense_legacy() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SAVP_DENSE_LEGACY"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,
                               const float* bias, const float* scale, float* out, float* ws, int64_t ws_floats) {
     if (!x || !W || !out || M < 1 || K < 1 || C < 1) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (M > 64 || C > 256) return SAVP_EINVAL;
     if (ws && ws_floats >= (int64_t)M * C) {
-        // K slices: multiples of DP_KT rows, as many as the workspace holds, at most 64 (the reduction kernel reads them all)
+        // K slices: multiples of 256 rows (8 waves x 32), as many as the workspace holds, at most 64 (the reduction kernel reads them all)
         long long S = ws_floats / ((long long)M * C);
         if (S > 64) S = 64;
-        long long kslice = ((K + S - 1) / S + DP_KT - 1) / DP_KT * DP_KT;
+        const bool legacy = dense_legacy();
+        const long long unit = legacy ? DP_KT : 256;
+        long long kslice = ((K + S - 1) / S + unit - 1) / unit * unit;
         S = (K + kslice - 1) / kslice;
-        if ((C & 3) == 0 && ((uintptr_t)W & 15) == 0)
+        if (!legacy) {
+            if (C <= 32) launch_dense_mfma<1>(st, (unsigned)S, x, (long long)x_row_stride, M, (long long)K, C, W, ws, kslice);
+            else if (C <= 64) launch_dense_mfma<2>(st, (unsigned)S, x, (long long)x_row_stride, M, (long long)K, C, W, ws, kslice);
+            else if (C <= 128) launch_dense_mfma<4>(st, (unsigned)S, x, (long long)x_row_stride, M, (long long)K, C, W, ws, kslice);
+            else launch_dense_mfma<8>(st, (unsigned)S, x, (long long)x_row_stride, M, (long long)K, C, W, ws, kslice);
+        } else if ((C & 3) == 0 && ((uintptr_t)W & 15) == 0)
             hipLaunchKernelGGL(dense_partial_kernel<true>, dim3((unsigned)S), dim3(NT), 0, st, x, (long long)x_row_stride, M, (long long)K, C,
                                W, ws, kslice);
         else
