@@ -1,6 +1,6 @@
 /* savp_io.h -- C ABI of the input pipeline (libsavp_io.so, host C++).
  *
- * Replaces, for the BAIR / softmotion record layout, what the reference builds from TensorFlow's C++ runtime:
+ * Replaces, for the BAIR / softmotion record layout (one feature per frame) and the KTH layout (one bytes_list per sequence), what the reference builds from TensorFlow's C++ runtime:
  *   tf.data.TFRecordDataset(filenames, buffer_size=8 MiB)            video_prediction/datasets/base_dataset.py:135
  *   shuffle_and_repeat(buffer_size=1024, count=num_epochs) / repeat  base_dataset.py:137-140
  *   tf.parse_single_example(FixedLenFeature([1], tf.string) per frame, FixedLenFeature(shape, tf.float32) for states /
@@ -40,6 +40,8 @@ void savp_tfr_close(SavpTfrFile* f);
  * bytes_list: *ptr / *len = the index-th value.  float_list / int64_list: *ptr = packed payload, *len = element count. */
 int savp_example_feature(const uint8_t* ex, uint64_t ex_len, const char* name, int32_t index, int32_t* kind,
                          const uint8_t** ptr, uint64_t* len);
+/* The index-th value of an int64_list feature (e.g. "sequence_length", "height" of the KTH records, kth_dataset.py:20-24). */
+int savp_example_int64(const uint8_t* ex, uint64_t ex_len, const char* name, int32_t index, int64_t* out);
 /* Copy a float_list feature (packed or not) into out[0..n); returns SAVP_IO_EINVAL if the element count differs. */
 int savp_example_floats(const uint8_t* ex, uint64_t ex_len, const char* name, float* out, int64_t n);
 
@@ -60,6 +62,9 @@ typedef struct SavpVideoPipelineArgs {
     const char* const* float_keys_fmt; const int32_t* float_dims; const int32_t* float_per_frame_minus; int32_t num_float_keys;
                                     /* optional state-like (minus 0) / action-like (minus 1) float features, e.g.
                                        "%d/endeffector_pos" dim 3, "%d/action" dim 4 minus 1 (softmotion_dataset.py:38-40) */
+    int32_t var_len;                /* 1: VarLenFeatureVideoDataset layout (base_dataset.py:394-453, KTH): image_key_fmt names ONE
+                                       bytes_list feature holding every frame of the sequence, int64 feature "sequence_length" gives its
+                                       length; examples shorter than sequence_length are dropped (filter, :401-407); example_frames unused */
 } SavpVideoPipelineArgs;
 typedef struct SavpVideoPipeline SavpVideoPipeline;
 int savp_pipeline_create(const SavpVideoPipelineArgs* a, SavpVideoPipeline** out);

@@ -504,16 +504,17 @@ __global__ __launch_bounds__(NT) void cdna_bwd_img_tiled_kernel(CdnaP p, int til
     for (int c = 0; c < TC; ++c) di[c] = p.dimg_beta ? di[c] + acc[c] : acc[c];
 }
 
-// dkern[n, tap, k] += sum over a strip of tiles.  A workgroup walks `tiles_x` tiles of one tile row; wave w owns the taps
-// t_lo(w) .. (7 + 6 + 6 + 6 = 25), lane l the pixels l, l + 64, l + 128, l + 192 of the tile: 28 accumulators per thread
-// instead of 100, so the wave reduction at the end (one butterfly per accumulator) stays small against the tile work.
+// dkern[n, tap, k] += the contribution of one 16x16 tile.  Wave w owns the taps t_lo(w) .. (7 + 6 + 6 + 6 = 25), lane l the
+// pixels l, l + 64, l + 128, l + 192 of the tile: 28 accumulators per thread instead of 100, so the wave reduction at the end (one
+// butterfly per accumulator) stays comparable to the tile work, and every workgroup needs exactly one staging round trip
+// (a strip of tiles per workgroup serialised four of them: 23 us).  100 global atomics per workgroup.
 template <int TK, int TC>
 __global__ __launch_bounds__(NT) void cdna_bwd_kern_tiled_kernel(CdnaP p, int tiles_x, int vec) {
     constexpr int KC = TK * TC;
     __shared__ __attribute__((aligned(16))) float img[CT_HS * CT_HS * 4];
     __shared__ __attribute__((aligned(16))) float dts[NT * KC];
     const int n = blockIdx.y;
-    const int ty0 = blockIdx.x * CT_TS;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_TS, tx0 = (blockIdx.x % tiles_x) * CT_TS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t_lo = wave == 0 ? 0 : 1 + 6 * wave, nt = wave == 0 ? 7 : 6;
@@ -523,58 +524,54 @@ __global__ __launch_bounds__(NT) void cdna_bwd_kern_tiled_kernel(CdnaP p, int ti
 #pragma unroll
         for (int k = 0; k < TK; ++k) acc[t][k] = 0.f;
     const float* dout = p.dout + (long long)n * p.do_sn;
-    for (int tile = 0; tile < tiles_x; ++tile) {
-        const int tx0 = tile * CT_TS;
-        __syncthreads();                                  // the previous tile's reads are done
-        stage_img_halo<TC>(p, n, ty0, tx0, img);
-        {
-            const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-            const int y = ty0 + ty, x = tx0 + tx;
-            const bool ok = y < p.H && x < p.W;
-            const float* d = dout + (long long)((ok ? y : 0) * p.W + (ok ? x : 0)) * p.do_sp;
-            float* dst = dts + threadIdx.x * KC;
-            if (vec && KC % 4 == 0) {
+    {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        const int y = ty0 + ty, x = tx0 + tx;
+        const bool ok = y < p.H && x < p.W;
+        const float* d = dout + (long long)((ok ? y : 0) * p.W + (ok ? x : 0)) * p.do_sp;
+        float* dst = dts + threadIdx.x * KC;
+        if (vec && KC % 4 == 0) {
 #pragma unroll
-                for (int q = 0; q < KC / 4; ++q) {
-                    float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
-                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(dst + 4 * q) = t;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < KC; ++q) dst[q] = ok ? d[q] : 0.f;
+            for (int q = 0; q < KC / 4; ++q) {
+                float4 t = *reinterpret_cast<const float4*>(d + 4 * q);
+                if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(dst + 4 * q) = t;
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KC; ++q) dst[q] = ok ? d[q] : 0.f;
         }
-        __syncthreads();
+    }
+    stage_img_halo<TC>(p, n, ty0, tx0, img);
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pxl = lane + 64 * j;
-            const int ty = pxl >> 4, tx = pxl & 15;
-            float dv[KC];
-            if (KC % 4 == 0) {
+    for (int j = 0; j < 4; ++j) {
+        const int pxl = lane + 64 * j;
+        const int ty = pxl >> 4, tx = pxl & 15;
+        float dv[KC];
+        if (KC % 4 == 0) {
 #pragma unroll
-                for (int q = 0; q < KC / 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(dts + pxl * KC + 4 * q);
-                    dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < KC; ++q) dv[q] = dts[pxl * KC + q];
+            for (int q = 0; q < KC / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(dts + pxl * KC + 4 * q);
+                dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
             }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                if (t < nt) {
-                    const int tap = t_lo + t;
-                    const int u = (tap * 13) >> 6, v = tap - 5 * u;          // tap / 5, tap % 5 for tap < 25
-                    const float4 pv = *reinterpret_cast<const float4*>(img + ((ty + u) * CT_HS + tx + v) * 4);
-                    const float pix[4] = {pv.x, pv.y, pv.z, pv.w};
+            for (int q = 0; q < KC; ++q) dv[q] = dts[pxl * KC + q];
+        }
 #pragma unroll
-                    for (int k = 0; k < TK; ++k) {
-                        float s = 0.f;
+        for (int t = 0; t < 7; ++t) {
+            if (t < nt) {
+                const int tap = t_lo + t;
+                const int u = (tap * 13) >> 6, v = tap - 5 * u;          // tap / 5, tap % 5 for tap < 25
+                const float4 pv = *reinterpret_cast<const float4*>(img + ((ty + u) * CT_HS + tx + v) * 4);
+                const float pix[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-                        for (int c = 0; c < TC; ++c) s += pix[c] * dv[k * TC + c];
-                        acc[t][k] += s;
-                    }
+                for (int k = 0; k < TK; ++k) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) s += pix[c] * dv[k * TC + c];
+                    acc[t][k] += s;
                 }
             }
         }
@@ -650,7 +647,7 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
         }
         if (p.dkern) {
             hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
-            dim3 grid(tiles_y, a->N);
+            dim3 grid(tiles_x * tiles_y, a->N);
             if (kind == 3) hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
             else hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
         }

@@ -448,20 +448,26 @@ __global__ __launch_bounds__(NT) void dense_partial_kernel(const float* __restri
 }
 
 // MFMA form of the K-sliced partial products (the default): exact fp32 on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain per
-// output, MI355X guide 3).  A workgroup owns one K slice; its 8 waves take 32-row groups of the slice round-robin; a wave holds its
-// 32 x 32 k block of x in registers (lane (m, half): 16 consecutive k of row m) and streams the matching W rows straight from
-// global memory (per MFMA one coalesced 128-byte row piece per half-wave) -- no LDS staging, no barrier in the K loop.  MFMA i of a
-// group contracts k = base + 16*half + i: any bijection of the group's 32 k onto (instruction, half) is a valid order of the sum.
+// output, MI355X guide 3).  A workgroup (4 waves) owns one K slice; its waves take 32-row groups of the slice round-robin.  A wave
+// holds its 32 x 32 k block of x in registers (lane (m, half): 16 consecutive k of row m) and reads the matching W rows straight
+// from global memory -- no LDS staging, no barrier in the K loop.  Column mapping: lane l of tile t owns output column NTL*l + t,
+// so the NTL tiles' B operands of one k row are ONE NTL-wide vector load per lane (dwordx4 for the 100-column CDNA head) and the
+// 32 lanes of a half-wave read one contiguous row piece.  EVERY load of a k group is issued before the first MFMA (sched_barrier):
+// the kernel's time is a single memory round trip plus 16 NTL MFMAs; with the loads interleaved between dependent MFMAs, as hipcc
+// schedules them by default, a group paid 6-7 serial round trips (52 us for the 3.3 MB CDNA head).
+// MFMA i of a group contracts k = base + 16*half + i: any bijection of the group's 32 k onto (instruction, half) is a valid order.
 // The waves' accumulators meet in LDS (ds_add_f32), one plain store per output of the slice.
 typedef float dm_f32x16 __attribute__((ext_vector_type(16)));
-template <int NTL>           // 32-column tiles: NTL * 32 >= C
-__global__ __launch_bounds__(512) void dense_mfma_partial_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
+template <int NTL, bool VEC>   // 32-column tiles: NTL * 32 >= C; VEC: W rows allow aligned NTL-wide vector loads (C % NTL == 0)
+__global__ __launch_bounds__(256) void dense_mfma_partial_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
                                                                  const float* __restrict__ W, float* __restrict__ part, long long kslice) {
     __shared__ float red[32 * 32 * NTL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const long long k_lo = (long long)blockIdx.x * kslice, k_hi = min(Kd, k_lo + kslice);
     const bool xvec = ((xs & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+    // first column of this lane's NTL-wide piece; pieces beyond C are clamped onto the last full piece (results never stored)
+    const int cbase = min(NTL * l31, (C - 1) / NTL * NTL);
     for (int m0 = 0; m0 < M; m0 += 32) {
         const int mb = min(32, M - m0);
         dm_f32x16 acc[NTL];
@@ -470,9 +476,10 @@ __global__ __launch_bounds__(512) void dense_mfma_partial_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         const float* xrow = x + (long long)(m0 + min(l31, mb - 1)) * xs;
-        for (long long k0 = k_lo + wave * 32; k0 < k_hi; k0 += 8 * 32) {
+        for (long long k0 = k_lo + wave * 32; k0 < k_hi; k0 += 4 * 32) {
             const long long kb = k0 + half * 16;
             float a[16];
+            float b[16][NTL];
             if (xvec && kb + 16 <= k_hi) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -483,29 +490,40 @@ __global__ __launch_bounds__(512) void dense_mfma_partial_kernel(const float* __
 #pragma unroll
                 for (int i = 0; i < 16; ++i) a[i] = (kb + i < k_hi) ? xrow[kb + i] : 0.f;
             }
-            float b[NTL][16];
 #pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                const int col = min(t * 32 + l31, C - 1);          // columns >= C: computed on valid data, never stored
+            for (int i = 0; i < 16; ++i) {
+                const float* wr = W + min(kb + i, Kd - 1) * C + cbase;                       // rows >= k_hi meet a == 0
+                if constexpr (VEC && NTL == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(wr);
+                    b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
+                } else if constexpr (VEC && NTL == 8) {
+                    const float4 v = *reinterpret_cast<const float4*>(wr), w = *reinterpret_cast<const float4*>(wr + 4);
+                    b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w; b[i][4] = w.x; b[i][5] = w.y; b[i][6] = w.z; b[i][7] = w.w;
+                } else if constexpr (VEC && NTL == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(wr);
+                    b[i][0] = v.x; b[i][1] = v.y;
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) b[t][i] = W[min(kb + i, Kd - 1) * C + col];     // rows >= k_hi meet a == 0
+                    for (int t = 0; t < NTL; ++t) b[i][t] = wr[min(t, C - 1 - cbase)];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);          // all loads of the group are in flight before the first MFMA waits
 #pragma unroll
-            for (int t = 0; t < NTL; ++t)
+            for (int i = 0; i < 16; ++i)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][i], acc[t], 0, 0, 0);
+                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][t], acc[t], 0, 0, 0);
         }
-        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 512) red[i] = 0.f;
+        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 256) red[i] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;                            // C/D layout of the 32x32 MFMAs
-                unsafeAtomicAdd(&red[row * (32 * NTL) + t * 32 + l31], acc[t][r]);           // ds_add_f32
+                unsafeAtomicAdd(&red[row * (32 * NTL) + NTL * l31 + t], acc[t][r]);          // ds_add_f32
             }
         __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 512) {
+        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 256) {
             const int row = i / (32 * NTL), c = i - row * (32 * NTL);
             if (row < mb && c < C) part[((long long)blockIdx.x * M + m0 + row) * C + c] = red[i];
         }
@@ -516,7 +534,9 @@ __global__ __launch_bounds__(512) void dense_mfma_partial_kernel(const float* __
 template <int NTL>
 static void launch_dense_mfma(hipStream_t st, unsigned S, const float* x, long long xs, int M, long long K, int C, const float* W, float* ws,
                               long long kslice) {
-    hipLaunchKernelGGL(dense_mfma_partial_kernel<NTL>, dim3(S), dim3(512), 0, st, x, xs, M, K, C, W, ws, kslice);
+    const bool vec = (C % NTL == 0) && ((((uintptr_t)W) & 15) == 0) && NTL > 1;
+    if (vec) hipLaunchKernelGGL((dense_mfma_partial_kernel<NTL, true>), dim3(S), dim3(256), 0, st, x, xs, M, K, C, W, ws, kslice);
+    else hipLaunchKernelGGL((dense_mfma_partial_kernel<NTL, false>), dim3(S), dim3(256), 0, st, x, xs, M, K, C, W, ws, kslice);
 }
 
 // 32 outputs x 8 slice groups per workgroup: lane = 8 * output + group; every thread adds S/8 partials, then a shuffle tree
@@ -549,11 +569,11 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
     hipStream_t st = (hipStream_t)stream;
     if (M > 64 || C > 256) return SAVP_EINVAL;
     if (ws && ws_floats >= (int64_t)M * C) {
-        // K slices: multiples of 256 rows (8 waves x 32), as many as the workspace holds, at most 64 (the reduction kernel reads them all)
+        // K slices: multiples of 128 rows (4 waves x 32), as many as the workspace holds, at most 64 (the reduction kernel reads them all)
         long long S = ws_floats / ((long long)M * C);
         if (S > 64) S = 64;
         const bool legacy = dense_legacy();
-        const long long unit = legacy ? DP_KT : 256;
+        const long long unit = legacy ? DP_KT : 128;
         long long kslice = ((K + S - 1) / S + unit - 1) / unit * unit;
         S = (K + kslice - 1) / kslice;
         if (!legacy) {

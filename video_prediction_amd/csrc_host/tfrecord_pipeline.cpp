@@ -205,6 +205,20 @@ extern "C" int savp_example_feature(const uint8_t* ex, uint64_t ex_len, const ch
     return ok ? SAVP_IO_EMISSING : SAVP_IO_ECORRUPT;
 }
 
+extern "C" int savp_example_int64(const uint8_t* ex, uint64_t ex_len, const char* name, int32_t index, int64_t* out) {
+    if (!ex || !name || !out || index < 0) return SAVP_IO_EINVAL;
+    int32_t kind; const uint8_t* p; uint64_t n;
+    int rc = savp_example_feature(ex, ex_len, name, 0, &kind, &p, &n);
+    if (rc) return rc;
+    if (kind != 3 || (uint64_t)index >= n) return SAVP_IO_EINVAL;
+    const uint8_t* end = p + 10 * n;                                         // a varint is at most 10 bytes; the count was validated above
+    uint64_t v = 0;
+    for (int32_t i = 0; i <= index; ++i)
+        if (!varint(p, end, v)) return SAVP_IO_ECORRUPT;
+    *out = (int64_t)v;
+    return SAVP_IO_OK;
+}
+
 extern "C" int savp_example_floats(const uint8_t* ex, uint64_t ex_len, const char* name, float* out, int64_t n) {
     if (!ex || !name || !out || n < 0) return SAVP_IO_EINVAL;
     Span feat;
@@ -256,6 +270,7 @@ struct SavpVideoPipeline {
     std::string image_fmt;
     std::vector<FloatKey> fkeys;
     int example_frames, H, W, C, seq, frame_skip, time_shift, batch, shuffle, shuffle_buffer, num_epochs, prefetch;
+    int var_len = 0;                  // 1: one bytes_list feature holds all frames of a sequence + int64 'sequence_length' (KTH)
     uint64_t seed;
 
     std::thread th;
@@ -272,23 +287,34 @@ struct SavpVideoPipeline {
         cv_ready.notify_all();
     }
 
-    // decode one serialized Example into the slot `b` of the batch under construction
+    // decode one serialized Example into the slot `b` of the batch under construction; SKIP = filtered out (too short, var_len only)
+    enum { SKIP = 1 };
     int decode(const std::vector<uint8_t>& ex, Rng& rng, Batch& out, int b) {
         const int fs1 = frame_skip + 1;
+        int frames = example_frames;
+        if (var_len) {                                                     // VarLenFeatureVideoDataset.filter / parser (base_dataset.py:401-429)
+            int64_t n64 = 0;
+            int rc = savp_example_int64(ex.data(), ex.size(), "sequence_length", 0, &n64);
+            if (rc) { errmsg = "feature sequence_length missing or not an int64"; return rc; }
+            if (n64 < (int64_t)seq) return SKIP;                           // tf.greater_equal(example_sequence_length, sequence_length)
+            frames = (int)n64;
+        }
         int t_start = 0;
         if (time_shift > 0) {                                              // base_dataset.py:198-211
-            const int num_shifts = ((example_frames - 1) - (seq - 1) * fs1) / time_shift;
-            if (num_shifts < 0) { errmsg = "example_sequence_length too short for sequence_length / frame_skip"; return SAVP_IO_EINVAL; }
+            const int num_shifts = ((frames - 1) - (seq - 1) * fs1) / time_shift;
+            if ((frames - 1) - (seq - 1) * fs1 < 0) { errmsg = "example_sequence_length too short for sequence_length / frame_skip"; return SAVP_IO_EINVAL; }
             t_start = (int)rng.below((uint64_t)num_shifts + 1) * time_shift;
-        } else if ((seq - 1) * fs1 + 1 > example_frames) {
+        } else if ((seq - 1) * fs1 + 1 > frames) {
             errmsg = "example_sequence_length too short for sequence_length / frame_skip"; return SAVP_IO_EINVAL;
         }
         const size_t frame = (size_t)H * W * C;
         char name[256];
         for (int t = 0; t < seq; ++t) {                                    // state-like slice (:213)
-            snprintf(name, sizeof(name), image_fmt.c_str(), t_start + t * fs1);
+            const int src_t = t_start + t * fs1;
+            if (var_len) snprintf(name, sizeof(name), "%s", image_fmt.c_str());
+            else snprintf(name, sizeof(name), image_fmt.c_str(), src_t);
             int32_t kind; const uint8_t* p; uint64_t n;
-            int rc = savp_example_feature(ex.data(), ex.size(), name, 0, &kind, &p, &n);
+            int rc = savp_example_feature(ex.data(), ex.size(), name, var_len ? src_t : 0, &kind, &p, &n);
             if (rc) { errmsg = std::string("feature ") + name + (rc == SAVP_IO_EMISSING ? " not found in tfrecord" : " is corrupt"); return rc; }
             if (kind != 1 || n != frame) { errmsg = std::string("feature ") + name + ": expected one raw uint8 image of H*W*C bytes"; return SAVP_IO_EINVAL; }
             memcpy(out.images.data() + ((size_t)b * seq + t) * frame, p, frame);
@@ -335,6 +361,7 @@ struct SavpVideoPipeline {
         auto emit = [&](const std::vector<uint8_t>& ex) -> bool {
             std::string msg;
             int rc = decode(ex, rng, cur, filled);
+            if (rc == SKIP) return true;
             if (rc) { fail(rc, errmsg); return false; }
             if (++filled == batch) {
                 std::unique_lock<std::mutex> l(mu);
@@ -387,10 +414,10 @@ struct SavpVideoPipeline {
 };
 
 extern "C" int savp_pipeline_create(const SavpVideoPipelineArgs* a, SavpVideoPipeline** out) {
-    if (!a || !out || a->num_files < 1 || !a->filenames || !a->image_key_fmt || a->example_frames < 1 || a->height < 1 ||
+    if (!a || !out || a->num_files < 1 || !a->filenames || !a->image_key_fmt || (a->example_frames < 1 && !a->var_len) || a->height < 1 ||
         a->width < 1 || a->channels < 1 || a->sequence_length < 1 || a->frame_skip < 0 || a->time_shift < 0 || a->batch_size < 1)
         return SAVP_IO_EINVAL;
-    if ((a->sequence_length - 1) * (a->frame_skip + 1) + 1 > a->example_frames) return SAVP_IO_EINVAL;
+    if (!a->var_len && (a->sequence_length - 1) * (a->frame_skip + 1) + 1 > a->example_frames) return SAVP_IO_EINVAL;
     SavpVideoPipeline* p = new SavpVideoPipeline();
     for (int i = 0; i < a->num_files; ++i) p->files.emplace_back(a->filenames[i]);
     p->image_fmt = a->image_key_fmt;
@@ -400,6 +427,7 @@ extern "C" int savp_pipeline_create(const SavpVideoPipelineArgs* a, SavpVideoPip
     p->seq = a->sequence_length; p->frame_skip = a->frame_skip; p->time_shift = a->time_shift; p->batch = a->batch_size;
     p->shuffle = a->shuffle; p->shuffle_buffer = a->shuffle_buffer; p->num_epochs = a->num_epochs; p->seed = a->seed;
     p->prefetch = a->prefetch_batches > 0 ? a->prefetch_batches : 2;
+    p->var_len = a->var_len ? 1 : 0;
     p->th = std::thread([p] { p->run(); });
     *out = p;
     return SAVP_IO_OK;

@@ -1,5 +1,6 @@
 """Datasets with the reference's class API (video_prediction/datasets/__init__.py:9-24) on the C++ input pipeline."""
 from .softmotion_dataset import SoftmotionVideoDataset
+from .kth_dataset import KTHVideoDataset
 
 
 def get_dataset_class(dataset):
@@ -7,6 +8,7 @@ def get_dataset_class(dataset):
         'bair': 'SoftmotionVideoDataset',
         'softmotion': 'SoftmotionVideoDataset',
         'softmotion30_v1': 'SoftmotionVideoDataset',
+        'kth': 'KTHVideoDataset',
     }
     dataset_class = dataset_mappings.get(dataset, dataset)
     dataset_class = globals().get(dataset_class)

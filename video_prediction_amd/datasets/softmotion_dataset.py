@@ -123,43 +123,68 @@ class SoftmotionVideoDataset(object):
             count += int(match.group(2)) - int(match.group(1)) + 1
         return count
 
-    def make_pipeline(self, batch_size, prefetch_batches=2):
+    def _shard(self, rank, world):
+        """Files (and the seed) of one data-parallel replica: every replica reads its own share of the record files -- the
+        reference feeds all towers from ONE iterator and tf.split()s the batch (base_model.py:523-527), so distinct towers see
+        distinct sequences; with one process per GPU that becomes distinct files per rank (round-robin; with fewer files than
+        ranks every rank reads everything in its own shuffled order)."""
+        files = self.filenames[rank::world] if len(self.filenames) >= world else self.filenames
+        seed = ((self.seed or 0) * 1000003 + rank * 7919) & 0xffffffffffffffff
+        if self.seed is None and world == 1:
+            seed = 0
+        return files, seed
+
+    def make_pipeline(self, batch_size, prefetch_batches=2, rank=0, world=1):
         hp = self.hparams
         shuffle = self.mode == 'train' or (self.mode == 'val' and hp.shuffle_on_val)        # base_dataset.py:131
         time_shift = hp.time_shift if ((hp.time_shift and self.mode == 'train') or hp.force_time_shift) else 0   # :198
         float_keys = []
         if hp.use_state:
             float_keys = [('%d/endeffector_pos', 3, 0), ('%d/action', 4, 1)]
-        return sio.VideoPipeline(self.filenames, self.image_key_fmt, self._max_sequence_length, self.image_shape,
+        files, seed = self._shard(rank, world)
+        return sio.VideoPipeline(files, self.image_key_fmt, self._max_sequence_length, self.image_shape,
                                  hp.sequence_length, batch_size, frame_skip=hp.frame_skip, time_shift=time_shift, shuffle=shuffle,
-                                 num_epochs=self.num_epochs, seed=self.seed or 0, prefetch_batches=prefetch_batches,
-                                 float_keys=float_keys)
+                                 num_epochs=self.num_epochs, seed=seed, prefetch_batches=prefetch_batches,
+                                 float_keys=float_keys, var_len=self.var_len)
 
-    def make_batch(self, batch_size, device='cuda:0'):
+    var_len = False          # one feature per frame (softmotion); KTHVideoDataset: one bytes_list per sequence
+
+    def make_batch(self, batch_size, device='cuda:0', rank=0, world=1):
         """base_dataset.py:153-156: an iterator of input dicts {'images': float32 [B,T,H,W,C] in [0,1] on the device, ('states',
-        'actions')}.  Frames cross PCIe as uint8 from pinned memory; conversion + layout change happen in one HIP kernel."""
-        return _BatchIterator(self, batch_size, device)
+        'actions')}.  Frames cross PCIe as uint8 from pinned memory; conversion + layout change happen in one HIP kernel.
+        rank / world: the data-parallel replica this iterator feeds (see _shard)."""
+        return _BatchIterator(self, batch_size, device, rank, world)
+
+    def set_sequence_length(self, sequence_length):
+        """base_dataset.py:103-104."""
+        self.hparams.sequence_length = sequence_length
 
 
 class _BatchIterator(object):
-    def __init__(self, ds, batch_size, device):
+    def __init__(self, ds, batch_size, device, rank=0, world=1):
         from .. import kernels as K
         self.K = K
         self.ds, self.device = ds, torch.device(device)
-        self.pipe = ds.make_pipeline(batch_size)
+        self.pipe = ds.make_pipeline(batch_size, rank=rank, world=world)
         B, T = batch_size, ds.hparams.sequence_length
         self.host = torch.empty((B, T) + ds.image_shape, dtype=torch.uint8).pin_memory()
         self.dev_u8 = torch.empty((B, T) + ds.image_shape, dtype=torch.uint8, device=self.device)
+        self.copied = None           # event recorded behind the H2D copy out of the pinned buffer
 
     def __iter__(self):
         return self
 
     def __next__(self):
+        if self.copied is not None:
+            self.copied.synchronize()     # the previous batch has left the pinned buffer before the reader refills it
         got = self.pipe.next(self.host.numpy())
         if got is None:
             raise StopIteration
         _, floats = got
         self.dev_u8.copy_(self.host, non_blocking=True)
+        if self.device.type == 'cuda':
+            self.copied = torch.cuda.Event()
+            self.copied.record(torch.cuda.current_stream(self.device))
         B, T = self.dev_u8.shape[:2]
         images_tm = torch.empty((T, B) + self.ds.image_shape, device=self.device)
         self.K.u8_frames_to_f32(self.dev_u8, images_tm)

@@ -18,7 +18,7 @@ class SavpVideoPipelineArgs(ctypes.Structure):
         ('time_shift', c_i32), ('batch_size', c_i32), ('shuffle', c_i32), ('shuffle_buffer', c_i32), ('num_epochs', c_i32),
         ('seed', c_u64), ('prefetch_batches', c_i32),
         ('float_keys_fmt', ctypes.POINTER(c_cp)), ('float_dims', ctypes.POINTER(c_i32)),
-        ('float_per_frame_minus', ctypes.POINTER(c_i32)), ('num_float_keys', c_i32),
+        ('float_per_frame_minus', ctypes.POINTER(c_i32)), ('num_float_keys', c_i32), ('var_len', c_i32),
     ]
 
 
@@ -41,6 +41,7 @@ def get():
         L.savp_example_feature.argtypes = [c_vp, c_u64, c_cp, c_i32, P(c_i32), P(c_vp), P(c_u64)]
         L.savp_example_feature.restype = c_i32
         L.savp_example_floats.argtypes, L.savp_example_floats.restype = [c_vp, c_u64, c_cp, c_vp, c_i64], c_i32
+        L.savp_example_int64.argtypes, L.savp_example_int64.restype = [c_vp, c_u64, c_cp, c_i32, P(c_i64)], c_i32
         L.savp_pipeline_create.argtypes, L.savp_pipeline_create.restype = [P(SavpVideoPipelineArgs), P(c_vp)], c_i32
         L.savp_pipeline_next.argtypes, L.savp_pipeline_next.restype = [c_vp, c_vp, P(c_vp)], c_i32
         L.savp_pipeline_error.argtypes, L.savp_pipeline_error.restype = [c_vp], c_cp
@@ -97,12 +98,20 @@ def example_feature(example, name, index=0):
     return kind.value, n.value
 
 
+def example_int64(example, name, index=0):
+    """The index-th value of an int64_list feature of a serialized tf.train.Example."""
+    v = c_i64()
+    check(get().savp_example_int64(example, len(example), name.encode(), index, ctypes.byref(v)), 'int64 feature %s' % name)
+    return int(v.value)
+
+
 class VideoPipeline(object):
     """Batched, shuffling, prefetching reader (one C++ thread): next() fills caller buffers with uint8 frames
     [B, T, H, W, C] and the optional float features."""
 
     def __init__(self, filenames, image_key_fmt, example_frames, image_shape, sequence_length, batch_size, frame_skip=0,
-                 time_shift=0, shuffle=False, shuffle_buffer=1024, num_epochs=1, seed=0, prefetch_batches=2, float_keys=()):
+                 time_shift=0, shuffle=False, shuffle_buffer=1024, num_epochs=1, seed=0, prefetch_batches=2, float_keys=(),
+                 var_len=False):
         import numpy as np
         self._np = np
         L = get()
@@ -112,6 +121,7 @@ class VideoPipeline(object):
         a.filenames, a.num_files = self._files, len(files)
         a.image_key_fmt = image_key_fmt.encode()
         a.example_frames = example_frames
+        a.var_len = int(bool(var_len))
         a.height, a.width, a.channels = image_shape
         a.sequence_length, a.frame_skip, a.time_shift, a.batch_size = sequence_length, frame_skip, time_shift, batch_size
         a.shuffle, a.shuffle_buffer, a.num_epochs, a.seed, a.prefetch_batches = int(shuffle), shuffle_buffer, num_epochs or 0, seed, prefetch_batches

@@ -123,7 +123,7 @@ class SAVPEngine(object):
     def attach_process_group(self, dist_module):
         """One process per GPU; see parallel.ReplicaGroup."""
         from ..parallel import ReplicaGroup
-        self.replicas = ReplicaGroup(self.store, dist_module)
+        self.replicas = ReplicaGroup(self.store, dist_module, overlap=os.environ.get('SAVP_DP_OVERLAP', '1') == '1')
         self.dist = dist_module
         self.world = self.replicas.world
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
@@ -465,6 +465,8 @@ class SAVPEngine(object):
             store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
         for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
+        if discs and self.world > 1:
+            self.replicas.sync_aux()          # u vectors: bit-identical replicas (parallel.ReplicaGroup.sync_aux)
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
         d_losses, g_losses = OrderedDict(), OrderedDict()
         for d in discs:

@@ -95,6 +95,28 @@ class ReplicaGroup(object):
                 cur.wait_event(done)
         self.pending[group] = []
 
+    def sync_aux(self):
+        """Non-trainable state that every replica recomputes from identical weights (the spectral-norm power-iteration vectors
+        u): the GEMVs behind it sum in a hardware-dependent order, so the replicas' copies drift apart in the last bit.  One
+        small broadcast of the 'aux' arena per step (a few KB, on the side stream) keeps the replicas bit-identical."""
+        if self.world == 1:
+            return
+        aux = self.store.groups.get('aux')
+        if aux is None or aux.p.numel() == 0:
+            return
+        if self.comm_stream is not None:
+            cur = torch.cuda.current_stream(aux.p.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self.comm_stream.wait_event(ready)
+            with torch.cuda.stream(self.comm_stream):
+                self.dist.broadcast(aux.p, src=0)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+            cur.wait_event(done)
+        else:
+            self.dist.broadcast(aux.p, src=0)
+
     def allreduce_grads(self, group, async_op=False):
         """Sum the whole flat gradient bucket of one optimiser group (blocking with respect to the current stream)."""
         if self.world > 1:
