@@ -12,14 +12,17 @@ from video_prediction_amd import kernels as K  # noqa: E402
 
 DEV = 'cuda:0'
 N, H, W, C, KK, M = 32, 64, 64, 3, 4, 7
-big = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+big = torch.zeros(128 << 20, dtype=torch.int32, device=DEV)
+FLUSH = os.environ.get('FLUSH', 'read')      # read: evict with clean lines (a 512 MB reduction); write: with dirty lines; none: hot
 
 
 def t(fn, n=30, flush=True):
     ts = []
     for _ in range(n):
-        if flush:
-            big.zero_()            # evict L2 / Infinity Cache: inside a train step these operands arrive cold
+        if flush and FLUSH == 'read':
+            big.sum()              # evict L2 / Infinity Cache: inside a train step these operands arrive cold
+        elif flush and FLUSH == 'write':
+            big.zero_()            # ... and leave the caches full of dirty lines (pessimistic: every miss first writes a line back)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)

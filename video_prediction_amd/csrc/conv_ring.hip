@@ -101,6 +101,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     __bf16* patch = reinterpret_cast<__bf16*>(ring + RING * SLABB);                    // [ni][PH][pitch]
     const unsigned ring_lds = (unsigned)(uintptr_t)ring;                               // LDS byte address of the ring
 
+    RT(7);
     if (ABL(16)) return;
     const int split = blockIdx.z;
     const int tlog = xcd_logical(blockIdx.x, p.tm * p.tn);
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         goffF[q] = (unsigned)(row * ldb + j * 8) * 2u;
         goffL[q] = (unsigned)(row * ldb + (okL ? j * 8 : 0)) * 2u;
     }
+    RT(8);
     int g_slabs = 1, g_first = 0, g_jd = 0;
     // Per-entry offsets come from a small LDS table filled once per group (below): the walk over (tap, slab) entries then costs
     // no scalar arithmetic.  (The CU has ONE scalar unit for all its waves: the tap / slab state machine of conv_patch.hip, run
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         }
     };
 
+    RT(9);
     // ---- group-outer loop; inside a group the weight slabs stream through the four-deep DMA ring -----------------------------
     // entry e: its slab is DMAed three iterations ahead, its fragments are read one iteration ahead, its MFMAs run in iteration e.
     const int gsz = ntaps * spp;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         if (t_begin >= t_end) continue;
         const int len = t_end - t_begin;
         __syncthreads();                                   // previous group's patch, ring and table are dead (no DMA in flight here)
+        RT(10);
         for (int e = tid; e < len; e += NT) {              // entry table of this group
             const int ent = t_begin + e;
             const int tap = ent / g_slabs, sl = ent - tap * g_slabs;

@@ -19,6 +19,19 @@
 #include <stdlib.h>
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+#ifdef SAVP_CONV_ABLATE
+__device__ unsigned long long g_wgp_t[8];         // developer build: cycles of workgroup 0 / wave 0 per phase (savp_debug_wgp_times)
+extern "C" int savp_debug_wgp_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgp_t), sizeof(g_wgp_t)) == hipSuccess ? 0 : -1;
+}
+#define WT_DECL unsigned long long wt_[6] = {0, 0, 0, 0, 0, 0}, wt_last = __builtin_readcyclecounter();
+#define WT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); wt_[i] += n_ - wt_last; wt_last = n_; } while (0)
+#define WT_FLUSH(ntiles) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) g_wgp_t[i_] = wt_[i_]; g_wgp_t[6] = (ntiles); } } while (0)
+#else
+#define WT_DECL
+#define WT(i) do {} while (0)
+#define WT_FLUSH(n) do {} while (0)
+#endif
 #define LDS_AS __attribute__((address_space(3)))
 
 struct WgP {
@@ -28,11 +41,21 @@ struct WgP {
     int H, W, Ho, Wo, Cx, Cy, ph, pw, kw, sh, sw;
     int D, Do, kd, pd, khw;            // depth (3-D convs, depth stride 1): input / output planes, depth taps, pad, kh*kw
     long long x_sd, y_sd;
-    int taps, G16, CG, S;              // taps, 16-channel groups of Cx, groups per chunk, pixel splits
+    int taps, G16, CG, S, NB, MC;      // taps, 16-channel groups of Cx, groups per chunk, pixel splits, column blocks, channel chunks
     int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
     int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
     unsigned long long magC4, magPW, magTaps, magTHW, magTW, magPP, magDo, magKHW;
 };
+
+// issue order of the MFMA block: in front of MFMA J go the two transpose reads of MFMA J + PD (four when it opens a k-step: + B)
+template <int MTW, int PD, int J>
+__device__ __forceinline__ void wgp_sched() {
+    if constexpr (J < 4 * MTW) {
+        if constexpr (J + PD < 4 * MTW) __builtin_amdgcn_sched_group_barrier(0x100, ((J + PD) % MTW == 0) ? 4 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        wgp_sched<MTW, PD, J + 1>();
+    }
+}
 
 // NW waves x MTW row tiles (32 rows of dW each) per workgroup.  NPF = float4 prefetch registers per thread for the patch.
 template <int NW, int MTW, int NPF>
@@ -41,7 +64,12 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     constexpr int NPD = (64 * 8 + NT - 1) / NT;                // float4 prefetch registers for the dy tile (64 px x 32 ch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = blockIdx.y, mc = blockIdx.z, sp = blockIdx.x;
+    // 1-D grid, XCD-aware order: the NB column blocks (and MC channel chunks) of one pixel split are consecutive LOGICAL ids, i.e.
+    // they run at the same time on CUs of ONE XCD and read the same x patches / dy tiles through one L2.  With the split index
+    // fastest (the first version) the four column blocks of a tile ran hundreds of workgroups apart: every x patch came from HBM
+    // four times (2.9 GB of traffic for the 0.76 GB 32x32 ConvLSTM problem).
+    const int logical = xcd_logical((int)blockIdx.x, q.S * q.NB * q.MC);
+    const int nb = logical % q.NB, mc = (logical / q.NB) % q.MC, sp = logical / (q.NB * q.MC);
     const int ca = mc * q.CG;                                  // first 16-channel group of this chunk
     const int cgc = min(q.CG, q.G16 - ca);                     // groups in this chunk
     const int ngroups = cgc * q.taps;                          // (cx16, tap) row groups of this workgroup
@@ -56,8 +84,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int t_begin = sp * per, t_end = min(q.PT, t_begin + per);
     if (t_begin >= t_end) return;
 
-    // ---- staging maps, two packed registers per slot: LDS offset | valid << 31 ; c4 | py << 8 | px << 16 | plane << 24 -------
-    unsigned pinfo[NPF], pcoord[NPF];
+    // ---- staging maps, three registers per slot: LDS offset | valid << 31 ; py | px << 8 | plane << 16 ; element offset of the
+    // slot relative to the patch origin.  Everything that does not depend on the tile is folded in here once: per tile a slot
+    // then costs one mask test and one add (the first version re-derived channel / row / column / plane bounds and the address
+    // from the packed coordinates for every slot of every tile: ~35 VALU instructions per load, more than the MFMA work of a tile).
+    unsigned pinfo[NPF], pcoord[NPF], poff[NPF];
     {
         const int c4n = q.CG * 4;
         const int per_plane = q.PH * q.PW * c4n;
@@ -72,8 +103,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             const int pyy = (int)fastdiv((unsigned)pix, q.magPW);
             const int pxx = pix - pyy * q.PW;
             const bool ok = idx < ptotal;
+            const bool chan_ok = ca * 16 + c4 * 4 < q.Cx;         // channels beyond Cx: staged as zeros (slot stays valid)
             pinfo[i] = ok ? ((unsigned)(plane * pplane + pyy * q.pitch + pxx * q.CP + c4 * 4) | (1u << 31)) : 0u;
-            pcoord[i] = (unsigned)c4 | ((unsigned)pyy << 8) | ((unsigned)pxx << 16) | ((unsigned)plane << 24);
+            pcoord[i] = (unsigned)pyy | ((unsigned)pxx << 8) | ((unsigned)plane << 16) | ((ok && chan_ok) ? (1u << 31) : 0u);
+            // byte offset of the slot from the patch origin; < 2^31 (checked by the launcher)
+            poff[i] = (unsigned)(((long long)plane * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c4 * 4) * 4);
         }
     }
     float4 pf[NPF], pd[NPD];
@@ -90,18 +124,34 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         const int ty = (int)fastdiv((unsigned)r, q.magTW);
         const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
         const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw;       // patch origin in the input plane
-        const float* __restrict__ xs = q.x + (long long)img * q.x_sn + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw + ca * 16;
+        const int dz0 = dout - q.pd;                                       // input plane under patch plane 0 (depth stride 1)
+        // wave-uniform validity masks of the patch rows / columns / planes of this tile (PH, PW <= 22, kd <= 8)
+        auto range_mask = [](int lo, int hi) -> unsigned {               // bits lo .. hi-1, clamped to [0, 32)
+            lo = max(lo, 0); hi = min(hi, 32);
+            if (hi <= lo) return 0u;
+            return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        };
+        const unsigned rowmask = range_mask(-iy0, q.H - iy0), colmask = range_mask(-ix0, q.W - ix0), plmask = range_mask(-dz0, q.D - dz0);
+        // The patch origin may lie outside the tensor (border tiles).  Loads are addressed from the first VALID element of the
+        // patch (wave-uniform base, inside the tensor) plus a non-negative 32-bit byte offset per slot; masked slots read offset 0.
+        const int lo_y = max(0, -iy0), lo_x = max(0, -ix0), lo_z = max(0, -dz0);
+        const unsigned adj = (unsigned)(((long long)lo_z * q.x_sd + lo_y * q.x_sh + lo_x * q.x_sw) * 4);
+        const char* __restrict__ base = reinterpret_cast<const char*>(
+            q.x + (long long)img * q.x_sn + (long long)(dz0 + lo_z) * q.x_sd + (long long)(iy0 + lo_y) * q.x_sh +
+            (long long)(ix0 + lo_x) * q.x_sw + ca * 16);
+        const bool flat = q.kd == 1;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            unsigned inf = pinfo[i], co = pcoord[i];
-            asm volatile("" : "+v"(inf), "+v"(co));            // keep the unpacking inside the loop (register pressure)
-            const int c = (int)(co & 255u) << 2, pyy = (int)((co >> 8) & 255u), pxx = (int)((co >> 16) & 255u);
-            const int dz = dout - q.pd + (int)(co >> 24);      // input plane of this patch plane (depth stride 1)
-            const bool ok = (inf >> 31) && (unsigned)(iy0 + pyy) < (unsigned)q.H && (unsigned)(ix0 + pxx) < (unsigned)q.W &&
-                            ca * 16 + c < q.Cx && (unsigned)dz < (unsigned)q.D;
+            unsigned co = pcoord[i], po = poff[i];
+            asm volatile("" : "+v"(co), "+v"(po));             // keep the unpacking inside the loop (register pressure)
+            const unsigned pyy = co & 255u, pxx = (co >> 8) & 255u, pl = (co >> 16) & 127u;
+            unsigned bit = (rowmask >> pyy) & (colmask >> pxx);
+            if (!flat) bit &= plmask >> pl;
+            const bool ok = (co >> 31) && (bit & 1u);
             // unconditional load from a clamped address, zeroed at stage() time through the mask: a branch around the load (or
             // a select right behind it) makes hipcc wait for every element here instead of behind the MFMAs of the current tile
-            pf[i] = ldg4(ok ? xs + (long long)dz * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c : q.x);
+            const unsigned offb = ok ? po - adj : 0u;           // valid slots lie at or behind the first valid element
+            pf[i] = *reinterpret_cast<const float4*>(base + offb);
             fmask |= (ok ? 1u : 0u) << i;
         }
         const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh +
@@ -168,31 +218,62 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+    WT_DECL
     fetch(t_begin);
+    WT(0);
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         stage(buf);
+        WT(1);
         __syncthreads();
-        if (t + 1 < t_end) fetch(t + 1);
-        const LDS_AS char* pa = (const LDS_AS char*)(patch + buf * patch_elems);
-        const LDS_AS char* pb = (const LDS_AS char*)(dyt + buf * 64 * 32) + b_lane * 2;
-#pragma unroll 1
-        for (int s = 0; s < 4; ++s) {
-            const bf16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024));
-            const bf16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + s * 1024 + 256));
-            const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            const LDS_AS char* pa0 = pa + 4 * s * q.sh * q.pitch;   // output rows 2 s of the tile (bytes)
-            const LDS_AS char* pa1 = pa0 + 8 * q.sw * q.CP;         // + 4 output pixels
+        WT(2);
+        auto mma_block = [&]() {
+            const LDS_AS char* pa = (const LDS_AS char*)(patch + buf * patch_elems);
+            const LDS_AS char* pb = (const LDS_AS char*)(dyt + buf * 64 * 32) + b_lane * 2;
+            // 4 k-steps x MTW row tiles = one straight-line block of 4 MTW MFMAs with the transpose reads of MFMA j + PD issued in
+            // front of MFMA j (fragment ring of PD + 1 register sets).  The first version looped with a wave-uniform `break` on the
+            // valid tile count: hipcc then emitted {2 reads, lgkmcnt(0), MFMA} per tile into ONE register pair -- every MFMA waited for
+            // a full LDS round trip (13.4k of 18.8k cycles per tile on the 32x32 ConvLSTM layer, MFMA pipe 15 % busy).  Row tiles past
+            // the wave's valid count recompute the last valid group (a_tile is clamped) and are dropped in the epilogue.
+            if (nt > 0) {
+                constexpr int TOT = 4 * MTW, PD = (MTW >= 4 ? 3 : 2);
+                const int rstep = 4 * q.sh * q.pitch, cstep = 8 * q.sw * q.CP;      // bytes: two output rows / four output pixels
+                bf16x8 af[PD + 1], bfr[2];
+                auto load_a = [&](int j) {
+                    const int ks = j / MTW, i = j % MTW;
+                    const LDS_AS char* p0 = pa + ks * rstep + a_tile[i];
+                    const bf16x4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)p0);
+                    const bf16x4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(p0 + cstep));
+                    af[j % (PD + 1)] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                };
+                auto load_b = [&](int ks) {
+                    const bf16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + ks * 1024));
+                    const bf16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pb + ks * 1024 + 256));
+                    bfr[ks & 1] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                };
+                load_b(0);
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                if (i >= nt) break;                            // wave-uniform
-                const bf16x4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa0 + a_tile[i]));
-                const bf16x4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa1 + a_tile[i]));
-                const bf16x8 afr = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+                for (int j = 0; j < PD; ++j) load_a(j);
+#pragma unroll
+                for (int j = 0; j < TOT; ++j) {
+                    if (j + PD < TOT) {
+                        if ((j + PD) % MTW == 0) load_b((j + PD) / MTW);
+                        load_a(j + PD);
+                    }
+                    acc[j % MTW] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j % (PD + 1)], bfr[(j / MTW) & 1], acc[j % MTW], 0, 0, 0);
+                }
+                // pin the issue order: the reads of MFMA j + PD go out in front of MFMA j (left alone, hipcc folds the ring back to
+                // a distance of one MFMA to save registers)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * PD, 0);
+                wgp_sched<MTW, PD, 0>();
             }
-        }
+        };
+        if (t + 1 < t_end) fetch(t + 1);
+        WT(3);
+        mma_block();
+        WT(4);
     }
+    WT_FLUSH(t_end - t_begin);
 
     if (do_db) {                                               // every slot of this thread is channel quad (tid & 7)
 #pragma unroll
@@ -251,6 +332,8 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
           a->Cy % 4 == 0 && xs4 && ys4 && a->kh <= 8 && a->kw <= 8 && a->Ho * a->Wo >= 64))
         return false;
     if (a->x_sh * (long long)(a->H + 8) >= (1ll << 31) || a->y_sh * (long long)(a->Ho + 8) >= (1ll << 31)) return false;
+    // byte offsets inside one patch (kd planes x PH rows) are 32-bit
+    if (((long long)a->kd * a->x_sd + (long long)(7 * a->sh + a->kh + 1) * a->x_sh) * 4 >= (1ll << 31)) return false;
     WgP q;
     q.x = (const float*)a->x; q.y = (const float*)a->y; q.dw = (float*)a->w; q.db = (float*)a->bias;
     q.x_sn = a->x_sn; q.y_sn = a->y_sn;
@@ -286,12 +369,17 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     while ((cpu % 8) != 2 && (cpu % 8) != 6) ++cpu;
     q.CP = cpu * 16;
     q.pitch = q.PW * q.CP;
-    if (q.PH > 255 || q.PW > 255 || cg * 4 > 255 || a->kd > 127) return false;   // packed staging coordinates are 8 bits each
+    if (q.PH > 31 || q.PW > 31 || a->kd > 31) return false;      // per-tile validity masks are 32 bits; packed coordinates 8 / 8 / 7 bits
     const int tH = (a->Ho + 7) / 8;
     q.tW = (a->Wo + 7) / 8; q.tHW = tH * q.tW;
     q.PT = a->N * a->Do * q.tHW;
-    long long s = 768 / ((long long)NB * MC);
+    long long s = 768 / ((long long)NB * MC);                      // ~3 rounds of one 8-wave workgroup per CU
     if (s < 1) s = 1;
+    {
+        static int ovs = -1;
+        if (ovs < 0) { const char* e = getenv("SAVP_WGP_SPLIT"); ovs = e ? atoi(e) : 0; }      // developer override: total workgroups
+        if (ovs > 0) s = ovs / ((long long)NB * MC) > 0 ? ovs / ((long long)NB * MC) : 1;
+    }
     if (s > q.PT) s = q.PT;
     q.S = (int)s;
     q.magC4 = magic40(cg * 4); q.magPW = magic40(q.PW); q.magTaps = magic40(q.taps);
@@ -301,7 +389,8 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     const size_t lds = (size_t)2 * a->kd * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
     if (lds > 160 * 1024) return false;
     const int npf = (a->kd * q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
-    dim3 grid((unsigned)q.S, (unsigned)NB, (unsigned)MC);
+    q.NB = NB; q.MC = MC;
+    dim3 grid((unsigned)(q.S * NB * MC), 1u, 1u);
     hipError_t err;
     if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp<8, 4, 4>(q, grid, lds, st) : launch_wgp<8, 4, 8>(q, grid, lds, st);
     else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp<8, 2, 4>(q, grid, lds, st) : launch_wgp<8, 2, 8>(q, grid, lds, st);

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsavp_hip.so')
+LIB_PATH = os.environ.get('SAVP_LIB') or os.path.join(_HERE, 'libsavp_hip.so')      # SAVP_LIB: developer A/B of two builds
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
