@@ -350,6 +350,9 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     // the 3x3 heads: 8x2 305 us, 8x4 424 us, 4x4 476 us, 4x8 831 us -- fewer tiles per wave = better balance and occupancy)
     nw = 8;
     mtw = groups_all <= 32 ? 2 : (groups_all <= 64 ? 4 : 8);
+    // few row groups (3x3 heads: 18): these problems are bound by streaming x / dy, and 4-wave workgroups (three per CU, each at its
+    // own phase of fetch / stage / multiply) overlap that better than one barrier-coupled 8-wave group: 490 -> 379 us on 64x64x32->32
+    if (groups_all <= 32) { nw = 4; mtw = 4; }
     {   // developer override: SAVP_WGP_CFG=<nw><mtw> (e.g. 84)
         static int ov = -1;
         if (ov < 0) { const char* e = getenv("SAVP_WGP_CFG"); ov = e ? atoi(e) : 0; }
