@@ -88,7 +88,8 @@ typedef struct SavpView { void* p; int64_t sn; int64_t sp; } SavpView;
  * fwd: out[k] = act(gamma*(x-mean)/sqrt(var+eps)+beta) for k < nout (multi-destination so that concat buffers are
  *      filled without copy kernels); saves mean/rstd [N,C].
  * bwd: dy = sum_k dy[k]; masks by the saved activation output out[0]; writes dx (accumulates if dx_beta) and
- *      atomically accumulates dgamma/dbeta.   act: 0 none, 1 relu, 2 lrelu(alpha).
+ *      atomically accumulates dgamma/dbeta.   act: 0 none, 1 relu, 2 lrelu(alpha).  The activation mask is recomputed from
+ *      x, mean, rstd, gamma, beta (y > 0 <=> z > 0): bwd does not read the saved output (`out` is ignored).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct SavpInormArgs {
     int32_t N, HW, C;
@@ -103,6 +104,10 @@ typedef struct SavpInormArgs {
     float* ws;                     /* optional scratch [N*C*2]: selects the coalesced two-kernel path for planes of >= 256 pixels */
     int32_t ws_clean;              /* 1: the caller guarantees ws is all zero (e.g. a slice of an arena cleared once per step),
                                       0: the library clears it with a memset per call */
+    int32_t out_c0[4], out_nc[4];  /* fwd: output k receives channels [out_c0, out_c0 + out_nc) of the normalised tensor, stored from
+                                      channel 0 of its view (multiples of 4; out_nc == 0: all C channels) -- one launch can normalise
+                                      the concatenated output of two convolutions that feed different consumers */
+    int32_t dy_c0[4], dy_nc[4];    /* bwd: gradient k covers channels [dy_c0, dy_c0 + dy_nc) (dy_nc == 0: all C) */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);

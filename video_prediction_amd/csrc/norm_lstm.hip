@@ -75,10 +75,11 @@ struct InormP {
     const float* gamma; const float* beta;
     float eps; int act; float alpha;
     int nout; float* out[4]; long long o_sn[4], o_sp[4];
+    int o_c0[4], o_c1[4];           // output k receives channels [o_c0, o_c1) of x (multiples of 4; default: all C)
     float* mean; float* rstd;       // [N, C]
     // backward
     int ndy; const float* dy[4]; long long dy_sn[4], dy_sp[4];
-    const float* yout; long long y_sn, y_sp;    // saved activation output (for the activation mask)
+    int dy_c0[4], dy_c1[4];         // gradient k covers channels [dy_c0, dy_c1) of the output (default: all C)
     float* dx; long long dx_sn, dx_sp; int dx_beta;
     float* dgamma; float* dbeta;
 };
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(NT) void inorm_fwd_kernel(InormP p) {
         o.y = act_fwd((v.y - m1) * r1 * g.y + b.y, p.act, p.alpha);
         o.z = act_fwd((v.z - m2) * r2 * g.z + b.z, p.act, p.alpha);
         o.w = act_fwd((v.w - m3) * r3 * g.w + b.w, p.act, p.alpha);
-        for (int k = 0; k < p.nout; ++k) st4(p.out[k] + (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k] + c0, o);
+        for (int k = 0; k < p.nout; ++k)
+            if (c0 >= p.o_c0[k] && c0 < p.o_c1[k]) st4(p.out[k] + (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k] + (c0 - p.o_c0[k]), o);
     }
 }
 
@@ -127,20 +129,21 @@ __global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
     const int cg = p.C / 4;
     const int n = blockIdx.x / cg, c0 = (blockIdx.x % cg) * 4;
     const float* x = p.x + (long long)n * p.x_sn + c0;
-    const float* yo = p.yout + (long long)n * p.y_sn + c0;
     const float4 m = ld4(p.mean + (long long)n * p.C + c0), r = ld4(p.rstd + (long long)n * p.C + c0);
-    const float4 g = ld4(p.gamma + c0);
+    const float4 g = ld4(p.gamma + c0), bt = ld4(p.beta + c0);
+    // the activation mask is recomputed from the pre-activation z = xh * gamma + beta (y > 0 <=> z > 0 for relu / lrelu): the saved
+    // activation output is not read back
     auto load_dz = [&](int px, float4& xh) -> float4 {
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < p.ndy; ++k) {
-            float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + c0);
+            if (c0 < p.dy_c0[k] || c0 >= p.dy_c1[k]) continue;
+            float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + (c0 - p.dy_c0[k]));
             d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
         }
-        float4 y = ld4(yo + (long long)px * p.y_sp);
-        d.x *= act_grad_from_out(y.x, p.act, p.alpha); d.y *= act_grad_from_out(y.y, p.act, p.alpha);
-        d.z *= act_grad_from_out(y.z, p.act, p.alpha); d.w *= act_grad_from_out(y.w, p.act, p.alpha);
         float4 v = ld4(x + (long long)px * p.x_sp);
         xh.x = (v.x - m.x) * r.x; xh.y = (v.y - m.y) * r.y; xh.z = (v.z - m.z) * r.z; xh.w = (v.w - m.w) * r.w;
+        d.x *= act_grad_from_out((v.x - m.x) * r.x * g.x + bt.x, p.act, p.alpha); d.y *= act_grad_from_out((v.y - m.y) * r.y * g.y + bt.y, p.act, p.alpha);
+        d.z *= act_grad_from_out((v.z - m.z) * r.z * g.z + bt.z, p.act, p.alpha); d.w *= act_grad_from_out((v.w - m.w) * r.w * g.w + bt.w, p.act, p.alpha);
         return d;
     };
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -235,22 +238,25 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* 
         o.y = act_fwd((v.y - m[1]) * r[1] * g.y + b.y, p.act, p.alpha);
         o.z = act_fwd((v.z - m[2]) * r[2] * g.z + b.z, p.act, p.alpha);
         o.w = act_fwd((v.w - m[3]) * r[3] * g.w + b.w, p.act, p.alpha);
-        for (int kq = 0; kq < p.nout; ++kq) st4(p.out[kq] + (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + c4 * 4, o);
+        for (int kq = 0; kq < p.nout; ++kq)
+            if (c4 * 4 >= p.o_c0[kq] && c4 * 4 < p.o_c1[kq])
+                st4(p.out[kq] + (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + (c4 * 4 - p.o_c0[kq]), o);
     }
 }
 
-__device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c0, const float* yo, const float* x, const float m[4],
-                                           const float r[4], float4& xh) {
+__device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c0, const float* x, const float m[4], const float r[4],
+                                           const float4 g, const float4 bt, float4& xh) {
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < p.ndy; ++k) {
-        float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + c0);
+        if (c0 < p.dy_c0[k] || c0 >= p.dy_c1[k]) continue;
+        float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + (c0 - p.dy_c0[k]));
         d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
     }
-    float4 y = ld4(yo + (long long)px * p.y_sp + c0);
-    d.x *= act_grad_from_out(y.x, p.act, p.alpha); d.y *= act_grad_from_out(y.y, p.act, p.alpha);
-    d.z *= act_grad_from_out(y.z, p.act, p.alpha); d.w *= act_grad_from_out(y.w, p.act, p.alpha);
     float4 v = ld4(x + (long long)px * p.x_sp + c0);
     xh.x = (v.x - m[0]) * r[0]; xh.y = (v.y - m[1]) * r[1]; xh.z = (v.z - m[2]) * r[2]; xh.w = (v.w - m[3]) * r[3];
+    // activation mask from the pre-activation (same expression as the forward apply pass): y > 0 <=> z > 0
+    d.x *= act_grad_from_out((v.x - m[0]) * r[0] * g.x + bt.x, p.act, p.alpha); d.y *= act_grad_from_out((v.y - m[1]) * r[1] * g.y + bt.y, p.act, p.alpha);
+    d.z *= act_grad_from_out((v.z - m[2]) * r[2] * g.z + bt.z, p.act, p.alpha); d.w *= act_grad_from_out((v.w - m[3]) * r[3] * g.w + bt.w, p.act, p.alpha);
     return d;
 }
 
@@ -259,15 +265,15 @@ __global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, float* ws
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
     const float* x = p.x + (long long)n * p.x_sn;
-    const float* yo = p.yout + (long long)n * p.y_sn;
     float m[4], r[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { m[e] = p.mean[(long long)n * C + c4 * 4 + e]; r[e] = p.rstd[(long long)n * C + c4 * 4 + e]; }
+    const float4 gm = ld4(p.gamma + c4 * 4), bt = ld4(p.beta + c4 * 4);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
     if (prow < rows)
         for (int px = p0 + prow; px < p1; px += rows) {
-            float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, yo, x, m, r, xh);
+            float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, x, m, r, gm, bt, xh);
             s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
             q.x += d.x * xh.x; q.y += d.y * xh.y; q.z += d.z * xh.z; q.w += d.w * xh.w;
         }
@@ -290,7 +296,6 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
     if (prow >= rows) return;
     const float* x = p.x + (long long)n * p.x_sn;
-    const float* yo = p.yout + (long long)n * p.y_sn;
     float m[4], r[4], s1[4], s2[4];
     const float inv = 1.f / (float)p.HW;
 #pragma unroll
@@ -306,11 +311,11 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[e] *= inv; s2[e] *= inv; }
-    const float4 g = ld4(p.gamma + c4 * 4);
+    const float4 g = ld4(p.gamma + c4 * 4), bt = ld4(p.beta + c4 * 4);
     float* dx = p.dx + (long long)n * p.dx_sn + c4 * 4;
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
     for (int px = p0 + prow; px < p1; px += rows) {
-        float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, yo, x, m, r, xh);
+        float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, x, m, r, g, bt, xh);
         float4 o;
         o.x = g.x * r[0] * (d.x - s1[0] - xh.x * s2[0]);
         o.y = g.y * r[1] * (d.y - s1[1] - xh.y * s2[1]);
@@ -344,7 +349,11 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     p.x = (const float*)a->x.p; p.x_sn = a->x.sn; p.x_sp = a->x.sp;
     p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.act = a->act; p.alpha = a->alpha;
     p.nout = a->nout;
-    for (int i = 0; i < a->nout; ++i) { p.out[i] = (float*)a->out[i].p; p.o_sn[i] = a->out[i].sn; p.o_sp[i] = a->out[i].sp; }
+    for (int i = 0; i < a->nout; ++i) {
+        p.out[i] = (float*)a->out[i].p; p.o_sn[i] = a->out[i].sn; p.o_sp[i] = a->out[i].sp;
+        p.o_c0[i] = a->out_c0[i]; p.o_c1[i] = a->out_nc[i] > 0 ? a->out_c0[i] + a->out_nc[i] : a->C;
+        if ((p.o_c0[i] & 3) || (p.o_c1[i] & 3) || p.o_c0[i] < 0 || p.o_c1[i] > a->C) return SAVP_EINVAL;
+    }
     p.mean = a->mean; p.rstd = a->rstd;
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
@@ -368,8 +377,11 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
     p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps; p.act = a->act; p.alpha = a->alpha;
     p.mean = a->mean; p.rstd = a->rstd;
     p.ndy = a->ndy;
-    for (int i = 0; i < a->ndy; ++i) { p.dy[i] = (const float*)a->dy[i].p; p.dy_sn[i] = a->dy[i].sn; p.dy_sp[i] = a->dy[i].sp; }
-    p.yout = (const float*)a->out[0].p; p.y_sn = a->out[0].sn; p.y_sp = a->out[0].sp;
+    for (int i = 0; i < a->ndy; ++i) {
+        p.dy[i] = (const float*)a->dy[i].p; p.dy_sn[i] = a->dy[i].sn; p.dy_sp[i] = a->dy[i].sp;
+        p.dy_c0[i] = a->dy_c0[i]; p.dy_c1[i] = a->dy_nc[i] > 0 ? a->dy_c0[i] + a->dy_nc[i] : a->C;
+        if ((p.dy_c0[i] & 3) || (p.dy_c1[i] & 3) || p.dy_c0[i] < 0 || p.dy_c1[i] > a->C) return SAVP_EINVAL;
+    }
     p.dx = (float*)a->dx.p; p.dx_sn = a->dx.sn; p.dx_sp = a->dx.sp; p.dx_beta = a->dx_beta;
     p.dgamma = a->dgamma; p.dbeta = a->dbeta;
     if (use_large_plane_path(a)) {

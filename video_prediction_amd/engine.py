@@ -335,6 +335,84 @@ class ConvLayer(object):
         self.dwf.zero_()
 
 
+class _TensorStore(object):
+    """Minimal stand-in for ParamStore around private tensors (ConvLayer only needs [], grad() and group_of)."""
+
+    def __init__(self, tensors, grads):
+        self.t, self.g = tensors, grads
+        self.group_of = {k: 'g' for k in tensors}
+
+    def __getitem__(self, name):
+        return self.t[name]
+
+    def grad(self, name):
+        return self.g[name]
+
+
+class ConcatConv(object):
+    """Several plain convolutions that read the SAME input with the same geometry, run as ONE convolution whose output channels are
+    the concatenation of theirs (the 3x3 heads of SAVPCell.call that all read the last decoder layer: h6_scratch, h6_masks and,
+    for flow / dna, the transformation head -- savp_model.py:522-544,562-567,625-631).  One launch reads the input once instead
+    of once per head, forward and backward (the data gradient of the concatenation IS the sum of the heads' data gradients), and
+    one weight-gradient launch serves all of them.  The master variables stay separate TF-named tensors: per step they are copied
+    into the channel slices of a concatenated HWIO kernel / bias (prep), and the concatenated gradient is added back slice by slice
+    (finish_weight_grad)."""
+
+    def __init__(self, store, parts, ksize, stride, pad):
+        self.parts = []
+        off = 0
+        W0 = store[parts[0][0]]
+        self.lead = tuple(W0.shape[:-1])                           # (kh, kw, cx)
+        dev = W0.device
+        for kname, bname in parts:
+            W = store[kname]
+            if tuple(W.shape[:-1]) != self.lead:
+                raise ValueError('ConcatConv parts must share kernel size and input channels')
+            cy = W.shape[-1]
+            self.parts.append(dict(W=W, dW=store.grad(kname), b=store[bname], db=store.grad(bname), off=off, cy=cy))
+            off += cy
+        self.cy = off
+        self.Wcat = torch.empty(self.lead + (off,), device=dev)
+        self.dWcat = torch.zeros(self.lead + (off,), device=dev)
+        self.bcat = torch.zeros(off, device=dev)
+        self.dbcat = torch.zeros(off, device=dev)
+        shim = _TensorStore({'k': self.Wcat, 'b': self.bcat}, {'k': self.dWcat, 'b': self.dbcat})
+        self.inner = ConvLayer(shim, 'k', 'b', 'conv', ksize, stride, pad)
+        self.R = int(np.prod(self.lead))
+
+    @property
+    def prof(self):
+        return self.inner.prof
+
+    def prep(self, update_u=False):
+        R = self.R
+        for P in self.parts:
+            copy_view(P['W'].reshape(R, P['cy']), [self.Wcat.reshape(R, self.cy)[:, P['off']:P['off'] + P['cy']]])
+            copy_view(P['b'].reshape(1, P['cy']), [self.bcat.reshape(1, self.cy)[:, P['off']:P['off'] + P['cy']]])
+        self.inner.prep()
+
+    def forward(self, x, y, **kw):
+        self.inner.forward(x, y, **kw)
+
+    def backward_data(self, dy, dx, **kw):
+        self.inner.backward_data(dy, dx, **kw)
+
+    def backward_weights(self, x, dy):
+        self.inner.backward_weights(x, dy)
+
+    def finish_weight_grad(self):
+        self.inner.finish_weight_grad()
+        R = self.R
+        for P in self.parts:
+            add_views([self.dWcat.reshape(R, self.cy)[:, P['off']:P['off'] + P['cy']]], P['dW'].reshape(R, P['cy']))
+            add_views([self.dbcat.reshape(1, self.cy)[:, P['off']:P['off'] + P['cy']]], P['db'].reshape(1, P['cy']))
+        self.dWcat.zero_()
+        self.dbcat.zero_()
+
+    def commit_u(self):
+        pass
+
+
 class Tape(object):
     """Minimal reverse-mode tape: forward code appends closures, backward() runs them in reverse."""
 

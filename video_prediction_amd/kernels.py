@@ -268,7 +268,15 @@ def _inorm_ws(x):
     return zero_arena(x.device).take(x.shape[0] * x.shape[-1] * 2)
 
 
-def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6):
+def _set_ranges(c0_arr, nc_arr, ranges):
+    """ranges: None or [(first channel, channel count), ...] per view (multiples of 4); None / (0, 0) = all channels."""
+    for i, r in enumerate(ranges or ()):
+        if r:
+            c0_arr[i], nc_arr[i] = int(r[0]), int(r[1])
+
+
+def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6, out_ranges=None):
+    """out_ranges: per output view the (first channel, count) slice of the normalised tensor it receives (default: all)."""
     a = lib.SavpInormArgs()
     a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
@@ -277,23 +285,26 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
     a.nout = len(outs)
     _set_views(a.out, outs)
+    _set_ranges(a.out_c0, a.out_nc, out_ranges)
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     lib.check(lib.get().savp_instnorm_act_fwd(lib.stream(), ctypes.byref(a)), 'savp_instnorm_act_fwd')
 
 
 def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, dx_beta=0, act='relu', alpha=0.0,
-                     eps=1e-6):
+                     eps=1e-6, dy_ranges=None):
+    """out0 is not read (the activation mask is recomputed from x, mean, rstd, gamma, beta); dy_ranges: per gradient view the
+    (first channel, count) slice of the output it is the gradient of (default: all channels)."""
     a = lib.SavpInormArgs()
     a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
-    a.nout = 1
-    a.out[0] = view(out0)
+    a.nout = 0
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     a.ndy = len(dys)
     _set_views(a.dy, dys)
+    _set_ranges(a.dy_c0, a.dy_nc, dy_ranges)
     a.dx = view(dx)
     a.dx_beta = int(dx_beta)
     a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()

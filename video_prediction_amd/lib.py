@@ -125,6 +125,7 @@ class SavpInormArgs(ctypes.Structure):
         ('nout', c_i32), ('out', SavpView * 4), ('mean', c_vp), ('rstd', c_vp),
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
         ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
+        ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4),
     ]
 
 

@@ -19,7 +19,7 @@ import torch
 
 from .. import kernels as K
 from .. import lib
-from ..engine import ConvLayer, same_pad_before, copy_view, add_views
+from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_views
 from ..variables import layer_specs, num_masks
 
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
@@ -50,6 +50,37 @@ class Norm(object):
         self.dgamma, self.dbeta = store.grad(scope + 'gamma'), store.grad(scope + 'beta')
         self.mean = torch.empty(T1, N, C, device=device)
         self.rstd = torch.empty(T1, N, C, device=device)
+
+
+class ConcatNorm(object):
+    """Instance norms of several heads that are normalised by ONE launch over their concatenated channels (instance norm is per
+    channel, so concatenation changes nothing numerically): gamma / beta are gathered into one vector per step, their gradients
+    are scattered back to the master variables after the backward pass."""
+
+    def __init__(self, norms, T1, N, device):
+        self.norms = norms
+        self.sizes = [n.gamma.numel() for n in norms]
+        C = sum(self.sizes)
+        self.gamma, self.beta = torch.empty(C, device=device), torch.empty(C, device=device)
+        self.dgamma, self.dbeta = torch.zeros(C, device=device), torch.zeros(C, device=device)
+        self.mean = torch.empty(T1, N, C, device=device)
+        self.rstd = torch.empty(T1, N, C, device=device)
+
+    def prep(self):
+        off = 0
+        for n, c in zip(self.norms, self.sizes):
+            K.axpby(1.0, n.gamma, 0.0, None, self.gamma[off:off + c])
+            K.axpby(1.0, n.beta, 0.0, None, self.beta[off:off + c])
+            off += c
+
+    def finish(self):
+        off = 0
+        for n, c in zip(self.norms, self.sizes):
+            K.axpby(1.0, self.dgamma[off:off + c], 1.0, n.dgamma, n.dgamma)
+            K.axpby(1.0, self.dbeta[off:off + c], 1.0, n.dbeta, n.dbeta)
+            off += c
+        self.dgamma.zero_()
+        self.dbeta.zero_()
 
 
 class SAVPGenerator(object):
@@ -183,9 +214,11 @@ class SAVPGenerator(object):
                     raise NotImplementedError('dna with kh*kw*nk not a multiple of 4')
                 self.dna_kern = torch.empty(T1, N, H, W, cy, device=dev)
             tf_convs = [self.tf_conv, self.tf_out]
+        self.merge_heads = os.environ.get('SAVP_MERGE_HEADS', '1') == '1' and ngf % 4 == 0
+        sep = not self.merge_heads          # separate pre-activation buffers only when every head has its own launch
         s = prefix + 'h%d_scratch/' % nl
         self.scratch_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
-        self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g)
+        self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
         self.scratch_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
         self.scratch_h = Act((T1, N, H, W, ngf), dev, grad=g)
         s = prefix + 'scratch_image/'
@@ -194,7 +227,7 @@ class SAVPGenerator(object):
         self.dscratch_pre = torch.empty(T1, N, H, W, Cs, device=dev) if g else None
         s = prefix + 'h%d_masks/' % nl
         self.masks_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
-        self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g)
+        self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
         self.masks_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
         # maskin = [h_masks (ngf) | nk CDNA images | prev image | first image | scratch image]   (savp_model.py:632)
         self.Cmask = Cmask = ceil4(ngf + M * C + (Cs - C))        # scratch slot is last: room for its padded write
@@ -221,9 +254,25 @@ class SAVPGenerator(object):
                 self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
                 self.z_cs = torch.empty(T1, N, nz, device=dev)
         self.gru = hp.conv_rnn == 'gru'
+        # ---- merged 3x3 heads on the last decoder layer (SAVP_MERGE_HEADS=0: one launch per head, the reference's structure) ----
+        # h6_scratch, h6_masks (and h6_flow / h6_dna_kernel) all read h_last through a 3x3 conv + instance norm + relu: ONE conv with
+        # concatenated output channels, ONE instance norm over them, outputs routed by channel range; backward likewise.
+        head_convs = [self.scratch_conv, self.masks_conv]
+        if self.merge_heads:
+            parts = [(self.scratch_conv.kernel_name, self.scratch_conv.bias_name), (self.masks_conv.kernel_name, self.masks_conv.bias_name)]
+            norms = [self.scratch_norm, self.masks_norm]
+            if self.tf != 'cdna':
+                parts.append((self.tf_conv.kernel_name, self.tf_conv.bias_name))
+                norms.append(self.tf_norm)
+                tf_convs = [self.tf_out]
+            self.nheads = len(parts)
+            self.heads_conv = ConcatConv(store, parts, (3, 3), (1, 1), (1, 1))
+            self.heads_norm = ConcatNorm(norms, T1, N, dev)
+            self.heads_pre = Act((T1, N, H, W, self.nheads * ngf), dev, grad=g)
+            head_convs = [self.heads_conv]
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
                      [L['cconv'] for L in self.layers if L['rnn'] and self.gru] + \
-                     tf_convs + [self.scratch_conv, self.scratch_out, self.masks_conv, self.masks_out]
+                     tf_convs + head_convs + [self.scratch_out, self.masks_out]
         # only FPROP packs needed at inference
         self._routes()
 
@@ -253,6 +302,8 @@ class SAVPGenerator(object):
     def prep_weights(self):
         for c in self.convs:
             c.prep()
+        if self.merge_heads:
+            self.heads_norm.prep()
 
     # ---------------------------------------------------------------------------------------------------------
     def _out_views(self, L, t):
@@ -329,33 +380,44 @@ class SAVPGenerator(object):
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
             tslot = maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C]
+            ngf = self.hp.ngf
+            if self.merge_heads:
+                # one conv + one instance norm for every 3x3 head on h_last; outputs routed by channel range
+                hn = self.heads_norm
+                self.heads_conv.forward(self.h_last.v[t], self.heads_pre.v[t])
+                outs = [self.scratch_h.v[t], maskin.v[t][..., 0:ngf]] + ([self.tf_h.v[t]] if self.tf != 'cdna' else [])
+                K.instnorm_act_fwd(self.heads_pre.v[t], hn.gamma, hn.beta, outs, hn.mean[t], hn.rstd[t], act='relu', eps=EPS_IN,
+                                   out_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
             if self.tf == 'cdna':
                 # CDNA kernels from the smallest layer (savp_model.py:546-559) and their application (:580, :893-923)
                 self.cdna_dense.forward(self.hsmall.v[t].reshape(N, -1), self.cdna_raw.v[t])
                 K.cdna_kernels_fwd(self.cdna_raw.v[t], self.cdna_kern.v[t], self.kh, self.kw, self.nk)
                 K.cdna_apply_fwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], tslot, self.kh, self.kw, self.nk)
             else:
-                self.tf_conv.forward(self.h_last.v[t], self.tf_pre.v[t])
-                tn = self.tf_norm
-                K.instnorm_act_fwd(self.tf_pre.v[t], tn.gamma, tn.beta, [self.tf_h.v[t]], tn.mean[t], tn.rstd[t], act='relu',
-                                   eps=EPS_IN)
+                if not self.merge_heads:
+                    self.tf_conv.forward(self.h_last.v[t], self.tf_pre.v[t])
+                    tn = self.tf_norm
+                    K.instnorm_act_fwd(self.tf_pre.v[t], tn.gamma, tn.beta, [self.tf_h.v[t]], tn.mean[t], tn.rstd[t], act='relu',
+                                       eps=EPS_IN)
                 self.tf_out.forward(self.tf_h.v[t], self.tf_raw.v[t])
                 if self.tf == 'flow':
                     K.image_warp_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], tslot, self.nk)            # apply_flows :955-965
                 else:
                     K.dna_apply_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], tslot, self.kh, self.kw, self.nk)
             # scratch image (savp_model.py:561-572): sigmoid fused into the conv epilogue, written into its mask-conv slot
-            self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
-            sn = self.scratch_norm
-            K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
-                               act='relu', eps=EPS_IN)
+            if not self.merge_heads:
+                self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
+                sn = self.scratch_norm
+                K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
+                                   act='relu', eps=EPS_IN)
             self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs],
                                      act=lib.ACT_SIGMOID)
             # masks (savp_model.py:623-646)
-            self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
-            mn = self.masks_norm
-            K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
-                               act='relu', eps=EPS_IN)
+            if not self.merge_heads:
+                self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
+                mn = self.masks_norm
+                K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
+                                   act='relu', eps=EPS_IN)
             self.masks_out.forward(maskin.v[t], self.logits.v[t])
             K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:self.hp.ngf + self.M * C], self.gen.v[t],
                             self.masks[t] if collect_masks else None, M=self.M)
@@ -382,19 +444,11 @@ class SAVPGenerator(object):
             K.composite_bwd(self.logits.v[t], maskin.v[t][..., ngf:ngf + self.M * C], self.gen.g[t], self.logits.g[t], maskin.g[t],
                             ngf, M=self.M)
             self.masks_out.backward_data(self.logits.g[t], maskin.g[t], beta=1)
-            mn = self.masks_norm
-            K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
-                               [maskin.g[t][..., 0:ngf]], self.masks_pre.g[t], mn.dgamma, mn.dbeta, act='relu', eps=EPS_IN)
-            self.masks_conv.backward_data(self.masks_pre.g[t], self.h_last.g[t], beta=0)
-            # scratch head
+            # scratch head: d(sigmoid) then the scratch_image conv's data gradient
             K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + self.Cs],
                           maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs], self.dscratch_pre[t])
             self.scratch_out.backward_data(self.dscratch_pre[t], self.scratch_h.g[t], beta=0)
-            sn = self.scratch_norm
-            K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
-                               [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
-            self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
-            # pixel transformation head
+            # pixel transformation head (everything behind its 3x3 feature conv)
             dslot = maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             if self.tf == 'cdna':
                 K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], dslot, self.dimg_cdna, self.cdna_kern.g[t], self.kh,
@@ -408,10 +462,27 @@ class SAVPGenerator(object):
                     K.dna_apply_bwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], dslot, self.tf_raw.g[t],
                                     self.dimg_cdna, self.kh, self.kw, self.nk)
                 self.tf_out.backward_data(self.tf_raw.g[t], self.tf_h.g[t], beta=0)
-                tn = self.tf_norm
-                K.instnorm_act_bwd(self.tf_pre.v[t], tn.gamma, tn.beta, self.tf_h.v[t], tn.mean[t], tn.rstd[t], [self.tf_h.g[t]],
-                                   self.tf_pre.g[t], tn.dgamma, tn.dbeta, act='relu', eps=EPS_IN)
-                self.tf_conv.backward_data(self.tf_pre.g[t], self.h_last.g[t], beta=1)
+            # the 3x3 feature convs on h_last: instance norm + conv data gradients into h_last.g
+            if self.merge_heads:
+                hn = self.heads_norm
+                dys = [self.scratch_h.g[t], maskin.g[t][..., 0:ngf]] + ([self.tf_h.g[t]] if self.tf != 'cdna' else [])
+                K.instnorm_act_bwd(self.heads_pre.v[t], hn.gamma, hn.beta, None, hn.mean[t], hn.rstd[t], dys, self.heads_pre.g[t],
+                                   hn.dgamma, hn.dbeta, act='relu', eps=EPS_IN, dy_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
+                self.heads_conv.backward_data(self.heads_pre.g[t], self.h_last.g[t], beta=0)
+            else:
+                mn = self.masks_norm
+                K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
+                                   [maskin.g[t][..., 0:ngf]], self.masks_pre.g[t], mn.dgamma, mn.dbeta, act='relu', eps=EPS_IN)
+                self.masks_conv.backward_data(self.masks_pre.g[t], self.h_last.g[t], beta=0)
+                sn = self.scratch_norm
+                K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
+                                   [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
+                self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
+                if self.tf != 'cdna':
+                    tn = self.tf_norm
+                    K.instnorm_act_bwd(self.tf_pre.v[t], tn.gamma, tn.beta, self.tf_h.v[t], tn.mean[t], tn.rstd[t], [self.tf_h.g[t]],
+                                       self.tf_pre.g[t], tn.dgamma, tn.dbeta, act='relu', eps=EPS_IN)
+                    self.tf_conv.backward_data(self.tf_pre.g[t], self.h_last.g[t], beta=1)
             # decoder / encoder ladder in reverse
             for L in reversed(self.layers):
                 f = L['f']
@@ -472,11 +543,16 @@ class SAVPGenerator(object):
             hs = self.hsmall
             self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
         else:
-            self.tf_conv.backward_weights(hl.flat(hl.v), hl.flat(self.tf_pre.g))
+            if not self.merge_heads:
+                self.tf_conv.backward_weights(hl.flat(hl.v), hl.flat(self.tf_pre.g))
             self.tf_out.backward_weights(hl.flat(self.tf_h.v), hl.flat(self.tf_raw.g))
-        self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
+        if self.merge_heads:
+            self.heads_conv.backward_weights(hl.flat(hl.v), hl.flat(self.heads_pre.g))
+            self.heads_norm.finish()
+        else:
+            self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
+            self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
         self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
-        self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
         self.masks_out.backward_weights(hl.flat(maskin.v), hl.flat(self.logits.g))
         for c in self.convs:
             c.finish_weight_grad()
