@@ -243,3 +243,63 @@ def test_checkpoint_save_restore_round_trip(tmp_path):
     ga = a.engine.generate(noise).clone()
     gb = b.engine.generate(noise)
     assert float((ga - gb).abs().max()) <= 2e-4          # same weights; the norm statistics are summed atomically (order noise, amplified by the recurrence)
+
+
+def test_plugin_functions_public_signatures_keys_and_shapes():
+    """generator_fn / posterior_fn / discriminator_fn through their reference signatures (savp_model.py:21,129,699): output keys
+    and time-major shapes of savp_model.py:109-125,157-160,735-741."""
+    from tests import gpu_model_checks as G
+    from video_prediction_amd.models import savp_model as SM
+    T, B, H, W, C = 12, 2, 64, 64, 3
+    hp = G.make_hparams(context_frames=2, sequence_length=T, nz=8, clip_length=10, video_sn_gan_weight=0.1, video_sn_vae_gan_weight=0.1)
+    images = G.synth(hp, B, H, W, C, 0).float().to('cuda:0')                      # [T,B,H,W,C]
+    inputs = {'images': images}
+    out = SM.generator_fn(inputs, 'train', hp)
+    T1, M = T - 1, 7
+    want = {'gen_images': (T1, B, H, W, C), 'gen_images_enc': (T1, B, H, W, C), 'transformed_images': (T1, B, H, W, C, M),
+            'transformed_images_enc': (T1, B, H, W, C, M), 'masks': (T1, B, H, W, 1, M), 'masks_enc': (T1, B, H, W, 1, M),
+            'zs_mu_enc': (T1, B, 8), 'zs_log_sigma_sq_enc': (T1, B, 8)}
+    for k, shp in want.items():
+        assert tuple(out[k].shape) == shp, (k, tuple(out[k].shape))
+    assert 'ground_truth_sampling_mean' in out and 'ground_truth_sampling_mean_enc' in out
+    m = out['masks'].sum(dim=-1)
+    assert float((m - 1).abs().max()) < 1e-5                                       # softmax masks
+    assert float(out['gen_images'].min()) >= 0.0 and float(out['gen_images'].max()) <= 1.0 + 1e-5      # convex combination of [0,1] layers
+    post = SM.posterior_fn(inputs, hp)
+    assert set(post) == {'zs_mu', 'zs_log_sigma_sq'} and tuple(post['zs_mu'].shape) == (T1, B, 8)
+    assert float(post['zs_log_sigma_sq'].abs().max()) <= 10.0                      # clip_by_value(-10, 10), savp_model.py:48
+    d = SM.discriminator_fn(inputs, out, 'train', hp)
+    for sfx in ('real', 'fake', 'enc_real', 'enc_fake'):
+        key = 'discrim_video_sn_logits_' + sfx
+        assert tuple(d[key].shape) == (B, 1), (key, tuple(d[key].shape))
+        for i in range(7):
+            assert 'discrim_video_sn_feature%d_%s' % (i, sfx) in d
+    assert tuple(d['discrim_video_sn_feature0_real'].shape)[:2] == (10, B)         # time-major clip features (clip_length first)
+    with pytest.raises(ValueError):
+        SM.prior_fn(inputs, hp)                                                    # learn_prior=False: no prior network
+
+
+def test_train_and_generate_scripts(tmp_path):
+    """scripts/train.py (3 steps on the synthetic dataset, checkpoint, --resume) and scripts/generate.py from that checkpoint."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    out = str(tmp_path / 'run')
+    base = [sys.executable, os.path.join(root, 'scripts', 'train.py'), '--input_dir', 'none', '--dataset', 'synthetic', '--model', 'savp',
+            '--output_dir', out, '--progress_freq', '1', '--summary_freq', '2', '--eval_summary_freq', '0', '--save_freq', '2',
+            '--dataset_hparams', 'sequence_length=12']
+    r = subprocess.run(base + ['--model_hparams', 'batch_size=2,max_steps=3'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'progress  global step 3' in r.stdout and 'g_loss' in r.stdout and 'gen_l1_loss' in r.stdout and 'learning_rate' in r.stdout
+    for f in ('options.json', 'dataset_hparams.json', 'model_hparams.json', 'summaries.jsonl', 'checkpoint', 'model-3.index'):
+        assert os.path.exists(os.path.join(out, f)), f
+    r2 = subprocess.run(base + ['--resume', '--model_hparams', 'max_steps=4'], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    assert 'progress  global step 4' in r2.stdout and os.path.exists(os.path.join(out, 'model-4.index'))
+    res = str(tmp_path / 'results')
+    g = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'generate.py'), '--input_dir', 'none', '--dataset', 'synthetic',
+                        '--checkpoint', out, '--results_dir', res, '--batch_size', '2', '--num_samples', '2', '--num_stochastic_samples', '2',
+                        '--dataset_hparams', 'sequence_length=12'], capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout[-2000:] + g.stderr[-2000:]
+    pngs = [f for f in os.listdir(os.path.join(res, 'run')) if f.endswith('.png')]
+    assert len(pngs) == 2 * 2 * 10 and 'gen_image_00001_01_09.png' in pngs          # 2 sequences x 2 samples x 10 future frames
