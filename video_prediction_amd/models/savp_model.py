@@ -117,6 +117,8 @@ class SAVPEngine(object):
         self.graph = None
         self.graph_info = None
         self.use_graph = self.train and os.environ.get('SAVP_GRAPH', '1') == '1'
+        self.side_prep = os.environ.get('SAVP_SIDE_PREP', '0') == '1' and self.device.type == 'cuda'
+        self._prep_stream = None
         self.eager_steps = 0
 
     # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
@@ -351,17 +353,37 @@ class SAVPEngine(object):
         lb = self.loss_buf
         lb.zero_()
         K.zero_arena(self.device).reset()          # one memset for every reduction workspace of the step
+        discs = self.discs
+        # The discriminators' weight preparation for the D step (spectral-norm power iteration, packs: ~110 tiny launches, ~1.3 ms)
+        # depends on nothing but the discriminator variables: it is forked onto a side stream and runs underneath the latency-bound
+        # generator forward; the D step joins it with an event.  Off by default (SAVP_SIDE_PREP=1 enables): measured 74.4 vs 74.3 ms
+        # per step -- the side stream's launches compete with the forward chain for the same CUs, like every other overlap tried.
+        d_prep_done = None
+        if discs and self.side_prep:
+            if self._prep_stream is None:
+                self._prep_stream = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self._prep_stream.wait_event(fork)
+            with torch.cuda.stream(self._prep_stream):
+                for D in {id(d['D']): d['D'] for d in discs}.values():
+                    D.prep_weights(update_u=True)
+                d_prep_done = torch.cuda.Event()
+                d_prep_done.record(self._prep_stream)
         self.prep_generator_weights()
         gen = self.forward_generator(None)
         gen_enc, gen_prior = (gen[:, :B], gen[:, B:]) if self.nz else (None, gen)
         info = OrderedDict()
-        discs = self.discs
         for d in discs:
             d['fake'] = gen_enc if d['enc'] else gen_prior
         # ---------------- discriminator step ---------------------------------------------------------------------------------
         if discs:
             store.groups['d'].zero_grad()
             prepped = set()
+            if d_prep_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(d_prep_done)        # join the side-stream preparation
+                prepped = set(id(d['D']) for d in discs)
             last_use = {id(d['D']): i for i, d in enumerate(discs)}
             for i, d in enumerate(discs):
                 D, w, slot = d['D'], d['w'], d['slot']
