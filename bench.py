@@ -195,6 +195,9 @@ def main():
     inst = convlstm_flops(engine) if not engine.use_graph else []
     for layer, _ in inst:
         layer.prof = []
+    cells = [L for L in engine.gen.layers if L['rnn']] if not engine.use_graph else []
+    for L in cells:
+        L['cell_prof'] = []
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -214,10 +217,26 @@ def main():
             launches += 1
         layer.prof = None
     achieved = tot_flops / tot_s / 1e12 if tot_s > 0 else None
+    # the fused ConvLSTM cell as a unit (gate conv with statistics epilogue + the two gate passes): HIP events around the whole cell
+    # of the timed steps.  Algorithmic bytes (read x, h, c and W once, write c', h'; fp32 activations, bf16
+    # weights in bf16 mode) and FLOPs (2*M*N*K of the gate conv) per cell launch-set, against both roofs.
+    cell_s, cell_flops, cell_bytes, cell_n = 0.0, 0.0, 0.0, 0
+    for L in cells:
+        h_, w_ = L['hw']
+        cin, f = L['a'].v.shape[-1], L['f']
+        wbytes = 25 * cin * 4 * f * (2 if args.precision == 'bf16' else 4)
+        abytes = engine.N * h_ * w_ * (cin + f + 2 * f) * 4          # x|z|h (cin) + c read, c' + h' written, fp32
+        fl = 2.0 * engine.N * h_ * w_ * (4 * f) * (25 * cin)
+        for e0, e1 in L['cell_prof']:
+            cell_s += e0.elapsed_time(e1) * 1e-3
+            cell_flops += fl
+            cell_bytes += wbytes + abytes
+            cell_n += 1
+        L['cell_prof'] = None
     # HBM traffic of the same kernel/shapes from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md); bench.py cannot collect counters itself.
     traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_convlstm_fprop_pmc_%s.json' % args.precision)
+    pmc_path = os.path.join(ROOT, 'profiles', 'r02_convlstm_cell_pmc_%s.json' % args.precision)
     if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
         try:
             traffic = json.load(open(pmc_path))['avg_hbm_bytes_per_launch_five_layers']
@@ -235,9 +254,18 @@ def main():
                    'sequences_per_s': world * args.batch * args.steps / dt},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic,
-                     'traffic_unit': 'bytes per launch, mean of the 5 layers (PMC, profiles/r01_convlstm_fprop_pmc_*.json); algorithmic 19.1 MB',
+                     'traffic_unit': 'HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
+                                     'profiles/r02_convlstm_cell_pmc_*.json); algorithmic 13.7 MB (fp32 input, bf16 weights, bf16 gates out)',
                      'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None},
+        'roofline_cell': {'what': 'fused ConvLSTM cell = gate conv (instance-norm statistics + bf16 gates in its epilogue) + cell pass + output pass, '
+                                  'five layers, HIP events around each cell of the timed steps',
+                          'avg_cell_us': (cell_s / cell_n * 1e6) if cell_n else None, 'cells_timed': cell_n,
+                          'mfma': {'achieved': (cell_flops / cell_s / 1e12) if cell_s else None, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
+                                   'frac': (cell_flops / cell_s / 1e12 / PEAK_TFLOPS[args.precision]) if cell_s else None},
+                          'hbm': {'achieved': (cell_bytes / cell_s / 1e9) if cell_s else None, 'peak': 8000.0, 'unit': 'GB/s',
+                                  'frac': (cell_bytes / cell_s / 1e9 / 8000.0) if cell_s else None,
+                                  'algorithmic_bytes_per_cell': (cell_bytes / cell_n) if cell_n else None}},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
     if rank == 0 and args.save_tuning:

@@ -48,7 +48,10 @@ def test_learned_prior_and_recurrent_encoder_vs_oracle():
     (two encoded context pairs + zero rows), then a train step (losses, per-variable gradients incl. generator/prior/*, Adam)."""
     from tests import gpu_model_checks as G
     res = G.check_generator_forward(nz=8, B=2, T=6, tag='gen_fwd_learn_prior', learn_prior=True, use_e_rnn=True, context_frames=3)
-    res += G.check_train_step(B=2, T=6, nz=8, steps=1, tag='train_learn_prior', learn_prior=True, use_e_rnn=True, nef=16)
+    # abs_floor: at initialisation the learned prior coincides with the posterior, so the posterior encoder's gradient is a small,
+    # heavily cancelling sum (it arrives through z only) -- its relative error is judged against the group's largest gradient, and
+    # the fp32 CPU yardstick itself moves by 40x between runs on such a sum (thread-order dependent)
+    res += G.check_train_step(B=2, T=6, nz=8, steps=1, tag='train_learn_prior', abs_floor=5e-4, learn_prior=True, use_e_rnn=True, nef=16)
     _assert_ok(res)
 
 

@@ -368,6 +368,10 @@ class SAVPGenerator(object):
                     stats1 = s1 = None
                     if L['fused']:
                         stats1, s1 = K.lstm_stats_ws(self.dev, N, f)
+                    cp = L.get('cell_prof')                  # bench.py: HIP events around the whole cell (gate conv + gate passes)
+                    if cp is not None:
+                        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ce0.record()
                     L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                     outs = self._out_views(L, t)
                     if t + 1 < T1:
@@ -376,6 +380,9 @@ class SAVPGenerator(object):
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
                                          eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
+                    if cp is not None:
+                        ce1.record()
+                        cp.append((ce0, ce1))
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
