@@ -193,16 +193,26 @@ def main():
     for _ in range(args.warmup):
         engine.train_step()
     inst = convlstm_flops(engine) if not engine.use_graph else []
-    for layer, _ in inst:
-        layer.prof = []
     cells = [L for L in engine.gen.layers if L['rnn']] if not engine.use_graph else []
-    for L in cells:
-        L['cell_prof'] = []
+    # HIP events around the instrumented launches on every INST_EVERY-th timed step (4 events per ConvLSTM cell and timestep: on
+    # every step they cost ~1 ms of a 73 ms step in host time and launch gaps)
+    INST_EVERY = 8
+    prof_lists = {id(layer): [] for layer, _ in inst}
+    cell_lists = {id(L): [] for L in cells}
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        on = (it % INST_EVERY == 0)
+        for layer, _ in inst:
+            layer.prof = prof_lists[id(layer)] if on else None
+        for L in cells:
+            L['cell_prof'] = cell_lists[id(L)] if on else None
         info = engine.train_step()
     sync()
+    for layer, _ in inst:
+        layer.prof = prof_lists[id(layer)]
+    for L in cells:
+        L['cell_prof'] = cell_lists[id(L)]
     dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
