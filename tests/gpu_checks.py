@@ -686,6 +686,7 @@ def check_weight_prep(seed=7):
     K.fold_bilinear(dev(g), dw, 3, 10, 6, adjoint=True)
     out.append(('fold_bilinear_adj', rel_err(dw, w.grad), 1e-6))
     # spectral norm
+    batch = []
     for shape in [(3, 3, 3, 16, 32), (4, 4, 4, 8, 16), (640, 1), (4, 4, 4, 16, 128), (3, 3, 3, 8, 24), (2, 2, 5, 256)]:
         W = (rnd(rng, *shape) * 0.05).requires_grad_(True)
         C = shape[-1]
@@ -705,6 +706,16 @@ def check_weight_prep(seed=7):
         dW = torch.empty(shape, device=DEV)
         K.sn_bwd(Wd, ud, ws, dev(G), dW)
         out.append((tag + '/dW', rel_err(dW, W.grad), 1e-4))
+        batch.append(dict(W=Wd, u=ud, ws=torch.zeros_like(ws), u_new=torch.empty(C, device=DEV), G=dev(G), dW=torch.zeros(shape, device=DEV), beta=1,
+                          ref=(sigma_ref.reshape(1), u_fin.detach().reshape(C), W.grad), tag=tag))
+    # the batched entries (all six tensors in 4 launches each way) against the same oracle values; beta = 1 accumulates into dW
+    K.sn_fwd_batch(batch)
+    K.sn_bwd_batch(batch)
+    K.sn_bwd_batch(batch)
+    for e in batch:
+        out.append((e['tag'] + '/batch_sigma', rel_err(e['ws'][0:1], e['ref'][0]), 1e-5))
+        out.append((e['tag'] + '/batch_u_final', rel_err(e['u_new'], e['ref'][1]), 1e-5))
+        out.append((e['tag'] + '/batch_dW_twice', rel_err(e['dW'], 2 * e['ref'][2]), 1e-4))
     torch.cuda.synchronize()
     return out
 

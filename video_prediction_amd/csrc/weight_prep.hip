@@ -153,12 +153,11 @@ extern "C" int savp_fold_bilinear(void* stream, const float* in, float* out, int
 #define SN_EPS 1e-12f
 
 // y[k] = sum_c W[k,c] x[c]; one wave per row; optionally accumulates sum_k y[k]^2 into *sq and sum_k y[k]*z[k] into *dotz
-__global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                          float xscale, float* __restrict__ y, float* sq, const float* z,
-                                                          float* dotz) {
+__device__ __forceinline__ void sn_rows_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                             float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sqacc = 0.f, dzacc = 0.f;
-    for (long long k = blockIdx.x * 4LL + wave; k < K; k += (long long)gridDim.x * 4) {
+    for (long long k = bx * 4LL + wave; k < K; k += (long long)gx * 4) {
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += W[k * C + c] * x[c];
         s = wsum(s) * xscale;
@@ -174,19 +173,24 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                          float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                          float* dotz) {
+    sn_rows_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
+}
+
 // Same product for C = 4 * LPR with LPR a power of two <= 64 (every spectrally normalised conv of the model: 32..256 output
 // channels): LPR lanes x float4 cover one row, a wave covers 64/LPR consecutive rows per pass = 1 KB of contiguous memory,
 // two passes in flight.  (The one-element-per-lane kernel above spends its time in shuffles and exposed load latency.)
-__global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                              float xscale, float* __restrict__ y, float* sq, const float* z,
-                                                              float* dotz) {
+__device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                 float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpr = C >> 2, rpw = 64 / lpr;
     const int c4 = lane & (lpr - 1), sub = lane / lpr;
     const float4 xv = *reinterpret_cast<const float4*>(x + c4 * 4);
     float sqacc = 0.f, dzacc = 0.f;
-    const long long stride = (long long)gridDim.x * 4 * rpw;
-    for (long long k0 = ((long long)blockIdx.x * 4 + wave) * rpw; k0 < K; k0 += 2 * stride) {
+    const long long stride = (long long)gx * 4 * rpw;
+    for (long long k0 = ((long long)bx * 4 + wave) * rpw; k0 < K; k0 += 2 * stride) {
         const long long ka = k0 + sub, kb = k0 + stride + sub;
         float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
         if (ka < K) wa = *reinterpret_cast<const float4*>(W + ka * C + c4 * 4);
@@ -207,18 +211,23 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                              float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                              float* dotz) {
+    sn_rows_vec_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
+}
+
 static bool sn_vec_ok(const float* W, const float* x, int C) {
     const int lpr = C >> 2;
     return (C % 4 == 0) && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ((((uintptr_t)W) | ((uintptr_t)x)) & 15) == 0;
 }
 
 // narrow matrices (C <= 16, e.g. the discriminators' final linear [65536, 1]): one THREAD per row
-__global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                                 float xscale, float* __restrict__ y, float* sq, const float* z,
-                                                                 float* dotz) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                    float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx,
+                                                    float* sh) {
     float sqacc = 0.f, dzacc = 0.f;
-    for (long long k = blockIdx.x * (long long)NT + threadIdx.x; k < K; k += (long long)gridDim.x * NT) {
+    for (long long k = bx * (long long)NT + threadIdx.x; k < K; k += (long long)gx * NT) {
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += W[k * C + c] * x[c];
         s *= xscale;
@@ -234,10 +243,17 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __
     }
 }
 
+__global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                                 float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                                 float* dotz) {
+    __shared__ float sh[4];
+    sn_rows_narrow_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x, sh);
+}
+
 // y[c] += sum_k W[k,c] x[k]   (atomic; y zeroed by the caller)
-__global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                          float* __restrict__ y, int rows_per_block) {
-    const long long k0 = (long long)blockIdx.x * rows_per_block;
+__device__ __forceinline__ void sn_cols_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                             float* __restrict__ y, int rows_per_block, int bx) {
+    const long long k0 = (long long)bx * rows_per_block;
     const long long k1 = min(K, k0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += NT) {
         float s = 0.f;
@@ -246,14 +262,18 @@ __global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                          float* __restrict__ y, int rows_per_block) {
+    sn_cols_body(W, K, C, x, y, rows_per_block, blockIdx.x);
+}
+
 // vectorised variant (C = 4 * LPR, LPR a power of two <= 64): thread = (column quad, row slot), float4 loads of full rows,
 // LDS reduction over the row slots, one atomic per column and block
-__global__ __launch_bounds__(NT) void sn_gemv_cols_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                              float* __restrict__ y, int rows_per_block) {
-    __shared__ float4 sh[NT];
+__device__ __forceinline__ void sn_cols_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                 float* __restrict__ y, int rows_per_block, int bx, float4* sh) {
     const int lpr = C >> 2, slots = NT / lpr;
     const int c4 = threadIdx.x & (lpr - 1), sub = threadIdx.x / lpr;
-    const long long k0 = (long long)blockIdx.x * rows_per_block;
+    const long long k0 = (long long)bx * rows_per_block;
     const long long k1 = min(K, k0 + rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long k = k0 + sub; k < k1; k += slots) {
@@ -271,9 +291,14 @@ __global__ __launch_bounds__(NT) void sn_gemv_cols_vec_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(NT) void sn_gemv_cols_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                              float* __restrict__ y, int rows_per_block) {
+    __shared__ float4 sh[NT];
+    sn_cols_vec_body(W, K, C, x, y, rows_per_block, blockIdx.x, sh);
+}
+
 // single workgroup: finish the forward scalars. bt = W^T a (unnormalised)
-__global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, int C, float* u_new) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void sn_finalize_body(float* ws, int C, float* u_new, float* sh) {
     const float na = sqrtf(ws[7]);
     const float s = na + SN_EPS;
     float* b = ws + 8;
@@ -288,6 +313,11 @@ __global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, int C, float
         ws[0] = sigma; ws[1] = 1.f / sigma; ws[2] = na; ws[3] = nb;
         ws[4] = (nb + 2.f * SN_EPS) / ((nb + SN_EPS) * (nb + SN_EPS));   // kappa: dsigma/db = kappa*b
     }
+}
+
+__global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, int C, float* u_new) {
+    __shared__ float sh[4];
+    sn_finalize_body(ws, C, u_new, sh);
 }
 
 extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, float* u_new) {
@@ -388,5 +418,145 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
                            (float*)nullptr, (const float*)a, ws + 6);
     }
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nb), dim3(NT), 0, st, G, (long long)K, C, u, (const float*)ws, dW, beta);
+    return LAUNCH_OK();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched spectral norm: the same arithmetic for up to SN_MAXB weight tensors per launch (blockIdx.y = tensor).  One discriminator
+// has 8 spectrally normalised layers, each needing memset + 3 launches forward and memset + 3 backward, twice per step for the
+// forward: ~190 launches of 5-20 us per train step for tensors of a few MB.  The batch entries run the 8 layers of a discriminator
+// in 4 launches each way; a layer's blocks beyond what its size needs exit immediately.
+// ---------------------------------------------------------------------------------------------------------------
+#define SN_MAXB 16
+struct SnB { const float* W; long long K; int C; const float* u; float* ws; float* u_new; const float* G; float* dW; int beta; int vec; };
+struct SnBatch { int n; SnB it[SN_MAXB]; };
+
+__global__ __launch_bounds__(NT) void snb_zero_kernel(SnBatch b, int off, int count_plus_c) {
+    const SnB& t = b.it[blockIdx.y];
+    const int n = count_plus_c < 0 ? -count_plus_c : count_plus_c + t.C;          // negative: fixed count; else count + C floats
+    for (int i = threadIdx.x; i < n; i += NT) t.ws[off + i] = 0.f;
+}
+
+// phase 0: a = W u (+ |a|^2 -> ws[7]);  phase 1 (backward): wb = W b (+ a . wb -> ws[6])
+__global__ __launch_bounds__(NT) void snb_rows_kernel(SnBatch b, int phase) {
+    __shared__ float sh[4];
+    const SnB& t = b.it[blockIdx.y];
+    float* a = t.ws + 8 + 2 * t.C;
+    const float* x = phase == 0 ? t.u : (const float*)(t.ws + 8);
+    float* y = phase == 0 ? a : a + t.K;
+    float* sq = phase == 0 ? t.ws + 7 : nullptr;
+    const float* z = phase == 0 ? nullptr : (const float*)a;
+    float* dotz = phase == 0 ? nullptr : t.ws + 6;
+    if (t.C <= 16) {
+        const int need = (int)min((t.K + NT - 1) / NT, 1024ll);
+        if ((int)blockIdx.x >= need) return;
+        sn_rows_narrow_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need, sh);
+    } else if (t.vec) {
+        const int rp = (256 / (t.C >> 2)) * 2;
+        const int need = (int)min((t.K + rp - 1) / rp, 1024ll);
+        if ((int)blockIdx.x >= need) return;
+        sn_rows_vec_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need);
+    } else {
+        const int need = (int)min((t.K + 3) / 4, 1024ll);
+        if ((int)blockIdx.x >= need) return;
+        sn_rows_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need);
+    }
+}
+
+// b = W^T a  (ws + 8, zeroed before)
+__global__ __launch_bounds__(NT) void snb_cols_kernel(SnBatch b) {
+    __shared__ float4 sh[NT];
+    const SnB& t = b.it[blockIdx.y];
+    const float* a = t.ws + 8 + 2 * t.C;
+    if (t.vec) {
+        int rpb = (int)((t.K + 511) / 512);
+        const int slots = NT / (t.C >> 2);
+        if (rpb < 4 * slots) rpb = 4 * slots;
+        if ((long long)blockIdx.x * rpb >= t.K) return;
+        sn_cols_vec_body(t.W, t.K, t.C, a, t.ws + 8, rpb, blockIdx.x, sh);
+    } else {
+        const int rpb = (int)max(64ll, (t.K + 511) / 512);
+        if ((long long)blockIdx.x * rpb >= t.K) return;
+        sn_cols_body(t.W, t.K, t.C, a, t.ws + 8, rpb, blockIdx.x);
+    }
+}
+
+__global__ __launch_bounds__(NT) void snb_finalize_kernel(SnBatch b) {
+    __shared__ float sh[4];
+    const SnB& t = b.it[blockIdx.y];
+    sn_finalize_body(t.ws, t.C, t.u_new, sh);
+}
+
+__global__ __launch_bounds__(NT) void snb_dot_kernel(SnBatch b) {
+    __shared__ float sh[4];
+    const SnB& t = b.it[blockIdx.y];
+    const long long n = t.K * t.C;
+    if ((long long)blockIdx.x * NT >= n) return;
+    float acc = 0.f;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) acc += t.G[i] * t.W[i];
+    const float s = block_sum1(acc, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(t.ws + 5, s);
+}
+
+__global__ __launch_bounds__(NT) void snb_apply_kernel(SnBatch b) {
+    const SnB& t = b.it[blockIdx.y];
+    const float* ws = t.ws;
+    const long long K = t.K;
+    const int C = t.C;
+    const long long total = K * C;
+    if ((long long)blockIdx.x * NT >= total) return;
+    const float sigma = ws[0], na = ws[2], kappa = ws[4];
+    const float s = na + SN_EPS;
+    const float alpha = -ws[5] / (sigma * sigma);
+    const float adotgv = ws[6] * kappa;
+    const float* bv = ws + 8;
+    const float* a = ws + 8 + 2 * C;
+    const float* wb = a + K;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const long long k = i / C;
+        const int c = (int)(i % C);
+        const float ak = a[k];
+        const float gvk = kappa * wb[k];
+        const float gak = gvk / s - (na > 0.f ? ak * adotgv / (na * s * s) : 0.f);
+        const float v = t.G[i] / sigma + alpha * (kappa * (ak / s) * bv[c] + gak * t.u[c]);
+        t.dW[i] = t.beta ? t.dW[i] + v : v;
+    }
+}
+
+static int snb_fill(SnBatch& b, int32_t n, const SavpSnItem* items, bool bwd) {
+    if (!items || n < 1 || n > SN_MAXB) return SAVP_EINVAL;
+    b.n = n;
+    for (int i = 0; i < n; ++i) {
+        const SavpSnItem& s = items[i];
+        if (!s.W || !s.u || !s.ws || s.K < 1 || s.C < 1 || (bwd && (!s.G || !s.dW))) return SAVP_EINVAL;
+        SnB& t = b.it[i];
+        t.W = s.W; t.K = s.K; t.C = s.C; t.u = s.u; t.ws = s.ws; t.u_new = s.u_new; t.G = s.G; t.dW = s.dW; t.beta = s.beta;
+        t.vec = (s.C > 16 && sn_vec_ok(s.W, s.u, s.C) && sn_vec_ok(s.W, s.ws + 8, s.C)) ? 1 : 0;
+    }
+    return SAVP_OK;
+}
+
+extern "C" int savp_sn_fwd_batch(void* stream, int32_t n, const SavpSnItem* items) {
+    SnBatch b;
+    int rc = snb_fill(b, n, items, false);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(snb_zero_kernel, dim3(1, n), dim3(NT), 0, st, b, 0, 8);            // ws[0 .. 8 + C)
+    hipLaunchKernelGGL(snb_rows_kernel, dim3(1024, n), dim3(NT), 0, st, b, 0);
+    hipLaunchKernelGGL(snb_cols_kernel, dim3(512, n), dim3(NT), 0, st, b);
+    hipLaunchKernelGGL(snb_finalize_kernel, dim3(1, n), dim3(NT), 0, st, b);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_sn_bwd_batch(void* stream, int32_t n, const SavpSnItem* items) {
+    SnBatch b;
+    int rc = snb_fill(b, n, items, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(snb_zero_kernel, dim3(1, n), dim3(NT), 0, st, b, 5, -2);           // ws[5], ws[6]
+    hipLaunchKernelGGL(snb_dot_kernel, dim3(1024, n), dim3(NT), 0, st, b);
+    hipLaunchKernelGGL(snb_rows_kernel, dim3(1024, n), dim3(NT), 0, st, b, 1);
+    hipLaunchKernelGGL(snb_apply_kernel, dim3(2048, n), dim3(NT), 0, st, b);
     return LAUNCH_OK();
 }

@@ -251,7 +251,14 @@ class ConvLayer(object):
         self.prof = None          # list of (start, end) events when bench.py instruments this layer's forward launches
 
     # -- weight preparation ---------------------------------------------------------------------------------
-    def prep(self, update_u=False):
+    def sn_entry(self, update_u=False):
+        """Arguments of this layer's spectral-norm forward for kernels.sn_fwd_batch (prep(..., sn_done=True) then skips its own)."""
+        return {'W': self.W, 'u': self.u.reshape(-1), 'ws': self.sn_ws, 'u_new': self.u_next.reshape(-1) if update_u else None}
+
+    def sn_bwd_entry(self):
+        return {'W': self.W, 'u': self.u.reshape(-1), 'ws': self.sn_ws, 'G': self.dwf, 'dW': self.dW, 'beta': 1}
+
+    def prep(self, update_u=False, sn_done=False):
         scale = None
         if self.kind == 'pool':
             K.fold_pool(self.W, self.wf, self.W.shape[0])
@@ -259,7 +266,8 @@ class ConvLayer(object):
             k, _, cin, f = self.W.shape
             K.fold_bilinear(self.W, self.wf, k, cin, f)
         if self.sn_u_name:
-            K.sn_fwd(self.W, self.u.reshape(-1), self.sn_ws, self.u_next.reshape(-1) if update_u else None)
+            if not sn_done:
+                K.sn_fwd(self.W, self.u.reshape(-1), self.sn_ws, self.u_next.reshape(-1) if update_u else None)
             scale = self.sn_ws[1:2]
         src = self.wf
         if self.padded:
@@ -313,7 +321,7 @@ class ConvLayer(object):
         else:       # bias gradient = column sums of dy: fused into the WGRAD pass (include/savp_hip.h, SavpConvArgs.bias)
             K.conv(lib.CONV_WGRAD, self.geom, x, dy, target, bias=self.dbias)
 
-    def finish_weight_grad(self):
+    def finish_weight_grad(self, sn_done=False):
         """Map the folded / spectrally-normalised kernel gradient back to the master variable and clear it."""
         if self.padded:
             copy_view(self.dwfp[:, :self.cx0, :self.cy0], [self.dw_tmp])
@@ -326,7 +334,8 @@ class ConvLayer(object):
         if self.dwf is None:
             return
         if self.sn_u_name:
-            K.sn_bwd(self.W, self.u.reshape(-1), self.sn_ws, self.dwf, self.dW, beta=1)
+            if not sn_done:
+                K.sn_bwd(self.W, self.u.reshape(-1), self.sn_ws, self.dwf, self.dW, beta=1)
         elif self.kind == 'pool':
             K.fold_pool(self.dwf, self.dW, self.W.shape[0], adjoint=True)
         elif self.kind == 'up':

@@ -636,6 +636,35 @@ def sn_fwd(W, u, ws, u_new=None):
     lib.check(_L().savp_sn_fwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(u_new)), 'savp_sn_fwd')
 
 
+def _sn_items(entries, bwd):
+    arr = (lib.SavpSnItem * len(entries))()
+    for i, e in enumerate(entries):
+        W = e['W']
+        C = W.shape[-1]
+        arr[i].W, arr[i].K, arr[i].C = W.data_ptr(), W.numel() // C, C
+        arr[i].u, arr[i].ws = e['u'].data_ptr(), e['ws'].data_ptr()
+        arr[i].u_new = e['u_new'].data_ptr() if e.get('u_new') is not None else None
+        if bwd:
+            arr[i].G, arr[i].dW, arr[i].beta = e['G'].data_ptr(), e['dW'].data_ptr(), int(e.get('beta', 0))
+    return arr
+
+
+def sn_fwd_batch(entries):
+    """entries: [{'W', 'u', 'ws', 'u_new' (optional)}] -- savp_sn_fwd for up to 16 tensors in 4 launches."""
+    for lo in range(0, len(entries), 16):
+        part = entries[lo:lo + 16]
+        arr = _sn_items(part, False)
+        lib.check(_L().savp_sn_fwd_batch(lib.stream(), len(part), arr), 'savp_sn_fwd_batch')
+
+
+def sn_bwd_batch(entries):
+    """entries: [{'W', 'u', 'ws', 'G', 'dW', 'beta'}] -- savp_sn_bwd for up to 16 tensors in 4 launches."""
+    for lo in range(0, len(entries), 16):
+        part = entries[lo:lo + 16]
+        arr = _sn_items(part, True)
+        lib.check(_L().savp_sn_bwd_batch(lib.stream(), len(part), arr), 'savp_sn_bwd_batch')
+
+
 def sn_bwd(W, u, ws, G, dW, beta=0):
     C = W.shape[-1]
     K = W.numel() // C

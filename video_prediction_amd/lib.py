@@ -199,6 +199,13 @@ register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, 
 register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
 register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
+class SavpSnItem(ctypes.Structure):
+    _fields_ = [('W', c_vp), ('K', c_i64), ('C', c_i32), ('u', c_vp), ('ws', c_vp), ('u_new', c_vp), ('G', c_vp), ('dW', c_vp),
+                ('beta', c_i32)]
+
+
+register('savp_sn_fwd_batch', [c_vp, c_i32, ctypes.POINTER(SavpSnItem)])
+register('savp_sn_bwd_batch', [c_vp, c_i32, ctypes.POINTER(SavpSnItem)])
 register('savp_sn_fwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp])
 register('savp_sn_bwd', [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32])
 register('savp_dense_fwd', [c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64])

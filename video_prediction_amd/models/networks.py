@@ -3,6 +3,8 @@
 Mirrors /root/reference/video_prediction/models/networks.py (encoder :12-32, video_sn_discriminator :72-108) and
 the wiring around them in savp_model.py (posterior_fn :21-51, discriminator_given_video_fn :88-126).
 """
+import os
+
 import torch
 
 from .. import kernels as K
@@ -231,8 +233,12 @@ class SNDiscriminator(object):
         self.convs = [L['conv'] for L in self.layers] + [self.fc]
 
     def prep_weights(self, update_u=False):
+        """Spectral norm of all layers in one batched call (4 launches for the 8 layers), then the per-layer packs."""
+        batch = os.environ.get('SAVP_SN_BATCH', '1') == '1'
+        if batch:
+            K.sn_fwd_batch([c.sn_entry(update_u) for c in self.convs])
         for c in self.convs:
-            c.prep(update_u=update_u)
+            c.prep(update_u=update_u, sn_done=batch)
 
     def commit_u(self):
         for c in self.convs:
@@ -276,8 +282,11 @@ class SNDiscriminator(object):
                 L['conv'].backward_weights(L['x'][lo:hi], dpre)
 
     def finish_weight_grads(self):
+        batch = os.environ.get('SAVP_SN_BATCH', '1') == '1'
+        if batch:
+            K.sn_bwd_batch([c.sn_bwd_entry() for c in self.convs])
         for c in self.convs:
-            c.finish_weight_grad()
+            c.finish_weight_grad(sn_done=batch)
 
 
 VideoDiscriminator = SNDiscriminator
