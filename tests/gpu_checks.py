@@ -398,6 +398,12 @@ def check_util(seed=4):
     o2 = torch.zeros(R, C, device=DEV)
     K.colsum(dev(x)[..., 8:16], o2, per_row=True)
     out.append(('colsum_rows', rel_err(o2, x[..., 8:16].sum(dim=(1, 2))), 1e-5))
+    # narrow-slice kernel: 16- / 8- / 4-byte aligned slices (float4 / float2 / scalar lanes), several pixel chunks per row
+    xw = rnd(rng, 5, 33, 40, 30)
+    for (lo, cc) in ((8, 8), (6, 8), (3, 4), (12, 16), (5, 1), (10, 2)):
+        ow = torch.zeros(5, cc, device=DEV)
+        K.colsum(dev(xw)[..., lo:lo + cc], ow, per_row=True, scale=0.5)
+        out.append(('colsum_rows_narrow_c%d_off%d' % (cc, lo), rel_err(ow, 0.5 * xw[..., lo:lo + cc].sum(dim=(1, 2))), 1e-5))
     x200 = rnd(rng, 3, 5, 7, 200)
     o3 = torch.zeros(200, device=DEV)
     K.colsum(dev(x200), o3)
