@@ -23,6 +23,17 @@ extern "C" {
 /* library / build info: returns a static string "savp_hip <version> gfx950" */
 const char* savp_version(void);
 
+/* Measurement aid (bench.py's roofline leg; no reference counterpart): time ONE kernel by itself.  savp_prof_arm hands an event
+ * pair to the next LDS-ring convolution launch of the calling thread (savp_conv, bf16 datapath); that launch stamps the events
+ * with the dispatch's own begin / end -- the duration rocprofv3's kernel trace reports -- and disarms.  savp_prof_armed() == 1
+ * afterwards means the convolution took another kernel and the pair is still waiting (disarm with savp_prof_arm(NULL, NULL)).
+ * savp_prof_elapsed_us needs both events complete (synchronise the stream first). */
+int savp_prof_event_create(void** ev);
+int savp_prof_event_destroy(void* ev);
+int savp_prof_arm(void* start, void* stop);
+int savp_prof_armed(void);
+int savp_prof_elapsed_us(void* start, void* stop, float* us);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), 2-D and 3-D, NHWC / NDHWC.
  *
@@ -251,6 +262,14 @@ int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, co
 /* wt_bf16 / wd_bf16: optional bf16 copies (same layouts) consumed by savp_conv in SAVP_PREC_BF16 mode */
 int savp_pack_weights(void* stream, const float* src, int64_t T, int32_t Cx, int32_t Cy, const float* scale, float* wt, float* wd,
                       void* wt_bf16, void* wd_bf16);
+
+/* The same for up to 32 layers in one launch (a network's layers after their optimiser step).  items is a HOST array. */
+typedef struct {
+    const float* src; const float* scale;          /* as savp_pack_weights; scale may be NULL */
+    float* wt; float* wd; void* wt_bf16; void* wd_bf16;
+    int64_t T; int32_t Cx, Cy;
+} SavpPackItem;
+int savp_pack_weights_batch(void* stream, int32_t n, const SavpPackItem* items);
 int savp_fold_pool(void* stream, const float* in, float* out, int32_t k, int64_t C, int32_t adjoint);
 int savp_fold_bilinear(void* stream, const float* in, float* out, int32_t k, int32_t Cin, int32_t F, int32_t adjoint);
 /* ws: 8 + 2C + 2K floats; after fwd ws[0]=sigma, ws[1]=1/sigma; u_new receives u_final */

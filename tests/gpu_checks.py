@@ -79,6 +79,10 @@ CONV_CASES = [
     ('s2_odd3', 3, (1, 13, 10), 24, 40, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1)),
     ('s2_odd5', 2, (1, 21, 18), 40, 24, (1, 5, 5), (1, 2, 2), (0, 2, 2), (0, 2, 2)),
     ('up6x6s2', 2, (1, 32, 32), 32, 72, (1, 6, 6), (1, 2, 2), (0, 2, 2), (0, 2, 2)),
+    # RGB / grey first layers of the discriminators (csrc/conv_thin.hip in bf16 mode): several column tiles, ragged edges, 2-D
+    ('thin_rgb_w72', 2, (4, 24, 72), 3, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    ('thin_grey_2d', 3, (1, 20, 40), 1, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1)),
+    ('thin_c4_odd', 1, (3, 9, 33), 4, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
 ]
 
 
@@ -668,6 +672,22 @@ def check_weight_prep(seed=7):
     K.pack_weights(dev(w), wt, wd, scale=dev(sc))
     out.append(('pack/wt', rel_err(wt, pack_wt(w) * 0.37), 1e-6))
     out.append(('pack/wd', rel_err(wd, pack_wd(w) * 0.37), 1e-6))
+    # batched pack of several layers == the single-layer packs, bit for bit (fp32 and bf16 copies, optional outputs / scale)
+    w2 = rnd(rng, 5, 5, 7, 32)
+    w3 = rnd(rng, 1, 64, 10)
+    wt_b, wd_b = torch.empty_like(wt), torch.empty_like(wd)
+    wt2, wt2_16 = torch.empty(32, 25 * 7, device=DEV), torch.empty(32, 25 * 7, device=DEV, dtype=torch.bfloat16)
+    wd3, wd3_16 = torch.empty(64, 10, device=DEV), torch.empty(64, 10, device=DEV, dtype=torch.bfloat16)
+    K.pack_weights_batch([{'src': dev(w), 'wt': wt_b, 'wd': wd_b, 'scale': dev(sc)},
+                          {'src': dev(w2), 'wt': wt2, 'wt16': wt2_16},
+                          {'src': dev(w3), 'wd': wd3, 'wd16': wd3_16, 'scale': dev(sc)}])
+    r2, r2_16 = torch.empty_like(wt2), torch.empty_like(wt2_16)
+    r3, r3_16 = torch.empty_like(wd3), torch.empty_like(wd3_16)
+    K.pack_weights(dev(w2), r2, None, wt16=r2_16)
+    K.pack_weights(dev(w3), None, r3, scale=dev(sc), wd16=r3_16)
+    same = bool((wt_b == wt).all() and (wd_b == wd).all() and (wt2 == r2).all() and (wt2_16 == r2_16).all() and
+                (wd3 == r3).all() and (wd3_16 == r3_16).all())
+    out.append(('pack_batch/bit_exact', 0.0 if same else 1.0, 0.5))
     # fold_pool + adjoint
     for k in (5, 3):
         w = rnd(rng, k, k, 6, 8).requires_grad_(True)
@@ -783,6 +803,37 @@ def check_conv_bf16():
                                                    0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721, 0x722))
     # 0x2xx: LDS patch kernel (0x6xx: 8 waves), 0x1xx: generic, 0x3xx / 0x7xx: LDS-DMA ring kernel (4 / 8 waves)
     return [('bf16/' + n, e, t) for (n, e, t) in res]
+
+
+def check_conv_thin(seed=23):
+    """conv_thin.hip beyond the plain cases of CONV_CASES: fused bias + LeakyReLU into a channel slice of a wider buffer, and
+    WGRAD accumulating into non-zero dW / db (the `+=` contract of SAVP_CONV_WGRAD)."""
+    out = []
+    rng = np.random.default_rng(seed)
+    N, dhw, Cx, Cy, k = 2, (3, 18, 70), 3, 32, (3, 3, 3)
+    x, w, b = rnd(rng, N, *dhw, Cx), rnd(rng, *k, Cx, Cy) * 0.2, rnd(rng, Cy)
+    y = torch.nn.functional.leaky_relu(_ref_conv(x, w, k, (1, 1, 1), (1, 1, 1), (1, 1, 1)) + b, 0.2)
+    geom = K.ConvGeom(k, (1, 1, 1), (1, 1, 1))
+    wide = torch.full((N,) + dhw + (48,), 7.0, device=DEV)
+    K.conv(lib.CONV_FPROP, geom, dev(x), wide[..., 8:40], dev(pack_wt(w)), bias=dev(b), act=lib.ACT_LRELU, alpha=0.2, precision=1)
+    out.append(('thin/fprop_lrelu_slice', rel_err(wide[..., 8:40], y), 1e-2))
+    untouched = bool((wide[..., :8] == 7.0).all() and (wide[..., 40:] == 7.0).all())
+    out.append(('thin/fprop_slice_untouched', 0.0 if untouched else 1.0, 0.5))
+    dy = rnd(rng, N, *dhw, Cy)
+    dw0, db0 = rnd(rng, *k, Cx, Cy), rnd(rng, Cy)
+    dwd, dbd = dev(dw0), dev(db0)
+    K.conv(lib.CONV_WGRAD, geom, dev(x), dev(dy), dwd, bias=dbd, precision=1)
+    xp = torch.nn.functional.pad(x.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 1, 1))
+    ref_dw = torch.zeros(*k, Cx, Cy, dtype=torch.float64)
+    for a in range(3):
+        for u in range(3):
+            for v in range(3):
+                xs = xp[:, :, a:a + dhw[0], u:u + dhw[1], v:v + dhw[2]]           # [N, Cx, D, H, W]
+                ref_dw[a, u, v] = torch.einsum('ncdhw,ndhwo->co', xs, dy)
+    out.append(('thin/wgrad_accumulates', rel_err(dwd, dw0 + ref_dw), 1e-2))
+    out.append(('thin/wgrad_bias_accumulates', rel_err(dbd, db0 + dy.sum(dim=(0, 1, 2, 3))), TOL_OP))
+    torch.cuda.synchronize()
+    return out
 
 
 def check_conv_cell(seed=21):

@@ -61,6 +61,11 @@ def test_conv_bf16_mode():
     _run(gpu_checks.check_conv_bf16)
 
 
+def test_conv_thin_rgb_first_layer():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv_thin)
+
+
 def test_fused_convlstm_cell_bf16():
     from tests import gpu_checks
     _run(gpu_checks.check_conv_cell)

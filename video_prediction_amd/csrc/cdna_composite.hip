@@ -29,55 +29,66 @@ __device__ __forceinline__ float ident_at(int u, int v, int kh, int kw) {
     return fu * fv;
 }
 
-// raw [N, kh*kw*K] (index (u*kw+v)*K + k) -> normalised kern, same layout.  one thread per (n, k)
-__global__ void cdna_kernels_fwd_kernel(const float* __restrict__ raw, float* __restrict__ kern, int N, int kh, int kw, int K) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * K) return;
-    int n = i / K, k = i % K;
-    const float* r = raw + (long long)n * kh * kw * K + k;
-    float* o = kern + (long long)n * kh * kw * K + k;
+// raw [N, kh*kw*K] (index (u*kw+v)*K + k) -> normalised kern, same layout.  One workgroup per sample, one thread per
+// (tap, k) element (kh*kw*K <= 512): every element is loaded once, all loads in flight together; the per-k sums over the taps go
+// through LDS.  (The first version walked the taps serially in one thread per (n, k): 75 dependent loads, 11 / 23 us for 3 KB.)
+#define CK_NT 512
+__device__ __forceinline__ float cdna_tap_sum(float* sh, float v, int e, int taps, int K, bool live) {
+    // sum over the taps of v for this thread's k; sh [taps*K] scratch, result broadcast to every thread of the same k
+    if (live) sh[e] = v;
+    __syncthreads();
     float s = 0.f;
-    for (int t = 0; t < kh * kw; ++t) {
-        float v = fmaxf(r[t * K] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT, 0.f) + RELU_SHIFT;
-        s += v;
+    if (live) {
+        const int k = e % K;
+        for (int t = 0; t < taps; ++t) s += sh[t * K + k];
     }
-    float inv = 1.f / s;
-    for (int t = 0; t < kh * kw; ++t) {
-        float v = fmaxf(r[t * K] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT, 0.f) + RELU_SHIFT;
-        o[t * K] = v * inv;
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(CK_NT) void cdna_kernels_fwd_kernel(const float* __restrict__ raw, float* __restrict__ kern, int kh, int kw, int K) {
+    __shared__ float sh[CK_NT];
+    const int n = blockIdx.x, e = threadIdx.x, taps = kh * kw;
+    const bool live = e < taps * K;
+    const long long base = (long long)n * taps * K;
+    float v = 0.f;
+    if (live) {
+        const int t = e / K;
+        v = fmaxf(raw[base + e] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT, 0.f) + RELU_SHIFT;
     }
+    const float s = cdna_tap_sum(sh, v, e, taps, K, live);
+    if (live) kern[base + e] = v * (1.f / s);
 }
 
 // draw = ((dkern - sum(dkern*kern)) / s) * [raw + ident - shift > 0]
-__global__ void cdna_kernels_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ dkern, float* __restrict__ draw,
-                                        int N, int kh, int kw, int K) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * K) return;
-    int n = i / K, k = i % K;
-    const long long base = (long long)n * kh * kw * K + k;
-    float s = 0.f;
-    for (int t = 0; t < kh * kw; ++t) s += fmaxf(raw[base + t * K] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT, 0.f) + RELU_SHIFT;
-    float inv = 1.f / s;
-    float dot = 0.f;
-    for (int t = 0; t < kh * kw; ++t) {
-        float v = fmaxf(raw[base + t * K] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT, 0.f) + RELU_SHIFT;
-        dot += dkern[base + t * K] * v * inv;
+__global__ __launch_bounds__(CK_NT) void cdna_kernels_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ dkern,
+                                                                 float* __restrict__ draw, int kh, int kw, int K) {
+    __shared__ float sh[CK_NT];
+    const int n = blockIdx.x, e = threadIdx.x, taps = kh * kw;
+    const bool live = e < taps * K;
+    const long long base = (long long)n * taps * K;
+    float pre = 0.f, v = 0.f, d = 0.f;
+    if (live) {
+        const int t = e / K;
+        pre = raw[base + e] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT;
+        d = dkern[base + e];
+        v = fmaxf(pre, 0.f) + RELU_SHIFT;
     }
-    for (int t = 0; t < kh * kw; ++t) {
-        float pre = raw[base + t * K] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT;
-        draw[base + t * K] = pre > 0.f ? (dkern[base + t * K] - dot) * inv : 0.f;
-    }
+    const float s = cdna_tap_sum(sh, v, e, taps, K, live);
+    const float inv = live ? 1.f / s : 0.f;
+    const float dot = cdna_tap_sum(sh, d * v * inv, e, taps, K, live);
+    if (live) draw[base + e] = pre > 0.f ? (d - dot) * inv : 0.f;
 }
 
 extern "C" int savp_cdna_kernels_fwd(void* stream, const float* raw, float* kern, int32_t N, int32_t kh, int32_t kw, int32_t K) {
-    if (!raw || !kern) return SAVP_EINVAL;
-    hipLaunchKernelGGL(cdna_kernels_fwd_kernel, dim3((N * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, raw, kern, N, kh, kw, K);
+    if (!raw || !kern || N < 1 || kh * kw * K > CK_NT) return SAVP_EINVAL;
+    hipLaunchKernelGGL(cdna_kernels_fwd_kernel, dim3(N), dim3(CK_NT), 0, (hipStream_t)stream, raw, kern, kh, kw, K);
     return LAUNCH_OK();
 }
 extern "C" int savp_cdna_kernels_bwd(void* stream, const float* raw, const float* dkern, float* draw, int32_t N, int32_t kh,
                                      int32_t kw, int32_t K) {
-    if (!raw || !dkern || !draw) return SAVP_EINVAL;
-    hipLaunchKernelGGL(cdna_kernels_bwd_kernel, dim3((N * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, raw, dkern, draw, N, kh, kw, K);
+    if (!raw || !dkern || !draw || N < 1 || kh * kw * K > CK_NT) return SAVP_EINVAL;
+    hipLaunchKernelGGL(cdna_kernels_bwd_kernel, dim3(N), dim3(CK_NT), 0, (hipStream_t)stream, raw, dkern, draw, kh, kw, K);
     return LAUNCH_OK();
 }
 
@@ -451,6 +462,11 @@ __global__ __launch_bounds__(NT) void cdna_bwd_img_tiled_kernel(CdnaP p, int til
     const int n = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles_x) * CT_TS, tx0 = (blockIdx.x % tiles_x) * CT_TS;
     for (int i = threadIdx.x; i < 25 * TK; i += NT) sk[i] = p.kern[(long long)n * 25 * TK + i];
+    // vec bit 1: clear this sample's kernel-gradient accumulator for the cdna_bwd_kern launch that follows on the stream (it
+    // adds with atomics; saves the launcher a 12 KB memset per timestep)
+    if ((vec & 2) && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 25 * TK; i += NT) p.dkern[(long long)n * 25 * TK + i] = 0.f;
+    vec &= 1;
     stage_dout_halo<TK, TC>(p, n, ty0, tx0, vec, dts);
     __syncthreads();
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
@@ -642,11 +658,12 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
         const int vec = al ? 1 : 0;
         if (p.dimg) {
             dim3 grid(tiles_x * tiles_y, a->N);
-            if (kind == 3) hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
-            else hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
+            const int v2 = vec | (p.dkern ? 2 : 0);
+            if (kind == 3) hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, v2);
+            else hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, v2);
         }
         if (p.dkern) {
-            hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            if (!p.dimg) hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
             dim3 grid(tiles_x * tiles_y, a->N);
             if (kind == 3) hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
             else hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);

@@ -3,3 +3,33 @@
 #include "savp_hip.h"
 
 extern "C" const char* savp_version(void) { return "savp_hip 0.1 gfx950"; }
+
+// ---- kernel-only timing of one instrumented launch (bench.py) -----------------------------------------------
+// savp_prof_arm(start, stop) hands an event pair to the NEXT ring-kernel launch of the calling thread: the launch goes through
+// hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end (what rocprofv3's kernel trace reports),
+// instead of hipEventRecord markers in front of and behind the dispatch, whose interval also holds the command processor's
+// hand-over between packets (10-15 us on a 30 us kernel).
+thread_local hipEvent_t g_savp_prof_start = nullptr;
+thread_local hipEvent_t g_savp_prof_stop = nullptr;
+
+extern "C" int savp_prof_event_create(void** ev) {
+    if (!ev) return SAVP_EINVAL;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return SAVP_ELAUNCH;
+    *ev = (void*)e;
+    return SAVP_OK;
+}
+extern "C" int savp_prof_event_destroy(void* ev) { return (ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess) ? SAVP_OK : SAVP_EINVAL; }
+extern "C" int savp_prof_arm(void* start, void* stop) {
+    if ((start == nullptr) != (stop == nullptr)) return SAVP_EINVAL;
+    g_savp_prof_start = (hipEvent_t)start; g_savp_prof_stop = (hipEvent_t)stop;
+    return SAVP_OK;
+}
+extern "C" int savp_prof_armed(void) { return g_savp_prof_start != nullptr; }
+extern "C" int savp_prof_elapsed_us(void* start, void* stop, float* us) {
+    if (!start || !stop || !us) return SAVP_EINVAL;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return SAVP_ELAUNCH;
+    *us = ms * 1e3f;
+    return SAVP_OK;
+}

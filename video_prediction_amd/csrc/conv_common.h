@@ -89,6 +89,11 @@ static inline unsigned long long magic40(int d) {
     return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
 }
 
+// conv_thin.hip: FPROP / WGRAD of a 3x3(x3) stride-1 convolution with Cx <= 4, Cy = 32 (bf16 mode).  true = handled.
+bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+
+extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Developer aid: build with SAVP_EXTRA_FLAGS=-DSAVP_CONV_ABLATE and set SAVP_ABLATE=<bits> to switch off parts of a kernel

@@ -781,6 +781,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     ablate_init();
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
+    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_WGRAD) {    // RGB-input first layer of the discriminators (conv_thin.hip)
+        int rc = SAVP_OK;
+        if (conv_thin_try(a, st, &rc)) return rc;
+    }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         const bool dg = a->mode == SAVP_CONV_DGRAD;
         p.out = (float*)(dg ? a->x : a->y);

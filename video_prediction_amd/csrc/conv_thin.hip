@@ -1,0 +1,401 @@
+// conv_thin.hip -- first layer of the spectral-norm discriminators (networks.py:35-108 of the reference: conv3d / conv2d, 3x3(x3),
+// stride 1, SAME) in bf16 mode: FPROP and WGRAD of a convolution whose input is the RGB / grey clip itself (Cx <= 4, Cy = 32).
+//
+// Why its own kernels.  On the BAIR workload the layer reads 16 MB and writes (or, in WGRAD, reads) 168 MB of fp32 activations
+// for 6.8 GFLOP: it is bound by HBM (~45 us at 4 TB/s), but the general kernels need 245 us (FPROP, implicit-GEMM gather with
+// K = 81 of a 32-wide tile) and 420 + 95 us (generic WGRAD + a separate bias column sum): their tiles are built for hundreds
+// of input channels, and the LDS-patch kernels want Cx % 4 == 0 (a spectrally normalised weight cannot be zero-padded).
+//
+// Layout used by both kernels: an input pixel is ONE 8-byte LDS word of 4 bf16 channels (the 4th, and for grey clips the
+// 2nd..4th, zero).  The GEMM K / M index that runs over (tap, channel) is therefore "slot" s = tap (27 or 9 of them) times 4
+// channels, and a slot of a pixel is one aligned ds_read_b64 at a tap-shifted address of the staged patch.
+//
+//   FPROP  y[px][co]   = sum_s  patch[px + shift(s)][0..3] * W[s][0..3][co]
+//          A (rows = 32 consecutive output pixels of one image row) k-step of 16 = 4 slots = two ds_read_b64 per lane;
+//          B (32 output channels) = the whole weight matrix, 7 (or 3) fragments held in registers for the kernel's lifetime;
+//          v_mfma_f32_32x32x16_bf16; epilogue bias + LeakyReLU, each store instruction writes two full 128-byte pixel rows.
+//   WGRAD  dW[s][c][co] += sum_px patch[px + shift(s)][c] * dy[px][co]          (K = pixels)
+//          both operands are pixel-major in LDS while the MFMA wants k (= pixel) contiguous fragments: ds_read_b64_tr_b16, the
+//          gfx950 transpose read (see conv_wgrad_patch.hip), with the four 4-channel chunks of a 16-row group mapped to four TAPS
+//          (lane t of 16 supplies [pixel t>>2][tap t&3, 4 channels] and receives row (tap t>>2, channel t&3) of 4 pixels).
+//          The bias gradient is summed in fp32 from the dy values as they are staged.  Each workgroup leaves its partial dW / db
+//          in a workspace row; a second small launch sums the rows into dW / db.
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+#define LDS_AS __attribute__((address_space(3)))
+
+struct ThinP {
+    const float* x; long long x_sn, x_sd, x_sh, x_sw;
+    float* y; long long y_sn, y_sd, y_sh, y_sw;        // FPROP: destination; WGRAD: dy (read only)
+    const float* w;                                    // FPROP: packed WT [32][taps * Cx] fp32
+    float* dw; float* db;                              // WGRAD: dW [taps][Cx][32] (+=), db [32] (+=, may be null)
+    float* ws;                                         // WGRAD: [workgroups][taps * Cx * 32 + 32] partial sums
+    const float* bias; int act; float alpha;
+    int N, D, H, W, Cx;
+    int tilesX, tilesY, items, per_wg;
+    const float* zero;                                 // 16 bytes of zeros in global memory (the source of out-of-range pixels)
+};
+
+// one input pixel (CX <= 4 channels, zero outside the tensor) as raw floats: converted when it is parked in LDS, so that the loads
+// of the NEXT work item stay in flight across the MFMAs of the current one.  Out-of-range pixels LOAD from a zero word instead of
+// being zeroed after the load: with `if (inside) load` per channel hipcc sank half of the loads behind the MFMA block and waited
+// for each group separately, and with a select on the loaded value it waits for the prefetch right where it is issued -- either
+// way two or three exposed memory round trips per work item.
+__device__ float4 g_thin_zero[1] = {{0.f, 0.f, 0.f, 0.f}};     // reached through ThinP.zero (a kernel-argument pointer = global
+                                                               // address space; the symbol itself would turn the loads into FLAT ones,
+                                                               // which also count on lgkmcnt and so cannot stay in flight across LDS reads)
+
+template <int CX>
+__device__ __forceinline__ float4 thin_fetch_pixel(const ThinP& p, int n, int iz, int iy, int ix) {
+    const bool ok = iz >= 0 && iz < p.D && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const float* __restrict__ s = ok ? p.x + ((long long)n * p.x_sn + (long long)iz * p.x_sd + (long long)iy * p.x_sh + (long long)ix * p.x_sw)
+                                     : p.zero;
+    float4 v;
+    v.x = s[0];
+    v.y = CX > 1 ? s[1] : 0.f;
+    v.z = CX > 2 ? s[2] : 0.f;
+    v.w = CX > 3 ? s[3] : 0.f;
+    return v;
+}
+
+struct ThinItem { int n, z, y0, x0; };
+__device__ __forceinline__ ThinItem thin_item(const ThinP& p, int it, int tile_r, int tile_c) {
+    const int tx = it % p.tilesX, t1 = it / p.tilesX;
+    const int ty = t1 % p.tilesY, t2 = t1 / p.tilesY;
+    ThinItem q;
+    q.z = t2 % p.D; q.n = t2 / p.D; q.y0 = ty * tile_r; q.x0 = tx * tile_c;
+    return q;
+}
+
+// the (plane, row, column) of patch slot s for a patch of PR x PC pixels per plane
+#define THIN_FETCH_SLOTS(NSL, PR, PC, KD_, pv, q)                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NSL; ++i_) {                                                       \
+        const int s_ = tid + 256 * i_;                                                                        \
+        const int a_ = s_ / ((PR) * (PC)), rem_ = s_ - a_ * ((PR) * (PC));                                    \
+        const int r_ = rem_ / (PC), c_ = rem_ - r_ * (PC);                                                    \
+        /* slots past the patch (last round of the 256-thread sweep) read pixel (-1, ..) = out of range = zero, never stored */ \
+        pv[i_] = thin_fetch_pixel<CX>(p, q.n, s_ < (KD_) * (PR) * (PC) ? q.z + a_ - (KD_) / 2 : -1, q.y0 + r_ - 1, q.x0 + c_ - 1); \
+    }
+#define THIN_STAGE_SLOTS(NSL, PR, PC, KD_, pv)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NSL; ++i_) {                                                       \
+        const int s_ = tid + 256 * i_;                                                                        \
+        if (s_ < (KD_) * (PR) * (PC)) patch[s_] = bf16x4v{(__bf16)pv[i_].x, (__bf16)pv[i_].y, (__bf16)pv[i_].z, (__bf16)pv[i_].w}; \
+    }
+
+// Pin prefetched registers behind the compute block: left alone, hipcc hoists the bf16 conversion of the NEXT item's pixels (the
+// first thing the next loop iteration does) above this item's MFMAs and waits for the prefetch right after issuing it.
+#define THIN_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+
+// ------------------------------------------------------------------------------------------------------------
+// FPROP: 8 x 32 output pixels of one (sample, plane) per work item; wave w owns rows 2w, 2w+1
+// ------------------------------------------------------------------------------------------------------------
+#define TF_R 8
+#define TF_C 32
+#define TF_PR (TF_R + 2)
+#define TF_PC (TF_C + 2)
+
+template <int KD, int CX>
+__global__ __launch_bounds__(256) void thin_fprop_kernel(ThinP p) {
+    constexpr int TAPS = 9 * KD, NS = (TAPS + 3) / 4;          // slots; k-steps of 4 slots (16 k)
+    constexpr int PPL = TF_PR * TF_PC, ZP = KD * PPL;           // pixels per patch plane; index of the all-zero pixel
+    __shared__ __attribute__((aligned(16))) bf16x4v patch[ZP + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    // weights: lane = output channel l31, k = 8 half + j  <->  slot 4 ks + 2 half + (j >> 2), channel j & 3
+    bf16x8 bw[NS];
+    int aoff[NS][2];                                            // byte offset of the lane's two slots per k-step (-1: zero pixel)
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = 4 * ks + 2 * half + (j >> 2), c = j & 3;
+            const bool live = s < TAPS && c < CX;               // unconditional (clamped) load + select: 56 loads in flight at once
+            const float v = p.w[live ? l31 * TAPS * CX + s * CX + c : 0];
+            bw[ks][j] = (__bf16)(live ? v : 0.f);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int s = 4 * ks + 2 * half + jj;
+            const int a = s / 9, u = (s % 9) / 3, v = s % 3;
+            aoff[ks][jj] = (s < TAPS) ? ((a * TF_PR + u) * TF_PC + v) * 8 : -1;
+        }
+    }
+    float bias = 0.f;
+    if (p.bias) bias = p.bias[l31];
+    if (tid == 0) patch[ZP] = bf16x4v{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    constexpr int NSL = (KD * PPL + 255) / 256;
+    float4 pv[NSL];
+    const int it_begin = blockIdx.x * p.per_wg, it_end = min(p.items, (int)(blockIdx.x + 1) * p.per_wg);
+    {
+        const ThinItem q0 = thin_item(p, it_begin, TF_R, TF_C);
+        THIN_FETCH_SLOTS(NSL, TF_PR, TF_PC, KD, pv, q0)
+    }
+    for (int it = it_begin; it < it_end; ++it) {
+        const ThinItem q = thin_item(p, it, TF_R, TF_C);
+        const int z = q.z, n = q.n, y0 = q.y0, x0 = q.x0;
+        __syncthreads();                                       // the previous item's reads are done
+        THIN_STAGE_SLOTS(NSL, TF_PR, TF_PC, KD, pv)
+        __syncthreads();
+        {   // next item's pixels fly while this one is multiplied and stored.  Unconditional (the last item is fetched twice): under
+            // `if (it + 1 < it_end)` the loop-carried registers become phis that hipcc resolves with copies of the loaded values
+            // right behind the loads, i.e. with a full wait for the prefetch
+            const ThinItem qn = thin_item(p, min(it + 1, it_end - 1), TF_R, TF_C);
+            THIN_FETCH_SLOTS(NSL, TF_PR, TF_PC, KD, pv, qn)
+        }
+        const LDS_AS char* pl = (const LDS_AS char*)patch;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr, oy = y0 + r;
+            const int base = (r * TF_PC + l31) * 8;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                const int ad0 = aoff[ks][0] < 0 ? ZP * 8 : base + aoff[ks][0];
+                const int ad1 = aoff[ks][1] < 0 ? ZP * 8 : base + aoff[ks][1];
+                const bf16x4v a0 = *(const LDS_AS bf16x4v*)(pl + ad0);
+                const bf16x4v a1 = *(const LDS_AS bf16x4v*)(pl + ad1);
+                const bf16x8 af = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[ks], acc, 0, 0, 0);
+            }
+            if (oy < p.H) {
+                float* __restrict__ dst = p.y + (long long)n * p.y_sn + (long long)z * p.y_sd + (long long)oy * p.y_sh + l31;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ox = x0 + (i & 3) + 8 * (i >> 2) + 4 * half;    // accumulator row = output pixel of the 32-wide row tile
+                    if (ox < p.W) {
+                        float v = acc[i] + bias;
+                        if (p.act == SAVP_ACT_LRELU) v = v > 0.f ? v : v * p.alpha;
+                        dst[(long long)ox * p.y_sw] = v;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // ... and keep the pins themselves below the MFMAs / stores
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) THIN_PIN4(pv[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// WGRAD: 4 x 64 output pixels of one (sample, plane) per work item; wave w reduces over row w (a larger item would need more
+// prefetch registers than two resident workgroups per CU allow)
+// ------------------------------------------------------------------------------------------------------------
+#define TW_R 4
+#define TW_C 64
+#define TW_PR (TW_R + 2)
+#define TW_PC (TW_C + 2)
+
+template <int KD, int CX>
+__global__ __launch_bounds__(256, 2) void thin_wgrad_kernel(ThinP p) {
+    constexpr int TAPS = 9 * KD, NG = (TAPS + 3) / 4, NT32 = (NG + 1) / 2;   // 16-row groups (4 taps x 4 channels); 32-row tiles
+    constexpr int PPL = TW_PR * TW_PC, ZP = KD * PPL;
+    constexpr int PATCH_BYTES = ((ZP + 1) * 8 + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16x4v* patch = reinterpret_cast<bf16x4v*>(smem);
+    char* dyt = smem + PATCH_BYTES;                               // [256 pixels][32 channels] bf16, 64 bytes per pixel (>= 16 KB: reused by the final reduction)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, g = (lane >> 4) & 1, r4 = (lane & 15) >> 2, q = lane & 3;
+    // A: this lane feeds tap 4 (2 i + g) + q of row tile i at k-pixel 8 h + 4 j + r4 (j = 0, 1: the two transpose reads of a k-step)
+    int toff[NT32];
+#pragma unroll
+    for (int i = 0; i < NT32; ++i) {
+        const int tap = 4 * (2 * i + g) + q;
+        const int a = tap / 9, u = (tap % 9) / 3, v = tap % 3;
+        toff[i] = (tap < TAPS) ? ((a * TW_PR + u) * TW_PC + v) * 8 : -1;
+    }
+    const int a_lane = (8 * h + r4) * 8;                           // bytes
+    const int b_lane = (8 * h + r4) * 64 + (16 * g + 4 * q) * 2;
+    f32x16 acc[NT32];
+#pragma unroll
+    for (int i = 0; i < NT32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) patch[ZP] = bf16x4v{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    constexpr int NSL = (KD * PPL + 255) / 256;
+    float4 pv[NSL], dv[8];
+    auto fetch = [&](int it) {
+        const ThinItem q = thin_item(p, it, TW_R, TW_C);
+        THIN_FETCH_SLOTS(NSL, TW_PR, TW_PC, KD, pv, q)
+        const float* __restrict__ dyb = p.y + (long long)q.n * p.y_sn + (long long)q.z * p.y_sd;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                              // 256 pixels x 8 channel quads; this thread's quad is tid & 7
+            const int slot = tid + 256 * i, px = slot >> 3, cq = slot & 7;
+            const int oy = q.y0 + (px >> 6), ox = q.x0 + (px & 63);
+            const bool ok = oy < p.H && ox < p.W;
+            dv[i] = ldg4(ok ? dyb + (long long)oy * p.y_sh + (long long)ox * p.y_sw + 4 * cq : p.zero);
+        }
+    };
+    const int it_begin = blockIdx.x * p.per_wg, it_end = min(p.items, (int)(blockIdx.x + 1) * p.per_wg);
+    fetch(it_begin);
+    for (int it = it_begin; it < it_end; ++it) {
+        __syncthreads();
+        THIN_STAGE_SLOTS(NSL, TW_PR, TW_PC, KD, pv)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int slot = tid + 256 * i, px = slot >> 3, cq = slot & 7;
+            const float4 v = dv[i];
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            *reinterpret_cast<bf16x4v*>(dyt + px * 64 + cq * 8) = bf16x4v{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        }
+        __syncthreads();
+        fetch(min(it + 1, it_end - 1));                            // next item's operands fly across this item's MFMAs (unconditional, see FPROP)
+        const LDS_AS char* pa = (const LDS_AS char*)patch;
+        const LDS_AS char* pb = (const LDS_AS char*)dyt + b_lane;
+        {
+            const int r = wave;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const LDS_AS char* b0p = pb + (r * 64 + 16 * ks) * 64;
+                const bf16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)b0p);
+                const bf16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(b0p + 4 * 64));
+                const bf16x8 bf = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const int abase = (r * TW_PC + 16 * ks) * 8 + a_lane;
+#pragma unroll
+                for (int i = 0; i < NT32; ++i) {
+                    const int ad = toff[i] < 0 ? ZP * 8 : abase + toff[i];
+                    const int ad1 = toff[i] < 0 ? ZP * 8 : ad + 4 * 8;
+                    const bf16x4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa + ad));
+                    const bf16x4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4v*)(pa + ad1));
+                    const bf16x8 af = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) THIN_PIN4(pv[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) THIN_PIN4(dv[i]);
+    }
+    // ---- this workgroup's partial dW / db goes to its own row of a workspace (plain stores); thin_wgrad_reduce_kernel sums the
+    //      rows.  Adding to dW directly costs 2.6 k atomics per workgroup onto the SAME 82 cache lines from 512 workgroups that all
+    //      finish together: ~16 k serialised read-modify-writes per line, 90 of the kernel's 139 us in the first version.
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dyt);                    // [NT32][32 rows][32 columns] fp32 (<= 16 KB = the dy tile)
+    float* bred = reinterpret_cast<float*>(patch);                 // [32] fp32 (the patch is dead)
+    const int l31 = lane & 31;
+    if (tid < 32) bred[tid] = 0.f;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NT32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // accumulator row of the 32-row tile
+                    float* e = red + (i * 32 + m) * 32 + l31;
+                    if (w == 0) *e = acc[i][r]; else *e += acc[i][r];
+                }
+        }
+        __syncthreads();
+    }
+    // bias gradient: all of a thread's dy slots are channel quad tid & 7
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+        bsum.x += __shfl_xor(bsum.x, m); bsum.y += __shfl_xor(bsum.y, m);
+        bsum.z += __shfl_xor(bsum.z, m); bsum.w += __shfl_xor(bsum.w, m);
+    }
+    if (lane < 8) {
+        atomicAdd(bred + 4 * lane, bsum.x); atomicAdd(bred + 4 * lane + 1, bsum.y);
+        atomicAdd(bred + 4 * lane + 2, bsum.z); atomicAdd(bred + 4 * lane + 3, bsum.w);
+    }
+    __syncthreads();
+    constexpr int ROW = TAPS * CX * 32 + 32;                       // floats per workspace row: dW then db
+    float* __restrict__ wsr = p.ws + (long long)blockIdx.x * ROW;
+    for (int e = tid; e < NT32 * 1024; e += 256) {
+        const int co = e & 31, m = (e >> 5) & 31, i = e >> 10;
+        const int tap = 4 * (2 * i + (m >> 4)) + ((m & 15) >> 2), c = m & 3;
+        if (tap < TAPS && c < CX) wsr[(tap * CX + c) * 32 + co] = red[e];
+    }
+    if (tid < 32) wsr[TAPS * CX * 32 + tid] = bred[tid];
+}
+
+// out[e] += sum over the workspace rows; grid (ceil(row / 256), G): block y sums rows y, y + G, ...
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ ws, int rows, int row, int ndw, float* dw, float* db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= row) return;
+    float s = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += ws[(long long)r * row + e];
+    if (e < ndw) unsafeAtomicAdd(dw + e, s);
+    else if (db) unsafeAtomicAdd(db + (e - ndw), s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static bool thin_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SAVP_THIN"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
+static bool thin_geometry_ok(const SavpConvArgs* a) {
+    return a->precision == SAVP_PREC_BF16 && (a->Cx == 1 || a->Cx == 3 || a->Cx == 4) && a->Cy == 32 && a->kh == 3 && a->kw == 3 && a->ph == 1 &&
+           a->pw == 1 && (a->kd == 1 || a->kd == 3) && a->pd == a->kd / 2 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->Do == a->D &&
+           a->Ho == a->H && a->Wo == a->W && !a->src_bf16 && !a->out_bf16 && !a->stats && a->N >= 1 && a->H >= 1 && a->W >= 1;
+}
+
+static void thin_fill(ThinP& p, const SavpConvArgs* a, int tile_r, int tile_c, int target_wgs) {
+    p.x = (const float*)a->x; p.x_sn = a->x_sn; p.x_sd = a->x_sd; p.x_sh = a->x_sh; p.x_sw = a->x_sw;
+    p.y = (float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
+    p.w = nullptr; p.dw = nullptr; p.db = nullptr; p.ws = nullptr; p.bias = nullptr; p.act = 0; p.alpha = 0.f;
+    p.N = a->N; p.D = a->D; p.H = a->H; p.W = a->W; p.Cx = a->Cx;
+    p.tilesX = (a->W + tile_c - 1) / tile_c; p.tilesY = (a->H + tile_r - 1) / tile_r;
+    p.items = a->N * a->D * p.tilesY * p.tilesX;
+    p.per_wg = (p.items + target_wgs - 1) / target_wgs;
+    if (p.per_wg < 1) p.per_wg = 1;
+}
+
+// Returns true when the call was handled (rc set); false = not this kernel's problem, the caller goes on to the general kernels.
+bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
+    if (!thin_enabled() || !thin_geometry_ok(a)) return false;
+    const long long px = (long long)a->N * a->D * a->H * a->W;
+    if (px >= (1ll << 31) / 64) return false;
+    static const float* zero = nullptr;
+    if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
+    ThinP p;
+    p.zero = zero;
+    if (a->mode == SAVP_CONV_FPROP) {
+        if (a->beta || a->aux || (a->act != SAVP_ACT_NONE && a->act != SAVP_ACT_LRELU)) return false;
+        thin_fill(p, a, TF_R, TF_C, 1024);                    // four resident workgroups per CU: one full wave of them
+        p.w = (const float*)a->w; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;
+        const dim3 grid((unsigned)((p.items + p.per_wg - 1) / p.per_wg));
+#define THIN_F(KD_, CX_) hipLaunchKernelGGL((thin_fprop_kernel<KD_, CX_>), grid, dim3(256), 0, st, p)
+        if (a->kd == 3) { if (a->Cx == 3) THIN_F(3, 3); else if (a->Cx == 1) THIN_F(3, 1); else THIN_F(3, 4); }
+        else { if (a->Cx == 3) THIN_F(1, 3); else if (a->Cx == 1) THIN_F(1, 1); else THIN_F(1, 4); }
+#undef THIN_F
+    } else if (a->mode == SAVP_CONV_WGRAD) {
+        if ((a->y_sn % 4) || (a->y_sd % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y)) return false;
+        thin_fill(p, a, TW_R, TW_C, 512);                     // two resident workgroups per CU (VGPRs): one full wave of them
+        p.dw = (float*)a->w; p.db = (float*)a->bias;
+        const int nwg = (p.items + p.per_wg - 1) / p.per_wg;
+        const int ndw = 9 * a->kd * a->Cx * 32, row = ndw + 32;
+        // partial-sum workspace, grown on demand and kept (5.4 MB for the BAIR layer).  One buffer: calls on different streams must
+        // not overlap (the engine issues every convolution on its compute stream).
+        static float* ws = nullptr;
+        static size_t ws_floats = 0;
+        if ((size_t)nwg * row > ws_floats) {
+            if (ws) hipFree(ws);
+            ws = nullptr; ws_floats = 0;
+            if (hipMalloc((void**)&ws, (size_t)nwg * row * sizeof(float)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
+            ws_floats = (size_t)nwg * row;
+        }
+        p.ws = ws;
+        const dim3 grid((unsigned)nwg);
+        const size_t lds = (size_t)((((a->kd * TW_PR * TW_PC + 1) * 8 + 15) & ~15) + 256 * 64);
+#define THIN_W(KD_, CX_) hipLaunchKernelGGL((thin_wgrad_kernel<KD_, CX_>), grid, dim3(256), lds, st, p)
+        if (a->kd == 3) { if (a->Cx == 3) THIN_W(3, 3); else if (a->Cx == 1) THIN_W(3, 1); else THIN_W(3, 4); }
+        else { if (a->Cx == 3) THIN_W(1, 3); else if (a->Cx == 1) THIN_W(1, 1); else THIN_W(1, 4); }
+#undef THIN_W
+        const int G = nwg < 16 ? nwg : 16;
+        hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((row + 255) / 256), (unsigned)G), dim3(256), 0, st,
+                           (const float*)ws, nwg, row, ndw, p.dw, p.db);
+    } else {
+        return false;
+    }
+    *rc = hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    return true;
+}

@@ -58,6 +58,55 @@ extern "C" int savp_pack_weights(void* stream, const float* src, int64_t T, int3
     return LAUNCH_OK();
 }
 
+// Several packs in ONE launch (a network's layers after their optimiser step): blockIdx.y = layer, grid-stride over its
+// elements.  52 single launches of ~11 us each per train step otherwise.
+#define PACK_MAX 32
+struct PackBatch {
+    const float* src[PACK_MAX]; const float* scale[PACK_MAX];
+    float* wt[PACK_MAX]; float* wd[PACK_MAX]; __bf16* wt16[PACK_MAX]; __bf16* wd16[PACK_MAX];
+    long long T[PACK_MAX]; int Cx[PACK_MAX], Cy[PACK_MAX];
+};
+
+__global__ void pack_weights_batch_kernel(PackBatch b) {
+    const int it = blockIdx.y;
+    const float* __restrict__ src = b.src[it];
+    const long long T = b.T[it];
+    const int Cx = b.Cx[it], Cy = b.Cy[it];
+    float* wt = b.wt[it]; float* wd = b.wd[it]; __bf16* wt16 = b.wt16[it]; __bf16* wd16 = b.wd16[it];
+    const long long total = T * Cx * Cy;
+    const float s = b.scale[it] ? *b.scale[it] : 1.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cy = (int)(i % Cy);
+        const long long r = i / Cy;
+        const int cx = (int)(r % Cx);
+        const long long t = r / Cx;
+        const float v = src[i] * s;
+        if (wt) wt[(long long)cy * (T * Cx) + t * Cx + cx] = v;
+        if (wd) wd[(long long)cx * (T * Cy) + t * Cy + cy] = v;
+        if (wt16) wt16[(long long)cy * (T * Cx) + t * Cx + cx] = (__bf16)v;
+        if (wd16) wd16[(long long)cx * (T * Cy) + t * Cy + cy] = (__bf16)v;
+    }
+}
+
+extern "C" int savp_pack_weights_batch(void* stream, int32_t n, const SavpPackItem* items) {
+    if (!items || n < 1 || n > PACK_MAX) return SAVP_EINVAL;
+    PackBatch b;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        const SavpPackItem& q = items[i];
+        if (!q.src || (!q.wt && !q.wd && !q.wt_bf16 && !q.wd_bf16) || q.T < 1 || q.Cx < 1 || q.Cy < 1) return SAVP_EINVAL;
+        b.src[i] = q.src; b.scale[i] = q.scale; b.wt[i] = q.wt; b.wd[i] = q.wd;
+        b.wt16[i] = (__bf16*)q.wt_bf16; b.wd16[i] = (__bf16*)q.wd_bf16;
+        b.T[i] = q.T; b.Cx[i] = q.Cx; b.Cy[i] = q.Cy;
+        const long long total = (long long)q.T * q.Cx * q.Cy;
+        if (total > most) most = total;
+    }
+    long long nb = (most + NT - 1) / NT;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)nb, (unsigned)n), dim3(NT), 0, (hipStream_t)stream, b);
+    return LAUNCH_OK();
+}
+
 // fold_pool: src [k,k,C] -> dst [k+1,k+1,C];  adjoint: dsrc[k,k,C] += from ddst
 __global__ void fold_pool_kernel(const float* __restrict__ in, float* __restrict__ out, int k, long long C, int adjoint) {
     const int ko = k + 1;

@@ -249,6 +249,7 @@ class ConvLayer(object):
             self.dwf = torch.zeros_like(W)                # dL/dW_bar, then sn_bwd -> master grad
         self.need_wt = self.need_wd = True
         self.prof = None          # list of (start, end) events when bench.py instruments this layer's forward launches
+        self.ktimer = None        # kernels.KernelTimer: kernel-only duration of the same launches (ring kernel)
 
     # -- weight preparation ---------------------------------------------------------------------------------
     def sn_entry(self, update_u=False):
@@ -258,7 +259,8 @@ class ConvLayer(object):
     def sn_bwd_entry(self):
         return {'W': self.W, 'u': self.u.reshape(-1), 'ws': self.sn_ws, 'G': self.dwf, 'dW': self.dW, 'beta': 1}
 
-    def prep(self, update_u=False, sn_done=False):
+    def prep(self, update_u=False, sn_done=False, defer_pack=None):
+        """defer_pack: a list -- the pack is appended to it for one kernels.pack_weights_batch over a network's layers."""
         scale = None
         if self.kind == 'pool':
             K.fold_pool(self.W, self.wf, self.W.shape[0])
@@ -276,8 +278,12 @@ class ConvLayer(object):
                 K.axpby(1.0, self.bias_master, 0.0, None, self.bias[:self.cy0])
             src = self.wfp
         b16 = K.PRECISION['value'] == 1
-        K.pack_weights(src, self.wt if self.need_wt else None, self.wd if self.need_wd else None, scale=scale,
-                       wt16=self.wt16 if (b16 and self.need_wt) else None, wd16=self.wd16 if (b16 and self.need_wd) else None)
+        entry = {'src': src, 'wt': self.wt if self.need_wt else None, 'wd': self.wd if self.need_wd else None, 'scale': scale,
+                 'wt16': self.wt16 if (b16 and self.need_wt) else None, 'wd16': self.wd16 if (b16 and self.need_wd) else None}
+        if defer_pack is not None:
+            defer_pack.append(entry)
+        else:
+            K.pack_weights(**entry)
 
     def commit_u(self):
         """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
@@ -292,6 +298,8 @@ class ConvLayer(object):
             # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
             K.dense_fwd(x, self.W.reshape(-1, self.cy), b, y, scale=self.sn_ws[1:2] if self.sn_u_name else None)
             return
+        if self.ktimer is not None:
+            self.ktimer.arm()
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -302,6 +310,8 @@ class ConvLayer(object):
         if self.prof is not None:
             e1.record()
             self.prof.append((e0, e1))
+        if self.ktimer is not None:
+            self.ktimer.taken()
 
     def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
         if self.kind == 'up':
@@ -358,6 +368,19 @@ class _TensorStore(object):
         return self.g[name]
 
 
+def prep_layers(convs, **kw):
+    """prep() of a network's layers with ONE batched weight pack at the end (SAVP_PACK_BATCH=0: a pack launch per layer)."""
+    if os.environ.get('SAVP_PACK_BATCH', '1') != '1':
+        for c in convs:
+            c.prep(**kw)
+        return
+    packs = []
+    for c in convs:
+        c.prep(defer_pack=packs, **kw)
+    if packs:
+        K.pack_weights_batch(packs)
+
+
 class ConcatConv(object):
     """Several plain convolutions that read the SAME input with the same geometry, run as ONE convolution whose output channels are
     the concatenation of theirs (the 3x3 heads of SAVPCell.call that all read the last decoder layer: h6_scratch, h6_masks and,
@@ -393,12 +416,12 @@ class ConcatConv(object):
     def prof(self):
         return self.inner.prof
 
-    def prep(self, update_u=False):
+    def prep(self, update_u=False, defer_pack=None):
         R = self.R
         for P in self.parts:
             copy_view(P['W'].reshape(R, P['cy']), [self.Wcat.reshape(R, self.cy)[:, P['off']:P['off'] + P['cy']]])
             copy_view(P['b'].reshape(1, P['cy']), [self.bcat.reshape(1, self.cy)[:, P['off']:P['off'] + P['cy']]])
-        self.inner.prep()
+        self.inner.prep(defer_pack=defer_pack)
 
     def forward(self, x, y, **kw):
         self.inner.forward(x, y, **kw)

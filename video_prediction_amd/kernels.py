@@ -617,6 +617,22 @@ def pack_weights(src, wt=None, wd=None, scale=None, wt16=None, wd16=None):
               'savp_pack_weights')
 
 
+def pack_weights_batch(entries):
+    """entries: [{'src', 'wt', 'wd', 'scale', 'wt16', 'wd16'}] (pack_weights' arguments) -- one launch per 32 layers."""
+    for lo in range(0, len(entries), 32):
+        part = entries[lo:lo + 32]
+        arr = (lib.SavpPackItem * len(part))()
+        for i, e in enumerate(part):
+            src = e['src']
+            lib.require_device(src)
+            it = arr[i]
+            it.src, it.scale = _p(src), _p(e.get('scale'))
+            it.wt, it.wd, it.wt_bf16, it.wd_bf16 = _p(e.get('wt')), _p(e.get('wd')), _p(e.get('wt16')), _p(e.get('wd16'))
+            it.Cx, it.Cy = src.shape[-2], src.shape[-1]
+            it.T = src.numel() // (it.Cx * it.Cy)
+        lib.check(_L().savp_pack_weights_batch(lib.stream(), len(part), arr), 'savp_pack_weights_batch')
+
+
 def fold_pool(inp, out, k, adjoint=False):
     C = (out.numel() if adjoint else inp.numel()) // (k * k)
     lib.check(_L().savp_fold_pool(lib.stream(), _p(inp), _p(out), k, C, int(adjoint)), 'savp_fold_pool')
@@ -855,3 +871,48 @@ def u8_frames_to_f32(frames_u8, out_tm):
     B, T = frames_u8.shape[:2]
     frame = frames_u8[0, 0].numel()
     lib.check(_L().savp_u8_frames_to_f32(lib.stream(), frames_u8.data_ptr(), out_tm.data_ptr(), B, T, frame), 'savp_u8_frames_to_f32')
+
+
+class KernelTimer(object):
+    """Kernel-only timing of single instrumented launches (bench.py): event pairs handed to the launcher through savp_prof_arm,
+    stamped by the dispatch itself (the duration rocprofv3's kernel trace reports).  arm() before the launch, taken() after it
+    (False: the call ran a kernel that does not take the pair; the pair is dropped); durations_us() after a synchronise."""
+
+    def __init__(self):
+        self.free, self.used, self.cur = [], [], None
+
+    def _event(self):
+        if self.free:
+            return self.free.pop()
+        ev = ctypes.c_void_p()
+        lib.check(_L().savp_prof_event_create(ctypes.byref(ev)), 'savp_prof_event_create')
+        return ev
+
+    def arm(self):
+        self.cur = (self._event(), self._event())
+        lib.check(_L().savp_prof_arm(self.cur[0], self.cur[1]), 'savp_prof_arm')
+
+    def taken(self):
+        ok = not _L().savp_prof_armed()
+        if ok:
+            self.used.append(self.cur)
+        else:
+            _L().savp_prof_arm(None, None)
+            self.free.extend(self.cur)
+        self.cur = None
+        return ok
+
+    def durations_us(self):
+        out = []
+        us = ctypes.c_float()
+        for e0, e1 in self.used:
+            lib.check(_L().savp_prof_elapsed_us(e0, e1, ctypes.byref(us)), 'savp_prof_elapsed_us')
+            out.append(us.value)
+        self.free.extend(e for pair in self.used for e in pair)
+        self.used = []
+        return out
+
+    def close(self):
+        for e in self.free:
+            _L().savp_prof_event_destroy(e)
+        self.free = []

@@ -189,6 +189,11 @@ register('savp_composite_bwd', [c_vp, ctypes.POINTER(SavpCompositeArgs)])
 register('savp_lstm_z_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_lstm_seq_fwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32])
 register('savp_lstm_seq_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32])
+register('savp_prof_event_create', [ctypes.POINTER(c_vp)])
+register('savp_prof_event_destroy', [c_vp])
+register('savp_prof_arm', [c_vp, c_vp])
+register('savp_prof_armed', [])
+register('savp_prof_elapsed_us', [c_vp, c_vp, ctypes.POINTER(c_f32)])
 register('savp_kl_gauss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
@@ -199,6 +204,14 @@ register('savp_cosine_distance', [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, 
 register('savp_pack_weights', [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_fold_pool', [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32])
 register('savp_fold_bilinear', [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32])
+class SavpPackItem(ctypes.Structure):
+    _fields_ = [('src', c_vp), ('scale', c_vp), ('wt', c_vp), ('wd', c_vp), ('wt_bf16', c_vp), ('wd_bf16', c_vp), ('T', c_i64),
+                ('Cx', c_i32), ('Cy', c_i32)]
+
+
+register('savp_pack_weights_batch', [c_vp, c_i32, ctypes.POINTER(SavpPackItem)])
+
+
 class SavpSnItem(ctypes.Structure):
     _fields_ = [('W', c_vp), ('K', c_i64), ('C', c_i32), ('u', c_vp), ('ws', c_vp), ('u_new', c_vp), ('G', c_vp), ('dW', c_vp),
                 ('beta', c_i32)]

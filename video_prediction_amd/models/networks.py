@@ -9,7 +9,7 @@ import torch
 
 from .. import kernels as K
 from .. import lib
-from ..engine import ConvLayer, copy_view
+from ..engine import ConvLayer, copy_view, prep_layers
 from ..variables import VIDEO_D_LAYERS, video_discriminator_shapes, image_discriminator_shapes
 
 EPS_IN = 1e-6
@@ -97,8 +97,7 @@ class PosteriorEncoder(object):
         self.convs = [L['conv'] for L in self.layers] + ([self.fc] if self.recurrent else []) + [self.mu_fc, self.ls_fc]
 
     def prep_weights(self):
-        for c in self.convs:
-            c.prep()
+        prep_layers(self.convs)
 
     def _head_input(self):
         return self.hout.reshape(self.R, -1) if self.recurrent else self.feat
@@ -237,8 +236,7 @@ class SNDiscriminator(object):
         batch = os.environ.get('SAVP_SN_BATCH', '1') == '1'
         if batch:
             K.sn_fwd_batch([c.sn_entry(update_u) for c in self.convs])
-        for c in self.convs:
-            c.prep(update_u=update_u, sn_done=batch)
+        prep_layers(self.convs, update_u=update_u, sn_done=batch)
 
     def commit_u(self):
         for c in self.convs:

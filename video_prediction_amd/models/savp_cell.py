@@ -19,7 +19,7 @@ import torch
 
 from .. import kernels as K
 from .. import lib
-from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_views
+from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_views, prep_layers
 from ..variables import layer_specs, num_masks
 
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
@@ -87,6 +87,7 @@ class SAVPGenerator(object):
     def __init__(self, store, hp, image_shape, N, train=True, prefix='generator/rnn/savp_cell/'):
         H, W, C = image_shape
         self.hp, self.store, self.N, self.H, self.W, self.C = hp, store, N, H, W, C
+        self._ones = None
         self.T1 = T1 = hp.sequence_length - 1
         self.train = train
         dev = store.device
@@ -300,8 +301,7 @@ class SAVPGenerator(object):
         return self.convs
 
     def prep_weights(self):
-        for c in self.convs:
-            c.prep()
+        prep_layers(self.convs)
         if self.merge_heads:
             self.heads_norm.prep()
 
@@ -319,7 +319,6 @@ class SAVPGenerator(object):
         (1 = take the ground-truth frame: self.ground_truth of savp_model.py:333-334).  Fills self.gen.v."""
         T1, N, C = self.T1, self.N, self.C
         nz = self.nz
-        ones = torch.ones(N, dtype=torch.int32, device=self.dev)
         self.images = images
         self.gt_mask = gt_mask
         if nz:
@@ -336,12 +335,19 @@ class SAVPGenerator(object):
                     a = L['a']
                     K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + nz])
         in0, maskin = self.layers[0]['in'], self.maskin
+        # the first frame feeds every step (savp_model.py:399-400): ONE launch writes it into all T1 steps' buffers -- time is the
+        # kernel's sample index (source stride 0), the N*H*W pixels of a step its pixel index
+        if self._ones is None:
+            self._ones = torch.ones(max(N, T1), dtype=torch.int32, device=self.dev)
+        NH = N * self.H
+        first = images[0].reshape(1, NH, self.W, C).expand(T1, NH, self.W, C)
+        K.select(self._ones, first, None, [in0.v.reshape(T1, NH, self.W, -1)[..., C:2 * C],
+                                           maskin.v.reshape(T1, NH, self.W, -1)[..., self.o_first:self.o_first + C]])
         for t in range(T1):
             # image = tf.where(ground_truth[t], inputs['images'], states['gen_image'])     (savp_model.py:406)
             prev_gen = self.gen.v[t - 1] if t > 0 else None
             K.select(gt_mask[t], images[t], prev_gen,
                      [in0.v[t][..., 0:C], maskin.v[t][..., self.o_prev:self.o_prev + C]])
-            K.select(ones, images[0], None, [in0.v[t][..., C:2 * C], maskin.v[t][..., self.o_first:self.o_first + C]])
             for L in self.layers:
                 f = L['f']
                 L['conv'].forward(L['in'].v[t], L['pre'].v[t])
