@@ -412,6 +412,15 @@ def check_util(seed=4):
     o3 = torch.zeros(200, device=DEV)
     K.colsum(dev(x200), o3)
     out.append(('colsum_c200', rel_err(o3, x200.sum(dim=(0, 1, 2))), 1e-5))
+    # wide power-of-two rows (the discriminators' bias gradients): float4 lanes, many pixel chunks per row
+    for (cc, hw) in ((32, (9, 40)), (64, (33, 31)), (256, (8, 8)), (1024, (8, 8))):
+        xc = rnd(rng, 3, hw[0], hw[1], cc)
+        oc = torch.zeros(cc, device=DEV)
+        K.colsum(dev(xc), oc, scale=0.25)
+        out.append(('colsum_wide_c%d' % cc, rel_err(oc, 0.25 * xc.sum(dim=(0, 1, 2))), 1e-5))
+        ocr = torch.zeros(3, cc, device=DEV)
+        K.colsum(dev(xc), ocr, per_row=True)
+        out.append(('colsum_wide_rows_c%d' % cc, rel_err(ocr, xc.sum(dim=(1, 2))), 1e-5))
     # select fwd / bwd
     N, C3 = 4, 3
     a, b = rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3)
@@ -421,6 +430,23 @@ def check_util(seed=4):
     K.select(mask.to(DEV), dev(a), dev(b), [o_a[..., :3], o_b])
     ref = torch.where(mask.bool()[:, None, None, None], a, b)
     out.append(('select', rel_err(o_a[..., :3], ref) + rel_err(o_b, ref), 1e-7))
+    # no second source (zeros), grey (1 channel) and 2-channel (generic kernel) variants
+    for cc in (1, 2, 3):
+        oz = torch.full((N, H, W, 6), 5.0, device=DEV)
+        K.select(mask.to(DEV), dev(a[..., :cc]), None, [oz[..., 2:2 + cc]])
+        refz = torch.where(mask.bool()[:, None, None, None], a[..., :cc], torch.zeros_like(a[..., :cc]))
+        keep = bool((oz[..., :2] == 5.0).all() and (oz[..., 2 + cc:] == 5.0).all())
+        out.append(('select_nob_c%d' % cc, rel_err(oz[..., 2:2 + cc], refz) + (0.0 if keep else 1.0), 1e-7))
+    # the generator's first-frame fill: one frame broadcast over T steps (source sample stride 0), two destinations
+    T_, Nn = 5, 3
+    frame = rnd(rng, Nn, H, W, C3)
+    fd = dev(frame)
+    bufa, bufb = torch.zeros(T_, Nn, H, W, 16, device=DEV), torch.zeros(T_, Nn, H, W, 9, device=DEV)
+    first = fd.reshape(1, Nn * H, W, C3).expand(T_, Nn * H, W, C3)
+    K.select(torch.ones(T_, dtype=torch.int32, device=DEV), first, None,
+             [bufa.reshape(T_, Nn * H, W, 16)[..., 3:6], bufb.reshape(T_, Nn * H, W, 9)[..., 6:9]])
+    refb = frame[None].expand(T_, Nn, H, W, C3)
+    out.append(('select_broadcast_first_frame', rel_err(bufa[..., 3:6], refb) + rel_err(bufb[..., 6:9], refb), 1e-7))
     d1, d2, db0 = rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3)
     dbd = dev(db0)
     K.select_bwd(mask.to(DEV), [dev(d1), dev(d2)], dbd)

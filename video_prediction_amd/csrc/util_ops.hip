@@ -89,6 +89,7 @@ __global__ __launch_bounds__(NT) void colsum_narrow_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
     const float* base = in + r * sn + cv * V;
+#pragma unroll 4
     for (int p = p0 + pl; p < p1; p += npl) {
         const float* a = base + (long long)p * sp;
         if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(a); acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w; }
@@ -120,11 +121,18 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
                            int32_t per_row) {
     // NOTE: always accumulates (atomically) into `out`; zero it first for an overwrite.
     if (!in.p || !out || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
-    if (C <= 16 && (C & (C - 1)) == 0 && HW >= 64) {
-        const uintptr_t al = (uintptr_t)in.p | (uintptr_t)(in.sn * 4) | (uintptr_t)(in.sp * 4);
+    // power-of-two channel counts: C / V lanes per pixel with V-wide loads (written for the narrow z slices, C <= 16; with float4
+    // loads it also serves the discriminators' 32..256-channel bias gradients, which the 64-lanes-per-row kernel below summed at
+    // 0.9 TB/s: one 4-byte load in flight per thread and only ~4 workgroups per sample)
+    const uintptr_t al = (uintptr_t)in.p | (uintptr_t)(in.sn * 4) | (uintptr_t)(in.sp * 4);
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("SAVP_COLSUM_WIDE"); wide = (e && e[0] == '0') ? 0 : 1; }
+    if ((C & (C - 1)) == 0 && HW >= 64 && (C <= 16 || (wide && C <= 4 * NT && (al & 15) == 0))) {
         const int V = (C >= 4 && (al & 15) == 0) ? 4 : ((C >= 2 && (al & 7) == 0) ? 2 : 1);
         const int per_pass = NT * V / C;
-        int chunk = ((HW + 3) / 4 + per_pass - 1) / per_pass * per_pass;             // ~4 workgroups per row, whole passes
+        long long per_row_wgs = C <= 16 ? 4 : (1024 + R - 1) / R;                     // wide rows: ~4 workgroups per CU in total
+        if (per_row_wgs < 4) per_row_wgs = 4;
+        int chunk = (int)(((HW + per_row_wgs - 1) / per_row_wgs + per_pass - 1) / per_pass * per_pass);   // whole passes
         if (chunk < per_pass) chunk = per_pass;
         dim3 grid((unsigned)R, (unsigned)((HW + chunk - 1) / chunk), 1u);
         hipStream_t st = (hipStream_t)stream;
@@ -163,6 +171,27 @@ __global__ void select_kernel(SelP p) {
     }
 }
 
+// One thread per pixel, C compile-time (1 / 3 colour channels): the element-per-thread kernel above pays two runtime integer
+// divisions per float and writes 4-byte pieces; here a pixel's channels are one 12-byte run and the sample index comes from the
+// grid (blockIdx.y), 350 -> ~100 us for the 29-step first-frame fill.
+template <int C>
+__global__ __launch_bounds__(NT) void select_px_kernel(SelP p) {
+    const int n = blockIdx.y;
+    const bool take_a = p.mask[n] != 0;
+    const float* __restrict__ src = take_a ? p.a + (long long)n * p.a_sn : (p.b ? p.b + (long long)n * p.b_sn : nullptr);
+    const long long s_sp = take_a ? p.a_sp : p.b_sp;
+    for (int px = blockIdx.x * NT + threadIdx.x; px < p.HW; px += gridDim.x * NT) {
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = src ? src[(long long)px * s_sp + c] : 0.f;
+        for (int k = 0; k < p.nout; ++k) {
+            float* __restrict__ o = p.out[k] + (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = v[c];
+        }
+    }
+}
+
 extern "C" int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, SavpView a, SavpView b,
                            int32_t nout, const SavpView* outs) {
     if (!mask || !a.p || nout < 1 || nout > 4 || !outs) return SAVP_EINVAL;
@@ -172,6 +201,13 @@ extern "C" int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const
     p.b = (const float*)b.p; p.b_sn = b.sn; p.b_sp = b.sp;
     p.nout = nout;
     for (int i = 0; i < nout; ++i) { p.out[i] = (float*)outs[i].p; p.o_sn[i] = outs[i].sn; p.o_sp[i] = outs[i].sp; }
+    if ((C == 1 || C == 3) && N <= 65535) {
+        unsigned bx = (unsigned)((HW + NT - 1) / NT);
+        if (bx > 1024) bx = 1024;
+        if (C == 3) hipLaunchKernelGGL(select_px_kernel<3>, dim3(bx, (unsigned)N), dim3(NT), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(select_px_kernel<1>, dim3(bx, (unsigned)N), dim3(NT), 0, (hipStream_t)stream, p);
+        return LAUNCH_OK();
+    }
     hipLaunchKernelGGL(select_kernel, dim3(nblocks((long long)N * HW * C)), dim3(NT), 0, (hipStream_t)stream, p);
     return LAUNCH_OK();
 }
