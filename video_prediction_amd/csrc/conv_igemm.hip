@@ -781,7 +781,8 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     ablate_init();
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
-    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_WGRAD) {    // RGB-input first layer of the discriminators (conv_thin.hip)
+    {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first layer
+        // (FPROP, WGRAD) and the data gradient of the generator's scratch-image head
         int rc = SAVP_OK;
         if (conv_thin_try(a, st, &rc)) return rc;
     }

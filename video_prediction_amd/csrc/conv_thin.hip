@@ -35,6 +35,7 @@ struct ThinP {
     const float* bias; int act; float alpha;
     int N, D, H, W, Cx;
     int tilesX, tilesY, items, per_wg;
+    int flip;                                          // FPROP kernel used as DGRAD: weight tap TAPS - 1 - s (the transposed conv's mirror)
     const float* zero;                                 // 16 bytes of zeros in global memory (the source of out-of-range pixels)
 };
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(ThinP p) {
         for (int j = 0; j < 8; ++j) {
             const int s = 4 * ks + 2 * half + (j >> 2), c = j & 3;
             const bool live = s < TAPS && c < CX;               // unconditional (clamped) load + select: 56 loads in flight at once
-            const float v = p.w[live ? l31 * TAPS * CX + s * CX + c : 0];
+            const float v = p.w[live ? l31 * TAPS * CX + (p.flip ? TAPS - 1 - s : s) * CX + c : 0];
             bw[ks][j] = (__bf16)(live ? v : 0.f);
         }
 #pragma unroll
@@ -333,16 +334,26 @@ static bool thin_enabled() {
 }
 
 static bool thin_geometry_ok(const SavpConvArgs* a) {
-    return a->precision == SAVP_PREC_BF16 && (a->Cx == 1 || a->Cx == 3 || a->Cx == 4) && a->Cy == 32 && a->kh == 3 && a->kw == 3 && a->ph == 1 &&
+    // DGRAD of a 32 -> (1 | 3 | 4)-channel convolution is the same problem with the tensors' roles swapped and the taps mirrored
+    const bool dg = a->mode == SAVP_CONV_DGRAD;
+    const int cthin = dg ? a->Cy : a->Cx, cwide = dg ? a->Cx : a->Cy;
+    return a->precision == SAVP_PREC_BF16 && (cthin == 1 || cthin == 3 || cthin == 4) && cwide == 32 && a->kh == 3 && a->kw == 3 && a->ph == 1 &&
            a->pw == 1 && (a->kd == 1 || a->kd == 3) && a->pd == a->kd / 2 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->Do == a->D &&
            a->Ho == a->H && a->Wo == a->W && !a->src_bf16 && !a->out_bf16 && !a->stats && a->N >= 1 && a->H >= 1 && a->W >= 1;
 }
 
 static void thin_fill(ThinP& p, const SavpConvArgs* a, int tile_r, int tile_c, int target_wgs) {
-    p.x = (const float*)a->x; p.x_sn = a->x_sn; p.x_sd = a->x_sd; p.x_sh = a->x_sh; p.x_sw = a->x_sw;
-    p.y = (float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
+    const bool dg = a->mode == SAVP_CONV_DGRAD;             // ThinP.x = the thin (source) tensor, ThinP.y = the 32-channel one
+    if (dg) {
+        p.x = (const float*)a->y; p.x_sn = a->y_sn; p.x_sd = a->y_sd; p.x_sh = a->y_sh; p.x_sw = a->y_sw;
+        p.y = (float*)a->x; p.y_sn = a->x_sn; p.y_sd = a->x_sd; p.y_sh = a->x_sh; p.y_sw = a->x_sw;
+    } else {
+        p.x = (const float*)a->x; p.x_sn = a->x_sn; p.x_sd = a->x_sd; p.x_sh = a->x_sh; p.x_sw = a->x_sw;
+        p.y = (float*)a->y; p.y_sn = a->y_sn; p.y_sd = a->y_sd; p.y_sh = a->y_sh; p.y_sw = a->y_sw;
+    }
     p.w = nullptr; p.dw = nullptr; p.db = nullptr; p.ws = nullptr; p.bias = nullptr; p.act = 0; p.alpha = 0.f;
-    p.N = a->N; p.D = a->D; p.H = a->H; p.W = a->W; p.Cx = a->Cx;
+    p.flip = dg ? 1 : 0;
+    p.N = a->N; p.D = a->D; p.H = a->H; p.W = a->W; p.Cx = dg ? a->Cy : a->Cx;
     p.tilesX = (a->W + tile_c - 1) / tile_c; p.tilesY = (a->H + tile_r - 1) / tile_r;
     p.items = a->N * a->D * p.tilesY * p.tilesX;
     p.per_wg = (p.items + target_wgs - 1) / target_wgs;
@@ -358,14 +369,14 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     ThinP p;
     p.zero = zero;
-    if (a->mode == SAVP_CONV_FPROP) {
+    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         if (a->beta || a->aux || (a->act != SAVP_ACT_NONE && a->act != SAVP_ACT_LRELU)) return false;
         thin_fill(p, a, TF_R, TF_C, 1024);                    // four resident workgroups per CU: one full wave of them
         p.w = (const float*)a->w; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;
         const dim3 grid((unsigned)((p.items + p.per_wg - 1) / p.per_wg));
 #define THIN_F(KD_, CX_) hipLaunchKernelGGL((thin_fprop_kernel<KD_, CX_>), grid, dim3(256), 0, st, p)
-        if (a->kd == 3) { if (a->Cx == 3) THIN_F(3, 3); else if (a->Cx == 1) THIN_F(3, 1); else THIN_F(3, 4); }
-        else { if (a->Cx == 3) THIN_F(1, 3); else if (a->Cx == 1) THIN_F(1, 1); else THIN_F(1, 4); }
+        if (a->kd == 3) { if (p.Cx == 3) THIN_F(3, 3); else if (p.Cx == 1) THIN_F(3, 1); else THIN_F(3, 4); }
+        else { if (p.Cx == 3) THIN_F(1, 3); else if (p.Cx == 1) THIN_F(1, 1); else THIN_F(1, 4); }
 #undef THIN_F
     } else if (a->mode == SAVP_CONV_WGRAD) {
         if ((a->y_sn % 4) || (a->y_sd % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y)) return false;

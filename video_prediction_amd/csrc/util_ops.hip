@@ -121,17 +121,14 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
                            int32_t per_row) {
     // NOTE: always accumulates (atomically) into `out`; zero it first for an overwrite.
     if (!in.p || !out || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
-    // power-of-two channel counts: C / V lanes per pixel with V-wide loads (written for the narrow z slices, C <= 16; with float4
-    // loads it also serves the discriminators' 32..256-channel bias gradients, which the 64-lanes-per-row kernel below summed at
-    // 0.9 TB/s: one 4-byte load in flight per thread and only ~4 workgroups per sample)
+    // Narrow power-of-two slices: C / V lanes per pixel with V-wide loads.  (Tried for the discriminators' 32..256-channel bias
+    // gradients too, with ~1024 workgroups: 0.8 ms per step SLOWER than the kernel below -- every workgroup ends in C atomics onto
+    // the same one to eight cache lines, and those serialise.)
     const uintptr_t al = (uintptr_t)in.p | (uintptr_t)(in.sn * 4) | (uintptr_t)(in.sp * 4);
-    static int wide = -1;
-    if (wide < 0) { const char* e = getenv("SAVP_COLSUM_WIDE"); wide = (e && e[0] == '0') ? 0 : 1; }
-    if ((C & (C - 1)) == 0 && HW >= 64 && (C <= 16 || (wide && C <= 4 * NT && (al & 15) == 0))) {
+    if (C <= 16 && (C & (C - 1)) == 0 && HW >= 64) {
         const int V = (C >= 4 && (al & 15) == 0) ? 4 : ((C >= 2 && (al & 7) == 0) ? 2 : 1);
         const int per_pass = NT * V / C;
-        long long per_row_wgs = C <= 16 ? 4 : (1024 + R - 1) / R;                     // wide rows: ~4 workgroups per CU in total
-        if (per_row_wgs < 4) per_row_wgs = 4;
+        const long long per_row_wgs = 4;
         int chunk = (int)(((HW + per_row_wgs - 1) / per_row_wgs + per_pass - 1) / per_pass * per_pass);   // whole passes
         if (chunk < per_pass) chunk = per_pass;
         dim3 grid((unsigned)R, (unsigned)((HW + chunk - 1) / chunk), 1u);
