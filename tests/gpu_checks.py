@@ -424,6 +424,14 @@ def check_util(seed=4):
         ocr = torch.zeros(3, cc, device=DEV)
         K.colsum(dev(xc), ocr, per_row=True)
         out.append(('colsum_wide_rows_c%d' % cc, rel_err(ocr, xc.sum(dim=(1, 2))), 1e-5))
+    # all-pixel sums of large tensors take the partial-rows + reduce path (>= 32768 pixels, pixel-linear, C / 4 a power of two);
+    # accumulation into a non-zero destination, ragged last chunk, a channel slice (pixel stride > C)
+    for (cc, shape, lo, width) in ((32, (6, 128, 97), 0, 32), (64, (37, 33, 31), 0, 64), (32, (5, 100, 80), 8, 48), (1024, (40, 30, 30), 0, 1024)):
+        xc = rnd(rng, *shape, width)
+        o0 = rnd(rng, cc)
+        oc = dev(o0)
+        K.colsum(dev(xc)[..., lo:lo + cc], oc, scale=0.5)
+        out.append(('colsum_2stage_c%d' % cc, rel_err(oc, o0 + 0.5 * xc[..., lo:lo + cc].sum(dim=(0, 1, 2))), 1e-5))
     # select fwd / bwd
     N, C3 = 4, 3
     a, b = rnd(rng, N, H, W, C3), rnd(rng, N, H, W, C3)

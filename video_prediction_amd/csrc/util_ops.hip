@@ -117,6 +117,45 @@ __global__ __launch_bounds__(NT) void colsum_narrow_kernel(const float* __restri
     }
 }
 
+// Sum over ALL pixels of a pixel-linear tensor [P = R * HW][C] (bias gradients of the 'up' layers and of the discriminators):
+// the kernels above end every workgroup in C atomics onto the same 1..8 cache lines, and with thousands of workgroups those
+// serialise (64x64x32 over 928 images: 14.8 k workgroups, 270 us, atomic-bound).  Here ~1 k workgroups each sum a contiguous
+// range of pixels with C / 4 lanes per pixel and float4 loads (4 in flight per thread), leave ONE partial row in a workspace, and
+// a second small launch adds the rows up (16 atomics per output element instead of thousands).
+__global__ __launch_bounds__(NT) void colsum_part_kernel(const float* __restrict__ in, long long sp, long long P, int C, long long chunk,
+                                                         float* __restrict__ part) {
+    __shared__ float sh[NT * 4];
+    const int q = C >> 2;                             // lanes per pixel (power of two, <= NT)
+    const int cv = threadIdx.x & (q - 1), pl = threadIdx.x / q, npl = NT / q;
+    const long long p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* base = in + cv * 4;
+#pragma unroll 4
+    for (long long p = p0 + pl; p < p1; p += npl) {
+        const float4 t = *reinterpret_cast<const float4*>(base + p * sp);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *reinterpret_cast<float4*>(sh + threadIdx.x * 4) = acc;
+    __syncthreads();
+    for (int off = npl >> 1; off > 0; off >>= 1) {
+        if (pl < off) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sh[threadIdx.x * 4 + v] += sh[(threadIdx.x + off * q) * 4 + v];
+        }
+        __syncthreads();
+    }
+    if (pl == 0) *reinterpret_cast<float4*>(part + (long long)blockIdx.x * C + cv * 4) = *reinterpret_cast<const float4*>(sh + threadIdx.x * 4);
+}
+
+// out[c] += scale * sum over rows of part[row][c]; grid (ceil(C / NT), G): block y takes rows y, y + G, ...
+__global__ __launch_bounds__(NT) void colsum_reduce_kernel(const float* __restrict__ part, int rows, int C, float scale, float* out) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += part[(long long)r * C + c];
+    unsafeAtomicAdd(out + c, s * scale);
+}
+
 extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out,
                            int32_t per_row) {
     // NOTE: always accumulates (atomically) into `out`; zero it first for an overwrite.
@@ -136,6 +175,31 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
         if (V == 4) hipLaunchKernelGGL(colsum_narrow_kernel<4>, grid, dim3(NT), 0, st, (const float*)in.p, (long long)in.sn, (long long)in.sp, HW, C, scale, out, per_row, chunk);
         else if (V == 2) hipLaunchKernelGGL(colsum_narrow_kernel<2>, grid, dim3(NT), 0, st, (const float*)in.p, (long long)in.sn, (long long)in.sp, HW, C, scale, out, per_row, chunk);
         else hipLaunchKernelGGL(colsum_narrow_kernel<1>, grid, dim3(NT), 0, st, (const float*)in.p, (long long)in.sn, (long long)in.sp, HW, C, scale, out, per_row, chunk);
+        return LAUNCH_OK();
+    }
+    // all-pixel sums of large pixel-linear tensors: partial rows + reduce launch (see colsum_part_kernel); SAVP_COLSUM_2STAGE=0 = off
+    static int two_stage = -1;
+    if (two_stage < 0) { const char* e = getenv("SAVP_COLSUM_2STAGE"); two_stage = (e && e[0] == '0') ? 0 : 1; }
+    const long long P = (long long)R * HW;
+    const int q4 = C >> 2;
+    if (two_stage && !per_row && (C & 3) == 0 && q4 >= 1 && q4 <= NT && (q4 & (q4 - 1)) == 0 && (al & 15) == 0 && in.sn == (long long)HW * in.sp &&
+        P >= 32768) {
+        const int npl = NT / q4;
+        const int nwg = 1024;
+        long long chunk2 = (P + nwg - 1) / nwg;
+        chunk2 = (chunk2 + 4 * npl - 1) / (4 * npl) * (4 * npl);                       // whole unrolled passes
+        const int rows = (int)((P + chunk2 - 1) / chunk2);
+        static float* ws = nullptr;                                                   // one buffer per process: calls on different streams
+        static size_t ws_floats = 0;                                                  // must not overlap (the engine uses its compute stream)
+        if ((size_t)rows * C > ws_floats) {
+            if (ws) hipFree(ws);
+            ws = nullptr; ws_floats = 0;
+            if (hipMalloc((void**)&ws, (size_t)nwg * 4 * NT * sizeof(float)) != hipSuccess) return SAVP_ELAUNCH;
+            ws_floats = (size_t)nwg * 4 * NT;
+        }
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)rows), dim3(NT), 0, st, (const float*)in.p, (long long)in.sp, P, C, chunk2, ws);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + NT - 1) / NT), 16u), dim3(NT), 0, st, (const float*)ws, rows, C, scale, out);
         return LAUNCH_OK();
     }
     int chunk = 256;
