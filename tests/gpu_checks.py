@@ -869,6 +869,26 @@ def check_conv_thin(seed=23):
                 ref_dw[a, u, v] = torch.einsum('ncdhw,ndhwo->co', xs, dy)
     out.append(('thin/wgrad_accumulates', rel_err(dwd, dw0 + ref_dw), 1e-2))
     out.append(('thin/wgrad_bias_accumulates', rel_err(dbd, db0 + dy.sum(dim=(0, 1, 2, 3))), TOL_OP))
+    # conv_s2dgrad.hip: data gradient of the 4x4 stride-(1,2,2) layer into a 32-channel activation; ragged tiles, accumulation into
+    # the destination (beta) and the fused LeakyReLU backward from the saved activation; 3-D (kd = 4) and 2-D (kd = 1, Cy = 32)
+    for (tag, N, dhw, Cy, k, s_, pp, beta, act) in (('s2dgrad/3d_beta_dlrelu', 2, (5, 18, 40), 64, (4, 4, 4), (1, 2, 2), (1, 1, 1), 1, True),
+                                                    ('s2dgrad/3d_plain', 1, (4, 32, 64), 64, (4, 4, 4), (1, 2, 2), (1, 1, 1), 0, False),
+                                                    ('s2dgrad/2d_c32', 3, (1, 32, 34), 32, (1, 4, 4), (1, 2, 2), (0, 1, 1), 0, True)):
+        x = rnd(rng, N, *dhw, 32).requires_grad_(True)
+        w = rnd(rng, *k, 32, Cy) * 0.1
+        y = _ref_conv(x, w, k, s_, pp, pp)
+        dy = rnd(rng, *y.shape)
+        (y * dy).sum().backward()
+        old = rnd(rng, N, *dhw, 32)
+        aux = rnd(rng, N, *dhw, 32)
+        ref = x.grad + (old if beta else 0.0)
+        if act:
+            ref = ref * torch.where(aux > 0, torch.ones_like(aux), torch.full_like(aux, 0.1))
+        dxd = dev(old) if beta else torch.full(x.shape, float('nan'), device=DEV)
+        wdp = dev(pack_wd(w))
+        K.conv(lib.CONV_DGRAD, K.ConvGeom(k, s_, pp), dxd, dev(dy), wdp, beta=beta, act=lib.ACT_DLRELU_FROM_OUT if act else 0, alpha=0.1,
+               aux=dev(aux) if act else None, precision=1, w16=wdp.to(torch.bfloat16))
+        out.append((tag, rel_err(dxd, ref), 1e-2))
     torch.cuda.synchronize()
     return out
 

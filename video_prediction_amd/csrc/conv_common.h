@@ -92,6 +92,9 @@ static inline unsigned long long magic40(int d) {
 // conv_thin.hip: FPROP / WGRAD of a 3x3(x3) stride-1 convolution with Cx <= 4, Cy = 32 (bf16 mode).  true = handled.
 bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc);
 
+// conv_s2dgrad.hip: DGRAD of a 4x4 stride-(1,2,2) convolution with 32 input channels, all four output phases per workgroup.
+bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+
 extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -786,6 +786,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         int rc = SAVP_OK;
         if (conv_thin_try(a, st, &rc)) return rc;
     }
+    if (a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
+        int rc = SAVP_OK;
+        if (conv_s2dgrad_try(a, st, &rc)) return rc;
+    }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         const bool dg = a->mode == SAVP_CONV_DGRAD;
         p.out = (float*)(dg ? a->x : a->y);
