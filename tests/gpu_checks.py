@@ -82,6 +82,7 @@ CONV_CASES = [
     # RGB / grey first layers of the discriminators (csrc/conv_thin.hip in bf16 mode): several column tiles, ragged edges, 2-D
     ('thin_rgb_w72', 2, (4, 24, 72), 3, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     ('thin_grey_2d', 3, (1, 20, 40), 1, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1)),
+    ('thin_grey_3d', 2, (4, 12, 40), 1, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     ('thin_c4_odd', 1, (3, 9, 33), 4, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     # 32 -> 4 / 1 channels: the DGRAD of these is the thin kernel with mirrored taps (the generator's scratch-image head)
     ('thin_dgrad_c4', 2, (1, 20, 70), 32, 4, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1)),
