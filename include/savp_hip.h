@@ -77,8 +77,9 @@ typedef struct SavpConvArgs {
     const float* aux;              /* act==3: saved activation, addressed like the destination */
     const void* w_bf16;            /* optional bf16 copy of w (FPROP/DGRAD, SAVP_PREC_BF16): halves the weight stream */
     /* bf16 activations (SAVP_PREC_BF16, FPROP/DGRAD, ring kernel; EINVAL where it does not apply -- no silent fp32 fallback): */
-    int32_t src_bf16;              /* the source tensor (x for FPROP, y for DGRAD) holds bf16; its strides count bf16 elements */
-    int32_t out_bf16;              /* the destination receives bf16 (strides in bf16 elements; no bias / act / beta / split-K).
+    int32_t src_bf16;              /* the source tensor (x for FPROP and WGRAD, y for DGRAD) holds bf16; its strides count bf16 elements */
+    int32_t out_bf16;              /* the destination receives bf16 (strides in bf16 elements; no bias / act / beta / split-K); WGRAD: the
+                                      y (output-gradient) operand holds bf16.
                                       This is the ConvLSTM gate convolution (rnn_ops.py:121): the gate tensor makes its round trip to
                                       the gate kernels in half the bytes */
     float* stats;                  /* with out_bf16: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
@@ -119,6 +120,8 @@ typedef struct SavpInormArgs {
                                       channel 0 of its view (multiples of 4; out_nc == 0: all C channels) -- one launch can normalise
                                       the concatenated output of two convolutions that feed different consumers */
     int32_t dy_c0[4], dy_nc[4];    /* bwd: gradient k covers channels [dy_c0, dy_c0 + dy_nc) (dy_nc == 0: all C) */
+    int32_t out_bf16;              /* fwd: bit k set = output view k is a bf16 tensor (its strides count bf16 elements): a destination
+                                      that only feeds convolutions of the bf16 datapath (they round to bf16 anyway) in half the bytes */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);
@@ -154,6 +157,10 @@ typedef struct SavpLstmArgs {
     int32_t stats1_ready;          /* fwd: the first N*4F*2 floats of ws_stats already hold the per-(sample, gate channel) sum / sum of
                                       squares of the gate tensor (savp_conv's `stats` epilogue; the remaining N*F*3 floats zero): the
                                       statistics pass over the gates is skipped -> conv + 2 launches per ConvLSTM cell */
+    int32_t h_bf16;                /* fwd: bit k set = destination k of h' is a bf16 tensor (strides in bf16 elements) */
+    int32_t dgates_bf16;           /* bwd: `dgates` receives bf16 (its readers are the gate convolution's DGRAD / WGRAD, which round to
+                                      bf16 anyway); the raw gate gradients between the passes then live in dgates_raw.  Coalesced kernels only */
+    float* dgates_raw;             /* bwd, with dgates_bf16: fp32 scratch [N,HW,4F] */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
@@ -163,6 +170,8 @@ int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
  * ------------------------------------------------------------------------------------------------------------ */
 /* out[r,p,c] (=|+=) scale*z[r,c]  : tile_concat broadcast (ops.py:968-1006) / backward of global average pool */
 int savp_tile_channels(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out, int32_t beta);
+/* the same into a bf16 view (strides in bf16 elements; overwrite) */
+int savp_tile_channels_bf16(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out);
 /* out[(r,)c] += scale*sum_p in[r,p,c] (atomic accumulate; per_row keeps r) : bias grads, d(tile_concat), avg pool */
 int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out, int32_t per_row);
 /* out_k = mask[n] ? a : b   (scheduled sampling tf.where, savp_model.py:406); b.p may be NULL (zeros) */

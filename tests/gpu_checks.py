@@ -1026,3 +1026,76 @@ def check_metrics(seed=11):
 
 
 ALL_CHECKS.append(('metrics', check_metrics))
+
+
+def check_bf16_activation_io(seed=31):
+    """bf16 destinations / operands of the kernels around the ConvLSTM gate convolution (SAVP_BF16_ACT=1 in the engine; experimental):
+    a bf16 view receives exactly the fp32 result rounded to nearest even, and the weight gradient from bf16 operand tensors equals
+    the one from the same values held in fp32."""
+    out = []
+    rng = np.random.default_rng(seed)
+    N, H, W, C = 2, 32, 32, 32
+    # instance norm + ReLU into one fp32 and one bf16 slice (large-plane two-kernel path and the single-kernel path)
+    for (hh, ww) in ((32, 32), (8, 8)):
+        x = dev(rnd(rng, N, hh, ww, C))
+        g, b = dev(rnd(rng, C) * 0.3 + 1), dev(rnd(rng, C) * 0.3)
+        o32 = torch.zeros(N, hh, ww, C + 8, device=DEV)
+        o16 = torch.zeros(N, hh, ww, C + 8, device=DEV, dtype=torch.bfloat16)
+        mean, rstd = torch.empty(N, C, device=DEV), torch.empty(N, C, device=DEV)
+        K.instnorm_act_fwd(x, g, b, [o32[..., :C], o16[..., 8:]], mean, rstd, act='relu')
+        same = bool((o16[..., 8:] == o32[..., :C].to(torch.bfloat16)).all()) and float(o16[..., :8].float().abs().max()) == 0.0
+        out.append(('bf16io/inorm_%dx%d' % (hh, ww), 0.0 if same else 1.0, 0.5))
+    # ConvLSTM gate block: h' into an fp32 and a bf16 destination (coalesced and single-kernel paths)
+    for (hh, ww, F, use_ws) in ((32, 32, 32, True), (8, 8, 16, False)):
+        gates = dev(rnd(rng, N, hh, ww, 4 * F) * 1.5)
+        c = dev(rnd(rng, N, hh, ww, F))
+        p = [dev(rnd(rng, 4 * F) * 0.3 + 1), dev(rnd(rng, 4 * F) * 0.3), dev(rnd(rng, F) * 0.3 + 1), dev(rnd(rng, F) * 0.3)]
+        c_new = torch.empty(N, hh, ww, F, device=DEV)
+        h32 = torch.zeros(N, hh, ww, F, device=DEV)
+        h16 = torch.zeros(N, hh, ww, 2 * F + 8, device=DEV, dtype=torch.bfloat16)
+        stats = [torch.empty(N, 4 * F, device=DEV), torch.empty(N, 4 * F, device=DEV), torch.empty(N, F, device=DEV), torch.empty(N, F, device=DEV)]
+        ws = torch.empty(K.lstm_ws_floats(N, hh * ww, F), device=DEV) if use_ws else None
+        K.convlstm_gates_fwd(gates, c, p[0], p[1], p[2], p[3], c_new, [h32, h16[..., F + 8:]], stats, ws=ws)
+        same = bool((h16[..., F + 8:] == h32.to(torch.bfloat16)).all()) and float(h16[..., :F + 8].float().abs().max()) == 0.0
+        out.append(('bf16io/lstm_h_%dx%d' % (hh, ww), 0.0 if same else 1.0, 0.5))
+        if use_ws:        # backward: bf16 gate gradient == the fp32 one rounded; everything else unchanged
+            dh, dcn = dev(rnd(rng, N, hh, ww, F)), dev(rnd(rng, N, hh, ww, F))
+            res = []
+            for dt in (torch.float32, torch.bfloat16):
+                dg = torch.empty(N, hh, ww, 4 * F, device=DEV, dtype=dt)
+                dcp = torch.empty(N, hh, ww, F, device=DEV)
+                dpar = [torch.zeros(4 * F, device=DEV), torch.zeros(4 * F, device=DEV), torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)]
+                raw = torch.empty(N, hh, ww, 4 * F, device=DEV) if dt == torch.bfloat16 else None
+                K.convlstm_gates_bwd(gates, c, p[0], p[1], p[2], p[3], stats, [dh], dcn, dg, dcp, dpar, ws=ws, dgates_raw=raw)
+                res.append((dg, dcp, dpar))
+            same = bool((res[1][0] == res[0][0].to(torch.bfloat16)).all()) and bool((res[1][1] == res[0][1]).all())
+            out.append(('bf16io/lstm_dgates_%dx%d' % (hh, ww), 0.0 if same else 1.0, 0.5))
+            for nm, a_, b_ in zip(('dg1', 'db1', 'dg2', 'db2'), res[1][2], res[0][2]):
+                out.append(('bf16io/lstm_%s' % nm, rel_err(a_, b_.double().cpu()), 1e-5))
+    # tile_channels into a bf16 slice
+    z = dev(rnd(rng, 6, 8))
+    t16 = torch.zeros(6, 16, 16, 24, device=DEV, dtype=torch.bfloat16)
+    t32 = torch.zeros(6, 16, 16, 8, device=DEV)
+    K.tile_channels(z, t16[..., 8:16], scale=0.5)
+    K.tile_channels(z, t32, scale=0.5)
+    same = bool((t16[..., 8:16] == t32.to(torch.bfloat16)).all()) and float(t16[..., :8].float().abs().max()) == 0.0 and \
+        float(t16[..., 16:].float().abs().max()) == 0.0
+    out.append(('bf16io/tile_channels', 0.0 if same else 1.0, 0.5))
+    # weight gradient of a 5x5 gate convolution (8-wave x 8-tile shape) from bf16 x and / or dy tensors
+    Nn, hh, ww, Cx, Cy = 4, 16, 16, 72, 128
+    geom = K.ConvGeom((1, 5, 5), (1, 1, 1), (0, 2, 2))
+    xr = rnd(rng, Nn, hh, ww, Cx).to(torch.bfloat16)                   # values exactly representable in bf16
+    dyr = rnd(rng, Nn, hh, ww, Cy).to(torch.bfloat16)
+    x32, dy32 = xr.float().to(DEV).contiguous(), dyr.float().to(DEV).contiguous()
+    x16, dy16 = xr.to(DEV).contiguous(), dyr.to(DEV).contiguous()
+    ref = torch.zeros(5, 5, Cx, Cy, device=DEV)
+    refb = torch.zeros(Cy, device=DEV)
+    K.conv(lib.CONV_WGRAD, geom, x32, dy32, ref, bias=refb, precision=1)
+    for tag, xa, ya in (('x16', x16, dy32), ('y16', x32, dy16), ('x16_y16', x16, dy16)):
+        dw = torch.zeros(5, 5, Cx, Cy, device=DEV)
+        db = torch.zeros(Cy, device=DEV)
+        K.conv(lib.CONV_WGRAD, geom, xa, ya, dw, bias=db, precision=1)
+        out.append(('bf16io/wgrad_' + tag, rel_err(dw, ref.double().cpu()), 1e-5))
+        out.append(('bf16io/wgrad_bias_' + tag, rel_err(db, refb.double().cpu()), 1e-5))
+    torch.cuda.synchronize()
+    return out

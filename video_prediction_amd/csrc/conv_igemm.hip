@@ -860,6 +860,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
             if (conv_wgrad_patch_try(p, a, st, &rc)) return rc;
             if (algo == 2) return SAVP_EINVAL;
         }
+        if (a->src_bf16 || a->out_bf16) return SAVP_EINVAL;    // bf16 operand tensors: only the LDS-patch kernel reads them
         const long long M = (long long)a->kd * a->kh * a->kw * a->Cx;
         const long long Ktot = (long long)a->N * a->Do * a->Ho * a->Wo;
         // fastdiv exactness domain: p * d < 2^40 for every (pixel index p, divisor d)

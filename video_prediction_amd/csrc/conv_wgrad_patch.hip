@@ -58,9 +58,11 @@ __device__ __forceinline__ void wgp_sched() {
 }
 
 // NW waves x MTW row tiles (32 rows of dW each) per workgroup.  NPF = float4 prefetch registers per thread for the patch.
-template <int NW, int MTW, int NPF>
+// X16 / Y16: the x / dy tensor holds bf16 (strides in bf16 elements): 8-byte loads, no conversion when parked in LDS.
+template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     constexpr int NT = 64 * NW;
+    constexpr int XES = X16 ? 2 : 4;                           // bytes per x element
     constexpr int NPD = (64 * 8 + NT - 1) / NT;                // float4 prefetch registers for the dy tile (64 px x 32 ch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             pinfo[i] = ok ? ((unsigned)(plane * pplane + pyy * q.pitch + pxx * q.CP + c4 * 4) | (1u << 31)) : 0u;
             pcoord[i] = (unsigned)pyy | ((unsigned)pxx << 8) | ((unsigned)plane << 16) | ((ok && chan_ok) ? (1u << 31) : 0u);
             // byte offset of the slot from the patch origin; < 2^31 (checked by the launcher)
-            poff[i] = (unsigned)(((long long)plane * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c4 * 4) * 4);
+            poff[i] = (unsigned)(((long long)plane * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c4 * 4) * XES);
         }
     }
     float4 pf[NPF], pd[NPD];
@@ -135,10 +137,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         // The patch origin may lie outside the tensor (border tiles).  Loads are addressed from the first VALID element of the
         // patch (wave-uniform base, inside the tensor) plus a non-negative 32-bit byte offset per slot; masked slots read offset 0.
         const int lo_y = max(0, -iy0), lo_x = max(0, -ix0), lo_z = max(0, -dz0);
-        const unsigned adj = (unsigned)(((long long)lo_z * q.x_sd + lo_y * q.x_sh + lo_x * q.x_sw) * 4);
-        const char* __restrict__ base = reinterpret_cast<const char*>(
-            q.x + (long long)img * q.x_sn + (long long)(dz0 + lo_z) * q.x_sd + (long long)(iy0 + lo_y) * q.x_sh +
-            (long long)(ix0 + lo_x) * q.x_sw + ca * 16);
+        const unsigned adj = (unsigned)(((long long)lo_z * q.x_sd + lo_y * q.x_sh + lo_x * q.x_sw) * XES);
+        const char* __restrict__ base = reinterpret_cast<const char*>(q.x) +
+            ((long long)img * q.x_sn + (long long)(dz0 + lo_z) * q.x_sd + (long long)(iy0 + lo_y) * q.x_sh +
+             (long long)(ix0 + lo_x) * q.x_sw + ca * 16) * XES;
         const bool flat = q.kd == 1;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -151,17 +153,27 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             // unconditional load from a clamped address, zeroed at stage() time through the mask: a branch around the load (or
             // a select right behind it) makes hipcc wait for every element here instead of behind the MFMAs of the current tile
             const unsigned offb = ok ? po - adj : 0u;           // valid slots lie at or behind the first valid element
-            pf[i] = *reinterpret_cast<const float4*>(base + offb);
+            if constexpr (X16) {                                // 4 bf16 = 8 bytes, kept as raw bits in .x / .y
+                const uint2 u = *reinterpret_cast<const uint2*>(base + offb);
+                pf[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+            } else {
+                pf[i] = *reinterpret_cast<const float4*>(base + offb);
+            }
             fmask |= (ok ? 1u : 0u) << i;
         }
-        const float* __restrict__ ys = q.y + (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh +
-                                       (long long)ox0 * q.y_sw + cy0;
+        const long long yoff = (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw + cy0;
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
             const int idx = tid + NT * i;                      // 64 pixels x 8 float4
             const int px = idx >> 3, c = (idx & 7) << 2;
             const bool ok = idx < 512 && oy0 + (px >> 3) < q.Ho && ox0 + (px & 7) < q.Wo && cy0 + c < q.Cy;
-            pd[i] = ldg4(ok ? ys + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c : q.y);
+            if constexpr (Y16) {
+                const unsigned short* y16 = reinterpret_cast<const unsigned short*>(q.y);
+                const uint2 u = *reinterpret_cast<const uint2*>(ok ? y16 + yoff + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c : y16);
+                pd[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+            } else {
+                pd[i] = ldg4(ok ? q.y + yoff + (px >> 3) * q.y_sh + (px & 7) * q.y_sw + c : q.y);
+            }
             dmask |= (ok ? 1u : 0u) << i;
         }
     };
@@ -173,9 +185,13 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             asm volatile("" : "+v"(inf));
             if (inf >> 31) {
                 float4 v = pf[i];
-                if (!((fmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffffffu)) = o;
+                if (!((fmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);      // all-zero bits are zero in both formats
+                if constexpr (X16) {
+                    *reinterpret_cast<uint2*>(pa + (inf & 0x7fffffffu)) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+                } else {
+                    bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                    *reinterpret_cast<bf16x4*>(pa + (inf & 0x7fffffffu)) = o;
+                }
             }
         }
         __bf16* pb = dyt + buf * 64 * 32;
@@ -185,9 +201,18 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             if (idx < 512) {
                 float4 v = pd[i];
                 if (!((dmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (do_db) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                *reinterpret_cast<bf16x4*>(pb + (idx >> 3) * 32 + ((idx & 7) << 2)) = o;
+                if constexpr (Y16) {
+                    const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y);
+                    if (do_db) {
+                        bsum.x += __uint_as_float(u0 << 16); bsum.y += __uint_as_float(u0 & 0xffff0000u);
+                        bsum.z += __uint_as_float(u1 << 16); bsum.w += __uint_as_float(u1 & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2*>(pb + (idx >> 3) * 32 + ((idx & 7) << 2)) = make_uint2(u0, u1);
+                } else {
+                    if (do_db) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+                    bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                    *reinterpret_cast<bf16x4*>(pb + (idx >> 3) * 32 + ((idx & 7) << 2)) = o;
+                }
             }
         }
     };
@@ -313,14 +338,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     }
 }
 
-template <int NW, int MTW, int NPF>
+template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false>
 static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st) {
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hipFuncSetAttribute((const void*)wgrad_patch_kernel<NW, MTW, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)wgrad_patch_kernel<NW, MTW, NPF, X16, Y16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((wgrad_patch_kernel<NW, MTW, NPF>), grid, dim3(64 * NW), lds, st, q);
+    hipLaunchKernelGGL((wgrad_patch_kernel<NW, MTW, NPF, X16, Y16>), grid, dim3(64 * NW), lds, st, q);
     return hipGetLastError();
 }
 
@@ -395,6 +420,17 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.NB = NB; q.MC = MC;
     dim3 grid((unsigned)(q.S * NB * MC), 1u, 1u);
     hipError_t err;
+    const bool x16 = a->src_bf16 != 0, y16 = a->out_bf16 != 0;     // WGRAD: src = x, "out" = the dy operand
+    if (x16 || y16) {
+        // bf16 operand tensors: instantiated for the 8-wave x 8-tile shape only (the ConvLSTM gate convolutions' weight gradients,
+        // the one place the engine keeps bf16 activations); anything else is refused, never read as fp32
+        if (!(nw == 8 && mtw == 8)) { *rc = SAVP_EINVAL; return true; }
+        if (x16 && y16) err = (npf <= 4) ? launch_wgp<8, 8, 4, true, true>(q, grid, lds, st) : launch_wgp<8, 8, 8, true, true>(q, grid, lds, st);
+        else if (x16) err = (npf <= 4) ? launch_wgp<8, 8, 4, true, false>(q, grid, lds, st) : launch_wgp<8, 8, 8, true, false>(q, grid, lds, st);
+        else err = (npf <= 4) ? launch_wgp<8, 8, 4, false, true>(q, grid, lds, st) : launch_wgp<8, 8, 8, false, true>(q, grid, lds, st);
+        *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
+        return true;
+    }
     if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp<8, 4, 4>(q, grid, lds, st) : launch_wgp<8, 4, 8>(q, grid, lds, st);
     else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp<8, 2, 4>(q, grid, lds, st) : launch_wgp<8, 2, 8>(q, grid, lds, st);
     else if (nw == 8) err = (npf <= 4) ? launch_wgp<8, 8, 4>(q, grid, lds, st) : launch_wgp<8, 8, 8>(q, grid, lds, st);

@@ -53,6 +53,17 @@ __device__ __forceinline__ float4 ld4x(const float* base, long long idx, int is1
     return ld4(base + idx);
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// four consecutive elements at element index idx of a tensor that holds fp32 or (is16) bf16 (round to nearest even, as every
+// bf16 operand of the convolutions is rounded when it is staged: a bf16 destination feeds ONLY convolutions)
+__device__ __forceinline__ void st4x(float* base, long long idx, float4 v, int is16) {
+    if (is16) {
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        const bf16x4_t o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(base) + idx) = o;
+    } else {
+        st4(base + idx, v);
+    }
+}
 
 __device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -76,6 +87,7 @@ struct InormP {
     float eps; int act; float alpha;
     int nout; float* out[4]; long long o_sn[4], o_sp[4];
     int o_c0[4], o_c1[4];           // output k receives channels [o_c0, o_c1) of x (multiples of 4; default: all C)
+    int o16[4];                     // output k is a bf16 tensor (strides in bf16 elements)
     float* mean; float* rstd;       // [N, C]
     // backward
     int ndy; const float* dy[4]; long long dy_sn[4], dy_sp[4];
@@ -120,7 +132,8 @@ __global__ __launch_bounds__(NT) void inorm_fwd_kernel(InormP p) {
         o.z = act_fwd((v.z - m2) * r2 * g.z + b.z, p.act, p.alpha);
         o.w = act_fwd((v.w - m3) * r3 * g.w + b.w, p.act, p.alpha);
         for (int k = 0; k < p.nout; ++k)
-            if (c0 >= p.o_c0[k] && c0 < p.o_c1[k]) st4(p.out[k] + (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k] + (c0 - p.o_c0[k]), o);
+            if (c0 >= p.o_c0[k] && c0 < p.o_c1[k])
+                st4x(p.out[k], (long long)n * p.o_sn[k] + (long long)px * p.o_sp[k] + (c0 - p.o_c0[k]), o, p.o16[k]);
     }
 }
 
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* 
         o.w = act_fwd((v.w - m[3]) * r[3] * g.w + b.w, p.act, p.alpha);
         for (int kq = 0; kq < p.nout; ++kq)
             if (c4 * 4 >= p.o_c0[kq] && c4 * 4 < p.o_c1[kq])
-                st4(p.out[kq] + (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + (c4 * 4 - p.o_c0[kq]), o);
+                st4x(p.out[kq], (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + (c4 * 4 - p.o_c0[kq]), o, p.o16[kq]);
     }
 }
 
@@ -352,6 +365,7 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     for (int i = 0; i < a->nout; ++i) {
         p.out[i] = (float*)a->out[i].p; p.o_sn[i] = a->out[i].sn; p.o_sp[i] = a->out[i].sp;
         p.o_c0[i] = a->out_c0[i]; p.o_c1[i] = a->out_nc[i] > 0 ? a->out_c0[i] + a->out_nc[i] : a->C;
+        p.o16[i] = (a->out_bf16 >> i) & 1;
         if ((p.o_c0[i] & 3) || (p.o_c1[i] & 3) || p.o_c0[i] < 0 || p.o_c1[i] > a->C) return SAVP_EINVAL;
     }
     p.mean = a->mean; p.rstd = a->rstd;
@@ -412,11 +426,14 @@ struct LstmP {
     float eps, forget_bias;
     float* c_new;                                         // [N, HW, F] contiguous
     int nh; float* h[4]; long long h_sn[4], h_sp[4];
+    int h16[4];                                           // destination k of h' is a bf16 tensor (strides in bf16 elements)
     float *mean1, *rstd1, *mean2, *rstd2;                 // [N,4F], [N,F]
     // backward
     int ndh; const float* dh[4]; long long dh_sn[4], dh_sp[4];
     const float* dc_new;                                  // [N,HW,F] contiguous or null
-    float* dgates;                                        // [N,HW,4F]
+    float* dgates;                                        // [N,HW,4F]; bf16 when dgates16 (coalesced kernels only)
+    float* draw;                                          // fp32 [N,HW,4F] scratch of the raw gate gradients between the passes
+    int dgates16;                                         //   (= dgates itself unless dgates16)
     float* dc_prev;                                       // [N,HW,F] contiguous or null
     float *dg1, *db1, *dg2, *db2;
 };
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmP p) {
             }
             st4(p.c_new + ((long long)n * p.HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
             const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
-            for (int k = 0; k < p.nh; ++k) st4(p.h[k] + (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4);
+            for (int k = 0; k < p.nh; ++k) st4x(p.h[k], (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4, p.h16[k]);
         }
     }
 }
@@ -781,7 +798,7 @@ __global__ __launch_bounds__(NT) void lstm_out_kernel(LstmP p, LstmWs w, int chu
         }
         st4(cq, make_float4(cn[0], cn[1], cn[2], cn[3]));
         const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
-        for (int k = 0; k < p.nh; ++k) st4(p.h[k] + (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4);
+        for (int k = 0; k < p.nh; ++k) st4x(p.h[k], (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4, p.h16[k]);
     }
 }
 
@@ -866,7 +883,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd1_kernel(LstmP p, LstmBws w, int c
             ra[c] += dz[c]; rb[c] += dz[c] * x2;
         }
         st4(w.dz2 + ((long long)n * p.HW + px) * F + c0, make_float4(dz[0], dz[1], dz[2], dz[3]));
-        st4(p.dgates + ((long long)n * p.HW + px) * 4 * F + 3 * F + c0, make_float4(don[0], don[1], don[2], don[3]));
+        st4(p.draw + ((long long)n * p.HW + px) * 4 * F + 3 * F + c0, make_float4(don[0], don[1], don[2], don[3]));
     }
     float* d = sh + prow * 2 * F + c0;
 #pragma unroll
@@ -905,7 +922,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd2_kernel(LstmP p, LstmBws w, int c
         lstm_load_px(p, L, n, px, c0, xh, cp);
         const float4 dz4 = ld4(w.dz2 + ((long long)n * p.HW + px) * F + c0);
         const float dz[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
-        float* gq = p.dgates + ((long long)n * p.HW + px) * 4 * F + c0;
+        float* gq = p.draw + ((long long)n * p.HW + px) * 4 * F + c0;
         const float4 don4 = ld4(gq + 3 * F);
         const float don[4] = {don4.x, don4.y, don4.z, don4.w};
         float dg[16], dcp[4];
@@ -974,7 +991,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
     const int p0 = blockIdx.x * chunk, p1 = min(p.HW, p0 + chunk);
     for (int px = p0 + prow; px < p1; px += rows) {
         const long long q = ((long long)n * p.HW + px) * 4 * F + c0;
-        float* gq = p.dgates + ((long long)n * p.HW + px) * 4 * F + c0;
+        const float* gq = p.draw + q;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 raw = ld4x(p.gates, q + g * F, p.gates16), dgv = ld4(gq + g * F);
@@ -986,7 +1003,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
                 const float xh = (rv[c] - mu[i]) * rs[i];
                 o[c] = ga[i] * rs[i] * (dv[c] - s1[i] - xh * s2[i]);
             }
-            st4(gq + g * F, make_float4(o[0], o[1], o[2], o[3]));
+            st4x(p.dgates, q + g * F, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
         }
     }
 }
@@ -1001,11 +1018,13 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     p.c_new = a->c_new;
     p.nh = a->nh;
     if (a->nh < 0 || a->nh > 4 || a->ndh < 0 || a->ndh > 4) return SAVP_EINVAL;
-    for (int i = 0; i < a->nh; ++i) { p.h[i] = (float*)a->h[i].p; p.h_sn[i] = a->h[i].sn; p.h_sp[i] = a->h[i].sp; }
+    for (int i = 0; i < a->nh; ++i) { p.h[i] = (float*)a->h[i].p; p.h_sn[i] = a->h[i].sn; p.h_sp[i] = a->h[i].sp; p.h16[i] = (a->h_bf16 >> i) & 1; }
     p.mean1 = a->mean1; p.rstd1 = a->rstd1; p.mean2 = a->mean2; p.rstd2 = a->rstd2;
     p.ndh = a->ndh;
     for (int i = 0; i < a->ndh; ++i) { p.dh[i] = (const float*)a->dh[i].p; p.dh_sn[i] = a->dh[i].sn; p.dh_sp[i] = a->dh[i].sp; }
     p.dc_new = a->dc_new; p.dgates = a->dgates; p.dc_prev = a->dc_prev;
+    p.dgates16 = a->dgates_bf16 ? 1 : 0;
+    p.draw = a->dgates_bf16 ? a->dgates_raw : a->dgates;
     p.dg1 = a->dgamma1; p.db1 = a->dbeta1; p.dg2 = a->dgamma2; p.db2 = a->dbeta2;
     return SAVP_OK;
 }
@@ -1062,6 +1081,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
+    if (a->dgates_bf16 && !a->dgates_raw) return SAVP_EINVAL;
     if (lstm_coalesced_ok(a)) {
         hipStream_t st = (hipStream_t)stream;
         const int N = a->N, F = a->F, HW = a->HW;
@@ -1080,7 +1100,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
         hipLaunchKernelGGL(lstm_bwd3_kernel, grid, dim3(NT), 0, st, p, w, (int)c);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
-    if (a->HW > MAXPPT * NT || a->gates_bf16) return SAVP_EINVAL;
+    if (a->HW > MAXPPT * NT || a->gates_bf16 || a->dgates_bf16) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(a->N * (a->F / 4)), dim3(NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
 }

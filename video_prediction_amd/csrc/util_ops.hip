@@ -39,6 +39,30 @@ __global__ void tile_channels_kernel(const float* __restrict__ z, long long R, i
     }
 }
 
+// bf16 destination (a slice of a buffer that only feeds convolutions of the bf16 datapath): overwrite only
+__global__ void tile_channels_bf16_kernel(const float* __restrict__ z, long long R, int HW, int C, float scale, unsigned short* out,
+                                          long long sn, long long sp) {
+    long long total = R * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long rp = i / C;
+        int p = (int)(rp % HW);
+        long long r = rp / HW;
+        const __bf16 v = (__bf16)(z[r * C + c] * scale);
+        out[r * sn + (long long)p * sp + c] = __builtin_bit_cast(unsigned short, v);
+    }
+}
+
+extern "C" int savp_tile_channels_bf16(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out) {
+    if (!z || !out.p || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
+    long long total = (long long)R * HW * C;
+    unsigned nb = nblocks(total);
+    if (nb > 65535u * 8) nb = 65535u * 8;
+    hipLaunchKernelGGL(tile_channels_bf16_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, z, (long long)R, HW, C, scale,
+                       (unsigned short*)out.p, (long long)out.sn, (long long)out.sp);
+    return LAUNCH_OK();
+}
+
 extern "C" int savp_tile_channels(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out,
                                   int32_t beta) {
     if (!z || !out.p || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;

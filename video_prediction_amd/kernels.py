@@ -97,7 +97,8 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     # bf16 activations (ring kernel): the source / destination tensor's dtype says so; strides are in elements of that dtype
     src, dst = (y, x) if mode == lib.CONV_DGRAD else (x, y)
     a.src_bf16 = int(src.dtype == torch.bfloat16)
-    a.out_bf16 = int(dst.dtype == torch.bfloat16) if mode != lib.CONV_WGRAD else 0
+    # WGRAD: `out_bf16` says that the y (output-gradient) operand holds bf16
+    a.out_bf16 = int((y if mode == lib.CONV_WGRAD else dst).dtype == torch.bfloat16)
     a.stats = stats.data_ptr() if stats is not None else None
     taps = geom.k[0] * geom.k[1] * geom.k[2]
     if w.numel() != taps * Cx * Cy:
@@ -229,6 +230,17 @@ def _set_views(arr, tensors):
         arr[i] = view(t)
 
 
+def _bf16_mask(tensors):
+    """Bit k set = tensor k holds bfloat16 (only the entry points that take such a mask accept bf16 views)."""
+    m = 0
+    for i, t in enumerate(tensors):
+        if t.dtype == torch.bfloat16:
+            m |= 1 << i
+        elif t.dtype != torch.float32:
+            raise TypeError('expected float32 or bfloat16, got %s' % t.dtype)
+    return m
+
+
 class ZeroArena(object):
     """Pre-zeroed scratch for the atomically accumulated per-(sample, channel) reductions of the coalesced norm / ConvLSTM
     kernels: every call takes a fresh all-zero slice, the whole arena is cleared by ONE memset when it is reset (the train
@@ -285,6 +297,7 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
     a.nout = len(outs)
     _set_views(a.out, outs)
+    a.out_bf16 = _bf16_mask(outs)
     _set_ranges(a.out_c0, a.out_nc, out_ranges)
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     lib.check(lib.get().savp_instnorm_act_fwd(lib.stream(), ctypes.byref(a)), 'savp_instnorm_act_fwd')
@@ -359,12 +372,20 @@ def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6
         a.stats1_ready = int(stats1 is not None)
     a.nh = len(hs)
     _set_views(a.h, hs)
+    a.h_bf16 = _bf16_mask(hs)
     lib.check(lib.get().savp_convlstm_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_fwd')
 
 
 def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates, dc_prev, dparams, eps=1e-6,
-                       forget_bias=1.0, ws=None):
+                       forget_bias=1.0, ws=None, dgates_raw=None):
+    """dgates may be a bfloat16 tensor (coalesced kernels, i.e. with ws): dgates_raw is then the fp32 scratch [N, HW, 4F] the raw
+    gate gradients live in between the passes."""
     a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
+    if dgates.dtype == torch.bfloat16:
+        if dgates_raw is None or dgates_raw.dtype != torch.float32 or dgates_raw.numel() < dgates.numel():
+            raise ValueError('bf16 dgates need an fp32 dgates_raw scratch of the same size')
+        a.dgates_bf16 = 1
+        a.dgates_raw = dgates_raw.data_ptr()
     if ws is not None:
         _lstm_ws(a, gates, ws)
     a.ndh = len(dhs)
@@ -396,6 +417,11 @@ def tile_channels(z, out, scale=1.0, beta=0):
     """out[r, p, c] (=|+=) scale * z[r, c]; z [R, C] contiguous; out view [R, spatial..., C]."""
     lib.require_device(z, out)
     R, C = z.shape
+    if out.dtype == torch.bfloat16:
+        if beta:
+            raise ValueError('tile_channels into a bf16 view overwrites (beta=0 only)')
+        lib.check(_L().savp_tile_channels_bf16(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out)), 'savp_tile_channels_bf16')
+        return
     lib.check(_L().savp_tile_channels(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out), int(beta)),
               'savp_tile_channels')
 

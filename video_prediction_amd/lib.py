@@ -125,7 +125,7 @@ class SavpInormArgs(ctypes.Structure):
         ('nout', c_i32), ('out', SavpView * 4), ('mean', c_vp), ('rstd', c_vp),
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
         ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
-        ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4),
+        ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4), ('out_bf16', c_i32),
     ]
 
 
@@ -139,7 +139,7 @@ class SavpLstmArgs(ctypes.Structure):
         ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
         ('ws', c_vp), ('ws_floats', ctypes.c_int64), ('ws_stats', c_vp), ('ws_stats_clean', c_i32),
-        ('gates_bf16', c_i32), ('stats1_ready', c_i32),
+        ('gates_bf16', c_i32), ('stats1_ready', c_i32), ('h_bf16', c_i32), ('dgates_bf16', c_i32), ('dgates_raw', c_vp),
     ]
 
 
@@ -167,6 +167,7 @@ class SavpCompositeArgs(ctypes.Structure):
 
 _PV = ctypes.POINTER(SavpView)
 register('savp_tile_channels', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView, c_i32])
+register('savp_tile_channels_bf16', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView])
 register('savp_colsum', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32, c_vp, c_i32])
 register('savp_select', [c_vp, c_i32, c_i32, c_i32, c_vp, SavpView, SavpView, c_i32, _PV])
 register('savp_select_bwd', [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, _PV, SavpView])

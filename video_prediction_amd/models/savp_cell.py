@@ -32,12 +32,12 @@ def ceil4(n):
 class Act(object):
     """Time-major activation buffer with an optional gradient twin."""
 
-    def __init__(self, shape, device, grad=True, zero_grad=False, dtype=torch.float32):
-        self.v = torch.zeros(shape, device=device, dtype=dtype)            # the gradient twin is always fp32
+    def __init__(self, shape, device, grad=True, zero_grad=False, dtype=torch.float32, grad_dtype=torch.float32):
+        self.v = torch.zeros(shape, device=device, dtype=dtype)            # the gradient twin is fp32 unless asked otherwise
         self.g = None
         if grad:
-            self.g = torch.zeros(shape, device=device, dtype=torch.float32) if zero_grad else \
-                torch.empty(shape, device=device, dtype=torch.float32)
+            self.g = torch.zeros(shape, device=device, dtype=grad_dtype) if zero_grad else \
+                torch.empty(shape, device=device, dtype=grad_dtype)
 
     def flat(self, t):
         """[T, N, ...] -> [T*N, ...] view (time folded into the batch for the batched weight gradients)."""
@@ -160,12 +160,23 @@ class SAVPGenerator(object):
                 L['n2'] = Norm(store, r + 'candidate/state/', T1, N, f, dev)
             elif use_rnn:
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
-                L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g)
                 # fused ConvLSTM cell of the bf16 datapath: the gate convolution's epilogue produces the statistics of the first
                 # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
                 L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
                               h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0)
-                L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32)
+                # SAVP_BF16_ACT=1 (experimental, off: written at the end of round 2 without GPU time left to validate it): the cell's
+                # input buffer [x | z | h] itself is bf16.  Its only readers are the gate convolution (FPROP, WGRAD), which round to
+                # bf16 when they stage their operands anyway, so the numbers do not change; the producers (instance norm of the
+                # layer's conv, tile_channels, the h' output of the gate kernels) write bf16 through their out_bf16 / h_bf16 masks.
+                a_dt = torch.bfloat16 if (L['fused'] and os.environ.get('SAVP_BF16_ACT', '0') == '1') else torch.float32
+                L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g, dtype=a_dt)
+                # SAVP_BF16_DGATES=1 (experimental, off, see SAVP_BF16_ACT above): the gate gradient is stored as bf16 as well -- its
+                # readers are the gate convolution's DGRAD and WGRAD; the three gate-gradient passes keep their raw fp32 values in a
+                # per-layer scratch
+                dg_dt = torch.bfloat16 if (L['fused'] and g and os.environ.get('SAVP_BF16_DGATES', '0') == '1') else torch.float32
+                L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32,
+                                 grad_dtype=dg_dt)
+                L['dg_raw'] = torch.empty(N, h_, w_, 4 * f, device=dev) if dg_dt == torch.bfloat16 else None
                 L['c'] = Act((T1, N, h_, w_, f), dev, grad=False)
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
                 L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
@@ -527,7 +538,8 @@ class SAVPGenerator(object):
                     dc_prev = L['dc'][t & 1] if t > 0 else None
                     K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
-                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L))
+                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L),
+                                         dgates_raw=L.get('dg_raw'))
                     L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
                                        [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
