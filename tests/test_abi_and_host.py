@@ -145,3 +145,33 @@ def test_tuning_table_round_trip(tmp_path):
     finally:
         K.AUTOTUNE['cache'].clear()
         K.AUTOTUNE['cache'].update(saved)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every argument struct mirrored in lib.py has the size and field offsets gcc gives the struct of the same name in
+    include/savp_hip.h (a field appended on one side only would silently shift everything behind it)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from video_prediction_amd import lib
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    header = open(os.path.join(ROOT, 'include', 'savp_hip.h')).read()
+    structs = [(n, c) for n, c in vars(lib).items()
+               if isinstance(c, type) and issubclass(c, ctypes.Structure) and n.startswith('Savp') and ('} %s;' % n) in header]
+    assert len(structs) >= 5
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "savp_hip.h"', 'int main() {']
+    for n, c in structs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (n, n))
+        for f in c._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (n, f[0]))
+        lines.append('printf("\\n");')
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = {ln.split()[0]: [int(v) for v in ln.split()[1:]] for ln in subprocess.check_output([str(exe)], text=True).splitlines()}
+    for n, c in structs:
+        want = [ctypes.sizeof(c)] + [getattr(c, f[0]).offset for f in c._fields_]
+        assert got[n] == want, (n, got[n], want)
