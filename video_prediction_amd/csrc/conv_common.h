@@ -39,6 +39,7 @@ struct ConvP {
     int src16;                                // source activations are bf16 (strides in elements)
     int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
     float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
+    int epi_batch;                            // batched read-modify-write epilogue (SAVP_EPI_BATCH=1, experimental)
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {

@@ -333,6 +333,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
         const float bias = (p.bias && split == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
+            if (p.epi_batch && p.splitk == 1 && (p.beta || p.act == SAVP_ACT_DLRELU_FROM_OUT)) {
+                // batched read-modify-write epilogue (experimental, SAVP_EPI_BATCH=1): see conv_patch.hip
+                const bool use_old = p.beta != 0, use_aux = p.act == SAVP_ACT_DLRELU_FROM_OUT;
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) {
+                    long long off4[4];
+                    float old4[4], aux4[4], v4[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int r = hb * 4 + q4;
+                        off4[q4] = rowoff[wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
+                    }
+                    if (use_old) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) old4[q4] = *(off4[q4] >= 0 ? dst + off4[q4] + col : dst);
+                    }
+                    if (use_aux) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) aux4[q4] = *(off4[q4] >= 0 ? p.aux + off4[q4] + col : p.aux);
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float v = acc[i][j][hb * 4 + q4] + bias;
+                        if (use_old) v += old4[q4];
+                        if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
+                        else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                        else if (use_aux) v *= (aux4[q4] > 0.f ? 1.f : p.alpha);
+                        v4[q4] = v;
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) asm volatile("" : "+v"(v4[q4]));
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (off4[q4] >= 0) dst[off4[q4] + col] = v4[q4];
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -772,6 +809,11 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.bias = a->bias; p.aux = a->aux;
     p.splitk = 1; p.tm = p.tn = 1;
     p.src16 = a->src_bf16 ? 1 : 0; p.cell = 0; p.stats = nullptr;
+    {
+        static int eb = -1;
+        if (eb < 0) { const char* e = getenv("SAVP_EPI_BATCH"); eb = (e && e[0] == '1') ? 1 : 0; }
+        p.epi_batch = eb;
+    }
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
