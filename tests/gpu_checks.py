@@ -1099,3 +1099,24 @@ def check_bf16_activation_io(seed=31):
         out.append(('bf16io/wgrad_bias_' + tag, rel_err(db, refb.double().cpu()), 1e-5))
     torch.cuda.synchronize()
     return out
+
+
+def check_s2fprop(seed=37):
+    """conv_s2fprop.hip (experimental; the process must run with SAVP_S2FPROP=1): FPROP of the 4x4 stride-(1,2,2) 32 -> 64 layer with
+    bias + LeakyReLU, 3-D and 2-D, full and ragged tiles, into a channel slice of a wider buffer."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for (tag, N, dhw, k, pp) in (('s2fprop/3d', 2, (5, 32, 64), (4, 4, 4), (1, 1, 1)), ('s2fprop/3d_ragged', 1, (4, 20, 36), (4, 4, 4), (1, 1, 1)),
+                                 ('s2fprop/2d', 3, (1, 16, 40), (1, 4, 4), (0, 1, 1))):
+        x = rnd(rng, N, *dhw, 32)
+        w = rnd(rng, *k, 32, 64) * 0.1
+        b = rnd(rng, 64)
+        y = torch.nn.functional.leaky_relu(_ref_conv(x, w, k, (1, 2, 2), pp, pp) + b, 0.2)
+        wide = torch.full(tuple(y.shape[:-1]) + (80,), 3.0, device=DEV)
+        wtp = dev(pack_wt(w))
+        K.conv(lib.CONV_FPROP, K.ConvGeom(k, (1, 2, 2), pp), dev(x), wide[..., 8:72], wtp, bias=dev(b), act=lib.ACT_LRELU, alpha=0.2,
+               precision=1, w16=wtp.to(torch.bfloat16))
+        keep = bool((wide[..., :8] == 3.0).all() and (wide[..., 72:] == 3.0).all())
+        out.append((tag, rel_err(wide[..., 8:72], y) + (0.0 if keep else 1.0), 1e-2))
+    torch.cuda.synchronize()
+    return out

@@ -76,6 +76,13 @@ def test_bf16_activation_io_experimental():
     _run(gpu_checks.check_bf16_activation_io)
 
 
+@pytest.mark.skipif(os.environ.get('SAVP_TEST_EXPERIMENTAL', '0') != '1' or os.environ.get('SAVP_S2FPROP', '0') != '1',
+                    reason='experimental FPROP kernel of the stride-(1,2,2) discriminator layer: run with SAVP_TEST_EXPERIMENTAL=1 SAVP_S2FPROP=1')
+def test_s2fprop_experimental():
+    from tests import gpu_checks
+    _run(gpu_checks.check_s2fprop)
+
+
 def test_fused_convlstm_cell_bf16():
     from tests import gpu_checks
     _run(gpu_checks.check_conv_cell)

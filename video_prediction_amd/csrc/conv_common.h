@@ -95,6 +95,8 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc);
 
 // conv_s2dgrad.hip: DGRAD of a 4x4 stride-(1,2,2) convolution with 32 input channels, all four output phases per workgroup.
 bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+// conv_s2fprop.hip: FPROP of the same layer (experimental, SAVP_S2FPROP=1)
+bool conv_s2fprop_try(const SavpConvArgs* a, hipStream_t st, int* rc);
 
 extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
 

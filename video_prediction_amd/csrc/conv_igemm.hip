@@ -832,6 +832,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         int rc = SAVP_OK;
         if (conv_s2dgrad_try(a, st, &rc)) return rc;
     }
+    if (a->mode == SAVP_CONV_FPROP) {     // its forward companion (conv_s2fprop.hip; experimental, SAVP_S2FPROP=1)
+        int rc = SAVP_OK;
+        if (conv_s2fprop_try(a, st, &rc)) return rc;
+    }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         const bool dg = a->mode == SAVP_CONV_DGRAD;
         p.out = (float*)(dg ? a->x : a->y);
