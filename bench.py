@@ -143,7 +143,7 @@ def main():
         # launch line), rank 0 prints the JSON line
         import socket
         import subprocess
-        if args.gpus > torch.cuda.device_count():
+        if args.gpus > torch.cuda.device_count() and os.environ.get('SAVP_DIST_BACKEND', 'nccl') == 'nccl':
             raise SystemExit('bench.py --gpus %d: this node has %d GPU(s)' % (args.gpus, torch.cuda.device_count()))
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
@@ -157,14 +157,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world and rank == 0:
         print('bench.py: --gpus %d but launched with WORLD_SIZE=%d; reporting n_gpus=%d' % (args.gpus, world, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # SAVP_DIST_BACKEND=gloo: several ranks may share one GPU (tests/test_gpu_dp.py runs the whole multi-rank path of this script
+    # on a one-GPU box: launcher, rendezvous, tuning broadcast, chunked exchange, MAX-over-ranks clock, one JSON line)
+    backend = os.environ.get('SAVP_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist_mod.init_process_group(backend='nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
         dist = dist_mod
 
     from video_prediction_amd import kernels as K
@@ -304,6 +308,8 @@ def main():
                                   'algorithmic_bytes_per_cell': (cell_bytes / cell_n) if cell_n else None}},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
+    if dist is not None and os.environ.get('SAVP_BENCH_CHECK_REPLICAS', '0') == '1':
+        result['replicas_identical'] = bool(engine.replicas.checksum_identical())      # collective: every rank calls it
     if rank == 0 and args.save_tuning:
         K.save_tuning(args.save_tuning)
     if rank == 0:

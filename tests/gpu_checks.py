@@ -1120,3 +1120,145 @@ def check_s2fprop(seed=37):
         out.append((tag, rel_err(wide[..., 8:72], y) + (0.0 if keep else 1.0), 1e-2))
     torch.cuda.synchronize()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Every (problem, tile, split-K) instantiation the shipped tuning tables select -- i.e. exactly the savp_conv launches bench.py
+# runs at B=16 / N=32 -- against an independent fp64 reference at the table's own shapes.
+# The reference is a loop over the kernel taps of fp64 matmuls on strided slices (torch on the device: rocBLAS dgemm, no
+# convolution code of this repository, and no CPU convolution of 1.2 M-pixel batches).
+# ---------------------------------------------------------------------------------------------------------------
+def _taps_ref(mode, x, w, y, k, s, p):
+    """x [N,D,H,W,Cx], w [kd,kh,kw,Cx,Cy], y [N,Do,Ho,Wo,Cy] fp64 device tensors.  FPROP: returns F(x); DGRAD: F^T(y);
+    WGRAD: dW = x (*) y."""
+    N, D, H, W, Cx = x.shape
+    Do, Ho, Wo, Cy = y.shape[1:]
+    need = [(o - 1) * st + kk for o, st, kk in zip((Do, Ho, Wo), s, k)]
+    ext = [max(i + pb, nd) for i, pb, nd in zip((D, H, W), p, need)]
+    xp = torch.zeros(N, ext[0], ext[1], ext[2], Cx, dtype=torch.float64, device=x.device)
+    if mode != lib.CONV_DGRAD:
+        xp[:, p[0]:p[0] + D, p[1]:p[1] + H, p[2]:p[2] + W] = x
+    out = None
+    if mode == lib.CONV_FPROP:
+        out = torch.zeros(y.shape, dtype=torch.float64, device=x.device)
+    elif mode == lib.CONV_WGRAD:
+        out = torch.zeros(w.shape, dtype=torch.float64, device=x.device)
+        y2 = y.reshape(-1, Cy)
+    for a in range(k[0]):
+        for u in range(k[1]):
+            for v in range(k[2]):
+                sl = (slice(None), slice(a, a + (Do - 1) * s[0] + 1, s[0]), slice(u, u + (Ho - 1) * s[1] + 1, s[1]),
+                      slice(v, v + (Wo - 1) * s[2] + 1, s[2]))
+                if mode == lib.CONV_FPROP:
+                    out += xp[sl] @ w[a, u, v]
+                elif mode == lib.CONV_WGRAD:
+                    out[a, u, v] = xp[sl].reshape(-1, Cx).t() @ y2
+                else:
+                    xp[sl] += y @ w[a, u, v].t()
+    if mode == lib.CONV_DGRAD:
+        return xp[:, p[0]:p[0] + D, p[1]:p[1] + H, p[2]:p[2] + W].contiguous()
+    return out
+
+
+def check_tuning_table(precision='bf16', max_entries=None, seed=41):
+    """Runs every entry of video_prediction_amd/tuning_gfx950_<precision>.json as that exact savp_conv call (mode, shapes, view
+    strides, bias / w16 / act / beta / bf16 source / bf16 destination / statistics epilogue, the table's tile code and split-K)."""
+    import ast
+    import json
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(os.path.join(here, 'video_prediction_amd', 'tuning_gfx950_%s.json' % precision)))
+    prec = 1 if precision == 'bf16' else 0
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32)
+
+    def strided(shape5, sw, dtype, fill):
+        """[N,D,H,W,C] view with pixel stride sw (>= C: a channel slice of a wider buffer); sw == 0: the 2-D dense form [N,C]."""
+        N, D, H, W, C = shape5
+        if sw == 0:
+            assert D == H == W == 1
+            t = torch.empty(N, C, device=DEV, dtype=dtype)
+            t.copy_(fill.reshape(N, C))
+            return t
+        big = torch.zeros(N, D, H, W, max(sw, C), device=DEV, dtype=dtype)
+        v = big[..., :C]
+        v.copy_(fill)
+        return v if D > 1 else v[:, 0]
+
+    for n_done, (kstr, (tile, sk)) in enumerate(sorted(table.items())):
+        if max_entries and n_done >= max_entries:
+            break
+        key = ast.literal_eval(kstr)
+        (mode, pr, N, D, H, W, Cx, Do, Ho, Wo, Cy, k, s, p, act, beta, x_sw, y_sw, has_b, has_w16) = key[:20]
+        src16, out16, has_stats = (key[20:23] if len(key) >= 23 else (0, 0, False))
+        if pr != prec:
+            continue
+        tag = 'table_%s/m%d_N%d_%dx%dx%dx%d->%dx%dx%dx%d_k%s_s%s_t%x_sk%d%s' % (
+            precision, mode, N, D, H, W, Cx, Do, Ho, Wo, Cy, 'x'.join(map(str, k)), 'x'.join(map(str, s)), tile, sk,
+            ('_a%d' % act if act else '') + ('_beta' if beta else '') + ('_s16' if src16 else '') + ('_o16' if out16 else ''))
+        x32 = rn(N, D, H, W, Cx)
+        y32 = rn(N, Do, Ho, Wo, Cy)
+        w32 = rn(*k, Cx, Cy) * 0.1
+        bf = torch.bfloat16
+        # operand dtypes exactly as the keyed call had them
+        x_dt = bf if ((mode != lib.CONV_DGRAD and src16) or (mode == lib.CONV_DGRAD and out16)) else torch.float32
+        y_dt = bf if ((mode == lib.CONV_DGRAD and src16) or (mode != lib.CONV_DGRAD and out16)) else torch.float32
+        if x_dt == bf:
+            x32 = x32.to(bf).float()
+        if y_dt == bf:
+            y32 = y32.to(bf).float()
+        xv = strided((N, D, H, W, Cx), x_sw, x_dt, x32.to(x_dt))
+        yv = strided((N, Do, Ho, Wo, Cy), y_sw, y_dt, y32.to(y_dt))
+        geom = K.ConvGeom(k, s, p)
+        x64, y64, w64 = x32.double(), y32.double(), w32.double()
+        alpha = 0.2
+        try:
+            if mode == lib.CONV_WGRAD:
+                ref = _taps_ref(mode, x64, w64, y64, k, s, p)
+                dw = torch.zeros(w32.shape, device=DEV)
+                db = torch.zeros(Cy, device=DEV) if has_b else None
+                K.conv(mode, geom, xv, yv, dw, bias=db, splitk=sk, tile=tile, precision=prec)
+                out.append((tag + '/wgrad', rel_err(dw, ref), 1e-2 if prec else 2e-5 * max(1.0, (N * Do * Ho * Wo / 65536.0) ** 0.5)))
+                if has_b:
+                    out.append((tag + '/wgrad_bias', rel_err(db, y64.reshape(-1, Cy).sum(0)), 1e-4))
+                continue
+            fprop = mode == lib.CONV_FPROP
+            dst_shape = (N, Do, Ho, Wo, Cy) if fprop else (N, D, H, W, Cx)
+            cdst = dst_shape[-1]
+            ref = _taps_ref(mode, x64, w64, y64, k, s, p)
+            bias = rn(cdst) if has_b else None
+            dst = yv if fprop else xv
+            old = None
+            if beta:
+                old = (y32 if fprop else x32)
+                ref = ref + old.double()
+            else:
+                dst.fill_(float('nan'))
+            if bias is not None:
+                ref = ref + bias.double()
+            aux = None
+            if act == lib.ACT_LRELU:
+                ref = torch.where(ref > 0, ref, alpha * ref)
+            elif act == lib.ACT_SIGMOID:
+                ref = torch.sigmoid(ref)
+            elif act == lib.ACT_DLRELU_FROM_OUT:
+                a32 = rn(*dst_shape)
+                aux = strided(dst_shape, (y_sw if fprop else x_sw), torch.float32, a32)
+                ref = ref * torch.where(a32.double() > 0, torch.ones_like(ref), torch.full_like(ref, alpha))
+            wp = (pack_wt(w32) if fprop else pack_wd(w32)).contiguous()
+            stats = torch.zeros(N, cdst, 2, device=DEV) if has_stats else None
+            K.conv(mode, geom, xv, yv, wp, bias=bias, beta=beta, act=act, alpha=alpha, aux=aux, splitk=sk, tile=tile, precision=prec,
+                   w16=wp.to(bf) if has_w16 else None, stats=stats)
+            got = dst.float().reshape(dst_shape)
+            out.append((tag + ('/fprop' if fprop else '/dgrad'), rel_err(got, ref.reshape(dst_shape)), 1e-2 if prec else 2e-5))
+            if has_stats:
+                r2 = ref.reshape(N, -1, cdst)
+                out.append((tag + '/stats_sum', rel_err(stats[..., 0], r2.sum(1)), 1e-2))
+                out.append((tag + '/stats_sumsq', rel_err(stats[..., 1], (r2 * r2).sum(1)), 1e-2))
+        except RuntimeError as ex:
+            out.append((tag + '/REFUSED:%s' % str(ex)[:60], float('inf'), 0.0))
+    torch.cuda.synchronize()
+    return out

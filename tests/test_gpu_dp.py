@@ -131,3 +131,75 @@ def test_two_replicas_on_one_gpu_match_the_global_batch_step(joint):
         tot += float(d.sum())
         cnt += d.size
     assert tot / cnt <= 0.05 * hp.lr, tot / cnt      # Adam's first step is sign-like: compare in units of lr
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The whole multi-rank path of bench.py before the driver's 8-GPU lease runs it: `python bench.py --gpus 2` becomes the
+    torch.distributed.run launcher, both ranks rendezvous on 127.0.0.1 (SAVP_DIST_BACKEND=gloo: two ranks on cuda:0), replicas
+    are broadcast, tuning choices come from rank 0, gradients go through the chunked side-stream exchange, the clock is the MAX
+    over ranks, and rank 0 prints exactly ONE JSON line with the whole-job numbers (base_model.py:523-527,590-592,640-646)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SAVP_DIST_BACKEND='gloo', SAVP_BENCH_CHECK_REPLICAS='1')
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 32
+    assert d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['value'] > 0
+    assert abs(d['value'] - 2 * 16 * 30 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']      # whole-job frames / max-over-ranks time
+    assert d['replicas_identical'] is True
+    assert 'cpu_baseline' not in d
+
+
+def _tune_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from video_prediction_amd import kernels as K
+        from video_prediction_amd import lib
+        K.set_conv_precision('bf16')
+        K.enable_autotune(True)
+        K.set_tuning_group(dist)
+        # make the two ranks disagree on purpose: rank 1's tuner always answers something else
+        real = K._tune
+        if rank == 1:
+            K._tune = lambda a, mode, dst, w: (0x111, 1)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(2, 16, 16, 32, generator=g).cuda()
+        w = (torch.randn(3, 3, 32, 64, generator=g) * 0.1).cuda()
+        wt = w.reshape(-1, 64).t().contiguous()
+        y = torch.empty(2, 16, 16, 64, device='cuda')
+        K.conv(lib.CONV_FPROP, K.ConvGeom((3, 3), (1, 1), (1, 1)), x, y, wt, w16=wt.to(torch.bfloat16))
+        torch.cuda.synchronize()
+        K._tune = real
+        (key, cfg), = K.AUTOTUNE['log']
+        q.put({'rank': rank, 'cfg': tuple(cfg), 'y': y.cpu().numpy()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_live_tuning_choice_is_rank0s_on_every_replica():
+    """kernels.set_tuning_group: an unknown conv problem is timed on every rank, rank 0's (tile, split-K) is what all of them cache."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=250) for _ in range(2)], key=lambda r: r['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]['cfg'] == res[1]['cfg'] and res[0]['cfg'] != (0x111, 1)
+    assert np.array_equal(res[0]['y'], res[1]['y'])

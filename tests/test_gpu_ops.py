@@ -140,3 +140,14 @@ def test_metric_kernels_against_committed_golden():
     K.frame_ssim(a, b, ssim)
     for name, got in (('mse', mse), ('psnr', psnr), ('ssim', ssim)):
         assert np.allclose(got.cpu().numpy(), d[name], rtol=2e-5, atol=0), name
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'f32'])
+def test_every_shipped_tuning_table_instantiation_vs_fp64(precision):
+    """The (problem, tile, split-K) pairs bench.py actually launches (video_prediction_amd/tuning_gfx950_*.json, N = 32 / 464 / 928 ...
+    at their own shapes), each against an fp64 tap-loop reference: rel <= 1e-2 (bf16 operands) / 2e-5 (exact fp32)."""
+    from tests import gpu_checks
+    res = gpu_checks.check_tuning_table(precision)
+    assert len(res) >= 90
+    bad = gpu_checks.failures(res)
+    assert not bad, 'parity failures (name, rel err, tol): %r' % bad[:20]

@@ -48,7 +48,7 @@ def set_conv_precision(name):
     PRECISION['value'] = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
 
 
-AUTOTUNE = {'enabled': False, 'cache': {}, 'log': []}
+AUTOTUNE = {'enabled': False, 'cache': {}, 'log': [], 'dist': None}
 CONV_CALL_LOG = None
 
 
@@ -68,6 +68,13 @@ def load_tuning(path):
     for k, v in d.items():
         AUTOTUNE['cache'][ast.literal_eval(k)] = (int(v[0]), int(v[1]))
     return len(d)
+
+
+def set_tuning_group(dist_module):
+    """Data-parallel runs: every replica executes the same launch sequence, so all of them meet an unknown conv problem at the
+    same call; each times the candidates on its own GPU, then rank 0's choice is broadcast and used by everyone (identical
+    kernels -> identical per-rank step time; without this the ranks could settle on different tiles)."""
+    AUTOTUNE['dist'] = dist_module if (dist_module is not None and dist_module.get_world_size() > 1) else None
 
 
 def enable_autotune(flag=True):
@@ -187,7 +194,12 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
-            cfg = AUTOTUNE['cache'][key] = _tune(a, mode, dst, w)
+            cfg = _tune(a, mode, dst, w)
+            if AUTOTUNE['dist'] is not None:
+                t = torch.tensor([int(cfg[0]), int(cfg[1])], dtype=torch.int32, device=dst.device)
+                AUTOTUNE['dist'].broadcast(t, src=0)
+                cfg = tuple(int(v) for v in t.tolist())
+            AUTOTUNE['cache'][key] = cfg
             AUTOTUNE['log'].append((key, cfg))
         a.tile, a.splitk = cfg
     if CONV_CALL_LOG is not None:      # profiling aid (tests/conv_shape_profile.py): launch order -> problem shape

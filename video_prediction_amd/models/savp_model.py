@@ -129,6 +129,7 @@ class SAVPEngine(object):
         self.dist = dist_module
         self.world = self.replicas.world
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
+        K.set_tuning_group(dist_module)         # rank 0's tile choice for every conv problem tuned live
 
     def _begin_allreduce(self, group, prefix):
         """Start the exchange of the gradients of the variables under `prefix` (one network = one contiguous chunk)."""
@@ -359,6 +360,8 @@ class SAVPEngine(object):
         # generator forward; the D step joins it with an event.  Off by default (SAVP_SIDE_PREP=1 enables): measured 74.4 vs 74.3 ms
         # per step -- the side stream's launches compete with the forward chain for the same CUs, like every other overlap tried.
         d_prep_done = None
+        if discs and self.world > 1:
+            self.replicas.wait_aux()               # last step's u broadcast (side stream) before anything touches u again
         if discs and self.side_prep:
             if self._prep_stream is None:
                 self._prep_stream = torch.cuda.Stream(device=self.device)
@@ -855,6 +858,8 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         powers of both optimizers) as a V2 checkpoint at `prefix`."""
         from .. import checkpoint as CK
         store, hp = self.engine.store, self.hparams
+        if self.engine.world > 1:
+            self.engine.replicas.wait_aux()        # the u broadcast of the last step runs on the side stream
         vals = store.to_numpy()
         vals['global_step'] = np.asarray(self.engine.step, dtype=np.int64)
         if self.mode == 'train':

@@ -98,7 +98,10 @@ class ReplicaGroup(object):
     def sync_aux(self):
         """Non-trainable state that every replica recomputes from identical weights (the spectral-norm power-iteration vectors
         u): the GEMVs behind it sum in a hardware-dependent order, so the replicas' copies drift apart in the last bit.  One
-        small broadcast of the 'aux' arena per step (a few KB, on the side stream) keeps the replicas bit-identical."""
+        small broadcast of the 'aux' arena per step (a few KB, on the side stream) keeps the replicas bit-identical.  The compute
+        stream does NOT wait here: the next reader of u is the discriminators' weight preparation of the NEXT step, a whole
+        generator forward later -- wait_aux() in front of it finds the broadcast long finished, so the collective is off the
+        critical path of every step."""
         if self.world == 1:
             return
         aux = self.store.groups.get('aux')
@@ -113,9 +116,17 @@ class ReplicaGroup(object):
                 self.dist.broadcast(aux.p, src=0)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
-            cur.wait_event(done)
+            self.aux_done = done
         else:
             self.dist.broadcast(aux.p, src=0)
+
+    def wait_aux(self):
+        """Order the current stream behind the last sync_aux() broadcast (call before anything reads or writes the 'aux' arena)."""
+        done = getattr(self, 'aux_done', None)
+        if done is not None:
+            aux = self.store.groups['aux']
+            torch.cuda.current_stream(aux.p.device).wait_event(done)
+            self.aux_done = None
 
     def allreduce_grads(self, group, async_op=False):
         """Sum the whole flat gradient bucket of one optimiser group (blocking with respect to the current stream)."""
@@ -135,6 +146,7 @@ class ReplicaGroup(object):
         """True iff every replica holds bit-identical variables (they must: identical averaged grads, identical Adam)."""
         if self.world == 1:
             return True
+        self.wait_aux()
         ok = True
         for g in self.store.groups.values():
             s = g.p.double().sum().reshape(1).clone()
