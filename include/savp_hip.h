@@ -3,9 +3,12 @@
  *
  * The reference (alexlee-gk/video_prediction) has no native plug-in point: its arithmetic is TensorFlow kernels
  * reached through Python.  Each entry below replaces the TF kernel call(s) of the cited reference lines.  All
- * entry points are stream-ordered, allocate nothing, keep no global state, and return 0 on success or a negative
- * SAVP_E* code.  Tensors are fp32, channels-last, addressed by raw device pointers + element strides
- * (channel stride is always 1), so channel-slice views of wider "concat" buffers are first-class.
+ * entry points are stream-ordered, allocate no device memory (every scratch buffer is an argument the caller owns), never read
+ * the environment, and return 0 on success or a negative SAVP_E* code.  The only process-wide state is the option table behind
+ * savp_set_option (kernel-selection switches; defaults = the shipped configuration), the event pair of savp_prof_arm, and
+ * one-time per-kernel attribute flags (hipFuncSetAttribute for > 64 KB of LDS).  Tensors are fp32, channels-last, addressed by
+ * raw device pointers + element strides (channel stride is always 1), so channel-slice views of wider "concat" buffers are
+ * first-class.
  */
 #ifndef SAVP_HIP_H
 #define SAVP_HIP_H
@@ -22,6 +25,12 @@ extern "C" {
 
 /* library / build info: returns a static string "savp_hip <version> gfx950" */
 const char* savp_version(void);
+
+/* Kernel-selection switches (process-wide; SAVP_EINVAL for an unknown name).  Names and defaults: "conv_ring" 0 (auto algorithm
+ * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1 (problem-specific kernels on), "colsum_2stage" 1,
+ * "inorm_min_hw" 256, and the developer overrides "wgp_cfg", "wgp_split", "dense_legacy", "cdna_legacy" (0). */
+int savp_set_option(const char* name, int32_t value);
+int savp_get_option(const char* name, int32_t* value);
 
 /* Measurement aid (bench.py's roofline leg; no reference counterpart): time ONE kernel by itself.  savp_prof_arm hands an event
  * pair to the next LDS-ring convolution launch of the calling thread (savp_conv, bf16 datapath); that launch stamps the events
@@ -85,9 +94,17 @@ typedef struct SavpConvArgs {
     float* stats;                  /* with out_bf16: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
                                       of every (sample, channel) of the destination, taken from the fp32 accumulators before rounding
                                       = the statistics of the instance norm that follows (rnn_ops.py:148-149); caller zeroes; may be NULL */
+    void* ws; int64_t ws_bytes;    /* optional caller-owned scratch (16-byte aligned; written before it is read, so one buffer can serve
+                                      every call on a stream).  savp_conv_workspace_bytes() says how much a call can use; without it
+                                      the call takes a kernel that needs none */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
+/* bytes of args->ws this call would use (0: none) -- today the RGB-side weight gradient's per-workgroup partial sums */
+int64_t savp_conv_workspace_bytes(const SavpConvArgs* args);
+/* 1 when, with tile bits 8-9 == 0 (automatic algorithm), a problem-specific kernel takes this call and tile / splitk are not
+ * looked at (a tuner can skip its search); 0 otherwise */
+int savp_conv_special(const SavpConvArgs* args);
 
 
 /* A channels-last activation view addressed as p[n*sn + pixel*sp + c] (pixel = flattened D*H*W index; valid for
@@ -172,8 +189,12 @@ int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
 int savp_tile_channels(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out, int32_t beta);
 /* the same into a bf16 view (strides in bf16 elements; overwrite) */
 int savp_tile_channels_bf16(void* stream, const float* z, int64_t R, int32_t HW, int32_t C, float scale, SavpView out);
-/* out[(r,)c] += scale*sum_p in[r,p,c] (atomic accumulate; per_row keeps r) : bias grads, d(tile_concat), avg pool */
-int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out, int32_t per_row);
+/* out[(r,)c] += scale*sum_p in[r,p,c] (atomic accumulate; per_row keeps r) : bias grads, d(tile_concat), avg pool.
+ * ws: optional caller-owned scratch of >= SAVP_COLSUM_WS_FLOATS floats (16-byte aligned, written before read): large all-pixel sums
+ * then go through partial rows + one reduce launch instead of ~10^4 workgroups of atomics onto a few cache lines */
+#define SAVP_COLSUM_WS_FLOATS (1024 * 4 * 256)
+int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out, int32_t per_row,
+                float* ws, int64_t ws_floats);
 /* out_k = mask[n] ? a : b   (scheduled sampling tf.where, savp_model.py:406); b.p may be NULL (zeros) */
 int savp_select(void* stream, int32_t N, int32_t HW, int32_t C, const int32_t* mask, SavpView a, SavpView b, int32_t nout,
                 const SavpView* outs);

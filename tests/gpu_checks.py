@@ -306,9 +306,29 @@ def _ref_lstm_gates(gates, c, g1, b1, g2, b2):
 
 
 def check_lstm(seed=3):
+    """ConvLSTM gate block vs the fp64 oracle: the one-launch kernels (option lstm_fused = 1, every (Q, PPT) shape class: N = 32
+    planes with 4 / 8 / 16-channel slabs, small N, ragged planes) and, with the option off, the three-pass / single-kernel paths."""
     out = []
-    rng = np.random.default_rng(seed)
-    for (N, H, W, F, zero_state) in [(2, 32, 32, 32, False), (3, 16, 16, 64, False), (2, 8, 8, 128, True), (2, 4, 6, 8, False)]:
+    cases = [(2, 32, 32, 32, False, (0, 1)), (3, 16, 16, 64, False, (0, 1)), (2, 8, 8, 128, True, (0, 1)), (2, 4, 6, 8, False, (0, 1)),
+             (2, 16, 24, 16, False, (1,)), (32, 32, 32, 32, False, (1,)), (32, 16, 16, 64, False, (1,)), (32, 8, 8, 128, True, (1,)),
+             (32, 8, 8, 128, False, (1,))]
+    try:
+        for fused in (1, 0):
+            lib.set_option('lstm_fused', fused)
+            rng = np.random.default_rng(seed)
+            for (N, H, W, F, zero_state, modes) in cases:
+                if fused not in modes:
+                    continue
+                out += _check_lstm_case(rng, N, H, W, F, zero_state, '_fused' if fused else '')
+    finally:
+        lib.set_option('lstm_fused', 1)
+    torch.cuda.synchronize()
+    return out
+
+
+def _check_lstm_case(rng, N, H, W, F, zero_state, sfx):
+    out = []
+    if True:
         gates = (rnd(rng, N, H, W, 4 * F) * 1.5 + 0.3).requires_grad_(True)
         c = (torch.zeros(N, H, W, F, dtype=torch.float64) if zero_state else rnd(rng, N, H, W, F)).requires_grad_(True)
         g1 = (rnd(rng, 4 * F) * 0.3 + 1).requires_grad_(True)
@@ -318,7 +338,7 @@ def check_lstm(seed=3):
         cn, hn = _ref_lstm_gates(gates, c, g1, b1, g2, b2)
         dh1, dh2, dcn = rnd(rng, *hn.shape), rnd(rng, *hn.shape), rnd(rng, *cn.shape)
         ((hn * (dh1 + dh2)).sum() + (cn * dcn).sum()).backward()
-        tag = 'lstm_%dx%dx%d%s' % (H, W, F, '_zero' if zero_state else '')
+        tag = 'lstm%s_N%d_%dx%dx%d%s' % (sfx, N, H, W, F, '_zero' if zero_state else '')
         gd = dev(gates)
         cd = None if zero_state else dev(c)
         p = [dev(t) for t in (g1, b1, g2, b2)]
@@ -331,8 +351,10 @@ def check_lstm(seed=3):
         out.append((tag + '/c', rel_err(c_new, cn), TOL_OP))
         out.append((tag + '/h', rel_err(h1, hn), TOL_OP))
         out.append((tag + '/h2', rel_err(h2, hn), TOL_OP))
-        # coalesced three-pass forward (selected by the workspace): same outputs and saved statistics
-        if F >= 16:
+        out.append((tag + '/pad_untouched', float(hbig[..., F:F + 8].abs().max()), 0.0))
+        # coalesced three-pass forward (selected by the workspace when the one-launch kernels are off): same outputs and statistics
+        three_pass = F >= 16 and not sfx
+        if three_pass:
             ws = torch.empty(K.lstm_ws_floats(N, H * W, F), device=DEV)
             c_ws = torch.empty(N, H, W, F, device=DEV)
             hbig2 = torch.zeros(N, H, W, 2 * F + 8, device=DEV)
@@ -352,7 +374,14 @@ def check_lstm(seed=3):
         out.append((tag + '/dc_prev', rel_err(dcp, c.grad), 1e-4))
         for nm, got, ref in zip(('dg1', 'db1', 'dg2', 'db2'), dpar, (g1.grad, b1.grad, g2.grad, b2.grad)):
             out.append((tag + '/' + nm, rel_err(got, ref), 1e-4))
-        if F >= 16:                       # coalesced three-pass backward
+        if sfx:        # one / three / four gradient sources of h', no d c' in or out: same result as the sum handed over as one source
+            dsum = dev(dh1 + dh2)
+            third = torch.zeros_like(dsum)
+            for srcs in ([dsum], [dev(dh1), dev(dh2), third], [dev(dh1), third, dev(dh2), third]):
+                dg3 = torch.empty_like(dgates)
+                K.convlstm_gates_bwd(gd, cd, p[0], p[1], p[2], p[3], stats, srcs, dev(dcn), dg3, None, [torch.zeros_like(t) for t in dpar])
+                out.append((tag + '/dgates_%dsrc' % len(srcs), rel_err(dg3, gates.grad), 1e-4))
+        if three_pass:                       # coalesced three-pass backward
             dgates2 = torch.empty(N, H, W, 4 * F, device=DEV)
             dcp2 = torch.empty(N, H, W, F, device=DEV)
             dpar2 = [torch.zeros_like(t) for t in dpar]
@@ -363,9 +392,7 @@ def check_lstm(seed=3):
                 out.append((tag + '/' + nm + '_ws', rel_err(got, ref), 1e-4))
             K.convlstm_gates_bwd(gd, cd, p[0], p[1], p[2], p[3], stats, [dev(dh1)], None, dgates2, None, dpar2, ws=ws)   # no dc in/out
             torch.cuda.synchronize()
-    torch.cuda.synchronize()
     return out
-
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -965,7 +992,7 @@ def failures(results):
 
 def smoke():
     """One small hot-path invocation on cuda:0 checked against the oracle (used by __graft_entry__.smoke)."""
-    res = check_conv(cases=('lstm5x5_32',)) + check_lstm()[:3]
+    res = check_conv(cases=('lstm5x5_32',)) + _check_lstm_case(np.random.default_rng(3), 2, 32, 32, 32, False, '_fused')
     # the bench datapath: bf16 LDS-patch FPROP / DGRAD / WGRAD kernels on the ConvLSTM gate-conv shape
     res += [('bf16/' + n, e, t) for (n, e, t) in check_conv(cases=('lstm5x5_32',), precision=1, tol=1e-2)]
     bad = failures(res)
@@ -1029,7 +1056,7 @@ ALL_CHECKS.append(('metrics', check_metrics))
 
 
 def check_bf16_activation_io(seed=31):
-    """bf16 destinations / operands of the kernels around the ConvLSTM gate convolution (SAVP_BF16_ACT=1 in the engine; experimental):
+    """bf16 destinations / operands of the kernels around the ConvLSTM gate convolution (SAVP_BF16_ACT=1 / SAVP_BF16_DGATES=1 in the engine):
     a bf16 view receives exactly the fp32 result rounded to nearest even, and the weight gradient from bf16 operand tensors equals
     the one from the same values held in fp32."""
     out = []
@@ -1097,27 +1124,6 @@ def check_bf16_activation_io(seed=31):
         K.conv(lib.CONV_WGRAD, geom, xa, ya, dw, bias=db, precision=1)
         out.append(('bf16io/wgrad_' + tag, rel_err(dw, ref.double().cpu()), 1e-5))
         out.append(('bf16io/wgrad_bias_' + tag, rel_err(db, refb.double().cpu()), 1e-5))
-    torch.cuda.synchronize()
-    return out
-
-
-def check_s2fprop(seed=37):
-    """conv_s2fprop.hip (experimental; the process must run with SAVP_S2FPROP=1): FPROP of the 4x4 stride-(1,2,2) 32 -> 64 layer with
-    bias + LeakyReLU, 3-D and 2-D, full and ragged tiles, into a channel slice of a wider buffer."""
-    out = []
-    rng = np.random.default_rng(seed)
-    for (tag, N, dhw, k, pp) in (('s2fprop/3d', 2, (5, 32, 64), (4, 4, 4), (1, 1, 1)), ('s2fprop/3d_ragged', 1, (4, 20, 36), (4, 4, 4), (1, 1, 1)),
-                                 ('s2fprop/2d', 3, (1, 16, 40), (1, 4, 4), (0, 1, 1))):
-        x = rnd(rng, N, *dhw, 32)
-        w = rnd(rng, *k, 32, 64) * 0.1
-        b = rnd(rng, 64)
-        y = torch.nn.functional.leaky_relu(_ref_conv(x, w, k, (1, 2, 2), pp, pp) + b, 0.2)
-        wide = torch.full(tuple(y.shape[:-1]) + (80,), 3.0, device=DEV)
-        wtp = dev(pack_wt(w))
-        K.conv(lib.CONV_FPROP, K.ConvGeom(k, (1, 2, 2), pp), dev(x), wide[..., 8:72], wtp, bias=dev(b), act=lib.ACT_LRELU, alpha=0.2,
-               precision=1, w16=wtp.to(torch.bfloat16))
-        keep = bool((wide[..., :8] == 3.0).all() and (wide[..., 72:] == 3.0).all())
-        out.append((tag, rel_err(wide[..., 8:72], y) + (0.0 if keep else 1.0), 1e-2))
     torch.cuda.synchronize()
     return out
 

@@ -68,19 +68,9 @@ def test_conv_thin_rgb_first_layer():
     _run(gpu_checks.check_conv_thin)
 
 
-@pytest.mark.skipif(os.environ.get('SAVP_TEST_EXPERIMENTAL', '0') != '1',
-                    reason='bf16 activation I/O around the gate convolution: written without GPU time left in round 2; '
-                           'SAVP_TEST_EXPERIMENTAL=1 runs it')
-def test_bf16_activation_io_experimental():
+def test_bf16_activation_io():
     from tests import gpu_checks
     _run(gpu_checks.check_bf16_activation_io)
-
-
-@pytest.mark.skipif(os.environ.get('SAVP_TEST_EXPERIMENTAL', '0') != '1' or os.environ.get('SAVP_S2FPROP', '0') != '1',
-                    reason='experimental FPROP kernel of the stride-(1,2,2) discriminator layer: run with SAVP_TEST_EXPERIMENTAL=1 SAVP_S2FPROP=1')
-def test_s2fprop_experimental():
-    from tests import gpu_checks
-    _run(gpu_checks.check_s2fprop)
 
 
 def test_fused_convlstm_cell_bf16():

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "savp_hip.h"
+#include "opts.h"
 
 #define NT 256
 #define RELU_SHIFT 1e-12f
@@ -619,9 +620,7 @@ static int fill_cdna(CdnaP& p, const SavpCdnaArgs* a) {
 
 // SAVP_CDNA_LEGACY=1: the one-thread-per-pixel global-memory kernels (developer A/B switch)
 static bool cdna_legacy() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_CDNA_LEGACY"); v = e ? atoi(e) : 0; }
-    return v != 0;
+    return savp_opt(OPT_CDNA_LEGACY) != 0;
 }
 // 3 / 1: the tiled 5x5, K = 4 kernels for C = 3 / 1 apply; 0: generic
 static int cdna_tiled_kind(const SavpCdnaArgs* a) {

@@ -1,6 +1,8 @@
 // common.hip -- library identification.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "savp_hip.h"
+#include "opts.h"
 
 extern "C" const char* savp_version(void) { return "savp_hip 0.1 gfx950"; }
 
@@ -32,4 +34,23 @@ extern "C" int savp_prof_elapsed_us(void* start, void* stop, float* us) {
     if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return SAVP_ELAUNCH;
     *us = ms * 1e3f;
     return SAVP_OK;
+}
+
+// ---- options (opts.h) ----------------------------------------------------------------------------------------
+static struct { const char* name; int value; } g_opts[OPT_COUNT] = {
+    {"conv_ring", 0}, {"s2dgrad", 1}, {"thin", 1}, {"wgp_cfg", 0}, {"wgp_split", 0}, {"inorm_min_hw", 256}, {"colsum_2stage", 1},
+    {"dense_legacy", 0}, {"cdna_legacy", 0}, {"lstm_fused", 1},
+};
+int savp_opt(int id) { return g_opts[id].value; }
+extern "C" int savp_set_option(const char* name, int value) {
+    if (!name) return SAVP_EINVAL;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(g_opts[i].name, name)) { g_opts[i].value = value; return SAVP_OK; }
+    return SAVP_EINVAL;
+}
+extern "C" int savp_get_option(const char* name, int* value) {
+    if (!name || !value) return SAVP_EINVAL;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(g_opts[i].name, name)) { *value = g_opts[i].value; return SAVP_OK; }
+    return SAVP_EINVAL;
 }

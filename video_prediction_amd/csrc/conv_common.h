@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "opts.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,7 +40,6 @@ struct ConvP {
     int src16;                                // source activations are bf16 (strides in elements)
     int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
     float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
-    int epi_batch;                            // batched read-modify-write epilogue (SAVP_EPI_BATCH=1, experimental)
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
@@ -92,11 +92,12 @@ static inline unsigned long long magic40(int d) {
 
 // conv_thin.hip: FPROP / WGRAD of a 3x3(x3) stride-1 convolution with Cx <= 4, Cy = 32 (bf16 mode).  true = handled.
 bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+bool conv_thin_applies(const SavpConvArgs* a);
+long long conv_thin_workspace_bytes(const SavpConvArgs* a);
 
 // conv_s2dgrad.hip: DGRAD of a 4x4 stride-(1,2,2) convolution with 32 input channels, all four output phases per workgroup.
 bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc);
-// conv_s2fprop.hip: FPROP of the same layer (experimental, SAVP_S2FPROP=1)
-bool conv_s2fprop_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+bool conv_s2dgrad_applies(const SavpConvArgs* a);
 
 extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
 

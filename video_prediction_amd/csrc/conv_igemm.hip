@@ -333,43 +333,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
         const float bias = (p.bias && split == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            if (p.epi_batch && p.splitk == 1 && (p.beta || p.act == SAVP_ACT_DLRELU_FROM_OUT)) {
-                // batched read-modify-write epilogue (experimental, SAVP_EPI_BATCH=1): see conv_patch.hip
-                const bool use_old = p.beta != 0, use_aux = p.act == SAVP_ACT_DLRELU_FROM_OUT;
-#pragma unroll
-                for (int hb = 0; hb < 4; ++hb) {
-                    long long off4[4];
-                    float old4[4], aux4[4], v4[4];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int r = hb * 4 + q4;
-                        off4[q4] = rowoff[wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
-                    }
-                    if (use_old) {
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) old4[q4] = *(off4[q4] >= 0 ? dst + off4[q4] + col : dst);
-                    }
-                    if (use_aux) {
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) aux4[q4] = *(off4[q4] >= 0 ? p.aux + off4[q4] + col : p.aux);
-                    }
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float v = acc[i][j][hb * 4 + q4] + bias;
-                        if (use_old) v += old4[q4];
-                        if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
-                        else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                        else if (use_aux) v *= (aux4[q4] > 0.f ? 1.f : p.alpha);
-                        v4[q4] = v;
-                    }
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) asm volatile("" : "+v"(v4[q4]));
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        if (off4[q4] >= 0) dst[off4[q4] + col] = v4[q4];
-                }
-                continue;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -786,9 +749,19 @@ static void pick_tile(long long M, long long N, int& wm, int& wn) {
 
 // auto algorithm choice between the two LDS-patch kernels when the caller gives no tile: SAVP_CONV_RING=1 prefers conv_ring.hip
 static bool ring_default() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_CONV_RING"); v = e ? atoi(e) : 0; }
-    return v != 0;
+    return savp_opt(OPT_CONV_RING) != 0;
+}
+
+extern "C" int64_t savp_conv_workspace_bytes(const SavpConvArgs* a) {
+    if (!a || a->mode != SAVP_CONV_WGRAD) return 0;
+    const long long thin = conv_thin_workspace_bytes(a);
+    const long long bias = a->bias ? (long long)SAVP_COLSUM_WS_FLOATS * 4 : 0;      // the separate bias-gradient pass (savp_colsum)
+    return thin > bias ? thin : bias;
+}
+
+extern "C" int savp_conv_special(const SavpConvArgs* a) {
+    if (!a || ((a->tile >> 8) & 3) != 0) return 0;
+    return (conv_thin_applies(a) || conv_s2dgrad_applies(a)) ? 1 : 0;
 }
 
 extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
@@ -809,11 +782,6 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.bias = a->bias; p.aux = a->aux;
     p.splitk = 1; p.tm = p.tn = 1;
     p.src16 = a->src_bf16 ? 1 : 0; p.cell = 0; p.stats = nullptr;
-    {
-        static int eb = -1;
-        if (eb < 0) { const char* e = getenv("SAVP_EPI_BATCH"); eb = (e && e[0] == '1') ? 1 : 0; }
-        p.epi_batch = eb;
-    }
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
@@ -823,18 +791,16 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     ablate_init();
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
-    {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first layer
-        // (FPROP, WGRAD) and the data gradient of the generator's scratch-image head
+    // problem-specific kernels, taken only when the caller leaves the algorithm to the library (tile bits 8-9 == 0): a forced
+    // algorithm gets exactly that kernel or EINVAL
+    if (algo == 0) {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first
+        // layer (FPROP, WGRAD) and the data gradient of the generator's scratch-image head
         int rc = SAVP_OK;
         if (conv_thin_try(a, st, &rc)) return rc;
     }
-    if (a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
+    if (algo == 0 && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
         int rc = SAVP_OK;
         if (conv_s2dgrad_try(a, st, &rc)) return rc;
-    }
-    if (a->mode == SAVP_CONV_FPROP) {     // its forward companion (conv_s2fprop.hip; experimental, SAVP_S2FPROP=1)
-        int rc = SAVP_OK;
-        if (conv_s2fprop_try(a, st, &rc)) return rc;
     }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         const bool dg = a->mode == SAVP_CONV_DGRAD;
@@ -948,7 +914,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
             const bool joint = (a->y_sh == a->Wo * a->y_sw) && (a->Do == 1 || a->y_sd == a->Ho * a->y_sh);
             if (!joint) return SAVP_EINVAL;
             SavpView yv; yv.p = (void*)a->y; yv.sn = a->y_sn; yv.sp = a->y_sw;
-            int rc2 = savp_colsum(stream, yv, a->N, (int32_t)px, a->Cy, 1.f, (float*)a->bias, 0);
+            int rc2 = savp_colsum(stream, yv, a->N, (int32_t)px, a->Cy, 1.f, (float*)a->bias, 0, (float*)a->ws, a->ws ? a->ws_bytes / 4 : 0);
             if (rc2 != SAVP_OK) return rc2;
         }
     } else {

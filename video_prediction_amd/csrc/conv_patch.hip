@@ -296,55 +296,6 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
         for (int j = 0; j < WN; ++j) {
             if (col0 + 32 * j >= Nout) continue;
             const float bias = (p.bias && split == 0) ? p.bias[col0 + 32 * j] : 0.f;
-            if (p.epi_batch && p.splitk == 1) {
-                // Batched read-modify-write epilogue (experimental, SAVP_EPI_BATCH=1; off: written without GPU time left to validate
-                // it).  The loop below loads the old value / the saved activation of ONE element, waits, stores, and only then turns
-                // to the next element -- `load; s_waitcnt vmcnt(0); load; s_waitcnt vmcnt(0); store` 16 times per 32 x 32 block in
-                // the ISA, i.e. up to 32 serialised L2 round trips per block for a beta + LeakyReLU' data gradient.  Here the loads
-                // of 4 elements are issued together (out-of-range elements read the tensor's first element and are not stored),
-                // the values are computed, and the 4 stores follow.
-                const bool use_old = p.beta != 0, use_aux = p.act == SAVP_ACT_DLRELU_FROM_OUT;
-#pragma unroll
-                for (int hb = 0; hb < 4; ++hb) {          // four elements per batch: more would cost the 4-wave variants a wave of occupancy
-                    int off8[4];
-                    bool ok8[4];
-                    float old8[4], aux8[4], v8[4];
-#pragma unroll
-                    for (int q8 = 0; q8 < 4; ++q8) {
-                        const int r = hb * 4 + q8;
-                        ok8[q8] = full || (py0 + (r >> 2) < Hm && px0 + (r & 3) < Wm);
-                        off8[q8] = (r >> 2) * e_sh + (r & 3) * e_sw + 32 * j;
-                    }
-                    if (use_old) {
-#pragma unroll
-                        for (int q8 = 0; q8 < 4; ++q8) old8[q8] = *(ok8[q8] ? dst + off8[q8] : p.out);
-                    }
-                    if (use_aux) {
-#pragma unroll
-                        for (int q8 = 0; q8 < 4; ++q8) aux8[q8] = *(ok8[q8] ? aux + off8[q8] : p.aux);
-                    }
-#pragma unroll
-                    for (int q8 = 0; q8 < 4; ++q8) {
-                        float v = acc[i][j][hb * 4 + q8] + bias;
-                        if (use_old) v += old8[q8];
-                        if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
-                        else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                        else if (use_aux) v *= (aux8[q8] > 0.f ? 1.f : p.alpha);
-                        v8[q8] = v;
-                    }
-#pragma unroll
-                    for (int q8 = 0; q8 < 4; ++q8) asm volatile("" : "+v"(v8[q8]));     // values first, stores after (no wait between stores)
-                    if (full) {
-#pragma unroll
-                        for (int q8 = 0; q8 < 4; ++q8) dst[off8[q8]] = v8[q8];
-                    } else {
-#pragma unroll
-                        for (int q8 = 0; q8 < 4; ++q8)
-                            if (ok8[q8]) dst[off8[q8]] = v8[q8];
-                    }
-                }
-                continue;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;

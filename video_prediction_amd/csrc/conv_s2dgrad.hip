@@ -185,21 +185,24 @@ __global__ __launch_bounds__(256, 2) void s2dgrad_kernel(S2P p) {
     }
 }
 
-static int s2_mode() {                 // SAVP_S2DGRAD=0 switches the kernel off (A/B against the general kernels)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_S2DGRAD"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-
-// Returns true when the call was handled (rc set); false = not this kernel's problem.
-bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
-    if (!s2_mode() || a->mode != SAVP_CONV_DGRAD || a->precision != SAVP_PREC_BF16 || !a->w_bf16) return false;
+// Is this call the kernel's problem?  (option "s2dgrad" = 0 switches the kernel off: A/B against the general kernels)
+bool conv_s2dgrad_applies(const SavpConvArgs* a) {
+    if (!savp_opt(OPT_S2DGRAD) || a->mode != SAVP_CONV_DGRAD || a->precision != SAVP_PREC_BF16 || !a->w_bf16) return false;
     if (!(a->Cx == 32 && (a->Cy == 64 || a->Cy == 32) && a->kh == 4 && a->kw == 4 && a->sh == 2 && a->sw == 2 && a->ph == 1 && a->pw == 1 &&
           a->sd == 1 && a->kd >= 1 && a->kd <= 4 && a->H == 2 * a->Ho && a->W == 2 * a->Wo && a->Do == a->D + 2 * a->pd - a->kd + 1 &&
           !a->src_bf16 && !a->out_bf16 && !a->stats && (a->beta == 0 || a->beta == 1) &&
           (a->act == SAVP_ACT_NONE || (a->act == SAVP_ACT_DLRELU_FROM_OUT && a->aux))))
         return false;
     if ((a->y_sn % 4) || (a->y_sd % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y) || !aligned16(a->w_bf16)) return false;
+    const long long items = (long long)a->N * a->D * ((a->H + S2_TR - 1) / S2_TR) * ((a->W + S2_TC - 1) / S2_TC);
+    if (items < 1 || items >= (1ll << 31)) return false;
+    if ((long long)a->H * a->x_sh + (long long)a->W * a->x_sw >= (1ll << 31)) return false;      // 32-bit offsets inside a plane
+    return true;
+}
+
+// Returns true when the call was handled (rc set); false = not this kernel's problem.
+bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
+    if (!conv_s2dgrad_applies(a)) return false;
     static const float* zero = nullptr;
     if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_s2_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     S2P p;
@@ -211,8 +214,6 @@ bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     p.tilesX = (a->W + S2_TC - 1) / S2_TC; p.tilesY = (a->H + S2_TR - 1) / S2_TR;
     p.zero = zero;
     const long long items = (long long)a->N * a->D * p.tilesY * p.tilesX;
-    if (items < 1 || items >= (1ll << 31)) return false;
-    if ((long long)a->H * a->x_sh + (long long)a->W * a->x_sw >= (1ll << 31)) return false;      // 32-bit offsets inside a plane
     if (a->Cy == 64) hipLaunchKernelGGL(s2dgrad_kernel<64>, dim3((unsigned)items), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(s2dgrad_kernel<32>, dim3((unsigned)items), dim3(256), 0, st, p);
     *rc = hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;

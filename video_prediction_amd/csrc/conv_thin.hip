@@ -327,11 +327,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static bool thin_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_THIN"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
+static bool thin_enabled() { return savp_opt(OPT_THIN) == 1; }
 
 static bool thin_geometry_ok(const SavpConvArgs* a) {
     // DGRAD of a 32 -> (1 | 3 | 4)-channel convolution is the same problem with the tensors' roles swapped and the taps mirrored
@@ -360,17 +356,44 @@ static void thin_fill(ThinP& p, const SavpConvArgs* a, int tile_r, int tile_c, i
     if (p.per_wg < 1) p.per_wg = 1;
 }
 
-// Returns true when the call was handled (rc set); false = not this kernel's problem, the caller goes on to the general kernels.
-bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
+// Floats of partial-sum workspace the WGRAD needs (one row of dW + db per workgroup); the caller owns it (SavpConvArgs.ws).
+static long long thin_wgrad_ws_floats(const SavpConvArgs* a) {
+    ThinP p;
+    thin_fill(p, a, TW_R, TW_C, 512);
+    const int nwg = (p.items + p.per_wg - 1) / p.per_wg;
+    return (long long)nwg * (9 * a->kd * a->Cx * 32 + 32);
+}
+
+// Is this call the kernel's problem (everything except the workspace)?
+static bool thin_applies_geom(const SavpConvArgs* a) {
     if (!thin_enabled() || !thin_geometry_ok(a)) return false;
     const long long px = (long long)a->N * a->D * a->H * a->W;
     if (px >= (1ll << 31) / 64) return false;
+    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD)
+        return !(a->beta || a->aux || (a->act != SAVP_ACT_NONE && a->act != SAVP_ACT_LRELU));
+    if (a->mode == SAVP_CONV_WGRAD)
+        return !((a->y_sn % 4) || (a->y_sd % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y));
+    return false;
+}
+
+long long conv_thin_workspace_bytes(const SavpConvArgs* a) {
+    return (thin_applies_geom(a) && a->mode == SAVP_CONV_WGRAD) ? thin_wgrad_ws_floats(a) * (long long)sizeof(float) : 0;
+}
+
+bool conv_thin_applies(const SavpConvArgs* a) {
+    if (!thin_applies_geom(a)) return false;
+    // the weight gradient leaves one partial dW per workgroup in caller-owned scratch; without it the general kernel runs
+    return a->mode != SAVP_CONV_WGRAD || (a->ws && aligned16(a->ws) && a->ws_bytes >= conv_thin_workspace_bytes(a));
+}
+
+// Returns true when the call was handled (rc set); false = not this kernel's problem, the caller goes on to the general kernels.
+bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
+    if (!conv_thin_applies(a)) return false;
     static const float* zero = nullptr;
     if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     ThinP p;
     p.zero = zero;
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
-        if (a->beta || a->aux || (a->act != SAVP_ACT_NONE && a->act != SAVP_ACT_LRELU)) return false;
         thin_fill(p, a, TF_R, TF_C, 1024);                    // four resident workgroups per CU: one full wave of them
         p.w = (const float*)a->w; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;
         const dim3 grid((unsigned)((p.items + p.per_wg - 1) / p.per_wg));
@@ -379,21 +402,12 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
         else { if (p.Cx == 3) THIN_F(1, 3); else if (p.Cx == 1) THIN_F(1, 1); else THIN_F(1, 4); }
 #undef THIN_F
     } else if (a->mode == SAVP_CONV_WGRAD) {
-        if ((a->y_sn % 4) || (a->y_sd % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y)) return false;
         thin_fill(p, a, TW_R, TW_C, 512);                     // two resident workgroups per CU (VGPRs): one full wave of them
         p.dw = (float*)a->w; p.db = (float*)a->bias;
         const int nwg = (p.items + p.per_wg - 1) / p.per_wg;
         const int ndw = 9 * a->kd * a->Cx * 32, row = ndw + 32;
-        // partial-sum workspace, grown on demand and kept (5.4 MB for the BAIR layer).  One buffer: calls on different streams must
-        // not overlap (the engine issues every convolution on its compute stream).
-        static float* ws = nullptr;
-        static size_t ws_floats = 0;
-        if ((size_t)nwg * row > ws_floats) {
-            if (ws) hipFree(ws);
-            ws = nullptr; ws_floats = 0;
-            if (hipMalloc((void**)&ws, (size_t)nwg * row * sizeof(float)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
-            ws_floats = (size_t)nwg * row;
-        }
+        // partial-sum workspace: caller-owned scratch (SavpConvArgs.ws; 5.4 MB for the BAIR layer), fully written before it is read
+        float* ws = (float*)a->ws;
         p.ws = ws;
         const dim3 grid((unsigned)nwg);
         const size_t lds = (size_t)((((a->kd * TW_PR * TW_PC + 1) * 8 + 15) & ~15) + 256 * 64);

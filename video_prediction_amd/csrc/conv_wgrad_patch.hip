@@ -379,8 +379,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     // own phase of fetch / stage / multiply) overlap that better than one barrier-coupled 8-wave group: 490 -> 379 us on 64x64x32->32
     if (groups_all <= 32) { nw = 4; mtw = 4; }
     {   // developer override: SAVP_WGP_CFG=<nw><mtw> (e.g. 84)
-        static int ov = -1;
-        if (ov < 0) { const char* e = getenv("SAVP_WGP_CFG"); ov = e ? atoi(e) : 0; }
+        const int ov = savp_opt(OPT_WGP_CFG);
         if (ov) { nw = ov / 10; mtw = ov % 10; if (2 * nw * mtw < groups_all && 2 * nw * mtw < q.taps) return false; }
     }
     const int nthreads = 64 * nw;
@@ -404,8 +403,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     long long s = 768 / ((long long)NB * MC);                      // ~3 rounds of one 8-wave workgroup per CU
     if (s < 1) s = 1;
     {
-        static int ovs = -1;
-        if (ovs < 0) { const char* e = getenv("SAVP_WGP_SPLIT"); ovs = e ? atoi(e) : 0; }      // developer override: total workgroups
+        const int ovs = savp_opt(OPT_WGP_SPLIT);      // developer override: total workgroups
         if (ovs > 0) s = ovs / ((long long)NB * MC) > 0 ? ovs / ((long long)NB * MC) : 1;
     }
     if (s > q.PT) s = q.PT;

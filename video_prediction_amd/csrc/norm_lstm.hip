@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "savp_hip.h"
+#include "opts.h"
 
 #define NT 256
 
@@ -341,9 +342,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
 }
 
 static int inorm_min_hw() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_INORM_MIN_HW"); v = e ? atoi(e) : 256; }
-    return v;
+    return savp_opt(OPT_INORM_MIN_HW);
 }
 static bool use_large_plane_path(const SavpInormArgs* a) { return a->ws && a->HW >= inorm_min_hw() && a->C % 4 == 0 && a->C <= 256 && (NT % (a->C / 4) == 0); }
 // pixels per workgroup: ~512 workgroups per launch, at least one pass of the block's pixel rows, at most 256
@@ -1008,6 +1007,415 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One-launch ConvLSTM gate block, forward and backward (option "lstm_fused", default on; round 3).
+// Ownership as in the first version of this file -- one workgroup = (sample, a slab of 4*Q channels) over the WHOLE plane, so both
+// per-sample reductions are workgroup-local and the three passes (and their two round trips of c_pre / sigmoid(o) / the raw gate
+// gradients through HBM) collapse into one launch -- with what made that version slow removed:
+//  * every global load of a thread (PPT pixel items x (4 gate quads + c_prev [+ dh, dc'])) is issued unconditionally, on clamped
+//    addresses, before the first use (under `if (px < HW) load` hipcc emits load / s_waitcnt vmcnt(0) pairs: 20 serialised L2 round
+//    trips per thread);
+//  * Q threads side by side cover a slab's 4*Q channels of one pixel (8..64 contiguous bytes per gate and pixel), Q chosen as large
+//    as still leaves one workgroup per CU;
+//  * the workgroups of one sample sit on ONE XCD (blockIdx -> (xcd, slab, sample)): the 4F-wide pixel rows they all take their
+//    slices from are fetched into that XCD's L2 once;
+//  * IN(4F) statistics come from the gate convolution's epilogue (stats1_ready) or are reduced locally from registers.
+// ------------------------------------------------------------------------------------------------------------
+// Sums NV per-thread values over the threads with the same (tid % Q); result broadcast to them.  Through LDS in a fixed order
+// (deterministic, unlike atomics; and ~10x cheaper than 6 * NV serialised ds_bpermute + wait pairs of a shuffle tree at NV = 32):
+// every thread parks its values, thread j sums value (j % NV) over NV rows of one q, NV * Q threads fold the NT / (NV * Q) partial
+// sums.  `sh` holds LSTM_SUM_FLOATS(NV, Q) floats.
+#define LSTM_SUM_FLOATS(NV_, Q_) (NT * ((NV_) + 1) + NT + (NV_) * (Q_))
+template <int NV, int Q>
+__device__ __forceinline__ void block_sum_q(float (&v)[NV], float* sh) {
+    static_assert(NT % (NV * Q) == 0, "NV * Q divides the workgroup");
+    float* part = sh + NT * (NV + 1);
+    float* fin = part + NT;
+    const int tid = threadIdx.x;
+    __syncthreads();                                    // earlier readers of sh are done
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sh[tid * (NV + 1) + i] = v[i];
+    __syncthreads();
+    {
+        const int i = tid % NV, rest = tid / NV, q = rest % Q, pt = rest / Q;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += sh[((pt * NV + k) * Q + q) * (NV + 1) + i];
+        part[tid] = s;                                  // tid == (pt * Q + q) * NV + i
+    }
+    __syncthreads();
+    constexpr int NP = NT / (NV * Q);
+    if (tid < NV * Q) {
+        const int i = tid % NV, q = tid / NV;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) s += part[(k * Q + q) * NV + i];
+        fin[q * NV + i] = s;
+    }
+    __syncthreads();
+    const int q = tid & (Q - 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = fin[q * NV + i];
+}
+
+template <bool G16> struct GateQuad;
+template <> struct GateQuad<true> {
+    uint2 u;
+    __device__ __forceinline__ void load(const float* base, long long idx) {
+        u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    }
+    __device__ __forceinline__ void get(float* o) const {
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+};
+template <> struct GateQuad<false> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* base, long long idx) { v = ld4(base + idx); }
+    __device__ __forceinline__ void get(float* o) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+
+__device__ __forceinline__ void lstm_block_owner(int nslab, int xcd_map, int& n, int& slab) {
+    const int b = blockIdx.x;
+    if (xcd_map) { const int r = b >> 3; slab = r % nslab; n = (b & 7) + 8 * (r / nslab); }
+    else { n = b / nslab; slab = b % nslab; }
+}
+
+template <int Q, int PPT, bool G16>
+__global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float* __restrict__ s1, int nslab, int xcd_map) {
+    __shared__ float sh[LSTM_SUM_FLOATS(16, Q)];
+    constexpr int ROWS = NT / Q;
+    int n, slab;
+    lstm_block_owner(nslab, xcd_map, n, slab);
+    const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
+    const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
+    const long long g0 = (long long)n * HW * 4 * F + c0;
+    // ---- every load of this thread, issued before anything is used ---------------------------------------------
+    GateQuad<G16> gq[PPT][4];
+    float4 cpq[PPT];
+    int pxs[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        const int px = prow + t * ROWS;
+        ok[t] = px < HW;
+        pxs[t] = ok[t] ? px : HW - 1;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
+    }
+    if (p.c_prev) {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
+    } else {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 g1q[4], b1q[4], sa[4], sb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { g1q[g] = ld4(p.g1 + g * F + c0); b1q[g] = ld4(p.b1 + g * F + c0); }
+    if (s1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* s = s1 + ((long long)n * 4 * F + g * F + c0) * 2;
+            sa[g] = ld4(s); sb[g] = ld4(s + 4);
+        }
+    }
+    const float4 g2q = ld4(p.g2 + c0), b2q = ld4(p.b2 + c0);
+    // ---- IN(4F) -----------------------------------------------------------------------------------------------
+    const float inv = 1.f / (float)HW;
+    float x[PPT][16];
+#pragma unroll
+    for (int t = 0; t < PPT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[t][g].get(&x[t][g * 4]);
+    float mu[16], rs[16];
+    if (s1) {          // unshifted sums of the fp32 accumulators (conv epilogue): [sum, sumsq] pairs per channel
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float su[4] = {sa[g].x, sa[g].z, sb[g].x, sb[g].z}, sq[4] = {sa[g].y, sa[g].w, sb[g].y, sb[g].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float m = su[c] * inv;
+                mu[g * 4 + c] = m;
+                rs[g * 4 + c] = rsqrtf(fmaxf(sq[c] * inv - m * m, 0.f) + p.eps);
+            }
+        }
+    } else {
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < PPT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] += ok[t] ? x[t][i] : 0.f;
+        block_sum_q<16, Q>(s, sh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { mu[i] = s[i] * inv; s[i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < PPT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float d = x[t][i] - mu[i]; s[i] += ok[t] ? d * d : 0.f; }
+        block_sum_q<16, Q>(s, sh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rs[i] = rsqrtf(s[i] * inv + p.eps);
+    }
+    if (prow == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long long o = (long long)n * 4 * F + g * F + c0;
+            st4(p.mean1 + o, make_float4(mu[g * 4], mu[g * 4 + 1], mu[g * 4 + 2], mu[g * 4 + 3]));
+            st4(p.rstd1 + o, make_float4(rs[g * 4], rs[g * 4 + 1], rs[g * 4 + 2], rs[g * 4 + 3]));
+        }
+    }
+    float ga[16], be[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        ga[g * 4] = g1q[g].x; ga[g * 4 + 1] = g1q[g].y; ga[g * 4 + 2] = g1q[g].z; ga[g * 4 + 3] = g1q[g].w;
+        be[g * 4] = b1q[g].x; be[g * 4 + 1] = b1q[g].y; be[g * 4 + 2] = b1q[g].z; be[g * 4 + 3] = b1q[g].w;
+    }
+    // ---- gates -> c_pre, sigmoid(o) ; IN(F) of c_pre -------------------------------------------------------------
+    float cpre[PPT][4], so[PPT][4];
+    float s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        const float cpv[4] = {cpq[t].x, cpq[t].y, cpq[t].z, cpq[t].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = (x[t][c] - mu[c]) * rs[c] * ga[c] + be[c];
+            const float jn = (x[t][4 + c] - mu[4 + c]) * rs[4 + c] * ga[4 + c] + be[4 + c];
+            const float fn = (x[t][8 + c] - mu[8 + c]) * rs[8 + c] * ga[8 + c] + be[8 + c];
+            const float on = (x[t][12 + c] - mu[12 + c]) * rs[12 + c] * ga[12 + c] + be[12 + c];
+            cpre[t][c] = cpv[c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+            so[t][c] = sigmoidf_(on);
+            s2[c] += ok[t] ? cpre[t][c] : 0.f;
+        }
+    }
+    block_sum_q<4, Q>(s2, sh);
+    float mu2[4], rs2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { mu2[c] = s2[c] * inv; s2[c] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < PPT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float d = cpre[t][c] - mu2[c]; s2[c] += ok[t] ? d * d : 0.f; }
+    block_sum_q<4, Q>(s2, sh);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rs2[c] = rsqrtf(s2[c] * inv + p.eps);
+    if (prow == 0) {
+        st4(p.mean2 + (long long)n * F + c0, make_float4(mu2[0], mu2[1], mu2[2], mu2[3]));
+        st4(p.rstd2 + (long long)n * F + c0, make_float4(rs2[0], rs2[1], rs2[2], rs2[3]));
+    }
+    const float g2v[4] = {g2q.x, g2q.y, g2q.z, g2q.w}, b2v[4] = {b2q.x, b2q.y, b2q.z, b2q.w};
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        if (!ok[t]) continue;
+        float cn[4], hv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cn[c] = (cpre[t][c] - mu2[c]) * rs2[c] * g2v[c] + b2v[c];
+            hv[c] = tanhf_(cn[c]) * so[t][c];
+        }
+        const int px = pxs[t];
+        st4(p.c_new + ((long long)n * HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < p.nh) st4x(p.h[k], (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4, p.h16[k]);
+    }
+}
+
+template <int Q, int PPT, bool G16>
+__global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, int xcd_map) {
+    __shared__ float sh[LSTM_SUM_FLOATS(32, Q)];
+    constexpr int ROWS = NT / Q;
+    int n, slab;
+    lstm_block_owner(nslab, xcd_map, n, slab);
+    const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
+    const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
+    const long long g0 = (long long)n * HW * 4 * F + c0;
+    // ---- every load of this thread up front ----------------------------------------------------------------------
+    GateQuad<G16> gq[PPT][4];
+    float4 cpq[PPT], dhq[PPT], dcq[PPT];
+    int pxs[PPT];
+    float okf[PPT];
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        const int px = prow + t * ROWS;
+        okf[t] = px < HW ? 1.f : 0.f;
+        pxs[t] = px < HW ? px : HW - 1;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
+        dhq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dcq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.c_prev) {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
+    }
+    if (p.dc_new) {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) dcq[t] = ld4(p.dc_new + ((long long)n * HW + pxs[t]) * F + c0);
+    }
+    // up to three gradient sources of h' (consumers of this step + the next step's gate conv); a fourth is rare.  Loads stay
+    // unconditional (source min(k, ndh-1), weight 0 beyond ndh): a load under `if (k < ndh)` is waited for inside its branch
+    float4 dhs[3][PPT];
+    {
+        const int nd = p.ndh > 0 ? p.ndh : 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kk = k < nd ? k : nd - 1;
+            const float* src = p.ndh > 0 ? p.dh[kk] : p.gates;          // ndh == 0: any valid address, weight 0
+            const long long sn = p.ndh > 0 ? p.dh_sn[kk] : 0, sp = p.ndh > 0 ? p.dh_sp[kk] : 0;
+#pragma unroll
+            for (int t = 0; t < PPT; ++t) dhs[k][t] = ld4(src + (long long)n * sn + (long long)pxs[t] * sp + (p.ndh > 0 ? c0 : 0));
+        }
+    }
+    if (p.ndh > 3) {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) dhq[t] = ld4(p.dh[3] + (long long)n * p.dh_sn[3] + (long long)pxs[t] * p.dh_sp[3] + c0);
+    }
+    float mu[16], rs[16], ga[16], be[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const long long o = (long long)n * 4 * F + g * F + c0;
+        const float4 m = ld4(p.mean1 + o), r = ld4(p.rstd1 + o), gg = ld4(p.g1 + g * F + c0), bb = ld4(p.b1 + g * F + c0);
+        mu[g * 4] = m.x; mu[g * 4 + 1] = m.y; mu[g * 4 + 2] = m.z; mu[g * 4 + 3] = m.w;
+        rs[g * 4] = r.x; rs[g * 4 + 1] = r.y; rs[g * 4 + 2] = r.z; rs[g * 4 + 3] = r.w;
+        ga[g * 4] = gg.x; ga[g * 4 + 1] = gg.y; ga[g * 4 + 2] = gg.z; ga[g * 4 + 3] = gg.w;
+        be[g * 4] = bb.x; be[g * 4 + 1] = bb.y; be[g * 4 + 2] = bb.z; be[g * 4 + 3] = bb.w;
+    }
+    const float4 m2q = ld4(p.mean2 + (long long)n * F + c0), r2q = ld4(p.rstd2 + (long long)n * F + c0), g2q = ld4(p.g2 + c0), b2q = ld4(p.b2 + c0);
+    const float mu2[4] = {m2q.x, m2q.y, m2q.z, m2q.w}, rs2[4] = {r2q.x, r2q.y, r2q.z, r2q.w};
+    const float g2v[4] = {g2q.x, g2q.y, g2q.z, g2q.w}, b2v[4] = {b2q.x, b2q.y, b2q.z, b2q.w};
+    const float inv = 1.f / (float)HW;
+    // ---- phase 1: d c_new (total), d o_n ; sums of the second norm's backward ---------------------------------------
+    float xh[PPT][16];          // normalised (pre-affine) gates
+    float dg[PPT][16];          // gradients of the post-affine normalised gates (o first, the rest in phase 2)
+    float dz[PPT][4];
+    float r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        float raw[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[t][g].get(&raw[g * 4]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xh[t][i] = (raw[i] - mu[i]) * rs[i];
+        const float cpv[4] = {cpq[t].x, cpq[t].y, cpq[t].z, cpq[t].w};
+        float dhv[4] = {dhq[t].x, dhq[t].y, dhq[t].z, dhq[t].w};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float wk = k < p.ndh ? 1.f : 0.f;
+            dhv[0] += wk * dhs[k][t].x; dhv[1] += wk * dhs[k][t].y; dhv[2] += wk * dhs[k][t].z; dhv[3] += wk * dhs[k][t].w;
+        }
+        const float dcnv[4] = {dcq[t].x, dcq[t].y, dcq[t].z, dcq[t].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = xh[t][c] * ga[c] + be[c];
+            const float jn = xh[t][4 + c] * ga[4 + c] + be[4 + c];
+            const float fn = xh[t][8 + c] * ga[8 + c] + be[8 + c];
+            const float on = xh[t][12 + c] * ga[12 + c] + be[12 + c];
+            const float cpre = cpv[c] * sigmoidf_(fn + p.forget_bias) + sigmoidf_(in_) * tanhf_(jn);
+            const float x2 = (cpre - mu2[c]) * rs2[c];
+            const float th = tanhf_(x2 * g2v[c] + b2v[c]), so = sigmoidf_(on);
+            dz[t][c] = (dhv[c] * so * (1.f - th * th) + dcnv[c]) * okf[t];
+            dg[t][12 + c] = dhv[c] * th * so * (1.f - so) * okf[t];
+            r2[c] += dz[t][c]; r2[4 + c] += dz[t][c] * x2;
+        }
+    }
+    block_sum_q<8, Q>(r2, sh);
+    if (prow == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { unsafeAtomicAdd(p.db2 + c0 + c, r2[c]); unsafeAtomicAdd(p.dg2 + c0 + c, r2[4 + c]); }
+    }
+    // ---- phase 2: through the second norm and the gates ; sums of the first norm's backward ------------------------------
+    float r1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r1[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        const float cpv[4] = {cpq[t].x, cpq[t].y, cpq[t].z, cpq[t].w};
+        float dcp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float in_ = xh[t][c] * ga[c] + be[c];
+            const float jn = xh[t][4 + c] * ga[4 + c] + be[4 + c];
+            const float fn = xh[t][8 + c] * ga[8 + c] + be[8 + c];
+            const float si = sigmoidf_(in_), tj = tanhf_(jn), sf = sigmoidf_(fn + p.forget_bias);
+            const float x2 = (cpv[c] * sf + si * tj - mu2[c]) * rs2[c];
+            const float dcpre = g2v[c] * rs2[c] * (dz[t][c] - r2[c] * inv - x2 * r2[4 + c] * inv) * okf[t];
+            dcp[c] = dcpre * sf;
+            dg[t][c] = dcpre * tj * si * (1.f - si);
+            dg[t][4 + c] = dcpre * si * (1.f - tj * tj);
+            dg[t][8 + c] = dcpre * cpv[c] * sf * (1.f - sf);
+        }
+        if (p.dc_prev && okf[t] != 0.f) st4(p.dc_prev + ((long long)n * HW + pxs[t]) * F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { r1[i] += dg[t][i]; r1[16 + i] += dg[t][i] * xh[t][i]; }
+    }
+    block_sum_q<32, Q>(r1, sh);
+    if (prow == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsafeAtomicAdd(p.db1 + g * F + c0 + c, r1[g * 4 + c]);
+                unsafeAtomicAdd(p.dg1 + g * F + c0 + c, r1[16 + g * 4 + c]);
+            }
+    }
+    // ---- phase 3: through the first norm --------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        if (okf[t] == 0.f) continue;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = g * 4 + c;
+                o[c] = ga[i] * rs[i] * (dg[t][i] - r1[i] * inv - xh[t][i] * r1[16 + i] * inv);
+            }
+            st4x(p.dgates, idx + g * F, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
+        }
+    }
+}
+
+// configuration of the one-launch kernels for a call: Q threads per pixel, PPT pixel items per thread; false = not applicable
+static bool lstm_fused_cfg(const SavpLstmArgs* a, bool fwd, int& Q, int& PPT, int& nslab, int& xcd_map) {
+    if (!savp_opt(OPT_LSTM_FUSED) || a->F % 4 || a->HW < 1 || a->HW > 4 * NT || a->N < 1) return false;
+    if (fwd && a->gates_bf16 && !a->stats1_ready) return false;       // bf16 gates come with their statistics from the conv epilogue
+    if (fwd && a->stats1_ready && !a->ws_stats) return false;
+    Q = 1;
+    for (int c = 4; c > 1; c >>= 1)
+        if (a->F % (4 * c) == 0 && a->HW <= 4 * (NT / c) && (long long)a->N * (a->F / (4 * c)) >= 256) { Q = c; break; }
+    const int rows = NT / Q;
+    PPT = a->HW <= rows ? 1 : (a->HW <= 2 * rows ? 2 : 4);
+    nslab = a->F / (4 * Q);
+    xcd_map = (a->N % 8 == 0) ? 1 : 0;
+    return true;
+}
+
+#define LSTM_FUSED_DISPATCH(KERNEL, ...)                                                                                   \
+    do {                                                                                                                   \
+        const dim3 grid((unsigned)(a->N * nslab));                                                                         \
+        if (a->gates_bf16) {                                                                                               \
+            if (Q == 1) { if (PPT == 1) KERNEL(1, 1, true, __VA_ARGS__); else if (PPT == 2) KERNEL(1, 2, true, __VA_ARGS__); else KERNEL(1, 4, true, __VA_ARGS__); } \
+            else if (Q == 2) { if (PPT == 1) KERNEL(2, 1, true, __VA_ARGS__); else if (PPT == 2) KERNEL(2, 2, true, __VA_ARGS__); else KERNEL(2, 4, true, __VA_ARGS__); } \
+            else { if (PPT == 1) KERNEL(4, 1, true, __VA_ARGS__); else if (PPT == 2) KERNEL(4, 2, true, __VA_ARGS__); else KERNEL(4, 4, true, __VA_ARGS__); } \
+        } else {                                                                                                           \
+            if (Q == 1) { if (PPT == 1) KERNEL(1, 1, false, __VA_ARGS__); else if (PPT == 2) KERNEL(1, 2, false, __VA_ARGS__); else KERNEL(1, 4, false, __VA_ARGS__); } \
+            else if (Q == 2) { if (PPT == 1) KERNEL(2, 1, false, __VA_ARGS__); else if (PPT == 2) KERNEL(2, 2, false, __VA_ARGS__); else KERNEL(2, 4, false, __VA_ARGS__); } \
+            else { if (PPT == 1) KERNEL(4, 1, false, __VA_ARGS__); else if (PPT == 2) KERNEL(4, 2, false, __VA_ARGS__); else KERNEL(4, 4, false, __VA_ARGS__); } \
+        }                                                                                                                  \
+    } while (0)
+#define LSTM_FWD_LAUNCH(Q_, P_, G_, ...) hipLaunchKernelGGL((lstm_fused_fwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, __VA_ARGS__)
+#define LSTM_BWD_LAUNCH(Q_, P_, G_, ...) hipLaunchKernelGGL((lstm_fused_bwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, __VA_ARGS__)
+
 static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     if (!a || a->F % 4 || a->HW < 1) return SAVP_EINVAL;
     p.N = a->N; p.HW = a->HW; p.F = a->F;
@@ -1041,6 +1449,14 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     int rc = fill_lstm(p, a);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    {
+        int Q, PPT, nslab, xcd_map;
+        if (lstm_fused_cfg(a, true, Q, PPT, nslab, xcd_map)) {
+            const float* s1 = a->stats1_ready ? (const float*)a->ws_stats : nullptr;
+            LSTM_FUSED_DISPATCH(LSTM_FWD_LAUNCH, p, s1, nslab, xcd_map);
+            return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+        }
+    }
     if (lstm_coalesced_ok(a)) {
         const int N = a->N, F = a->F, HW = a->HW;
         LstmWs w;
@@ -1081,6 +1497,14 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
+    {
+        int Q, PPT, nslab, xcd_map;
+        if (lstm_fused_cfg(a, false, Q, PPT, nslab, xcd_map)) {
+            hipStream_t st = (hipStream_t)stream;
+            LSTM_FUSED_DISPATCH(LSTM_BWD_LAUNCH, p, nslab, xcd_map);
+            return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+        }
+    }
     if (a->dgates_bf16 && !a->dgates_raw) return SAVP_EINVAL;
     if (lstm_coalesced_ok(a)) {
         hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,20 @@
+// opts.h -- the library's ONLY process-wide switches: a table of named integers behind savp_set_option / savp_get_option
+// (include/savp_hip.h).  The library never reads the environment; the host (video_prediction_amd/lib.py) may forward SAVP_*
+// variables through savp_set_option when it loads the library.  Defaults are the shipped configuration.
+#pragma once
+
+enum SavpOptId {
+    OPT_CONV_RING = 0,     // auto algorithm choice prefers the LDS-DMA ring kernel over the patch kernel (0)
+    OPT_S2DGRAD,           // all-phase stride-(1,2,2) data-gradient kernel (1)
+    OPT_THIN,              // RGB-side convolution kernels (1)
+    OPT_WGP_CFG,           // developer: force a configuration of the LDS-patch weight gradient (0 = auto)
+    OPT_WGP_SPLIT,         // developer: force its number of workgroups (0 = auto)
+    OPT_INORM_MIN_HW,      // smallest plane that takes the coalesced two-kernel instance norm (256)
+    OPT_COLSUM_2STAGE,     // partial rows + reduce launch for large column sums when a workspace is supplied (1)
+    OPT_DENSE_LEGACY,      // developer: pre-round-2 few-row dense kernel (0)
+    OPT_CDNA_LEGACY,       // developer: pre-round-2 CDNA kernels (0)
+    OPT_LSTM_FUSED,        // one-launch ConvLSTM gate block, forward and backward (1)
+    OPT_COUNT
+};
+
+int savp_opt(int id);

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "opts.h"
 
 #define NT 256
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(NT) void colsum_reduce_kernel(const float* __restri
 }
 
 extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out,
-                           int32_t per_row) {
+                           int32_t per_row, float* ws, int64_t ws_floats) {
     // NOTE: always accumulates (atomically) into `out`; zero it first for an overwrite.
     if (!in.p || !out || R < 1 || HW < 1 || C < 1) return SAVP_EINVAL;
     // Narrow power-of-two slices: C / V lanes per pixel with V-wide loads.  (Tried for the discriminators' 32..256-channel bias
@@ -201,9 +202,9 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
         else hipLaunchKernelGGL(colsum_narrow_kernel<1>, grid, dim3(NT), 0, st, (const float*)in.p, (long long)in.sn, (long long)in.sp, HW, C, scale, out, per_row, chunk);
         return LAUNCH_OK();
     }
-    // all-pixel sums of large pixel-linear tensors: partial rows + reduce launch (see colsum_part_kernel); SAVP_COLSUM_2STAGE=0 = off
-    static int two_stage = -1;
-    if (two_stage < 0) { const char* e = getenv("SAVP_COLSUM_2STAGE"); two_stage = (e && e[0] == '0') ? 0 : 1; }
+    // all-pixel sums of large pixel-linear tensors: partial rows in caller-owned scratch + reduce launch (see colsum_part_kernel);
+    // needs SAVP_COLSUM_WS_FLOATS floats of `ws` (written before read), without them the atomic kernel below runs
+    const int two_stage = savp_opt(OPT_COLSUM_2STAGE) && ws && ws_floats >= SAVP_COLSUM_WS_FLOATS && (((uintptr_t)ws) & 15) == 0;
     const long long P = (long long)R * HW;
     const int q4 = C >> 2;
     if (two_stage && !per_row && (C & 3) == 0 && q4 >= 1 && q4 <= NT && (q4 & (q4 - 1)) == 0 && (al & 15) == 0 && in.sn == (long long)HW * in.sp &&
@@ -213,14 +214,7 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
         long long chunk2 = (P + nwg - 1) / nwg;
         chunk2 = (chunk2 + 4 * npl - 1) / (4 * npl) * (4 * npl);                       // whole unrolled passes
         const int rows = (int)((P + chunk2 - 1) / chunk2);
-        static float* ws = nullptr;                                                   // one buffer per process: calls on different streams
-        static size_t ws_floats = 0;                                                  // must not overlap (the engine uses its compute stream)
-        if ((size_t)rows * C > ws_floats) {
-            if (ws) hipFree(ws);
-            ws = nullptr; ws_floats = 0;
-            if (hipMalloc((void**)&ws, (size_t)nwg * 4 * NT * sizeof(float)) != hipSuccess) return SAVP_ELAUNCH;
-            ws_floats = (size_t)nwg * 4 * NT;
-        }
+        static_assert(SAVP_COLSUM_WS_FLOATS >= 1024 * 4 * NT, "workspace covers nwg rows of up to 4*NT channels");
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)rows), dim3(NT), 0, st, (const float*)in.p, (long long)in.sp, P, C, chunk2, ws);
         hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + NT - 1) / NT), 16u), dim3(NT), 0, st, (const float*)ws, rows, C, scale, out);
@@ -735,9 +729,7 @@ __global__ __launch_bounds__(NT) void dense_reduce_kernel(const float* __restric
 
 // SAVP_DENSE_LEGACY=1: the VALU / LDS-broadcast partial kernel (developer A/B switch)
 static bool dense_legacy() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAVP_DENSE_LEGACY"); v = e ? atoi(e) : 0; }
-    return v != 0;
+    return savp_opt(OPT_DENSE_LEGACY) != 0;
 }
 
 extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride, int32_t M, int64_t K, int32_t C, const float* W,

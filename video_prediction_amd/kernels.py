@@ -119,6 +119,8 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
 
 def _tune(a, mode, dst, w):
     """Time candidate (tile, splitk) pairs for this problem; returns the fastest."""
+    if lib.get().savp_conv_special(ctypes.byref(a)):
+        return (0, 0)                    # a problem-specific kernel takes the call under tile 0: nothing to choose
     torch.cuda.synchronize()             # nothing else in flight (other streams would distort the timings)
     fn = lib.get().savp_conv
     st = lib.stream()
@@ -188,6 +190,11 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     lib.require_device(w, bias, aux, stats)
     lib.require_device_any(x, y)
     a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats)
+    if mode == lib.CONV_WGRAD:           # caller-owned scratch (today: the RGB-side weight gradient's partial sums)
+        need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
+        if need:
+            ws = scratch(w.device, (need + 3) // 4)
+            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
@@ -210,10 +217,13 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
 ACT_IDS = {None: 0, 'none': 0, 'relu': 1, 'lrelu': 2}
 
 
-def view(t):
+def view(t, any_dtype=False):
     """SavpView of a channels-last tensor [N, spatial..., C] whose spatial dims are jointly contiguous
-    (true for channel slices of contiguous buffers)."""
-    lib.require_device(t)
+    (true for channel slices of contiguous buffers).  any_dtype: the entry point takes a bf16 mask for this view."""
+    if any_dtype:
+        lib.require_device_any(t)
+    else:
+        lib.require_device(t)
     if t.dim() < 3:
         t = t.reshape(t.shape[0], 1, t.shape[-1])
     if t.stride(-1) != 1 and t.shape[-1] != 1:
@@ -237,9 +247,9 @@ def _hw(t):
     return n
 
 
-def _set_views(arr, tensors):
+def _set_views(arr, tensors, any_dtype=False):
     for i, t in enumerate(tensors):
-        arr[i] = view(t)
+        arr[i] = view(t, any_dtype)
 
 
 def _bf16_mask(tensors):
@@ -251,6 +261,36 @@ def _bf16_mask(tensors):
         elif t.dtype != torch.float32:
             raise TypeError('expected float32 or bfloat16, got %s' % t.dtype)
     return m
+
+
+class Scratch(object):
+    """Caller-owned scratch of the C ABI (SavpConvArgs.ws, the ws of savp_colsum / savp_dense_fwd): one buffer per device.  Every user
+    writes its part before reading it and all users are launched on the compute stream, so one buffer serves them all.  Growing
+    never frees: a captured hipGraph (SAVPEngine.graph) holds the pointers it was captured with, so a retired buffer stays
+    allocated for the life of the process and old replays keep reading and writing valid memory."""
+
+    def __init__(self, device):
+        self.device, self.buf, self.retired = device, None, []
+
+    def get(self, nfloats):
+        n = (int(nfloats) + 1023) & ~1023
+        if self.buf is None or self.buf.numel() < n:
+            if self.buf is not None:
+                self.retired.append(self.buf)
+            self.buf = torch.empty(max(n, 8 << 20), device=self.device, dtype=torch.float32)
+        return self.buf
+
+
+_SCRATCH = {}
+COLSUM_WS_FLOATS = 1024 * 4 * 256        # SAVP_COLSUM_WS_FLOATS of include/savp_hip.h
+
+
+def scratch(device, nfloats):
+    key = str(device)
+    s = _SCRATCH.get(key)
+    if s is None:
+        s = _SCRATCH[key] = Scratch(device)
+    return s.get(nfloats)
 
 
 class ZeroArena(object):
@@ -308,7 +348,7 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
     a.x = view(x)
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
     a.nout = len(outs)
-    _set_views(a.out, outs)
+    _set_views(a.out, outs, any_dtype=True)
     a.out_bf16 = _bf16_mask(outs)
     _set_ranges(a.out_c0, a.out_nc, out_ranges)
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
@@ -383,7 +423,7 @@ def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6
         _lstm_ws(a, gates, ws, stats1)
         a.stats1_ready = int(stats1 is not None)
     a.nh = len(hs)
-    _set_views(a.h, hs)
+    _set_views(a.h, hs, any_dtype=True)
     a.h_bf16 = _bf16_mask(hs)
     lib.check(lib.get().savp_convlstm_gates_fwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_fwd')
 
@@ -427,12 +467,14 @@ def _rows(t):
 
 def tile_channels(z, out, scale=1.0, beta=0):
     """out[r, p, c] (=|+=) scale * z[r, c]; z [R, C] contiguous; out view [R, spatial..., C]."""
-    lib.require_device(z, out)
+    lib.require_device(z)
+    lib.require_device_any(out)
     R, C = z.shape
     if out.dtype == torch.bfloat16:
         if beta:
             raise ValueError('tile_channels into a bf16 view overwrites (beta=0 only)')
-        lib.check(_L().savp_tile_channels_bf16(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out)), 'savp_tile_channels_bf16')
+        lib.check(_L().savp_tile_channels_bf16(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out, any_dtype=True)),
+                  'savp_tile_channels_bf16')
         return
     lib.check(_L().savp_tile_channels(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out), int(beta)),
               'savp_tile_channels')
@@ -441,8 +483,9 @@ def tile_channels(z, out, scale=1.0, beta=0):
 def colsum(x, out, scale=1.0, per_row=False):
     """out += scale * sum over pixels (and rows unless per_row) of x [R, spatial..., C]."""
     lib.require_device(x, out)
-    lib.check(_L().savp_colsum(lib.stream(), view(x), x.shape[0], _hw(x), x.shape[-1], float(scale), _p(out), int(per_row)),
-              'savp_colsum')
+    ws = scratch(x.device, COLSUM_WS_FLOATS)
+    lib.check(_L().savp_colsum(lib.stream(), view(x), x.shape[0], _hw(x), x.shape[-1], float(scale), _p(out), int(per_row), _p(ws),
+                               ws.numel()), 'savp_colsum')
 
 
 def _view_array(tensors):
@@ -725,19 +768,12 @@ def sn_bwd(W, u, ws, G, dW, beta=0):
     lib.check(_L().savp_sn_bwd(lib.stream(), _p(W), K, C, _p(u), _p(ws), _p(G), _p(dW), int(beta)), 'savp_sn_bwd')
 
 
-_DENSE_WS = {}
-
-
 def dense_fwd(x, W, bias, out, scale=None):
     """out[M,C] = scale * x[M,K] @ W[K,C] + bias for few rows (K-sliced partial sums + a reduction launch); out contiguous."""
     M, Kd = x.shape
     C = W.shape[-1]
     assert out.is_contiguous() and x.stride(1) == 1 and W.is_contiguous()
-    key = str(x.device)
-    ws = _DENSE_WS.get(key)
-    need = 64 * M * C
-    if ws is None or ws.numel() < need:
-        ws = _DENSE_WS[key] = torch.empty(max(need, 64 * 64 * 128), device=x.device)      # launches are stream-ordered: one buffer
+    ws = scratch(x.device, 64 * M * C)           # K-slice partial sums, written before the reduce launch reads them
     lib.check(_L().savp_dense_fwd(lib.stream(), _p(x), x.stride(0), M, Kd, C, _p(W), _p(bias), _p(scale), _p(out), _p(ws), ws.numel()),
               'savp_dense_fwd')
 

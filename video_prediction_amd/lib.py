@@ -31,6 +31,7 @@ class SavpConvArgs(ctypes.Structure):
         ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
         ('w', c_vp), ('bias', c_vp), ('aux', c_vp), ('w_bf16', c_vp),
         ('src_bf16', c_i32), ('out_bf16', c_i32), ('stats', c_vp),
+        ('ws', c_vp), ('ws_bytes', c_i64),
     ]
 
 
@@ -49,7 +50,31 @@ def get():
         lib.savp_version.restype = ctypes.c_char_p
         _declare(lib)
         _lib = lib
+        _forward_env_options(lib)
     return _lib
+
+
+# Kernel-selection switches of the library (include/savp_hip.h: savp_set_option).  The library itself never reads the environment;
+# for A/B runs the host forwards SAVP_<NAME>=<int> here, once, when the library is loaded.
+OPTION_NAMES = ('conv_ring', 's2dgrad', 'thin', 'wgp_cfg', 'wgp_split', 'inorm_min_hw', 'colsum_2stage', 'dense_legacy', 'cdna_legacy',
+                'lstm_fused')
+
+
+def set_option(name, value):
+    check(get().savp_set_option(name.encode(), int(value)), 'savp_set_option(%s)' % name)
+
+
+def get_option(name):
+    v = c_i32()
+    check(get().savp_get_option(name.encode(), ctypes.byref(v)), 'savp_get_option(%s)' % name)
+    return v.value
+
+
+def _forward_env_options(lib):
+    for name in OPTION_NAMES:
+        v = os.environ.get('SAVP_' + name.upper())
+        if v is not None:
+            check(lib.savp_set_option(name.encode(), int(v)), 'savp_set_option(%s)' % name)
 
 
 EXPORTS = {}     # name -> (restype, argtypes); filled by _declare, checked by tests against include/savp_hip.h
@@ -66,6 +91,10 @@ def _sig(lib, name, argtypes, restype=c_i32):
 def _declare(lib):
     P = ctypes.POINTER
     _sig(lib, 'savp_conv', [c_vp, P(SavpConvArgs)])
+    _sig(lib, 'savp_conv_workspace_bytes', [P(SavpConvArgs)], restype=c_i64)
+    _sig(lib, 'savp_conv_special', [P(SavpConvArgs)])
+    _sig(lib, 'savp_set_option', [ctypes.c_char_p, c_i32])
+    _sig(lib, 'savp_get_option', [ctypes.c_char_p, P(c_i32)])
     for name, argtypes in _EXTRA_SIGS.items():
         _sig(lib, name, argtypes)
 
@@ -168,7 +197,7 @@ class SavpCompositeArgs(ctypes.Structure):
 _PV = ctypes.POINTER(SavpView)
 register('savp_tile_channels', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView, c_i32])
 register('savp_tile_channels_bf16', [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, SavpView])
-register('savp_colsum', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32, c_vp, c_i32])
+register('savp_colsum', [c_vp, SavpView, c_i64, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64])
 register('savp_select', [c_vp, c_i32, c_i32, c_i32, c_vp, SavpView, SavpView, c_i32, _PV])
 register('savp_select_bwd', [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, _PV, SavpView])
 register('savp_gather_clips', [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_i32])
