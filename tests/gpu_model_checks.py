@@ -203,16 +203,9 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
     return out
 
 
-def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
-    """One train step at the recipe's sequence / clip lengths (hparams/bair_action_free/ours_savp/model_hparams.json: T=30,
-    clip_length=10, nz=8) with B scaled down, run on BOTH datapaths from the same variables / inputs / noise and compared with ONE
-    fp64 oracle step.  fp32 mode: same yardstick as check_train_step.  bf16 mode (bench default: conv operands rounded to bf16,
-    fp32 accumulate): losses within 2e-2 of max(|ref|, 0.05) (the LSGAN generator terms (D-1)^2 sit at ~1e-3 after the D update, so
-    a plain relative error would only measure cancellation), the generated frames within 5e-2 absolute, per-variable gradients
-    within 0.25 relative L2 = cosine >= 0.97 (measured on MI355X: 0.11 worst for D, 0.19 worst for G against the fp32 datapath;
-    the spread comes from ReLU / LeakyReLU masks that flip under the 4e-3 operand rounding, the fp32 CPU oracle shows the same
-    effect at 1e-2)."""
-    from video_prediction_amd import kernels as K
+def recipe_case(B, T=30, H=64, W=64, C=3, seed=0):
+    """The benchmarked step's inputs (hparams/bair_action_free/ours_savp recipe: T=30, clip_length=10, nz=8) at batch B, all seeded:
+    (hparams, variables (init + perturbed norm parameters / biases so that they matter), images [T,B,H,W,C] fp64, noise)."""
     hp = make_hparams(context_frames=2, sequence_length=T, clip_length=10, nz=8, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
                       vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
@@ -228,6 +221,20 @@ def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
             vals[k] = (vals[k] * 3).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
     noise = make_noise(hp, B, seed=100, sampling=True)
+    return hp, vals, images, noise
+
+
+def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
+    """One train step at the recipe's sequence / clip lengths (hparams/bair_action_free/ours_savp/model_hparams.json: T=30,
+    clip_length=10, nz=8) with B scaled down, run on BOTH datapaths from the same variables / inputs / noise and compared with ONE
+    fp64 oracle step.  fp32 mode: same yardstick as check_train_step.  bf16 mode (bench default: conv operands rounded to bf16,
+    fp32 accumulate): losses within 2e-2 of max(|ref|, 0.05) (the LSGAN generator terms (D-1)^2 sit at ~1e-3 after the D update, so
+    a plain relative error would only measure cancellation), the generated frames within 5e-2 absolute, per-variable gradients
+    within 0.25 relative L2 = cosine >= 0.97 (measured on MI355X: 0.11 worst for D, 0.19 worst for G against the fp32 datapath;
+    the spread comes from ReLU / LeakyReLU masks that flip under the 4e-3 operand rounding, the fp32 CPU oracle shows the same
+    effect at 1e-2)."""
+    from video_prediction_amd import kernels as K
+    hp, vals, images, noise = recipe_case(B, T, H, W, C, seed)
     P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
     P_new, _, ref = OT.train_step(P, OT.init_opt_state(P), {'images': images}, hp, noise, noise['d_indices_pre'],
                                   noise['d_indices_post'], step=0)

@@ -175,3 +175,65 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     for n, c in structs:
         want = [ctypes.sizeof(c)] + [getattr(c, f[0]).offset for f in c._fields_]
         assert got[n] == want, (n, got[n], want)
+
+
+def test_library_allocates_nothing_and_never_reads_the_environment():
+    """The header's contract (include/savp_hip.h: 'allocate no device memory ... never read the environment'): no hipMalloc /
+    hipFree / getenv in the shipped sources (SAVP_CONV_ABLATE is a developer build that is not compiled into the library)."""
+    csrc = os.path.join(ROOT, 'video_prediction_amd', 'csrc')
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not (f.endswith('.hip') or f.endswith('.h')):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        src = re.sub(r'#ifdef SAVP_CONV_ABLATE.*?#else', '', src, flags=re.S)
+        for m in re.finditer(r'\b(hipMalloc\w*|hipFree\w*|getenv)\s*\(', src):
+            bad.append((f, m.group(1)))
+    assert not bad, bad
+
+
+def test_option_table_round_trip(hip_lib):
+    """savp_set_option / savp_get_option: known names round-trip, unknown names are refused (host code, runs without a GPU)."""
+    from video_prediction_amd import lib
+    for name in lib.OPTION_NAMES:
+        old = lib.get_option(name)
+        lib.set_option(name, old + 5)
+        assert lib.get_option(name) == old + 5
+        lib.set_option(name, old)
+    assert hip_lib.savp_set_option(b'no_such_option', 1) != 0
+    assert lib.get_option('lstm_fused') == 1 and lib.get_option('thin') == 1 and lib.get_option('conv_ring') == 0
+
+
+def test_conv_workspace_query_and_special_probe(hip_lib):
+    """savp_conv_workspace_bytes / savp_conv_special are pure host-side predicates: the RGB-side weight gradient asks for its
+    partial-sum rows, the generic weight gradient with a bias gradient for the column-sum scratch, a forward gate conv for nothing;
+    the discriminators' first layer (3 -> 32 channels, 3x3x3) is a problem-specific kernel under tile 0 only."""
+    from video_prediction_amd import lib
+    a = lib.SavpConvArgs()
+    a.mode = lib.CONV_WGRAD
+    a.N, a.D, a.H, a.W, a.Cx = 32, 10, 64, 64, 3
+    a.Do, a.Ho, a.Wo, a.Cy = 10, 64, 64, 32
+    a.kd, a.kh, a.kw, a.sd, a.sh, a.sw, a.pd, a.ph, a.pw = 3, 3, 3, 1, 1, 1, 1, 1, 1
+    a.precision = 1
+    a.x, a.y, a.w = 0x10000, 0x20000, 0x30000
+    a.x_sw, a.x_sh, a.x_sd, a.x_sn = 3, 64 * 3, 64 * 64 * 3, 10 * 64 * 64 * 3
+    a.y_sw, a.y_sh, a.y_sd, a.y_sn = 32, 64 * 32, 64 * 64 * 32, 10 * 64 * 64 * 32
+    need = hip_lib.savp_conv_workspace_bytes(ctypes.byref(a))
+    assert need > 0 and need % 4 == 0
+    assert hip_lib.savp_conv_special(ctypes.byref(a)) == 0              # no workspace handed over -> the general kernel would run
+    a.ws, a.ws_bytes = 0x80000, need
+    assert hip_lib.savp_conv_special(ctypes.byref(a)) == 1
+    a.tile = 0x111                                                      # forced algorithm: the caller gets that kernel
+    assert hip_lib.savp_conv_special(ctypes.byref(a)) == 0
+    a.tile, a.mode = 0, lib.CONV_FPROP
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(a)) == 0 and hip_lib.savp_conv_special(ctypes.byref(a)) == 1
+    a.Cx, a.x_sw = 72, 72                                               # a gate-conv-like problem: nothing special, no scratch
+    assert hip_lib.savp_conv_special(ctypes.byref(a)) == 0
+
+
+def test_allreduce_bucket_entry_point_validates_its_arguments(hip_lib):
+    """savp_allreduce_bucket: exported, refuses a missing communicator / buffer, and an empty bucket is a no-op
+    that does not even load RCCL.  (The collective itself needs >= 2 GPUs: the driver's scaling run.)"""
+    assert hip_lib.savp_allreduce_bucket(None, None, 0x1000, 16) != 0
+    assert hip_lib.savp_allreduce_bucket(0x1000, None, None, 16) != 0
+    assert hip_lib.savp_allreduce_bucket(0x1000, None, 0x2000, 0) == 0

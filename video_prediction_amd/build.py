@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(OUT) or force:
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + ['-ldl'])
     build_io(force=force, verbose=verbose)
     return OUT
 

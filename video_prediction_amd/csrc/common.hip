@@ -1,5 +1,6 @@
 // common.hip -- library identification.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <string.h>
 #include "savp_hip.h"
 #include "opts.h"
@@ -53,4 +54,25 @@ extern "C" int savp_get_option(const char* name, int* value) {
     for (int i = 0; i < OPT_COUNT; ++i)
         if (!strcmp(g_opts[i].name, name)) { *value = g_opts[i].value; return SAVP_OK; }
     return SAVP_EINVAL;
+}
+
+// ---- gradient bucket all-reduce over RCCL (tf_utils.py:450-480 allreduce_grads) ----------------------------------
+// The communicator belongs to the caller (rendezvous / ncclCommInitRank happen in the host framework: torch.distributed in this
+// repository's own runners).  librccl.so is resolved at the first call so that the kernel library carries no link-time dependency
+// on it (single-GPU users never load RCCL).
+typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+extern "C" int savp_allreduce_bucket(void* comm, void* stream, void* buf, int64_t count) {
+    if (!comm || !buf || count < 0) return SAVP_EINVAL;
+    if (count == 0) return SAVP_OK;
+    static rccl_allreduce_fn fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return SAVP_ELAUNCH;
+        fn = (rccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) return SAVP_ELAUNCH;
+    }
+    // in place, fp32 (ncclFloat32 = 7), sum (ncclSum = 0); the 1/K of average=True is folded into savp_adam's gscale
+    return fn(buf, buf, (size_t)count, 7, 0, comm, (hipStream_t)stream) == 0 ? SAVP_OK : SAVP_ELAUNCH;
 }

@@ -433,6 +433,7 @@ struct LstmP {
     float* dgates;                                        // [N,HW,4F]; bf16 when dgates16 (coalesced kernels only)
     float* draw;                                          // fp32 [N,HW,4F] scratch of the raw gate gradients between the passes
     int dgates16;                                         //   (= dgates itself unless dgates16)
+    int gates_slab, c_slab;                               // one-launch kernels: slab-major gates / cell-state tensors (include/savp_hip.h)
     float* dc_prev;                                       // [N,HW,F] contiguous or null
     float *dg1, *db1, *dg2, *db2;
 };
@@ -1089,7 +1090,12 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
     lstm_block_owner(nslab, xcd_map, n, slab);
     const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
     const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
-    const long long g0 = (long long)n * HW * 4 * F + c0;
+    // gate quad g of pixel px: pixel-major  (n*HW + px)*4F + g*F + c0   |   slab-major  ((n*F/4 + c0/4)*HW + px)*16 + g*4
+    const long long g0 = p.gates_slab ? ((long long)n * (F >> 2) + (c0 >> 2)) * HW * 16 : (long long)n * HW * 4 * F + c0;
+    const int gpx = p.gates_slab ? 16 : 4 * F, gg = p.gates_slab ? 4 : F;
+    // cell-state quad of pixel px: pixel-major  n*sn + px*sp + c0   |   slab-major  n*sn + (c0/4)*HW*4 + px*4
+    const long long cs0 = p.c_slab ? (long long)(c0 >> 2) * HW * 4 : c0;
+    const long long cs_px = p.c_slab ? 4 : F;
     // ---- every load of this thread, issued before anything is used ---------------------------------------------
     GateQuad<G16> gq[PPT][4];
     float4 cpq[PPT];
@@ -1100,13 +1106,14 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
         const int px = prow + t * ROWS;
         ok[t] = px < HW;
         pxs[t] = ok[t] ? px : HW - 1;
-        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+        const long long idx = g0 + (long long)pxs[t] * gpx;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * gg);
     }
     if (p.c_prev) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
+        for (int t = 0; t < PPT; ++t)
+            cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (p.c_slab ? cs0 + (long long)pxs[t] * 4 : (long long)pxs[t] * p.cp_sp + c0));
     } else {
 #pragma unroll
         for (int t = 0; t < PPT; ++t) cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1114,10 +1121,10 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
     float4 g1q[4], b1q[4], sa[4], sb[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { g1q[g] = ld4(p.g1 + g * F + c0); b1q[g] = ld4(p.b1 + g * F + c0); }
-    if (s1) {
+    if (s1) {          // statistics in the GEMM's channel order: g*F + c0 (pixel-major gates) or (c0/4)*16 + g*4 (permuted weights)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float* s = s1 + ((long long)n * 4 * F + g * F + c0) * 2;
+            const float* s = s1 + ((long long)n * 4 * F + (p.gates_slab ? (c0 >> 2) * 16 + g * 4 : g * F + c0)) * 2;
             sa[g] = ld4(s); sb[g] = ld4(s + 4);
         }
     }
@@ -1217,7 +1224,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
             hv[c] = tanhf_(cn[c]) * so[t][c];
         }
         const int px = pxs[t];
-        st4(p.c_new + ((long long)n * HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(p.c_new + (long long)n * HW * F + cs0 + (long long)px * cs_px, make_float4(cn[0], cn[1], cn[2], cn[3]));
         const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1233,7 +1240,13 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
     lstm_block_owner(nslab, xcd_map, n, slab);
     const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
     const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
-    const long long g0 = (long long)n * HW * 4 * F + c0;
+    const long long g0 = p.gates_slab ? ((long long)n * (F >> 2) + (c0 >> 2)) * HW * 16 : (long long)n * HW * 4 * F + c0;
+    const int gpx = p.gates_slab ? 16 : 4 * F, gg = p.gates_slab ? 4 : F;
+    // gate GRADIENT: always pixel-major rows of 4F; channel order (slab, gate, c) with gates_slab, (gate, channel) without
+    const long long d0 = (long long)n * HW * 4 * F + (p.gates_slab ? (c0 >> 2) * 16 : c0);
+    const int dgg = p.gates_slab ? 4 : F;
+    const long long cs0 = p.c_slab ? (long long)(c0 >> 2) * HW * 4 : c0;
+    const long long cs_px = p.c_slab ? 4 : F;
     // ---- every load of this thread up front ----------------------------------------------------------------------
     GateQuad<G16> gq[PPT][4];
     float4 cpq[PPT], dhq[PPT], dcq[PPT];
@@ -1244,20 +1257,21 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
         const int px = prow + t * ROWS;
         okf[t] = px < HW ? 1.f : 0.f;
         pxs[t] = px < HW ? px : HW - 1;
-        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+        const long long idx = g0 + (long long)pxs[t] * gpx;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * gg);
         dhq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         dcq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (p.c_prev) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
+        for (int t = 0; t < PPT; ++t)
+            cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (p.c_slab ? cs0 + (long long)pxs[t] * 4 : (long long)pxs[t] * p.cp_sp + c0));
     }
     if (p.dc_new) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t) dcq[t] = ld4(p.dc_new + ((long long)n * HW + pxs[t]) * F + c0);
+        for (int t = 0; t < PPT; ++t) dcq[t] = ld4(p.dc_new + (long long)n * HW * F + cs0 + (long long)pxs[t] * cs_px);
     }
     // up to three gradient sources of h' (consumers of this step + the next step's gate conv); a fourth is rare.  Loads stay
     // unconditional (source min(k, ndh-1), weight 0 beyond ndh): a load under `if (k < ndh)` is waited for inside its branch
@@ -1353,7 +1367,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
             dg[t][4 + c] = dcpre * si * (1.f - tj * tj);
             dg[t][8 + c] = dcpre * cpv[c] * sf * (1.f - sf);
         }
-        if (p.dc_prev && okf[t] != 0.f) st4(p.dc_prev + ((long long)n * HW + pxs[t]) * F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+        if (p.dc_prev && okf[t] != 0.f) st4(p.dc_prev + (long long)n * HW * F + cs0 + (long long)pxs[t] * cs_px, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
 #pragma unroll
         for (int i = 0; i < 16; ++i) { r1[i] += dg[t][i]; r1[16 + i] += dg[t][i] * xh[t][i]; }
     }
@@ -1371,7 +1385,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
         if (okf[t] == 0.f) continue;
-        const long long idx = g0 + (long long)pxs[t] * 4 * F;
+        const long long idx = d0 + (long long)pxs[t] * 4 * F;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float o[4];
@@ -1380,7 +1394,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
                 const int i = g * 4 + c;
                 o[c] = ga[i] * rs[i] * (dg[t][i] - r1[i] * inv - xh[t][i] * r1[16 + i] * inv);
             }
-            st4x(p.dgates, idx + g * F, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
+            st4x(p.dgates, idx + g * dgg, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
         }
     }
 }
@@ -1433,6 +1447,7 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     p.dc_new = a->dc_new; p.dgates = a->dgates; p.dc_prev = a->dc_prev;
     p.dgates16 = a->dgates_bf16 ? 1 : 0;
     p.draw = a->dgates_bf16 ? a->dgates_raw : a->dgates;
+    p.gates_slab = a->gates_slab ? 1 : 0; p.c_slab = a->c_slab ? 1 : 0;
     p.dg1 = a->dgamma1; p.db1 = a->dbeta1; p.dg2 = a->dgamma2; p.db2 = a->dbeta2;
     return SAVP_OK;
 }
@@ -1457,6 +1472,7 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
             return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
         }
     }
+    if (a->gates_slab || a->c_slab) return SAVP_EINVAL;        // slab-major tensors: only the one-launch kernels address them
     if (lstm_coalesced_ok(a)) {
         const int N = a->N, F = a->F, HW = a->HW;
         LstmWs w;
@@ -1505,6 +1521,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
             return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
         }
     }
+    if (a->gates_slab || a->c_slab) return SAVP_EINVAL;
     if (a->dgates_bf16 && !a->dgates_raw) return SAVP_EINVAL;
     if (lstm_coalesced_ok(a)) {
         hipStream_t st = (hipStream_t)stream;
