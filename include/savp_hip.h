@@ -102,11 +102,6 @@ typedef struct SavpConvArgs {
     float* stats;                  /* with out_bf16: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
                                       of every (sample, channel) of the destination, taken from the fp32 accumulators before rounding
                                       = the statistics of the instance norm that follows (rnn_ops.py:148-149); caller zeroes; may be NULL */
-    int32_t out_slab16;            /* with out_bf16 (FPROP, 2-D, contiguous destination): the destination is stored slab-major,
-                                      [N][Cy/16][Ho*Wo][16] instead of [N][Ho*Wo][Cy] -- with the gate convolution's output channels
-                                      packed as (4-channel slab, gate, channel) by the caller (savp_gate_permute), the workgroup of
-                                      the gate kernels that owns (sample, slab) reads ONE contiguous run instead of an 8-byte piece
-                                      of every 4F-wide pixel row; `stats` keeps the GEMM's channel order */
     void* ws; int64_t ws_bytes;    /* optional caller-owned scratch (16-byte aligned; written before it is read, so one buffer can serve
                                       every call on a stream).  savp_conv_workspace_bytes() says how much a call can use; without it
                                       the call takes a kernel that needs none */
@@ -191,20 +186,9 @@ typedef struct SavpLstmArgs {
     int32_t dgates_bf16;           /* bwd: `dgates` receives bf16 (its readers are the gate convolution's DGRAD / WGRAD, which round to
                                       bf16 anyway); the raw gate gradients between the passes then live in dgates_raw.  Coalesced kernels only */
     float* dgates_raw;             /* bwd, with dgates_bf16: fp32 scratch [N,HW,4F] (three-pass kernels only) */
-    int32_t gates_slab;            /* one-launch kernels only (EINVAL otherwise): `gates` is slab-major [N][F/4][HW][16] with the 16 =
-                                      (gate i,j,f,o) x 4 channels (savp_conv out_slab16 on permuted weights), the statistics of
-                                      stats1_ready are indexed [n][slab*16 + gate*4 + c], and `dgates` is written pixel-major with
-                                      that channel order, [N][HW][F/4][16] = what the permuted gate convolution's DGRAD / WGRAD read */
-    int32_t c_slab;                /* one-launch kernels only: c_prev, c_new, dc_new, dc_prev are slab-major [N][F/4][HW][4] (tensors
-                                      only these kernels touch); c_prev.sn is still the sample stride, c_prev.sp is ignored */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
-
-/* Column permutation of a ConvLSTM gate kernel [R = taps*Cx][4F]: dst[r][slab*16 + g*4 + c] = src[r][g*F + slab*4 + c]
- * (g = gate i,j,f,o of rnn_ops.py:150; slab = c4 group) so that the gate convolution emits (slab, gate, channel)-ordered output
- * channels; adjoint != 0: src[r][g*F + slab*4 + c] += dst[r][slab*16 + g*4 + c] (its weight gradient back to the variable). */
-int savp_gate_permute(void* stream, float* src, float* dst, int64_t R, int32_t F, int32_t adjoint);
 
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound glue (util_ops.hip).  See the file header for the reference lines each one replaces.

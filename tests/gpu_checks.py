@@ -980,98 +980,9 @@ def check_conv_cell(seed=21):
     return out
 
 
-def check_lstm_slab(seed=27):
-    """The slab-major gate path end to end (round 3): savp_gate_permute packs the gate kernel's output channels as (slab, gate, c);
-    the gate convolution stores bf16 gates slab-major ([N][F/4][HW][16], out_slab16) + statistics in that channel order; the
-    one-launch gate kernels read them with slab-major cell state and write the gate gradient pixel-major in the permuted channel
-    order.  Everything is un-permuted on the host and compared with the fp64 oracle of the plain cell (rnn_ops.py:137-171)."""
-    out = []
-    rng = np.random.default_rng(seed)
-    for (N, H, W, Cx, F) in [(2, 32, 32, 72, 32), (32, 16, 16, 136, 64), (32, 8, 8, 264, 128), (2, 16, 24, 40, 16)]:
-        HW, S = H * W, F // 4
-        tag = 'slab_N%d_%dx%dx%d' % (N, H, W, F)
-        x = rnd(rng, N, H, W, Cx)
-        w = rnd(rng, 5, 5, Cx, 4 * F) * 0.05
-        c = rnd(rng, N, H, W, F)
-        g1, b1 = rnd(rng, 4 * F) * 0.3 + 1, rnd(rng, 4 * F) * 0.3
-        g2, b2 = rnd(rng, F) * 0.3 + 1, rnd(rng, F) * 0.3
-        gates = TF.conv2d(x, w, (1, 1), 'SAME')
-
-        def unslab_gates(t):      # [N][F/4][HW][4 gates][4] -> [N, H, W, 4F] in TF's (gate, channel) order
-            return t.reshape(N, S, HW, 4, 4).permute(0, 2, 3, 1, 4).reshape(N, H, W, 4 * F)
-
-        def unperm_channels(t):   # [..., F/4, 4 gates, 4] -> [..., 4F] (gate, channel)
-            return t.reshape(t.shape[:-1] + (S, 4, 4)).transpose(-3, -2).reshape(t.shape)
-
-        def to_cslab(t):          # [N, H, W, F] -> [N][F/4][HW][4]
-            return t.reshape(N, HW, S, 4).permute(0, 2, 1, 3).contiguous()
-
-        def from_cslab(t):
-            return t.reshape(N, S, HW, 4).permute(0, 2, 1, 3).reshape(N, H, W, F)
-        # (1) weight permutation and its adjoint, exact
-        wd_ = dev(w).reshape(25 * Cx, 4 * F)
-        wperm = torch.empty_like(wd_)
-        K.gate_permute(wd_, wperm, F)
-        want = w.reshape(25 * Cx, 4, S, 4).transpose(1, 2).reshape(25 * Cx, 4 * F)
-        out.append((tag + '/permute_exact', float((wperm.cpu().double() - want.float().double()).abs().max()), 0.0))
-        acc = dev(rnd(rng, 25 * Cx, 4 * F))
-        acc0 = acc.clone()
-        K.gate_permute(acc, wperm, F, adjoint=True)
-        out.append((tag + '/permute_adjoint', rel_err(acc, acc0.cpu().double() + w.reshape(25 * Cx, 4 * F).float().double()), 1e-6))
-        # (2) gate convolution on the permuted kernel: slab-major bf16 gates + statistics
-        geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
-        wt = pack_wt(wperm.reshape(5, 5, Cx, 4 * F)).contiguous()
-        yd = torch.full((N, H, W, 4 * F), float('nan'), device=DEV, dtype=torch.bfloat16)
-        ws, s1 = K.lstm_stats_ws(torch.device(DEV), N, F)
-        ws.zero_()
-        K.conv(lib.CONV_FPROP, geom, dev(x), yd, wt, precision=1, w16=wt.to(torch.bfloat16), stats=s1, out_slab16=True)
-        out.append((tag + '/gates_slab16', rel_err(unslab_gates(yd.float()), gates), 1e-2))
-        ref_s = torch.stack([gates.sum(dim=(1, 2)), (gates ** 2).sum(dim=(1, 2))], dim=-1)                 # [N, 4F, 2]
-        got_s = unperm_channels(s1.float().cpu().permute(0, 2, 1)).permute(0, 2, 1)
-        out.append((tag + '/stats_sum', rel_err(got_s[..., 0], ref_s[..., 0]), 1e-2))
-        out.append((tag + '/stats_sumsq', rel_err(got_s[..., 1], ref_s[..., 1]), 1e-2))
-        # (3) the whole cell from the conv's own output
-        p = [dev(t) for t in (g1, b1, g2, b2)]
-        cn, hn = _ref_lstm_gates(gates, c, g1, b1, g2, b2)
-        c_new = torch.empty(N, H, W, F, device=DEV)
-        hbig = torch.zeros(N, H, W, F + 8, device=DEV)
-        stats = [torch.empty(N, 4 * F, device=DEV), torch.empty(N, 4 * F, device=DEV), torch.empty(N, F, device=DEV), torch.empty(N, F, device=DEV)]
-        K.convlstm_gates_fwd(yd, dev(to_cslab(c)), p[0], p[1], p[2], p[3], c_new, [hbig[..., 8:]], stats, stats1=ws, gates_slab=True, c_slab=True)
-        out.append((tag + '/cell/c', rel_err(from_cslab(c_new), cn), 2e-2))
-        out.append((tag + '/cell/h', rel_err(hbig[..., 8:], hn), 2e-2))
-        out.append((tag + '/cell/pad_untouched', float(hbig[..., :8].abs().max()), 0.0))
-        # (4) gate kernels alone, exact: the bf16-rounded gate tensor + exact sums vs the oracle on the SAME rounded tensor
-        gq = gates.float().to(torch.bfloat16)
-        gq64 = gq.double().requires_grad_(True)
-        c64 = c.clone().requires_grad_(True)
-        cn2, hn2 = _ref_lstm_gates(gq64, c64, g1, b1, g2, b2)
-        dh1, dh2, dcn = rnd(rng, *hn2.shape), rnd(rng, *hn2.shape), rnd(rng, *cn2.shape)
-        ((hn2 * (dh1 + dh2)).sum() + (cn2 * dcn).sum()).backward()
-        gslab = gq.reshape(N, HW, 4, S, 4).permute(0, 3, 1, 2, 4).contiguous().to(DEV)                       # [N][F/4][HW][4][4]
-        ws, s1 = K.lstm_stats_ws(torch.device(DEV), N, F)
-        st = torch.stack([gq64.detach().sum(dim=(1, 2)), (gq64.detach() ** 2).sum(dim=(1, 2))], dim=-1)     # [N, 4F, 2] (gate, channel)
-        s1.copy_(st.reshape(N, 4, S, 4, 2).transpose(1, 2).reshape(N, 4 * F, 2).float().to(DEV))
-        K.convlstm_gates_fwd(gslab.reshape(N, H, W, 4 * F), dev(to_cslab(c)), p[0], p[1], p[2], p[3], c_new, [hbig[..., 8:]], stats, stats1=ws,
-                             gates_slab=True, c_slab=True)
-        out.append((tag + '/exact/c', rel_err(from_cslab(c_new), cn2), 2e-4))
-        out.append((tag + '/exact/h', rel_err(hbig[..., 8:], hn2), 2e-4))
-        for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 1e-2)):
-            dgates = torch.empty(N, H, W, 4 * F, device=DEV, dtype=dt)
-            raw = torch.empty(N, H, W, 4 * F, device=DEV) if dt == torch.bfloat16 else None
-            dcp = torch.empty(N, H, W, F, device=DEV)
-            dpar = [torch.zeros(4 * F, device=DEV), torch.zeros(4 * F, device=DEV), torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)]
-            K.convlstm_gates_bwd(gslab.reshape(N, H, W, 4 * F), dev(to_cslab(c)), p[0], p[1], p[2], p[3], stats, [dev(dh1), dev(dh2)],
-                                 dev(to_cslab(dcn)), dgates, dcp, dpar, dgates_raw=raw, gates_slab=True, c_slab=True)
-            sfx = '' if dt == torch.float32 else '_bf16'
-            out.append((tag + '/exact/dgates' + sfx, rel_err(unperm_channels(dgates.float().cpu()), gq64.grad), tol))
-            out.append((tag + '/exact/dc_prev' + sfx, rel_err(from_cslab(dcp), c64.grad), 1e-3))
-    torch.cuda.synchronize()
-    return out
-
-
 ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_cell', check_conv_cell),
               ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
-              ('lstm', check_lstm), ('lstm_slab', check_lstm_slab), ('util', check_util), ('dense', check_dense), ('cdna_composite', check_cdna_composite),
+              ('lstm', check_lstm), ('util', check_util), ('dense', check_dense), ('cdna_composite', check_cdna_composite),
               ('small', check_small), ('weight_prep', check_weight_prep), ('warp_dna', check_warp_dna)]
 
 

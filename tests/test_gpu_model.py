@@ -48,10 +48,16 @@ def test_learned_prior_and_recurrent_encoder_vs_oracle():
     (two encoded context pairs + zero rows), then a train step (losses, per-variable gradients incl. generator/prior/*, Adam)."""
     from tests import gpu_model_checks as G
     res = G.check_generator_forward(nz=8, B=2, T=6, tag='gen_fwd_learn_prior', learn_prior=True, use_e_rnn=True, context_frames=3)
-    # abs_floor: at initialisation the learned prior coincides with the posterior, so the posterior encoder's gradient is a small,
-    # heavily cancelling sum (it arrives through z only) -- its relative error is judged against the group's largest gradient, and
-    # the fp32 CPU yardstick itself moves by 40x between runs on such a sum (thread-order dependent)
-    res += G.check_train_step(B=2, T=6, nz=8, steps=1, tag='train_learn_prior', abs_floor=5e-4, learn_prior=True, use_e_rnn=True, nef=16)
+    # Absolute floor for the heavily cancelling sums of this configuration (at initialisation the learned prior coincides with the
+    # posterior, so the posterior encoder's gradient arrives through z only): relative error is meaningless there, the error is judged
+    # against the group's largest gradient.  The floor is NOT a hand-picked constant: profiles/r03_learn_prior_yardstick.json records how
+    # far the fp32 CPU oracle itself (1 / 2 / 8 threads = different summation orders) sits from the fp64 oracle on exactly this step
+    # (tests/tools/yardstick_spread.py: up to 3.7e-4 of the group's largest gradient); the HIP path gets 1.5x that.
+    import json
+    yard = json.load(open(os.path.join(os.path.dirname(HERE), 'profiles', 'r03_learn_prior_yardstick.json')))
+    floor = 1.5 * float(yard['max_abs_err_over_gmax'])
+    assert 1e-4 < floor < 1e-3
+    res += G.check_train_step(B=2, T=6, nz=8, steps=1, tag='train_learn_prior', abs_floor=floor, learn_prior=True, use_e_rnn=True, nef=16)
     _assert_ok(res)
 
 
@@ -306,3 +312,105 @@ def test_train_and_generate_scripts(tmp_path):
     assert g.returncode == 0, g.stdout[-2000:] + g.stderr[-2000:]
     pngs = [f for f in os.listdir(os.path.join(res, 'run')) if f.endswith('.png')]
     assert len(pngs) == 2 * 2 * 10 and 'gen_image_00001_01_09.png' in pngs          # 2 sequences x 2 samples x 10 future frames
+
+
+def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
+    """EXACTLY the benchmarked problem (BASELINE.json configs[1]: B=16, T=30, 64x64x3, nz=8, clip_length=10, recipe weights) on the
+    bf16 datapath with the shipped tuning table, i.e. the (problem, tile, split-K) instantiations bench.py launches, against one
+    step of the CPU oracle committed as tests/golden/b16_step_golden.npz (tests/golden/make_b16_step_golden.py; inputs re-created
+    here from the same seeds).  Tolerances = the bf16 gates of check_train_recipe_shapes: losses within 2e-2 (6e-2 per term) of
+    max(|ref|, 0.05), sampled frames within 5e-2, per-variable gradient (a seeded sample of <= 4096 elements) within 0.25 relative L2
+    unless its absolute error is below 2e-3 of the group's largest gradient."""
+    from tests import gpu_model_checks as G
+    from tests.golden.make_b16_step_golden import sample_index
+    from video_prediction_amd import kernels as K
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    gold = np.load(os.path.join(HERE, 'golden', 'b16_step_golden.npz'))
+    B, T = int(gold['B']), int(gold['T'])
+    assert (B, T) == (16, 30)
+    hp, vals, images, noise = G.recipe_case(B, T)
+    K.set_conv_precision('bf16')
+    saved = dict(K.AUTOTUNE, cache=dict(K.AUTOTUNE['cache']))
+    try:
+        K.enable_autotune(True)
+        n = K.load_tuning(os.path.join(os.path.dirname(HERE), 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
+        assert n >= 200
+        eng = SAVPEngine(hp, (64, 64, 3), B, mode='train', values=vals, device='cuda:0')
+        eng.set_images(images.float().cuda(), time_major=True)
+        info = eng.train_step(noise, return_grads=True)
+        torch.cuda.synchronize()
+    finally:
+        K.set_conv_precision('f32')
+        K.AUTOTUNE.update(enabled=saved['enabled'], cache=saved['cache'])
+    bad = []
+
+    def lrel(got, want):
+        return abs(float(got) - float(want)) / max(abs(float(want)), 0.05)
+    for nm, tol in (('d_loss', 2e-2), ('g_loss', 2e-2)):
+        if lrel(info[nm], gold[nm]) > tol:
+            bad.append((nm, float(info[nm]), float(gold[nm])))
+    for nm, (l, w) in info['g_losses'].items():
+        if lrel(l, gold['g_losses/' + nm]) > 6e-2:
+            bad.append((nm, float(l), float(gold['g_losses/' + nm])))
+    gen = eng.gen.gen.v
+    ts, bs = torch.as_tensor(gold['gen_t']), torch.as_tensor(gold['gen_b'])
+    for key, half in (('gen_images_enc', gen[:, :B]), ('gen_images', gen[:, B:])):
+        got = half[ts][:, bs].float().cpu().numpy()
+        err = float(np.abs(got - gold[key]).max())
+        if err > 5e-2:
+            bad.append((key, err))
+    checked = 0
+    for key in ('d_grads', 'g_grads'):
+        names = [k.split('/', 1)[1].rsplit('/', 1)[0] for k in gold.files if k.startswith(key + '/') and k.endswith('/norm')]
+        gmax = max(float(gold['%s/%s/max' % (key, nme)]) for nme in names)
+        for nme in names:
+            g = info[key][nme].detach().reshape(-1)
+            ref = gold['%s/%s/sample' % (key, nme)].astype(np.float64)
+            got = g[torch.from_numpy(sample_index(nme, g.numel())).to(g.device)].double().cpu().numpy()
+            checked += 1
+            if float(gold['%s/%s/max' % (key, nme)]) < 1e-9 * gmax:
+                if float(np.abs(got).max()) / gmax > 1e-2:
+                    bad.append((nme, 'analytically zero gradient', float(np.abs(got).max()) / gmax))
+                continue
+            e = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+            if e > 0.25 and float(np.abs(got - ref).max()) > 2e-3 * gmax:
+                bad.append((nme, 'rel L2 %.3f' % e, 'abs/gmax %.2e' % (float(np.abs(got - ref).max()) / gmax)))
+    assert checked >= 100
+    assert not bad, bad
+
+
+def test_bf16_loss_curve_tracks_fp32_over_50_steps():
+    """50 full train steps (D then G/E) on one fixed batch from the same variables and the same per-step noise, once on the exact
+    fp32 datapath and once on the bf16 datapath (the benchmarked one): the reconstruction loss -- the term the recipe weights 100x --
+    must follow the fp32 curve (GAN terms are chaotic by design and only have to stay finite and bounded).  Gates: both curves fall
+    by >= 25 %; |l1_bf16 - l1_fp32| <= 5 % of l1_fp32 at every step; mean deviation over the last 10 steps <= 3 %."""
+    from tests.gpu_model_checks import make_hparams
+    from video_prediction_amd import kernels as K
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    hp = make_hparams(context_frames=2, sequence_length=10, clip_length=4, nz=8, lr=1e-3, beta1=0.5, l1_weight=100.0, kl_weight=1.0,
+                      kl_anneal='none', video_sn_gan_weight=0.1, video_sn_vae_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0)
+    g = torch.Generator().manual_seed(1)
+    base = torch.rand(1, 4, 64, 64, 3, generator=g)
+    images = (base + 0.02 * torch.randn(10, 4, 64, 64, 3, generator=g)).clamp(0, 1)
+    curves = {}
+    try:
+        for prec in ('f32', 'bf16'):
+            K.set_conv_precision(prec)
+            eng = SAVPEngine(hp, (64, 64, 3), 4, mode='train', seed=4)
+            eng.use_graph = False
+            eng.set_images(images.cuda(), time_major=True)
+            l1, dl = [], []
+            for it in range(50):
+                noise = eng.default_noise(torch.Generator().manual_seed(1000 + it))
+                info = eng.train_step(noise)
+                l1.append(float(info['g_losses']['gen_l1_loss'][0]))
+                dl.append(float(info['d_loss']))
+            assert all(np.isfinite(l1)) and all(np.isfinite(dl)) and max(dl) < 10.0, (prec, max(dl))
+            curves[prec] = np.array(l1)
+    finally:
+        K.set_conv_precision('f32')
+    a, b = curves['f32'], curves['bf16']
+    assert a[-1] < 0.75 * a[0] and b[-1] < 0.75 * b[0], (a[0], a[-1], b[0], b[-1])
+    dev = np.abs(b - a) / a
+    assert dev.max() <= 0.05, (int(dev.argmax()), float(dev.max()), a.tolist(), b.tolist())
+    assert dev[-10:].mean() <= 0.03, float(dev[-10:].mean())

@@ -33,11 +33,6 @@ def test_convlstm_gates():
     _run(gpu_checks.check_lstm)
 
 
-def test_convlstm_slab_major_gate_path():
-    from tests import gpu_checks
-    _run(gpu_checks.check_lstm_slab)
-
-
 def test_util_ops():
     from tests import gpu_checks
     _run(gpu_checks.check_util)

@@ -40,7 +40,6 @@ struct ConvP {
     int src16;                                // source activations are bf16 (strides in elements)
     int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
     float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
-    int cell_slab;                            // cell mode: 0 = pixel-major destination; else the plane's pixel count, destination [N][Nout/16][pixels][16]
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {

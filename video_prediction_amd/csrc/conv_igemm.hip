@@ -767,7 +767,6 @@ extern "C" int savp_conv_special(const SavpConvArgs* a) {
 extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     if (!a || !a->x || !a->y || !a->w) return SAVP_EINVAL;
     if (a->sd < 1 || a->sh < 1 || a->sw < 1 || a->kd < 1 || a->kh < 1 || a->kw < 1) return SAVP_EINVAL;
-    if (a->out_slab16 && !(a->out_bf16 && a->mode == SAVP_CONV_FPROP)) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     ConvP p;
     p.mode = a->mode;

@@ -420,14 +420,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
             const int py = oy0 + (rr >> 3), px = ox0 + (rr & 7);
             const uint4 v = *reinterpret_cast<const uint4*>(T + row * TP + c8 * 4);
-            unsigned short* dst;
-            if (p.cell_slab) {           // slab-major: [N][Nout/16][pixels][16]; a 16-byte piece = half of one pixel's 16-channel group
-                const int co = n0 + c8 * 8;
-                dst = out16 + (long long)n * d_sn + (long long)(co >> 4) * p.cell_slab * 16 + (long long)(py * Wm + px) * 16 + (co & 15);
-            } else {
-                dst = out16 + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
-                      (long long)(gh.ob + py * gh.os) * d_sh + (long long)(gw.ob + px * gw.os) * d_sw + n0 + c8 * 8;
-            }
+            unsigned short* dst = out16 + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
+                                  (long long)(gh.ob + py * gh.os) * d_sh + (long long)(gw.ob + px * gw.os) * d_sw + n0 + c8 * 8;
             *reinterpret_cast<uint4*>(dst) = v;
         }
         if (p.stats) {
@@ -593,11 +587,6 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
     p.cell = cell ? 1 : 0;
     p.stats = cell ? (float*)a->stats : nullptr;
-    p.cell_slab = 0;
-    if (a->out_slab16) {             // contiguous 2-D FPROP destination only
-        if (!cell || dg || Dm != 1 || (Nout % 16) || d_sw != Nout || d_sh != dW_ * Nout || d_sn != dH * dW_ * Nout) return false;
-        p.cell_slab = (int)(dH * dW_);
-    }
     p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
     p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
     p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);

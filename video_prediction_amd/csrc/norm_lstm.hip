@@ -433,7 +433,6 @@ struct LstmP {
     float* dgates;                                        // [N,HW,4F]; bf16 when dgates16 (coalesced kernels only)
     float* draw;                                          // fp32 [N,HW,4F] scratch of the raw gate gradients between the passes
     int dgates16;                                         //   (= dgates itself unless dgates16)
-    int gates_slab, c_slab;                               // one-launch kernels: slab-major gates / cell-state tensors (include/savp_hip.h)
     float* dc_prev;                                       // [N,HW,F] contiguous or null
     float *dg1, *db1, *dg2, *db2;
 };
@@ -1059,6 +1058,21 @@ __device__ __forceinline__ void block_sum_q(float (&v)[NV], float* sh) {
     for (int i = 0; i < NV; ++i) v[i] = fin[q * NV + i];
 }
 
+// Developer build (SAVP_EXTRA_FLAGS=-DSAVP_LSTM_STAMPS, tests/tools/lstm_stamps.py): s_memtime stamps of three workgroups' first
+// wave at the phase boundaries of the one-launch kernels.  Not compiled into the shipped library.
+#ifdef SAVP_LSTM_STAMPS
+__device__ unsigned long long g_lstm_t[3][8];
+#define LT(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
+    g_lstm_t[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = __builtin_readcyclecounter(); } while (0)
+#define LT_WAITVM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+extern "C" int savp_debug_lstm_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_t), sizeof(g_lstm_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define LT(i) do {} while (0)
+#define LT_WAITVM() do {} while (0)
+#endif
+
 template <bool G16> struct GateQuad;
 template <> struct GateQuad<true> {
     uint2 u;
@@ -1085,17 +1099,13 @@ __device__ __forceinline__ void lstm_block_owner(int nslab, int xcd_map, int& n,
 template <int Q, int PPT, bool G16>
 __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float* __restrict__ s1, int nslab, int xcd_map) {
     __shared__ float sh[LSTM_SUM_FLOATS(16, Q)];
+    LT(0);
     constexpr int ROWS = NT / Q;
     int n, slab;
     lstm_block_owner(nslab, xcd_map, n, slab);
     const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
     const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
-    // gate quad g of pixel px: pixel-major  (n*HW + px)*4F + g*F + c0   |   slab-major  ((n*F/4 + c0/4)*HW + px)*16 + g*4
-    const long long g0 = p.gates_slab ? ((long long)n * (F >> 2) + (c0 >> 2)) * HW * 16 : (long long)n * HW * 4 * F + c0;
-    const int gpx = p.gates_slab ? 16 : 4 * F, gg = p.gates_slab ? 4 : F;
-    // cell-state quad of pixel px: pixel-major  n*sn + px*sp + c0   |   slab-major  n*sn + (c0/4)*HW*4 + px*4
-    const long long cs0 = p.c_slab ? (long long)(c0 >> 2) * HW * 4 : c0;
-    const long long cs_px = p.c_slab ? 4 : F;
+    const long long g0 = (long long)n * HW * 4 * F + c0;
     // ---- every load of this thread, issued before anything is used ---------------------------------------------
     GateQuad<G16> gq[PPT][4];
     float4 cpq[PPT];
@@ -1106,14 +1116,13 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
         const int px = prow + t * ROWS;
         ok[t] = px < HW;
         pxs[t] = ok[t] ? px : HW - 1;
-        const long long idx = g0 + (long long)pxs[t] * gpx;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * gg);
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
     }
     if (p.c_prev) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t)
-            cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (p.c_slab ? cs0 + (long long)pxs[t] * 4 : (long long)pxs[t] * p.cp_sp + c0));
+        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
     } else {
 #pragma unroll
         for (int t = 0; t < PPT; ++t) cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1121,14 +1130,17 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
     float4 g1q[4], b1q[4], sa[4], sb[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { g1q[g] = ld4(p.g1 + g * F + c0); b1q[g] = ld4(p.b1 + g * F + c0); }
-    if (s1) {          // statistics in the GEMM's channel order: g*F + c0 (pixel-major gates) or (c0/4)*16 + g*4 (permuted weights)
+    if (s1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float* s = s1 + ((long long)n * 4 * F + (p.gates_slab ? (c0 >> 2) * 16 + g * 4 : g * F + c0)) * 2;
+            const float* s = s1 + ((long long)n * 4 * F + g * F + c0) * 2;
             sa[g] = ld4(s); sb[g] = ld4(s + 4);
         }
     }
     const float4 g2q = ld4(p.g2 + c0), b2q = ld4(p.b2 + c0);
+    LT(1);
+    LT_WAITVM();
+    LT(2);
     // ---- IN(4F) -----------------------------------------------------------------------------------------------
     const float inv = 1.f / (float)HW;
     float x[PPT][16];
@@ -1198,7 +1210,9 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
             s2[c] += ok[t] ? cpre[t][c] : 0.f;
         }
     }
+    LT(3);
     block_sum_q<4, Q>(s2, sh);
+    LT(4);
     float mu2[4], rs2[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { mu2[c] = s2[c] * inv; s2[c] = 0.f; }
@@ -1214,6 +1228,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
         st4(p.rstd2 + (long long)n * F + c0, make_float4(rs2[0], rs2[1], rs2[2], rs2[3]));
     }
     const float g2v[4] = {g2q.x, g2q.y, g2q.z, g2q.w}, b2v[4] = {b2q.x, b2q.y, b2q.z, b2q.w};
+    LT(5);
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
         if (!ok[t]) continue;
@@ -1224,29 +1239,27 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
             hv[c] = tanhf_(cn[c]) * so[t][c];
         }
         const int px = pxs[t];
-        st4(p.c_new + (long long)n * HW * F + cs0 + (long long)px * cs_px, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(p.c_new + ((long long)n * HW + px) * F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
         const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < p.nh) st4x(p.h[k], (long long)n * p.h_sn[k] + (long long)px * p.h_sp[k] + c0, h4, p.h16[k]);
     }
+    LT(6);
+    LT_WAITVM();
+    LT(7);
 }
 
 template <int Q, int PPT, bool G16>
 __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, int xcd_map) {
     __shared__ float sh[LSTM_SUM_FLOATS(32, Q)];
+    LT(0);
     constexpr int ROWS = NT / Q;
     int n, slab;
     lstm_block_owner(nslab, xcd_map, n, slab);
     const int q = threadIdx.x & (Q - 1), prow = threadIdx.x / Q;
     const int F = p.F, HW = p.HW, c0 = (slab * Q + q) * 4;
-    const long long g0 = p.gates_slab ? ((long long)n * (F >> 2) + (c0 >> 2)) * HW * 16 : (long long)n * HW * 4 * F + c0;
-    const int gpx = p.gates_slab ? 16 : 4 * F, gg = p.gates_slab ? 4 : F;
-    // gate GRADIENT: always pixel-major rows of 4F; channel order (slab, gate, c) with gates_slab, (gate, channel) without
-    const long long d0 = (long long)n * HW * 4 * F + (p.gates_slab ? (c0 >> 2) * 16 : c0);
-    const int dgg = p.gates_slab ? 4 : F;
-    const long long cs0 = p.c_slab ? (long long)(c0 >> 2) * HW * 4 : c0;
-    const long long cs_px = p.c_slab ? 4 : F;
+    const long long g0 = (long long)n * HW * 4 * F + c0;
     // ---- every load of this thread up front ----------------------------------------------------------------------
     GateQuad<G16> gq[PPT][4];
     float4 cpq[PPT], dhq[PPT], dcq[PPT];
@@ -1257,21 +1270,20 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
         const int px = prow + t * ROWS;
         okf[t] = px < HW ? 1.f : 0.f;
         pxs[t] = px < HW ? px : HW - 1;
-        const long long idx = g0 + (long long)pxs[t] * gpx;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * gg);
+        for (int g = 0; g < 4; ++g) gq[t][g].load(p.gates, idx + g * F);
         dhq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         dcq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (p.c_prev) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t)
-            cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (p.c_slab ? cs0 + (long long)pxs[t] * 4 : (long long)pxs[t] * p.cp_sp + c0));
+        for (int t = 0; t < PPT; ++t) cpq[t] = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)pxs[t] * p.cp_sp + c0);
     }
     if (p.dc_new) {
 #pragma unroll
-        for (int t = 0; t < PPT; ++t) dcq[t] = ld4(p.dc_new + (long long)n * HW * F + cs0 + (long long)pxs[t] * cs_px);
+        for (int t = 0; t < PPT; ++t) dcq[t] = ld4(p.dc_new + ((long long)n * HW + pxs[t]) * F + c0);
     }
     // up to three gradient sources of h' (consumers of this step + the next step's gate conv); a fourth is rare.  Loads stay
     // unconditional (source min(k, ndh-1), weight 0 beyond ndh): a load under `if (k < ndh)` is waited for inside its branch
@@ -1305,6 +1317,9 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
     const float mu2[4] = {m2q.x, m2q.y, m2q.z, m2q.w}, rs2[4] = {r2q.x, r2q.y, r2q.z, r2q.w};
     const float g2v[4] = {g2q.x, g2q.y, g2q.z, g2q.w}, b2v[4] = {b2q.x, b2q.y, b2q.z, b2q.w};
     const float inv = 1.f / (float)HW;
+    LT(1);
+    LT_WAITVM();
+    LT(2);
     // ---- phase 1: d c_new (total), d o_n ; sums of the second norm's backward ---------------------------------------
     float xh[PPT][16];          // normalised (pre-affine) gates
     float dg[PPT][16];          // gradients of the post-affine normalised gates (o first, the rest in phase 2)
@@ -1341,7 +1356,9 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
             r2[c] += dz[t][c]; r2[4 + c] += dz[t][c] * x2;
         }
     }
+    LT(3);
     block_sum_q<8, Q>(r2, sh);
+    LT(4);
     if (prow == 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { unsafeAtomicAdd(p.db2 + c0 + c, r2[c]); unsafeAtomicAdd(p.dg2 + c0 + c, r2[4 + c]); }
@@ -1367,11 +1384,13 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
             dg[t][4 + c] = dcpre * si * (1.f - tj * tj);
             dg[t][8 + c] = dcpre * cpv[c] * sf * (1.f - sf);
         }
-        if (p.dc_prev && okf[t] != 0.f) st4(p.dc_prev + (long long)n * HW * F + cs0 + (long long)pxs[t] * cs_px, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+        if (p.dc_prev && okf[t] != 0.f) st4(p.dc_prev + ((long long)n * HW + pxs[t]) * F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
 #pragma unroll
         for (int i = 0; i < 16; ++i) { r1[i] += dg[t][i]; r1[16 + i] += dg[t][i] * xh[t][i]; }
     }
+    LT(5);
     block_sum_q<32, Q>(r1, sh);
+    LT(6);
     if (prow == 0) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1385,7 +1404,7 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
         if (okf[t] == 0.f) continue;
-        const long long idx = d0 + (long long)pxs[t] * 4 * F;
+        const long long idx = g0 + (long long)pxs[t] * 4 * F;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float o[4];
@@ -1394,9 +1413,11 @@ __global__ __launch_bounds__(NT) void lstm_fused_bwd_kernel(LstmP p, int nslab, 
                 const int i = g * 4 + c;
                 o[c] = ga[i] * rs[i] * (dg[t][i] - r1[i] * inv - xh[t][i] * r1[16 + i] * inv);
             }
-            st4x(p.dgates, idx + g * dgg, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
+            st4x(p.dgates, idx + g * F, make_float4(o[0], o[1], o[2], o[3]), p.dgates16);
         }
     }
+    LT_WAITVM();
+    LT(7);
 }
 
 // configuration of the one-launch kernels for a call: Q threads per pixel, PPT pixel items per thread; false = not applicable
@@ -1447,7 +1468,6 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
     p.dc_new = a->dc_new; p.dgates = a->dgates; p.dc_prev = a->dc_prev;
     p.dgates16 = a->dgates_bf16 ? 1 : 0;
     p.draw = a->dgates_bf16 ? a->dgates_raw : a->dgates;
-    p.gates_slab = a->gates_slab ? 1 : 0; p.c_slab = a->c_slab ? 1 : 0;
     p.dg1 = a->dgamma1; p.db1 = a->dbeta1; p.dg2 = a->dgamma2; p.db2 = a->dbeta2;
     return SAVP_OK;
 }
@@ -1472,7 +1492,6 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
             return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
         }
     }
-    if (a->gates_slab || a->c_slab) return SAVP_EINVAL;        // slab-major tensors: only the one-launch kernels address them
     if (lstm_coalesced_ok(a)) {
         const int N = a->N, F = a->F, HW = a->HW;
         LstmWs w;
@@ -1521,7 +1540,6 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
             return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
         }
     }
-    if (a->gates_slab || a->c_slab) return SAVP_EINVAL;
     if (a->dgates_bf16 && !a->dgates_raw) return SAVP_EINVAL;
     if (lstm_coalesced_ok(a)) {
         hipStream_t st = (hipStream_t)stream;

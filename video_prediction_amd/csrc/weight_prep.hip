@@ -639,31 +639,3 @@ extern "C" int savp_sn_bwd_batch(void* stream, int32_t n, const SavpSnItem* item
     hipLaunchKernelGGL(snb_apply_kernel, dim3(2048, n), dim3(NT), 0, st, b);
     return LAUNCH_OK();
 }
-
-// ------------------------------------------------------------------------------------------------------------
-// Column permutation of a ConvLSTM gate kernel (include/savp_hip.h: savp_gate_permute).  One float4 (4 channels of one gate and
-// one slab) per thread; the (gate, slab) <-> (slab, gate) swap is an index permutation of the row's float4s.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void gate_permute_kernel(float* __restrict__ src, float* __restrict__ dst, long long total4, int F4, int adjoint) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / (4 * F4);
-        const int j = (int)(i - r * (4 * F4));             // float4 index inside the permuted row: slab * 4 + gate
-        const int slab = j >> 2, g = j & 3;
-        float4* s = reinterpret_cast<float4*>(src) + r * (4 * F4) + g * F4 + slab;
-        float4* d = reinterpret_cast<float4*>(dst) + i;
-        if (adjoint) {
-            const float4 a = *s, b = *d;
-            *s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-        } else {
-            *d = *s;
-        }
-    }
-}
-
-extern "C" int savp_gate_permute(void* stream, float* src, float* dst, int64_t R, int32_t F, int32_t adjoint) {
-    if (!src || !dst || R < 1 || F < 4 || (F & 3) || ((((uintptr_t)src) | ((uintptr_t)dst)) & 15)) return SAVP_EINVAL;
-    const long long total4 = (long long)R * F;              // R rows of 4F floats = R * F float4
-    const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gate_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, total4, F / 4, adjoint);
-    return LAUNCH_OK();
-}

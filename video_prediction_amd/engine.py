@@ -184,7 +184,7 @@ class ConvLayer(object):
     ``sn_u`` names the spectral-norm vector of a discriminator layer (kernel is divided by sigma on the fly).
     """
 
-    def __init__(self, store, kernel_name, bias_name, kind, ksize, stride, pad, sn_u=None, cx_pad=None, cy_pad=None, gate_perm=0):
+    def __init__(self, store, kernel_name, bias_name, kind, ksize, stride, pad, sn_u=None, cx_pad=None, cy_pad=None):
         self.store = store
         self.kernel_name, self.bias_name, self.kind = kernel_name, bias_name, kind
         W = store[kernel_name]
@@ -193,19 +193,10 @@ class ConvLayer(object):
         self.bias = store[bias_name] if bias_name else None
         self.dbias = store.grad(bias_name) if bias_name else None
         dev = W.device
-        # gate_perm = F: a ConvLSTM gate kernel [.., 4F] run with (slab, gate, channel)-ordered output channels (kernels.gate_permute),
-        # so that its epilogue can store the gate tensor slab-major for the one-launch gate kernels; the variable keeps TF's order
-        self.gate_perm = int(gate_perm)
         if kind == 'conv':
             self.cx, self.cy = W.shape[-2], W.shape[-1]
-            if self.gate_perm:
-                if sn_u or bias_name or W.shape[-1] != 4 * self.gate_perm:
-                    raise ValueError('gate_perm: plain bias-free kernel with 4F output channels expected')
-                self.wf = torch.empty_like(W)
-                self.dwf = torch.zeros_like(W)
-            else:
-                self.wf = W                                   # folded == master
-                self.dwf = None                               # wgrad goes straight to the master grad (unless SN)
+            self.wf = W                                   # folded == master
+            self.dwf = None                               # wgrad goes straight to the master grad (unless SN)
             k3 = tuple(ksize)
         elif kind == 'pool':
             k, _, cin, cout = W.shape
@@ -271,9 +262,7 @@ class ConvLayer(object):
     def prep(self, update_u=False, sn_done=False, defer_pack=None):
         """defer_pack: a list -- the pack is appended to it for one kernels.pack_weights_batch over a network's layers."""
         scale = None
-        if self.gate_perm:
-            K.gate_permute(self.W, self.wf, self.gate_perm)
-        elif self.kind == 'pool':
+        if self.kind == 'pool':
             K.fold_pool(self.W, self.wf, self.W.shape[0])
         elif self.kind == 'up':
             k, _, cin, f = self.W.shape
@@ -302,8 +291,8 @@ class ConvLayer(object):
             self.u.copy_(self.u_next)
 
     # -- execution ----------------------------------------------------------------------------------------------
-    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True, stats=None, out_slab16=False):
-        """stats / out_slab16: see kernels.conv (bf16 destination only: the fused ConvLSTM gate convolution)."""
+    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True, stats=None):
+        """stats: see kernels.conv (bf16 destination only: the fused ConvLSTM gate convolution)."""
         b = self.bias if use_bias else None
         if self.kind == 'conv' and x.dim() == 2 and x.shape[0] <= 64 and not act and not beta and y.is_contiguous():
             # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
@@ -317,8 +306,7 @@ class ConvLayer(object):
         if self.kind == 'up':
             K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16)
         else:
-            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats,
-                   out_slab16=out_slab16)
+            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats)
         if self.prof is not None:
             e1.record()
             self.prof.append((e0, e1))
@@ -358,8 +346,6 @@ class ConvLayer(object):
         if self.sn_u_name:
             if not sn_done:
                 K.sn_bwd(self.W, self.u.reshape(-1), self.sn_ws, self.dwf, self.dW, beta=1)
-        elif self.gate_perm:
-            K.gate_permute(self.dW, self.dwf, self.gate_perm, adjoint=True)
         elif self.kind == 'pool':
             K.fold_pool(self.dwf, self.dW, self.W.shape[0], adjoint=True)
         elif self.kind == 'up':

@@ -83,10 +83,9 @@ def enable_autotune(flag=True):
     AUTOTUNE['enabled'] = bool(flag)
 
 
-def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, out_slab16=False):
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None):
     a = lib.SavpConvArgs()
     a.mode = mode
-    a.out_slab16 = int(bool(out_slab16))
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
     N2, Do, Ho, Wo, Cy, a.y_sn, a.y_sd, a.y_sh, a.y_sw = _nd(y)
     if N != N2:
@@ -184,14 +183,13 @@ def _tune(a, mode, dst, w):
     return best or (0, 0)
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
-         out_slab16=False):
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
     destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] fp32 (zeroed by the caller)
     receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only)."""
     lib.require_device(w, bias, aux, stats)
     lib.require_device_any(x, y)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, out_slab16)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats)
     if mode == lib.CONV_WGRAD:           # caller-owned scratch (today: the RGB-side weight gradient's partial sums)
         need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
         if need:
@@ -199,8 +197,7 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
             a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
-               a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None) + \
-            ((True,) if out_slab16 else ())      # shipped tables predate the slab-major destination: its keys carry one more field
+               a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
@@ -379,9 +376,8 @@ def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, d
     lib.check(lib.get().savp_instnorm_act_bwd(lib.stream(), ctypes.byref(a)), 'savp_instnorm_act_bwd')
 
 
-def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias, gates_slab=False, c_slab=False):
+def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
     a = lib.SavpLstmArgs()
-    a.gates_slab, a.c_slab = int(bool(gates_slab)), int(bool(c_slab))
     N = gates.shape[0]
     F = gates.shape[-1] // 4
     a.N, a.HW, a.F = N, _hw(gates), F
@@ -404,8 +400,9 @@ def lstm_ws_floats(N, HW, F):
 
 
 def _lstm_ws(a, gates, ws, ws_stats=None):
-    lib.require_device(ws)
-    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    if ws is not None:                 # scratch of the three-pass kernels; the one-launch kernels need none
+        lib.require_device(ws)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     if ws_stats is None:
         ws_stats = zero_arena(gates.device).take(a.N * a.F * 11)
     a.ws_stats, a.ws_stats_clean = ws_stats.data_ptr(), 1
@@ -418,14 +415,12 @@ def lstm_stats_ws(device, N, F):
     return ws, ws[:N * 4 * F * 2].view(N, 4 * F, 2)
 
 
-def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None, stats1=None,
-                       gates_slab=False, c_slab=False):
+def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None, stats1=None):
     """stats1: the workspace returned by lstm_stats_ws whose head the gate convolution's epilogue has already filled (the
-    statistics pass over the gate tensor is skipped); needed for bf16 gates.  gates_slab / c_slab: slab-major gate / cell-state
-    tensors (include/savp_hip.h; one-launch kernels only)."""
-    a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias, gates_slab, c_slab)
+    statistics pass over the gate tensor is skipped); needed for bf16 gates."""
+    a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     a.c_new = c_new.data_ptr()
-    if ws is not None:
+    if ws is not None or stats1 is not None:
         _lstm_ws(a, gates, ws, stats1)
         a.stats1_ready = int(stats1 is not None)
     a.nh = len(hs)
@@ -435,10 +430,10 @@ def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6
 
 
 def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates, dc_prev, dparams, eps=1e-6,
-                       forget_bias=1.0, ws=None, dgates_raw=None, gates_slab=False, c_slab=False):
+                       forget_bias=1.0, ws=None, dgates_raw=None):
     """dgates may be a bfloat16 tensor (coalesced kernels, i.e. with ws): dgates_raw is then the fp32 scratch [N, HW, 4F] the raw
     gate gradients live in between the passes."""
-    a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias, gates_slab, c_slab)
+    a = _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias)
     if dgates.dtype == torch.bfloat16:
         if dgates_raw is None or dgates_raw.dtype != torch.float32 or dgates_raw.numel() < dgates.numel():
             raise ValueError('bf16 dgates need an fp32 dgates_raw scratch of the same size')
@@ -702,13 +697,6 @@ def pack_weights(src, wt=None, wd=None, scale=None, wt16=None, wd16=None):
     T = src.numel() // (Cx * Cy)
     lib.check(_L().savp_pack_weights(lib.stream(), _p(src), T, Cx, Cy, _p(scale), _p(wt), _p(wd), _p(wt16), _p(wd16)),
               'savp_pack_weights')
-
-
-def gate_permute(src, dst, F, adjoint=False):
-    """ConvLSTM gate kernel [..., 4F] <-> its (slab, gate, channel)-ordered copy (include/savp_hip.h: savp_gate_permute)."""
-    lib.require_device(src, dst)
-    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and src.shape[-1] == 4 * F
-    lib.check(_L().savp_gate_permute(lib.stream(), _p(src), _p(dst), src.numel() // (4 * F), F, int(adjoint)), 'savp_gate_permute')
 
 
 def pack_weights_batch(entries):

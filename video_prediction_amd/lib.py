@@ -31,7 +31,6 @@ class SavpConvArgs(ctypes.Structure):
         ('y', c_vp), ('y_sn', c_i64), ('y_sd', c_i64), ('y_sh', c_i64), ('y_sw', c_i64),
         ('w', c_vp), ('bias', c_vp), ('aux', c_vp), ('w_bf16', c_vp),
         ('src_bf16', c_i32), ('out_bf16', c_i32), ('stats', c_vp),
-        ('out_slab16', c_i32),
         ('ws', c_vp), ('ws_bytes', c_i64),
     ]
 
@@ -171,7 +170,6 @@ class SavpLstmArgs(ctypes.Structure):
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
         ('ws', c_vp), ('ws_floats', ctypes.c_int64), ('ws_stats', c_vp), ('ws_stats_clean', c_i32),
         ('gates_bf16', c_i32), ('stats1_ready', c_i32), ('h_bf16', c_i32), ('dgates_bf16', c_i32), ('dgates_raw', c_vp),
-        ('gates_slab', c_i32), ('c_slab', c_i32),
     ]
 
 
@@ -242,7 +240,6 @@ class SavpPackItem(ctypes.Structure):
                 ('Cx', c_i32), ('Cy', c_i32)]
 
 
-register('savp_gate_permute', [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32])
 register('savp_pack_weights_batch', [c_vp, c_i32, ctypes.POINTER(SavpPackItem)])
 
 

@@ -177,14 +177,9 @@ class SAVPGenerator(object):
                 L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32,
                                  grad_dtype=dg_dt)
                 L['dg_raw'] = torch.empty(N, h_, w_, 4 * f, device=dev) if dg_dt == torch.bfloat16 else None
-                # slab-major gate / cell-state tensors for the one-launch gate kernels (SAVP_LSTM_SLAB=0: pixel-major): the gate kernel's
-                # output channels are packed (slab, gate, channel), the conv epilogue stores [N][F/4][HW][16], so the workgroup that
-                # owns (sample, 4-channel slab) streams contiguous memory instead of 8 bytes of every 4F-wide pixel row
-                L['slab'] = bool(L['fused'] and os.environ.get('SAVP_LSTM_SLAB', '1') == '1' and lib.get_option('lstm_fused') and
-                                 h_ * w_ <= 1024 and f % 4 == 0)
                 L['c'] = Act((T1, N, h_, w_, f), dev, grad=False)
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
-                L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2), gate_perm=f if L['slab'] else 0)
+                L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
                 L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
                 L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
             else:
@@ -394,14 +389,14 @@ class SAVPGenerator(object):
                     if cp is not None:
                         ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         ce0.record()
-                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1, out_slab16=L['slab'])
+                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                     outs = self._out_views(L, t)
                     if t + 1 < T1:
                         outs.append(a.v[t + 1][..., f + nz:f + nz + f])
                     n1, n2 = L['n1'], L['n2']
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
-                                         eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1, gates_slab=L['slab'], c_slab=L['slab'])
+                                         eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
                     if cp is not None:
                         ce1.record()
                         cp.append((ce0, ce1))
@@ -544,7 +539,7 @@ class SAVPGenerator(object):
                     K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
                                          dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L),
-                                         dgates_raw=L.get('dg_raw'), gates_slab=L['slab'], c_slab=L['slab'])
+                                         dgates_raw=L.get('dg_raw'))
                     L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
                                        [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
