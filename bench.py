@@ -6,11 +6,16 @@ One "step" = one full reference train step (D Adam update, then G+E Adam update 
 HBM.  Workload at every N: configs[1] of BASELINE.json per GPU (full VAE-GAN, action-free BAIR 64x64x3, seq 30,
 batch 16 per GPU, published ours_savp recipe) -> weak scaling; one process per GPU, gradients all-reduced by RCCL.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel family (LDS-patch / implicit-GEMM conv on the MFMA pipe), measured live with HIP events
-                  around the five ConvLSTM gate-conv FPROP launches of every timed step; algorithmic FLOPs per launch
-                  from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the dense MFMA peak of the
-                  datapath in use (bf16: 2.5 PFLOP/s; --precision f32: 157.3 TFLOP/s).
+Timed region: W untimed + exactly K timed steps between (barrier + synchronize) pairs, MAX over ranks; un-instrumented; on one
+GPU the step body (no host input) is replayed as a captured hipGraph (--eager: launch by launch; with replicas the collectives keep
+it eager).  Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel family (LDS-patch / implicit-GEMM conv on the MFMA pipe): 8 further EAGER steps after the
+                  timed region carry HIP events / dispatch stamps around the five ConvLSTM gate-conv FPROP launches; algorithmic
+                  FLOPs per launch from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the dense MFMA peak
+                  of the datapath in use (bf16: 2.5 PFLOP/s; --precision f32: 157.3 TFLOP/s).  `traffic` is read from the
+                  committed rocprofv3 PMC pass of the round (profiles/), not collected by this run.
+  roofline_cell-- the fused cell (gate conv + ONE gate-block launch) against both roofs, same instrumented steps.
+  f32          -- (N=1) the exact-fp32 datapath, the reference's own arithmetic, on the same workload, timed the same way.
   cpu_baseline -- the CPU oracle (a torch-CPU restatement of the reference step, kind "port") timed on this host's
                   cores on a bounded sample (one sequence), rank 0 at N=1 only.
 """
@@ -130,8 +135,9 @@ def main():
     ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16',
                     help='conv multiply precision: bf16 operands / fp32 accumulate (BASELINE configs[1]) or exact fp32')
     ap.add_argument('--no-autotune', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (no per-kernel HIP-event '
-                    'instrumentation inside the timed region -> the roofline object carries no live numbers)')
+    ap.add_argument('--eager', action='store_true', help='submit the timed steps launch by launch instead of replaying a captured hipGraph')
+    ap.add_argument('--graph', action='store_true', help='(default on one GPU; kept for older command lines)')
+    ap.add_argument('--no-f32', action='store_true', help='skip the second object: the exact-fp32 datapath on the same workload')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
     args = ap.parse_args()
@@ -173,26 +179,10 @@ def main():
 
     from video_prediction_amd import kernels as K
     from video_prediction_amd.models.savp_model import SAVPEngine
-    K.set_conv_precision(args.precision)
-    K.enable_autotune(not args.no_autotune)      # tile / split-K selection happens during the warm-up steps
-    # shipped table of the BASELINE workload (measured on MI355X by an earlier run of this script with --save-tuning):
-    # problems found in it are not timed again, anything else is tuned live during the warm-up
-    table = os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % args.precision)
-    if not args.no_autotune and not args.retune and os.path.exists(table):
-        K.load_tuning(table)
     cfg = CONFIGS[args.config]
     if not args.batch:
         args.batch = cfg['batch']
     shape, seq = cfg['shape'], cfg['seq']
-    model = make_hparams(args.batch, seq, cfg['context'], cfg['over'])
-    hp = model.hparams
-    engine = SAVPEngine(hp, shape, args.batch, mode='train', seed=4, device=str(device))
-    if dist is not None:
-        engine.attach_process_group(dist)
-    # The roofline numbers come from HIP events around the ConvLSTM gate-conv launches of the timed steps; events cannot be timed
-    # inside a graph replay, so the default run keeps the step eager (measured cost of eager launches: ~0.5 ms of an 84 ms step)
-    engine.use_graph = bool(args.graph) and world == 1
-    engine.set_images(synthetic_batch(args.batch, 1234 + rank, device, seq, shape))      # inputs resident in HBM before timing
 
     def sync():
         torch.cuda.synchronize()
@@ -200,38 +190,75 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        engine.train_step()
-    inst = convlstm_flops(engine) if not engine.use_graph else []
-    cells = [L for L in engine.gen.layers if L['rnn']] if not engine.use_graph else []
-    # HIP events around the instrumented launches on every INST_EVERY-th timed step (4 events per ConvLSTM cell and timestep: on
-    # every step they cost ~1 ms of a 73 ms step in host time and launch gaps)
-    INST_EVERY = 8
+    def build_engine(precision):
+        K.set_conv_precision(precision)
+        K.enable_autotune(not args.no_autotune)      # tile / split-K selection happens during the warm-up steps
+        # shipped table of the BASELINE workload (measured on MI355X by an earlier run of this script with --save-tuning):
+        # problems found in it are not timed again, anything else is tuned live during the warm-up
+        table = os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % precision)
+        if not args.no_autotune and not args.retune and os.path.exists(table):
+            K.load_tuning(table)
+        model = make_hparams(args.batch, seq, cfg['context'], cfg['over'])
+        eng = SAVPEngine(model.hparams, shape, args.batch, mode='train', seed=4, device=str(device))
+        if dist is not None:
+            eng.attach_process_group(dist)
+        eng.set_images(synthetic_batch(args.batch, 1234 + rank, device, seq, shape))      # inputs resident in HBM before timing
+        return eng, model.hparams
+
+    def timed_steps(eng, warmup, steps):
+        """W untimed steps, then EXACTLY K steps between (barrier + synchronize) pairs; returns (seconds = MAX over ranks, last info)."""
+        info = None
+        for _ in range(warmup):
+            info = eng.train_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            info = eng.train_step()
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, info
+
+    engine, hp = build_engine(args.precision)
+    # The timed region runs the step the way a training job does: un-instrumented, and on one GPU as a replayed hipGraph (the step
+    # body has no host input; --eager keeps per-launch submission; with replicas the collectives keep it eager).  The roofline
+    # numbers come from INST_STEPS further steps AFTER the timed region, eager, with HIP events / dispatch stamps around the
+    # ConvLSTM gate-conv launches and around whole cells -- instrumentation never sits inside the timed region.
+    engine.use_graph = (not args.eager) and world == 1
+    dt, info = timed_steps(engine, args.warmup, args.steps)
+    mode = 'hipGraph replay' if (engine.use_graph and engine.graph is not None) else 'eager launches'
+    eager_ms = None
+    INST_STEPS = 8
+    engine.use_graph = False
+    inst = convlstm_flops(engine)
+    cells = [L for L in engine.gen.layers if L['rnn']]
     prof_lists = {id(layer): [] for layer, _ in inst}
     ktimers = {id(layer): K.KernelTimer() for layer, _ in inst}       # kernel-only durations of the same launches
     cell_lists = {id(L): [] for L in cells}
-    sync()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        on = (it % INST_EVERY == 0)
-        for layer, _ in inst:
-            layer.prof = prof_lists[id(layer)] if on else None
-            layer.ktimer = ktimers[id(layer)] if on else None
-        for L in cells:
-            L['cell_prof'] = cell_lists[id(L)] if on else None
-        info = engine.train_step()
-    sync()
     for layer, _ in inst:
-        layer.prof = prof_lists[id(layer)]
+        layer.prof, layer.ktimer = prof_lists[id(layer)], ktimers[id(layer)]
     for L in cells:
         L['cell_prof'] = cell_lists[id(L)]
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(INST_STEPS):
+        engine.train_step()
+    sync()
+    inst_ms = (time.perf_counter() - t1) / INST_STEPS * 1e3
+    if mode != 'eager launches':                     # the same step submitted launch by launch, un-instrumented, for comparison
+        for layer, _ in inst:
+            layer.prof = layer.ktimer = None
+        for L in cells:
+            L['cell_prof'] = None
+        e_dt, _ = timed_steps(engine, 1, min(args.steps, 10))
+        eager_ms = e_dt / min(args.steps, 10) * 1e3
+        for layer, _ in inst:
+            layer.prof = prof_lists[id(layer)]
     # roofline of the dominant kernel family from the live event pairs
-    # Two clocks on the same launches of the timed steps: (1) the dispatch's own begin / end stamps (hipExtLaunchKernelGGL
+    # Two clocks on the same launches: (1) the dispatch's own begin / end stamps (hipExtLaunchKernelGGL
     # events handed over with savp_prof_arm: the kernel alone, the duration rocprofv3's kernel trace reports) -- this is
     # `achieved`; (2) hipEventRecord markers in front of / behind the launch, which also hold the command processor's
     # hand-over between packets -- reported beside it as avg_launch_us_with_gaps.  Kernels that do not take the pair (the
@@ -239,7 +266,7 @@ def main():
     tot_flops, tot_s, launches = 0.0, 0.0, 0
     k_flops, k_s, k_launches = 0.0, 0.0, 0
     for layer, fl in inst:
-        for e0, e1 in layer.prof:
+        for e0, e1 in prof_lists[id(layer)]:
             tot_s += e0.elapsed_time(e1) * 1e-3
             tot_flops += fl
             launches += 1
@@ -256,8 +283,8 @@ def main():
         k_flops, k_s, k_launches, clock = tot_flops, tot_s, launches, 'event markers around the launch (includes dispatch gaps)'
     achieved = k_flops / k_s / 1e12 if k_s > 0 else None
     tot_s, launches = k_s, k_launches
-    # the fused ConvLSTM cell as a unit (gate conv with statistics epilogue + the two gate passes): HIP events around the whole cell
-    # of the timed steps.  Algorithmic bytes (read x, h, c and W once, write c', h'; fp32 activations, bf16
+    # the fused ConvLSTM cell as a unit (gate conv with statistics epilogue + the one-launch gate block): HIP events around the whole cell.
+    # Algorithmic bytes (read x, h, c and W once, write c', h'; fp32 activations, bf16
     # weights in bf16 mode) and FLOPs (2*M*N*K of the gate conv) per cell launch-set, against both roofs.
     cell_s, cell_flops, cell_bytes, cell_n = 0.0, 0.0, 0.0, 0
     for L in cells:
@@ -266,40 +293,46 @@ def main():
         wbytes = 25 * cin * 4 * f * (2 if args.precision == 'bf16' else 4)
         abytes = engine.N * h_ * w_ * (cin + f + 2 * f) * 4          # x|z|h (cin) + c read, c' + h' written, fp32
         fl = 2.0 * engine.N * h_ * w_ * (4 * f) * (25 * cin)
-        for e0, e1 in L['cell_prof']:
+        for e0, e1 in cell_lists[id(L)]:
             cell_s += e0.elapsed_time(e1) * 1e-3
             cell_flops += fl
             cell_bytes += wbytes + abytes
             cell_n += 1
         L['cell_prof'] = None
-    # HBM traffic of the same kernel/shapes from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md); bench.py cannot collect counters itself.
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r02_convlstm_cell_pmc_%s.json' % args.precision)
-    if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
-        try:
-            traffic = json.load(open(pmc_path))['avg_hbm_bytes_per_launch_five_layers']
-        except Exception:
-            traffic = None
+    # HBM traffic of the same kernel / shapes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (FETCH_SIZE x2 on gfx950 per
+    # MI355X_MICROARCH.md).  bench.py cannot collect counters itself: the number is read from the committed PMC pass of the
+    # round (profiles/, written by tests/pmc_cell.sh on the same build) and labelled with its source.
+    traffic, traffic_src = None, None
+    for rnd in ('r03', 'r02'):
+        pmc_path = os.path.join(ROOT, 'profiles', '%s_convlstm_cell_pmc_%s.json' % (rnd, args.precision))
+        if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
+            try:
+                traffic = json.load(open(pmc_path))['avg_hbm_bytes_per_launch_five_layers']
+                traffic_src = 'profiles/' + os.path.basename(pmc_path)
+                break
+            except Exception:
+                traffic = None
     frames = world * args.batch * seq * args.steps
     result = {
-        'metric': 'train frames/sec (whole node), BAIR 64x64 seq30 SAVP',
+        'metric': 'train frames/sec (whole node), %s seq%d SAVP' % ({'c2': 'BAIR 64x64', 'c4': 'KTH 64x64', 'c5': 'synthetic 128x128'}[args.config], seq),
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': '%s: SAVP full VAE-GAN (ours_savp recipe), %s, seq=%d, context=%d, nz=%d, '
                                'batch=%d per GPU, D step + G/E step per train step' % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
                    'global_batch': world * args.batch, 'seq_len': seq, 'parallelism': 'dp%d' % world,
-                   'sequences_per_s': world * args.batch * args.steps / dt},
+                   'sequences_per_s': world * args.batch * args.steps / dt,
+                   'submission': mode, 'eager_ms_per_step': eager_ms, 'instrumented_ms_per_step': inst_ms},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic,
                      'traffic_unit': 'HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
-                                     'profiles/r02_convlstm_cell_pmc_*.json); algorithmic 13.7 MB (fp32 input, bf16 weights, bf16 gates out)',
+                                     'read from %s, not collected by this run); algorithmic 13.7 MB (fp32 input, bf16 weights, bf16 gates out)' % traffic_src,
                      'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None, 'clock': clock,
-                     'avg_launch_us_with_gaps': gaps_us},
-        'roofline_cell': {'what': 'fused ConvLSTM cell = gate conv (instance-norm statistics + bf16 gates in its epilogue) + cell pass + output pass, '
-                                  'five layers, HIP events around each cell of the timed steps',
+                     'avg_launch_us_with_gaps': gaps_us,
+                     'measured_on': '%d instrumented eager steps after the timed region' % INST_STEPS},
+        'roofline_cell': {'what': 'fused ConvLSTM cell = gate conv (instance-norm statistics + bf16 gates in its epilogue) + ONE gate-block launch, '
+                                  'five layers, HIP events around each cell of the instrumented steps',
                           'avg_cell_us': (cell_s / cell_n * 1e6) if cell_n else None, 'cells_timed': cell_n,
                           'mfma': {'achieved': (cell_flops / cell_s / 1e12) if cell_s else None, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                                    'frac': (cell_flops / cell_s / 1e12 / PEAK_TFLOPS[args.precision]) if cell_s else None},
@@ -312,6 +345,25 @@ def main():
         result['replicas_identical'] = bool(engine.replicas.checksum_identical())      # collective: every rank calls it
     if rank == 0 and args.save_tuning:
         K.save_tuning(args.save_tuning)
+    if world == 1 and not args.no_f32 and args.precision == 'bf16':
+        # The reference's own arithmetic is fp32: the exact-fp32 datapath (fp32 MFMA pipe, bit-equal to an fmaf chain; the parity
+        # mode of the tests) on the same workload, timed the same way (W_f untimed + K_f timed steps, graph replay) as a second object.
+        try:
+            del engine
+            torch.cuda.empty_cache()
+            eng32, _ = build_engine('f32')
+            eng32.use_graph = not args.eager
+            k32 = max(4, min(args.steps, 12))
+            dt32, info32 = timed_steps(eng32, 3, k32)
+            fl_step = 10.9e12 * args.batch / 16.0 if args.config == 'c2' else None         # 0.684 TFLOP per sequence
+            result['f32'] = {'dtype': 'f32', 'steps': k32, 'warmup': 3, 'ms_per_step': dt32 / k32 * 1e3,
+                             'value': args.batch * seq * k32 / dt32, 'unit': 'frames/s',
+                             'whole_step_tflops': (fl_step * k32 / dt32 / 1e12) if fl_step else None, 'peak_tflops': PEAK_TFLOPS['f32'],
+                             'losses': {'d_loss': float(info32['d_loss']), 'g_loss': float(info32['g_loss'])}}
+            del eng32
+            K.set_conv_precision(args.precision)
+        except Exception as ex:            # never lose the headline line to the second datapath
+            result['f32'] = {'error': repr(ex)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == 'c2':     # the CPU sample has the c2 workload's shape
             try:
