@@ -291,7 +291,8 @@ def main():
         h_, w_ = L['hw']
         cin, f = L['a'].v.shape[-1], L['f']
         wbytes = 25 * cin * 4 * f * (2 if args.precision == 'bf16' else 4)
-        abytes = engine.N * h_ * w_ * (cin + f + 2 * f) * 4          # x|z|h (cin) + c read, c' + h' written, fp32
+        ab = L['a'].v.element_size()                                  # the cell input [x | z | h] is bf16 on the bf16 datapath
+        abytes = engine.N * h_ * w_ * (cin * ab + f * 4 + f * 4 + f * ab)   # x|z|h + c read, c' + h' written
         fl = 2.0 * engine.N * h_ * w_ * (4 * f) * (25 * cin)
         for e0, e1 in cell_lists[id(L)]:
             cell_s += e0.elapsed_time(e1) * 1e-3
@@ -301,13 +302,15 @@ def main():
         L['cell_prof'] = None
     # HBM traffic of the same kernel / shapes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (FETCH_SIZE x2 on gfx950 per
     # MI355X_MICROARCH.md).  bench.py cannot collect counters itself: the number is read from the committed PMC pass of the
-    # round (profiles/, written by tests/pmc_cell.sh on the same build) and labelled with its source.
-    traffic, traffic_src = None, None
+    # round (profiles/, written by tests/tools/collect_profiles.sh on the same build) and labelled with its source.
+    traffic, traffic_src, traffic_alg = None, None, None
     for rnd in ('r03', 'r02'):
         pmc_path = os.path.join(ROOT, 'profiles', '%s_convlstm_cell_pmc_%s.json' % (rnd, args.precision))
         if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
             try:
-                traffic = json.load(open(pmc_path))['avg_hbm_bytes_per_launch_five_layers']
+                pmc = json.load(open(pmc_path))
+                traffic = pmc['avg_hbm_bytes_per_launch_five_layers']
+                traffic_alg = pmc.get('avg_algorithmic_bytes_five_layers')
                 traffic_src = 'profiles/' + os.path.basename(pmc_path)
                 break
             except Exception:
@@ -324,9 +327,9 @@ def main():
                    'sequences_per_s': world * args.batch * args.steps / dt,
                    'submission': mode, 'eager_ms_per_step': eager_ms, 'instrumented_ms_per_step': inst_ms},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
-                     'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic,
+                     'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic, 'algorithmic_bytes': traffic_alg,
                      'traffic_unit': 'HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
-                                     'read from %s, not collected by this run); algorithmic 13.7 MB (fp32 input, bf16 weights, bf16 gates out)' % traffic_src,
+                                     'read from %s, not collected by this run); algorithmic bytes: avg_algorithmic_bytes_five_layers of the same file' % traffic_src,
                      'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None, 'clock': clock,
                      'avg_launch_us_with_gaps': gaps_us,

@@ -1,6 +1,6 @@
 """GPU parity checks: HIP kernels (through the C ABI) vs the CPU oracle on identical seeded inputs.
 
-Used by tests/test_gpu_*.py (pytest -m gpu), by __graft_entry__.smoke() and by tests/run_gpu_checks.py (which
+Used by tests/test_gpu_*.py (pytest -m gpu), by __graft_entry__.smoke() and by tests/tools/run_gpu_checks.py (which
 dumps every result to gpurun_out/ instead of stopping at the first failure).  Each check returns a list of
 (name, err, tol) tuples; err is max|hip - oracle| / max(|oracle|) with the oracle evaluated in float64.
 """

@@ -1,6 +1,6 @@
 """Micro-benchmark of the implicit-GEMM conv kernel on the ConvLSTM layer shapes (TFLOP/s per mode/tile)."""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from video_prediction_amd import kernels as K, lib

@@ -5,7 +5,7 @@ algorithmic HBM bytes of the op and the bandwidth they imply."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from video_prediction_amd import kernels as K  # noqa: E402

@@ -1,7 +1,7 @@
 """Train-step losses for the first steps with the LDS patch kernels vs the generic implicit-GEMM kernels (same seeds).
-usage: ALGO=generic|auto python tests/compare_algos.py"""
+usage: ALGO=generic|auto python tests/tools/compare_algos.py"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from tests.gpu_model_checks import make_hparams

@@ -1,8 +1,8 @@
 """Per-shape time of the conv launches of one train step: run under
-   rocprofv3 --kernel-trace --output-format csv -d DIR -- python tests/conv_shape_profile.py run
-then  python tests/conv_shape_profile.py report DIR  (on the same box; the call log is written to /tmp/conv_calls.json)."""
+   rocprofv3 --kernel-trace --output-format csv -d DIR -- python tests/tools/conv_shape_profile.py run
+then  python tests/tools/conv_shape_profile.py report DIR  (on the same box; the call log is written to /tmp/conv_calls.json)."""
 import sys, os, json, csv, collections, re
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 def run():

@@ -1,10 +1,10 @@
-"""Time one conv configuration: SHAPE=lstm_h0 MODE=fprop TILE=0x222 python tests/micro_one.py"""
+"""Time one conv configuration: SHAPE=lstm_h0 MODE=fprop TILE=0x222 python tests/tools/micro_one.py"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from video_prediction_amd import kernels as K, lib
-from tests.bench_conv_micro import SHAPES
+from tests.tools.bench_conv_micro import SHAPES
 
 def main():
     K.set_conv_precision('bf16')

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for cfg in "lstm_h0 0x712" "lstm_h1 0x711" "lstm_h2 0x311"; do set -- $cfg
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pc_$1_$c
-    SHAPE=$1:fprop TILE=$2 CELL=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pc_$1_$c -- python $R/tests/pmc_one.py > /tmp/pc.log 2>&1
+    SHAPE=$1:fprop TILE=$2 CELL=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pc_$1_$c -- python $R/tests/tools/pmc_one.py > /tmp/pc.log 2>&1
   done
 done
 python - <<PY > $R/gpurun_out/r02_convlstm_cell_pmc_bf16.json

@@ -1,9 +1,9 @@
 """ConvLSTM gate-conv FPROP launches (the five layers at N=32, BAIR) for PMC collection.
-  python tests/pmc_conv.py tune    -> writes gpurun_out/pmc_tuned.json (autotuned tile/split per layer)
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tests/pmc_conv.py run
+  python tests/tools/pmc_conv.py tune    -> writes gpurun_out/pmc_tuned.json (autotuned tile/split per layer)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tests/tools/pmc_conv.py run
 """
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from video_prediction_amd import kernels as K, lib

@@ -1,14 +1,14 @@
-"""One conv configuration for PMC collection: SHAPE=lstm_h0:fprop TILE=0x712 [CELL=1] [SK=1] python tests/pmc_one.py
-   rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d DIR -- python tests/pmc_one.py ; python tests/pmc_one.py report DIR"""
+"""One conv configuration for PMC collection: SHAPE=lstm_h0:fprop TILE=0x712 [CELL=1] [SK=1] python tests/tools/pmc_one.py
+   rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d DIR -- python tests/tools/pmc_one.py ; python tests/tools/pmc_one.py report DIR"""
 import collections, csv, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
 def run():
     import torch
     from video_prediction_amd import kernels as K, lib
-    from tests.bench_ring_ab import SHAPES
+    from tests.tools.bench_ring_ab import SHAPES
     K.set_conv_precision('bf16')
     name, mname = os.environ.get('SHAPE', 'lstm_h0:fprop').split(':')
     sh = [s for s in SHAPES if s[0] == name and s[1] == mname][0]
@@ -17,6 +17,12 @@ def run():
     tile = int(os.environ.get('TILE', '0x712'), 16)
     cell = os.environ.get('CELL', '0') == '1'
     x = torch.randn(N, H, W, Cx, device='cuda')
+    if os.environ.get('SRC16', '0') == '1':          # the engine's default: the cell input [x | z | h] is a bf16 tensor
+        x = x.to(torch.bfloat16)
+    if os.environ.get('TABLE', '0') == '1':           # the exact instantiation bench.py launches: shipped tuning table, tile 0
+        K.enable_autotune(True)
+        K.load_tuning(os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
+        tile = 0
     y = torch.empty(N, H, W, Cy, device='cuda', dtype=torch.bfloat16 if cell else torch.float32)
     if mode == lib.CONV_DGRAD:
         y = torch.randn(N, H, W, Cy, device='cuda')
@@ -24,7 +30,7 @@ def run():
     st = torch.zeros(N, Cy, 2, device='cuda') if cell else None
     geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
     for _ in range(6):
-        K.conv(mode, geom, x, y, w, tile=tile, w16=w.to(torch.bfloat16), splitk=int(os.environ.get('SK', '1')), stats=st)
+        K.conv(mode, geom, x, y, w, tile=tile, w16=w.to(torch.bfloat16), splitk=0 if tile == 0 else int(os.environ.get('SK', '1')), stats=st)
     torch.cuda.synchronize()
 
 

@@ -1,9 +1,9 @@
 """Build profiles/<round>_convlstm_fprop_pmc_<prec>.json from two rocprofv3 --pmc passes of tests/pmc_conv.py run.
-usage: python tests/pmc_report.py FETCH_DIR WRITE_DIR TRACE_DIR out.json
+usage: python tests/tools/pmc_report.py FETCH_DIR WRITE_DIR TRACE_DIR out.json
 FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md) -> fetch x2."""
 import csv, json, os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.pmc_conv import LAYERS, N
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tests.tools.pmc_conv import LAYERS, N
 
 
 def find(d, suffix):

@@ -10,5 +10,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
 done
 mkdir -p $R/gpurun_out
-python $R/tests/pmc_step_report.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_pmc_step.json
+python $R/tests/tools/pmc_step_report.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_pmc_step.json
 head -c 1500 $R/gpurun_out/${TAG}_pmc_step.json

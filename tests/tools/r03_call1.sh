@@ -33,5 +33,5 @@ done
 timeout 300 python bench.py --steps 40 --warmup 4 --no-cpu-baseline --graph > $O/bench_graph.json 2> $O/bench_graph.err
 python -c "import json;d=json.loads(open('$O/bench_graph.json').read().strip().splitlines()[-1]);print('graph ms/step %.2f'%d['ms_per_step'])"
 echo "bench done $(( $(date +%s)-t0 ))s"
-bash tests/prof_step.sh r03a/base > $O/prof.log 2>&1; tail -2 $O/prof.log
+bash tests/tools/prof_step.sh r03a/base > $O/prof.log 2>&1; tail -2 $O/prof.log
 echo "total $(( $(date +%s)-t0 ))s"

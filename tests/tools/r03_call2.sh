@@ -22,5 +22,5 @@ PY
 done
 echo "bench done $(( $(date +%s)-t0 ))s"
 timeout 600 python -m pytest tests/test_gpu_dp.py -q > $O/dp.log 2>&1; echo "dp rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/dp.log
-bash tests/prof_step.sh r03b/fused > $O/prof.log 2>&1; tail -2 $O/prof.log
+bash tests/tools/prof_step.sh r03b/fused > $O/prof.log 2>&1; tail -2 $O/prof.log
 echo "total $(( $(date +%s)-t0 ))s"

@@ -19,5 +19,5 @@ except Exception as e:
 PY
 done
 echo "bench done $(( $(date +%s)-t0 ))s"
-bash tests/prof_step.sh r03c/slab > $O/prof.log 2>&1; tail -2 $O/prof.log
+bash tests/tools/prof_step.sh r03c/slab > $O/prof.log 2>&1; tail -2 $O/prof.log
 echo "total $(( $(date +%s)-t0 ))s"

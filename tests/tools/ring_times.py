@@ -1,10 +1,10 @@
 """Developer build only (SAVP_EXTRA_FLAGS=-DSAVP_CONV_ABLATE): cycle stamps of workgroup 0 / wave 0 of conv_ring_kernel."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from video_prediction_amd import kernels as K, lib
-from tests.bench_ring_ab import SHAPES
+from tests.tools.bench_ring_ab import SHAPES
 K.set_conv_precision('bf16')
 for spec in sys.argv[1:]:
     parts = spec.split(':')

@@ -1,6 +1,6 @@
-"""Run one model-level check by expression, e.g.: python tests/run_one_check.py "check_train_step(B=1,T=4,nz=8,steps=1,tag='g',conv_rnn='gru')" """
+"""Run one model-level check by expression, e.g.: python tests/tools/run_one_check.py "check_train_step(B=1,T=4,nz=8,steps=1,tag='g',conv_rnn='gru')" """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import gpu_model_checks as G  # noqa
 from tests.gpu_model_checks import *  # noqa

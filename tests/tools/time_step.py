@@ -1,6 +1,6 @@
 """Quick wall-clock of the full SAVP train step on one GPU (used while optimising)."""
 import sys, os, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from tests.gpu_model_checks import make_hparams

@@ -1,5 +1,5 @@
 """Run-length summary of a rocprofv3 kernel trace: consecutive dispatches of the same kernel/grid -> mean duration.
-usage: python tests/trace_groups.py <kernel_trace.csv> [min_count]"""
+usage: python tests/tools/trace_groups.py <kernel_trace.csv> [min_count]"""
 import csv, sys, re
 
 def main():

@@ -1,4 +1,4 @@
-"""python tests/trace_report.py gpurun_out/X_last_step_trace.csv [N] : per (kernel, grid) time of one step."""
+"""python tests/tools/trace_report.py gpurun_out/X_last_step_trace.csv [N] : per (kernel, grid) time of one step."""
 import csv, collections, re, sys, statistics
 st = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 60

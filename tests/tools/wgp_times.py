@@ -1,10 +1,10 @@
 """Developer build only (SAVP_EXTRA_FLAGS=-DSAVP_CONV_ABLATE): per-phase cycles of workgroup 0 / wave 0 of wgrad_patch_kernel."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from video_prediction_amd import kernels as K, lib
-from tests.bench_wgrad import SHAPES, N
+from tests.tools.bench_wgrad import SHAPES, N
 K.set_conv_precision('bf16')
 for name, H, W, Cx, Cy, k in SHAPES:
     if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -164,16 +164,14 @@ class SAVPGenerator(object):
                 # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
                 L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
                               h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0)
-                # SAVP_BF16_ACT=1 (experimental, off: written at the end of round 2 without GPU time left to validate it): the cell's
-                # input buffer [x | z | h] itself is bf16.  Its only readers are the gate convolution (FPROP, WGRAD), which round to
-                # bf16 when they stage their operands anyway, so the numbers do not change; the producers (instance norm of the
-                # layer's conv, tile_channels, the h' output of the gate kernels) write bf16 through their out_bf16 / h_bf16 masks.
-                a_dt = torch.bfloat16 if (L['fused'] and os.environ.get('SAVP_BF16_ACT', '0') == '1') else torch.float32
+                # The cell's input buffer [x | z | h] and the gate gradient are held in bf16 (round 3: validated on MI355X, identical
+                # numbers -- their only readers are the gate convolution's FPROP / DGRAD / WGRAD, which round to bf16 when they stage
+                # their operands anyway -- and half the bytes; step time unchanged within noise, 61.04 vs 61.21 ms).  The producers
+                # (instance norm of the layer's conv, tile_channels, the h' output and the gate gradient of the gate kernels) write bf16
+                # through their out_bf16 / h_bf16 / dgates_bf16 flags.  SAVP_BF16_ACT=0 / SAVP_BF16_DGATES=0 keep fp32 tensors.
+                a_dt = torch.bfloat16 if (L['fused'] and os.environ.get('SAVP_BF16_ACT', '1') == '1') else torch.float32
                 L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g, dtype=a_dt)
-                # SAVP_BF16_DGATES=1 (experimental, off, see SAVP_BF16_ACT above): the gate gradient is stored as bf16 as well -- its
-                # readers are the gate convolution's DGRAD and WGRAD; the three gate-gradient passes keep their raw fp32 values in a
-                # per-layer scratch
-                dg_dt = torch.bfloat16 if (L['fused'] and g and os.environ.get('SAVP_BF16_DGATES', '0') == '1') else torch.float32
+                dg_dt = torch.bfloat16 if (L['fused'] and g and os.environ.get('SAVP_BF16_DGATES', '1') == '1') else torch.float32
                 L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32,
                                  grad_dtype=dg_dt)
                 L['dg_raw'] = torch.empty(N, h_, w_, 4 * f, device=dev) if dg_dt == torch.bfloat16 else None
