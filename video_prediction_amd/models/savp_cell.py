@@ -162,8 +162,12 @@ class SAVPGenerator(object):
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
                 # fused ConvLSTM cell of the bf16 datapath: the gate convolution's epilogue produces the statistics of the first
                 # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
+                # SAVP_FUSED_MIN_HW (developer A/B): planes smaller than this keep fp32 gates from a plain convolution, which may then
+                # split K over workgroups (the 8x8 layer is M = 2048 pixels: 64 tiles of 128 x 128 do not fill 256 CUs, and the cell
+                # epilogue's statistics + bf16 rounding need complete sums); the gate kernel then reduces the IN(4F) statistics itself
                 L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
-                              h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0)
+                              h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0 and
+                              h_ * w_ >= int(os.environ.get('SAVP_FUSED_MIN_HW', '0')))
                 # The cell's input buffer [x | z | h] and the gate gradient are held in bf16 (round 3: validated on MI355X, identical
                 # numbers -- their only readers are the gate convolution's FPROP / DGRAD / WGRAD, which round to bf16 when they stage
                 # their operands anyway -- and half the bytes; step time unchanged within noise, 61.04 vs 61.21 ms).  The producers
