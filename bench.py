@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--no-autotune', action='store_true')
     ap.add_argument('--eager', action='store_true', help='submit the timed steps launch by launch instead of replaying a captured hipGraph')
     ap.add_argument('--graph', action='store_true', help='(default on one GPU; kept for older command lines)')
+    ap.add_argument('--inst-steps', type=int, default=8, help='instrumented eager steps after the timed region (0: none, roofline objects empty)')
     ap.add_argument('--no-f32', action='store_true', help='skip the second object: the exact-fp32 datapath on the same workload')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
@@ -231,7 +232,7 @@ def main():
     dt, info = timed_steps(engine, args.warmup, args.steps)
     mode = 'hipGraph replay' if (engine.use_graph and engine.graph is not None) else 'eager launches'
     eager_ms = None
-    INST_STEPS = 8
+    INST_STEPS = max(0, args.inst_steps)
     engine.use_graph = False
     inst = convlstm_flops(engine)
     cells = [L for L in engine.gen.layers if L['rnn']]
@@ -247,8 +248,8 @@ def main():
     for _ in range(INST_STEPS):
         engine.train_step()
     sync()
-    inst_ms = (time.perf_counter() - t1) / INST_STEPS * 1e3
-    if mode != 'eager launches':                     # the same step submitted launch by launch, un-instrumented, for comparison
+    inst_ms = ((time.perf_counter() - t1) / INST_STEPS * 1e3) if INST_STEPS else None
+    if mode != 'eager launches' and INST_STEPS:                     # the same step submitted launch by launch, un-instrumented, for comparison
         for layer, _ in inst:
             layer.prof = layer.ktimer = None
         for L in cells:

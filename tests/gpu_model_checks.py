@@ -315,6 +315,9 @@ def check_model_small():
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_flow', transformation='flow')
     res += check_generator_forward(nz=0, B=1, T=4, tag='gen_fwd_dna', transformation='dna')
     res += check_generator_forward(nz=8, B=2, T=4, tag='gen_fwd_gru', conv_rnn='gru')
+    # the latent enters only the first encoder conv / only the first decoder conv (savp_model.py:456-470,492-506)
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_where_add_input', where_add='input')
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_where_add_middle', where_add='middle')
     return res
 
 
@@ -329,6 +332,9 @@ def check_train_small():
                             video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     for tf in ('flow', 'dna'):
         res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_' + tf, transformation=tf, video_sn_vae_gan_weight=0.0,
+                                video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
+    for wa in ('input', 'middle'):
+        res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_where_add_' + wa, where_add=wa, video_sn_vae_gan_weight=0.0,
                                 video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)

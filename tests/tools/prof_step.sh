@@ -4,7 +4,7 @@ TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_s
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > /tmp/prof_s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-f32 --eager --inst-steps 0 ${BENCH_ARGS} > /tmp/prof_s.log 2>&1
 tail -1 /tmp/prof_s.log | cut -c1-400
 mkdir -p $R/gpurun_out
 f=$(find /tmp/prof_s -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/${TAG}_kernel_stats.csv

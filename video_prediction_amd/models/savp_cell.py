@@ -102,14 +102,18 @@ class SAVPGenerator(object):
             raise NotImplementedError('HIP path covers transformation in (cdna, flow, dna) with last_frames=1')
         if tuple(hp.dilation_rate) != (1, 1):
             raise NotImplementedError('dilation_rate != (1, 1)')
-        if hp.where_add != 'all' or hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
-            raise NotImplementedError('HIP path covers where_add=all without ablations')
+        if hp.where_add not in ('input', 'all', 'middle'):
+            raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
+        if hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
+            raise NotImplementedError('HIP path does not cover the rnn ablations / learn_initial_state')
         if not (hp.prev_image_background and hp.first_image_background and hp.generate_scratch_image and hp.dependent_mask) \
                 or hp.last_image_background or hp.last_context_image_background or hp.context_images_background:
             raise NotImplementedError('HIP path covers the default background/scratch/dependent-mask configuration')
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
-        zc = nz
+        # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
+        # every conv-RNN; 'input' = the first encoder conv only; 'middle' = the first decoder conv only
+        zr = nz if hp.where_add == 'all' else 0                         # z channels in a conv-RNN's input [x | z | h]
         g = train
         enc_specs, dec_specs = layer_specs(hp.ngf, H, W)
         self.ne, self.nd = len(enc_specs), len(dec_specs)
@@ -121,6 +125,9 @@ class SAVPGenerator(object):
         for i, (f, use_rnn) in enumerate(enc_specs + dec_specs):
             L = {'f': f, 'rnn': use_rnn, 'idx': i, 'dec': i >= self.ne}
             s = prefix + 'h%d/' % i
+            j_dec = i - len(enc_specs)
+            zc = nz if (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0) or (hp.where_add == 'middle' and j_dec == 0)) else 0
+            L['zc'], L['zr'] = zc, zr
             if i < self.ne:
                 cx = 2 * C if i == 0 else prev_f
                 k = 5 if i == 0 else 3
@@ -147,8 +154,8 @@ class SAVPGenerator(object):
                 # Conv2DGRUCell (rnn_ops.py:174-267): a = [x | z | h_prev | r*h_prev]; the gates conv reads the first
                 # f+zc+f channels of the same buffer (a channel-slice view), the candidate conv reads all of it
                 r = prefix + 'gru_h%d/conv2dgru_cell/' % i
-                L['cin1'] = f + zc + f
-                L['a'] = Act((T1, N, h_, w_, f + zc + 2 * f), dev, grad=g)
+                L['cin1'] = f + zr + f
+                L['a'] = Act((T1, N, h_, w_, f + zr + 2 * f), dev, grad=g)
                 L['gates'] = Act((T1, N, h_, w_, 2 * f), dev, grad=g)
                 L['cand'] = Act((T1, N, h_, w_, f), dev, grad=g)
                 L['u'] = torch.empty(T1, N, h_, w_, f, device=dev)
@@ -162,19 +169,15 @@ class SAVPGenerator(object):
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
                 # fused ConvLSTM cell of the bf16 datapath: the gate convolution's epilogue produces the statistics of the first
                 # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
-                # SAVP_FUSED_MIN_HW (developer A/B): planes smaller than this keep fp32 gates from a plain convolution, which may then
-                # split K over workgroups (the 8x8 layer is M = 2048 pixels: 64 tiles of 128 x 128 do not fill 256 CUs, and the cell
-                # epilogue's statistics + bf16 rounding need complete sums); the gate kernel then reduces the IN(4F) statistics itself
                 L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
-                              h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zc + f) % 8 == 0 and
-                              h_ * w_ >= int(os.environ.get('SAVP_FUSED_MIN_HW', '0')))
+                              h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zr + f) % 8 == 0)
                 # The cell's input buffer [x | z | h] and the gate gradient are held in bf16 (round 3: validated on MI355X, identical
                 # numbers -- their only readers are the gate convolution's FPROP / DGRAD / WGRAD, which round to bf16 when they stage
                 # their operands anyway -- and half the bytes; step time unchanged within noise, 61.04 vs 61.21 ms).  The producers
                 # (instance norm of the layer's conv, tile_channels, the h' output and the gate gradient of the gate kernels) write bf16
                 # through their out_bf16 / h_bf16 / dgates_bf16 flags.  SAVP_BF16_ACT=0 / SAVP_BF16_DGATES=0 keep fp32 tensors.
                 a_dt = torch.bfloat16 if (L['fused'] and os.environ.get('SAVP_BF16_ACT', '1') == '1') else torch.float32
-                L['a'] = Act((T1, N, h_, w_, f + zc + f), dev, grad=g, dtype=a_dt)
+                L['a'] = Act((T1, N, h_, w_, f + zr + f), dev, grad=g, dtype=a_dt)
                 dg_dt = torch.bfloat16 if (L['fused'] and g and os.environ.get('SAVP_BF16_DGATES', '1') == '1') else torch.float32
                 L['gates'] = Act((T1, N, h_, w_, 4 * f), dev, grad=g, dtype=torch.bfloat16 if L['fused'] else torch.float32,
                                  grad_dtype=dg_dt)
@@ -343,8 +346,9 @@ class SAVPGenerator(object):
             zflat = self.rnn_z.v.reshape(T1 * N, nz)
             for L in self.layers:
                 b = L['in']
-                K.tile_channels(zflat, b.flat(b.v)[..., L['zoff_in']:L['zoff_in'] + nz])
-                if L['rnn']:
+                if L['zc']:
+                    K.tile_channels(zflat, b.flat(b.v)[..., L['zoff_in']:L['zoff_in'] + nz])
+                if L['rnn'] and L['zr']:
                     a = L['a']
                     K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + nz])
         in0, maskin = self.layers[0]['in'], self.maskin
@@ -367,7 +371,7 @@ class SAVPGenerator(object):
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
                     a = L['a']
-                    hs, rs_, cin1 = f + nz, f + nz + f, L['cin1']
+                    hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
                                        act='relu', eps=EPS_IN)
                     n1, n2 = L['n1'], L['n2']
@@ -394,7 +398,7 @@ class SAVPGenerator(object):
                     L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                     outs = self._out_views(L, t)
                     if t + 1 < T1:
-                        outs.append(a.v[t + 1][..., f + nz:f + nz + f])
+                        outs.append(a.v[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
@@ -516,7 +520,7 @@ class SAVPGenerator(object):
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
                     a = L['a']
-                    hs, rs_, cin1 = f + nz, f + nz + f, L['cin1']
+                    hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
                     if t + 1 < T1:
                         dys.append(a.g[t + 1][..., hs:hs + f])
                     n1, n2 = L['n1'], L['n2']
@@ -534,7 +538,7 @@ class SAVPGenerator(object):
                 elif L['rnn']:
                     a = L['a']
                     if t + 1 < T1:
-                        dys.append(a.g[t + 1][..., f + nz:f + nz + f])
+                        dys.append(a.g[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
                     dc_new = L['dc'][(t + 1) & 1] if t + 1 < T1 else None
                     dc_prev = L['dc'][t & 1] if t > 0 else None
@@ -590,8 +594,9 @@ class SAVPGenerator(object):
         drz.zero_()
         for L in self.layers:
             b = L['in']
-            K.colsum(b.flat(b.g)[..., L['zoff_in']:L['zoff_in'] + nz], drz, per_row=True)
-            if L['rnn']:
+            if L['zc']:
+                K.colsum(b.flat(b.g)[..., L['zoff_in']:L['zoff_in'] + nz], drz, per_row=True)
+            if L['rnn'] and L['zr']:
                 a = L['a']
                 K.colsum(a.flat(a.g)[..., L['f']:L['f'] + nz], drz, per_row=True)
         if self.use_rnn_z:
