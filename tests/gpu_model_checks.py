@@ -318,6 +318,12 @@ def check_model_small():
     # the latent enters only the first encoder conv / only the first decoder conv (savp_model.py:456-470,492-506)
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_where_add_input', where_add='input')
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_where_add_middle', where_add='middle')
+    # other background image sets of the compositing step (savp_model.py:581-594): first + last + last-context frames (9 masks) and
+    # all context frames without the previous image (8 masks)
+    res += check_generator_forward(nz=8, B=1, T=5, tag='gen_fwd_bg_last_frames', context_frames=3, last_image_background=True,
+                                   last_context_image_background=True)
+    res += check_generator_forward(nz=0, B=1, T=5, tag='gen_fwd_bg_context_images', context_frames=3, context_images_background=True,
+                                   prev_image_background=False)
     return res
 
 
@@ -336,6 +342,9 @@ def check_train_small():
     for wa in ('input', 'middle'):
         res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_where_add_' + wa, where_add=wa, video_sn_vae_gan_weight=0.0,
                                 video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
+    res += check_train_step(B=1, T=5, nz=8, steps=1, tag='train_bg_context_images', context_frames=3, context_images_background=True,
+                            prev_image_background=False, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                            vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)
     return res

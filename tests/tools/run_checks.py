@@ -23,9 +23,23 @@ def where_add():
     return res
 
 
+def backgrounds():
+    res = G.check_generator_forward(nz=8, B=1, T=5, tag='gen_fwd_bg_last_frames', context_frames=3, last_image_background=True,
+                                    last_context_image_background=True)
+    res += G.check_generator_forward(nz=0, B=1, T=5, tag='gen_fwd_bg_context_images', context_frames=3, context_images_background=True,
+                                     prev_image_background=False)
+    res += G.check_train_step(B=1, T=5, nz=8, steps=1, tag='train_bg_context_images', context_frames=3, context_images_background=True,
+                              prev_image_background=False, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                              vae_gan_feature_cdist_weight=0.0)
+    res += G.check_train_step(B=1, T=5, nz=8, steps=1, tag='train_bg_last_frames', context_frames=3, last_image_background=True,
+                              last_context_image_background=True, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                              vae_gan_feature_cdist_weight=0.0)
+    return res
+
+
 if __name__ == '__main__':
     bad = 0
-    for n, e, t in {'where_add': where_add}[sys.argv[1]]():
+    for n, e, t in {'where_add': where_add, 'backgrounds': backgrounds}[sys.argv[1]]():
         ok = e <= t
         bad += not ok
         print('%-4s %-70s %.3e (tol %.1e)' % ('ok' if ok else 'FAIL', n, e, t))

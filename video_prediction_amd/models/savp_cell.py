@@ -106,9 +106,8 @@ class SAVPGenerator(object):
             raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
         if hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
             raise NotImplementedError('HIP path does not cover the rnn ablations / learn_initial_state')
-        if not (hp.prev_image_background and hp.first_image_background and hp.generate_scratch_image and hp.dependent_mask) \
-                or hp.last_image_background or hp.last_context_image_background or hp.context_images_background:
-            raise NotImplementedError('HIP path covers the default background/scratch/dependent-mask configuration')
+        if not (hp.generate_scratch_image and hp.dependent_mask):
+            raise NotImplementedError('HIP path covers generate_scratch_image=True, dependent_mask=True (any background image set)')
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
@@ -246,12 +245,25 @@ class SAVPGenerator(object):
         self.masks_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
         self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
         self.masks_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
-        # maskin = [h_masks (ngf) | nk CDNA images | prev image | first image | scratch image]   (savp_model.py:632)
+        # background images in the reference's order (savp_model.py:581-594): the step's input image, then frames of the INPUT video --
+        # ('fixed', k) = images[k] at every step, ('last_context',) = images[min(t, context_frames - 1)]
+        cf = hp.context_frames
+        self.bgs = [('prev',)] if hp.prev_image_background else []
+        if hp.context_images_background:
+            self.bgs += [('fixed', k) for k in range(cf)]
+        else:
+            self.bgs += ([('fixed', 0)] if hp.first_image_background else []) + ([('fixed', cf - 1)] if hp.last_image_background else []) + \
+                        ([('last_context',)] if hp.last_context_image_background else [])
+        nb = len(self.bgs)
+        assert M == nk + nb + 1
+        # maskin = [h_masks (ngf) | nk transformed images | background images | scratch image]   (savp_model.py:632)
         self.Cmask = Cmask = ceil4(ngf + M * C + (Cs - C))        # scratch slot is last: room for its padded write
         self.Ml = Ml = ceil4(M)                                    # padded logits row
         self.maskin = Act((T1, N, H, W, Cmask), dev, grad=g)
-        self.o_cdna, self.o_prev = ngf, ngf + nk * C
-        self.o_first, self.o_scratch = ngf + (nk + 1) * C, ngf + (nk + 2) * C
+        self.o_cdna = ngf
+        self.o_bg = [ngf + (nk + i) * C for i in range(nb)]
+        self.o_prev = self.o_bg[self.bgs.index(('prev',))] if ('prev',) in self.bgs else None
+        self.o_scratch = ngf + (nk + nb) * C
         s = prefix + 'masks/'
         self.masks_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1),
                                    cx_pad=Cmask, cy_pad=Ml)
@@ -357,14 +369,29 @@ class SAVPGenerator(object):
         if self._ones is None:
             self._ones = torch.ones(max(N, T1), dtype=torch.int32, device=self.dev)
         NH = N * self.H
-        first = images[0].reshape(1, NH, self.W, C).expand(T1, NH, self.W, C)
-        K.select(self._ones, first, None, [in0.v.reshape(T1, NH, self.W, -1)[..., C:2 * C],
-                                           maskin.v.reshape(T1, NH, self.W, -1)[..., self.o_first:self.o_first + C]])
+        mflat = maskin.v.reshape(T1, NH, self.W, -1)
+
+        def frame_all_steps(k, t0=0):          # images[k] seen from steps t0 .. T1-1 (source stride 0 over time)
+            return images[k].reshape(1, NH, self.W, C).expand(T1 - t0, NH, self.W, C)
+        first_dsts = [in0.v.reshape(T1, NH, self.W, -1)[..., C:2 * C]]
+        for bg, off in zip(self.bgs, self.o_bg):
+            if bg == ('fixed', 0):
+                first_dsts.append(mflat[..., off:off + C])
+        K.select(self._ones, frame_all_steps(0), None, first_dsts)
+        cf = self.hp.context_frames
+        for bg, off in zip(self.bgs, self.o_bg):
+            if bg[0] == 'fixed' and bg[1] != 0:
+                K.select(self._ones, frame_all_steps(bg[1]), None, [mflat[..., off:off + C]])
+            elif bg[0] == 'last_context':          # images[t] while t < context_frames, images[context_frames - 1] afterwards
+                n = min(cf, T1)
+                copy_view(images[:n].reshape(n, NH, self.W, C), [mflat[:n][..., off:off + C]])
+                if T1 > n:
+                    K.select(self._ones, frame_all_steps(cf - 1, n), None, [mflat[n:][..., off:off + C]])
         for t in range(T1):
             # image = tf.where(ground_truth[t], inputs['images'], states['gen_image'])     (savp_model.py:406)
             prev_gen = self.gen.v[t - 1] if t > 0 else None
             K.select(gt_mask[t], images[t], prev_gen,
-                     [in0.v[t][..., 0:C], maskin.v[t][..., self.o_prev:self.o_prev + C]])
+                     [in0.v[t][..., 0:C]] + ([maskin.v[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else []))
             for L in self.layers:
                 f = L['f']
                 L['conv'].forward(L['in'].v[t], L['pre'].v[t])
@@ -556,8 +583,8 @@ class SAVPGenerator(object):
                 L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0)
             # d image -> previous step's generated frame where it was fed back (not ground truth)
             if t > 0:
-                K.select_bwd(self.gt_mask[t], [in0.g[t][..., 0:C], maskin.g[t][..., self.o_prev:self.o_prev + C], self.dimg_cdna],
-                             self.gen.g[t - 1])
+                K.select_bwd(self.gt_mask[t], [in0.g[t][..., 0:C], self.dimg_cdna] +
+                             ([maskin.g[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else []), self.gen.g[t - 1])
         # ---- weight gradients: one split-K GEMM per layer over all (t, n) ----------------------------------------
         for L in self.layers:
             b, pre = L['in'], L['pre']
