@@ -324,6 +324,9 @@ def check_model_small():
                                    last_context_image_background=True)
     res += check_generator_forward(nz=0, B=1, T=5, tag='gen_fwd_bg_context_images', context_frames=3, context_images_background=True,
                                    prev_image_background=False)
+    # mask conv on h_masks alone (dependent_mask=False, savp_model.py:631-632) / no scratch image (:561-572, 6 masks)
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_independent_mask', dependent_mask=False)
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_no_scratch', generate_scratch_image=False)
     return res
 
 
@@ -344,6 +347,9 @@ def check_train_small():
                                 video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=1, T=5, nz=8, steps=1, tag='train_bg_context_images', context_frames=3, context_images_background=True,
                             prev_image_background=False, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                            vae_gan_feature_cdist_weight=0.0)
+    res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_no_scratch_independent_mask', generate_scratch_image=False,
+                            dependent_mask=False, transformation='flow', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)

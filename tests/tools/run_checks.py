@@ -37,9 +37,20 @@ def backgrounds():
     return res
 
 
+def mask_options():
+    res = G.check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_independent_mask', dependent_mask=False)
+    res += G.check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_no_scratch', generate_scratch_image=False)
+    off = dict(video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
+    res += G.check_train_step(B=1, T=4, nz=8, steps=1, tag='train_no_scratch_independent_mask_flow', generate_scratch_image=False,
+                              dependent_mask=False, transformation='flow', **off)
+    res += G.check_train_step(B=1, T=4, nz=8, steps=1, tag='train_independent_mask', dependent_mask=False, **off)
+    res += G.check_train_step(B=1, T=4, nz=8, steps=1, tag='train_no_scratch', generate_scratch_image=False, **off)
+    return res
+
+
 if __name__ == '__main__':
     bad = 0
-    for n, e, t in {'where_add': where_add, 'backgrounds': backgrounds}[sys.argv[1]]():
+    for n, e, t in {'where_add': where_add, 'backgrounds': backgrounds, 'mask_options': mask_options}[sys.argv[1]]():
         ok = e <= t
         bad += not ok
         print('%-4s %-70s %.3e (tol %.1e)' % ('ok' if ok else 'FAIL', n, e, t))

@@ -106,8 +106,6 @@ class SAVPGenerator(object):
             raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
         if hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
             raise NotImplementedError('HIP path does not cover the rnn ablations / learn_initial_state')
-        if not (hp.generate_scratch_image and hp.dependent_mask):
-            raise NotImplementedError('HIP path covers generate_scratch_image=True, dependent_mask=True (any background image set)')
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
@@ -232,15 +230,18 @@ class SAVPGenerator(object):
             tf_convs = [self.tf_conv, self.tf_out]
         self.merge_heads = os.environ.get('SAVP_MERGE_HEADS', '1') == '1' and ngf % 4 == 0
         sep = not self.merge_heads          # separate pre-activation buffers only when every head has its own launch
-        s = prefix + 'h%d_scratch/' % nl
-        self.scratch_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
-        self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
-        self.scratch_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
-        self.scratch_h = Act((T1, N, H, W, ngf), dev, grad=g)
-        s = prefix + 'scratch_image/'
+        self.scratch = bool(hp.generate_scratch_image)          # savp_model.py:561-572; without it the head and its mask slot do not exist
+        self.dep_mask = bool(hp.dependent_mask)                  # :631-632: the mask conv also reads the transformed images
         self.Cs = Cs = ceil4(C)                       # scratch conv writes a 4-aligned channel group into its maskin slot
-        self.scratch_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1), cy_pad=Cs)
-        self.dscratch_pre = torch.empty(T1, N, H, W, Cs, device=dev) if g else None
+        if self.scratch:
+            s = prefix + 'h%d_scratch/' % nl
+            self.scratch_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
+            self.scratch_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
+            self.scratch_norm = Norm(store, s + 'InstanceNorm/', T1, N, ngf, dev)
+            self.scratch_h = Act((T1, N, H, W, ngf), dev, grad=g)
+            s = prefix + 'scratch_image/'
+            self.scratch_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1), cy_pad=Cs)
+            self.dscratch_pre = torch.empty(T1, N, H, W, Cs, device=dev) if g else None
         s = prefix + 'h%d_masks/' % nl
         self.masks_conv = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1))
         self.masks_pre = Act((T1, N, H, W, ngf), dev, grad=g) if sep else None
@@ -255,9 +256,11 @@ class SAVPGenerator(object):
             self.bgs += ([('fixed', 0)] if hp.first_image_background else []) + ([('fixed', cf - 1)] if hp.last_image_background else []) + \
                         ([('last_context',)] if hp.last_context_image_background else [])
         nb = len(self.bgs)
-        assert M == nk + nb + 1
+        assert M == nk + nb + int(self.scratch)
+        if M < 2:
+            raise NotImplementedError('a single transformed image (mask == 1 everywhere, savp_model.py:636-637)')
         # maskin = [h_masks (ngf) | nk transformed images | background images | scratch image]   (savp_model.py:632)
-        self.Cmask = Cmask = ceil4(ngf + M * C + (Cs - C))        # scratch slot is last: room for its padded write
+        self.Cmask = Cmask = ceil4(ngf + M * C + ((Cs - C) if self.scratch else 0))     # scratch slot is last: room for its padded write
         self.Ml = Ml = ceil4(M)                                    # padded logits row
         self.maskin = Act((T1, N, H, W, Cmask), dev, grad=g)
         self.o_cdna = ngf
@@ -265,8 +268,9 @@ class SAVPGenerator(object):
         self.o_prev = self.o_bg[self.bgs.index(('prev',))] if ('prev',) in self.bgs else None
         self.o_scratch = ngf + (nk + nb) * C
         s = prefix + 'masks/'
+        self.mask_cin = Cmask if self.dep_mask else ngf            # channels of maskin the mask conv reads
         self.masks_out = ConvLayer(store, s + 'conv2d/kernel', s + 'conv2d/bias', 'conv', (3, 3), (1, 1), (1, 1),
-                                   cx_pad=Cmask, cy_pad=Ml)
+                                   cx_pad=self.mask_cin, cy_pad=Ml)
         self.logits = Act((T1, N, H, W, Ml), dev, grad=g)
         self.masks = torch.empty(T1, N, H, W, M, device=dev)
         self.gen = Act((T1, N, H, W, C), dev, grad=g, zero_grad=True)
@@ -286,10 +290,11 @@ class SAVPGenerator(object):
         # ---- merged 3x3 heads on the last decoder layer (SAVP_MERGE_HEADS=0: one launch per head, the reference's structure) ----
         # h6_scratch, h6_masks (and h6_flow / h6_dna_kernel) all read h_last through a 3x3 conv + instance norm + relu: ONE conv with
         # concatenated output channels, ONE instance norm over them, outputs routed by channel range; backward likewise.
-        head_convs = [self.scratch_conv, self.masks_conv]
+        head_convs = ([self.scratch_conv] if self.scratch else []) + [self.masks_conv]
         if self.merge_heads:
-            parts = [(self.scratch_conv.kernel_name, self.scratch_conv.bias_name), (self.masks_conv.kernel_name, self.masks_conv.bias_name)]
-            norms = [self.scratch_norm, self.masks_norm]
+            parts = ([(self.scratch_conv.kernel_name, self.scratch_conv.bias_name)] if self.scratch else []) + \
+                    [(self.masks_conv.kernel_name, self.masks_conv.bias_name)]
+            norms = ([self.scratch_norm] if self.scratch else []) + [self.masks_norm]
             if self.tf != 'cdna':
                 parts.append((self.tf_conv.kernel_name, self.tf_conv.bias_name))
                 norms.append(self.tf_norm)
@@ -301,7 +306,7 @@ class SAVPGenerator(object):
             head_convs = [self.heads_conv]
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
                      [L['cconv'] for L in self.layers if L['rnn'] and self.gru] + \
-                     tf_convs + head_convs + [self.scratch_out, self.masks_out]
+                     tf_convs + head_convs + ([self.scratch_out] if self.scratch else []) + [self.masks_out]
         # only FPROP packs needed at inference
         self._routes()
 
@@ -442,7 +447,8 @@ class SAVPGenerator(object):
                 # one conv + one instance norm for every 3x3 head on h_last; outputs routed by channel range
                 hn = self.heads_norm
                 self.heads_conv.forward(self.h_last.v[t], self.heads_pre.v[t])
-                outs = [self.scratch_h.v[t], maskin.v[t][..., 0:ngf]] + ([self.tf_h.v[t]] if self.tf != 'cdna' else [])
+                outs = ([self.scratch_h.v[t]] if self.scratch else []) + [maskin.v[t][..., 0:ngf]] + \
+                       ([self.tf_h.v[t]] if self.tf != 'cdna' else [])
                 K.instnorm_act_fwd(self.heads_pre.v[t], hn.gamma, hn.beta, outs, hn.mean[t], hn.rstd[t], act='relu', eps=EPS_IN,
                                    out_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
             if self.tf == 'cdna':
@@ -462,20 +468,21 @@ class SAVPGenerator(object):
                 else:
                     K.dna_apply_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], tslot, self.kh, self.kw, self.nk)
             # scratch image (savp_model.py:561-572): sigmoid fused into the conv epilogue, written into its mask-conv slot
-            if not self.merge_heads:
+            if self.scratch and not self.merge_heads:
                 self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
                 sn = self.scratch_norm
                 K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
                                    act='relu', eps=EPS_IN)
-            self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs],
-                                     act=lib.ACT_SIGMOID)
+            if self.scratch:
+                self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs],
+                                         act=lib.ACT_SIGMOID)
             # masks (savp_model.py:623-646)
             if not self.merge_heads:
                 self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
                 mn = self.masks_norm
                 K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
                                    act='relu', eps=EPS_IN)
-            self.masks_out.forward(maskin.v[t], self.logits.v[t])
+            self.masks_out.forward(maskin.v[t][..., 0:self.mask_cin], self.logits.v[t])
             K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:self.hp.ngf + self.M * C], self.gen.v[t],
                             self.masks[t] if collect_masks else None, M=self.M)
         return self.gen.v
@@ -500,11 +507,11 @@ class SAVPGenerator(object):
             # composite + masks head
             K.composite_bwd(self.logits.v[t], maskin.v[t][..., ngf:ngf + self.M * C], self.gen.g[t], self.logits.g[t], maskin.g[t],
                             ngf, M=self.M)
-            self.masks_out.backward_data(self.logits.g[t], maskin.g[t], beta=1)
-            # scratch head: d(sigmoid) then the scratch_image conv's data gradient
-            K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + self.Cs],
-                          maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs], self.dscratch_pre[t])
-            self.scratch_out.backward_data(self.dscratch_pre[t], self.scratch_h.g[t], beta=0)
+            self.masks_out.backward_data(self.logits.g[t], maskin.g[t][..., 0:self.mask_cin], beta=1)
+            if self.scratch:       # scratch head: d(sigmoid) then the scratch_image conv's data gradient
+                K.sigmoid_bwd(maskin.g[t][..., self.o_scratch:self.o_scratch + self.Cs],
+                              maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs], self.dscratch_pre[t])
+                self.scratch_out.backward_data(self.dscratch_pre[t], self.scratch_h.g[t], beta=0)
             # pixel transformation head (everything behind its 3x3 feature conv)
             dslot = maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             if self.tf == 'cdna':
@@ -522,7 +529,8 @@ class SAVPGenerator(object):
             # the 3x3 feature convs on h_last: instance norm + conv data gradients into h_last.g
             if self.merge_heads:
                 hn = self.heads_norm
-                dys = [self.scratch_h.g[t], maskin.g[t][..., 0:ngf]] + ([self.tf_h.g[t]] if self.tf != 'cdna' else [])
+                dys = ([self.scratch_h.g[t]] if self.scratch else []) + [maskin.g[t][..., 0:ngf]] + \
+                      ([self.tf_h.g[t]] if self.tf != 'cdna' else [])
                 K.instnorm_act_bwd(self.heads_pre.v[t], hn.gamma, hn.beta, None, hn.mean[t], hn.rstd[t], dys, self.heads_pre.g[t],
                                    hn.dgamma, hn.dbeta, act='relu', eps=EPS_IN, dy_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
                 self.heads_conv.backward_data(self.heads_pre.g[t], self.h_last.g[t], beta=0)
@@ -531,10 +539,11 @@ class SAVPGenerator(object):
                 K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
                                    [maskin.g[t][..., 0:ngf]], self.masks_pre.g[t], mn.dgamma, mn.dbeta, act='relu', eps=EPS_IN)
                 self.masks_conv.backward_data(self.masks_pre.g[t], self.h_last.g[t], beta=0)
-                sn = self.scratch_norm
-                K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
-                                   [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
-                self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
+                if self.scratch:
+                    sn = self.scratch_norm
+                    K.instnorm_act_bwd(self.scratch_pre.v[t], sn.gamma, sn.beta, self.scratch_h.v[t], sn.mean[t], sn.rstd[t],
+                                       [self.scratch_h.g[t]], self.scratch_pre.g[t], sn.dgamma, sn.dbeta, act='relu', eps=EPS_IN)
+                    self.scratch_conv.backward_data(self.scratch_pre.g[t], self.h_last.g[t], beta=1)
                 if self.tf != 'cdna':
                     tn = self.tf_norm
                     K.instnorm_act_bwd(self.tf_pre.v[t], tn.gamma, tn.beta, self.tf_h.v[t], tn.mean[t], tn.rstd[t], [self.tf_h.g[t]],
@@ -608,10 +617,12 @@ class SAVPGenerator(object):
             self.heads_conv.backward_weights(hl.flat(hl.v), hl.flat(self.heads_pre.g))
             self.heads_norm.finish()
         else:
-            self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
+            if self.scratch:
+                self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
             self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
-        self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
-        self.masks_out.backward_weights(hl.flat(maskin.v), hl.flat(self.logits.g))
+        if self.scratch:
+            self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
+        self.masks_out.backward_weights(hl.flat(maskin.v)[..., 0:self.mask_cin], hl.flat(self.logits.g))
         for c in self.convs:
             c.finish_weight_grad()
         # ---- z path ----------------------------------------------------------------------------------------------
