@@ -28,7 +28,7 @@ const char* savp_version(void);
 
 /* Kernel-selection switches (process-wide; SAVP_EINVAL for an unknown name).  Names and defaults: "conv_ring" 0 (auto algorithm
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1 (problem-specific kernels on), "colsum_2stage" 1,
- * "inorm_min_hw" 256, and the developer overrides "wgp_cfg", "wgp_split", "dense_legacy", "cdna_legacy" (0). */
+ * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
 
@@ -138,7 +138,7 @@ typedef struct SavpInormArgs {
     int32_t ndy; SavpView dy[4];
     SavpView dx; int32_t dx_beta;
     float* dgamma; float* dbeta;
-    float* ws;                     /* optional scratch [N*C*2]: selects the coalesced two-kernel path for planes of >= 256 pixels */
+    float* ws;                     /* optional scratch [N*C*2]: selects the coalesced two-kernel path for planes of >= "inorm_min_hw" (64) pixels */
     int32_t ws_clean;              /* 1: the caller guarantees ws is all zero (e.g. a slice of an arena cleared once per step),
                                       0: the library clears it with a memset per call */
     int32_t out_c0[4], out_nc[4];  /* fwd: output k receives channels [out_c0, out_c0 + out_nc) of the normalised tensor, stored from

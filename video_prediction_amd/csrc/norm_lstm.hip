@@ -1428,6 +1428,8 @@ static bool lstm_fused_cfg(const SavpLstmArgs* a, bool fwd, int& Q, int& PPT, in
     Q = 1;
     for (int c = 4; c > 1; c >>= 1)
         if (a->F % (4 * c) == 0 && a->HW <= 4 * (NT / c) && (long long)a->N * (a->F / (4 * c)) >= 256) { Q = c; break; }
+    const int fq = savp_opt(OPT_LSTM_Q);
+    if ((fq == 1 || fq == 2 || fq == 4) && a->F % (4 * fq) == 0 && a->HW <= 4 * (NT / fq)) Q = fq;
     const int rows = NT / Q;
     PPT = a->HW <= rows ? 1 : (a->HW <= 2 * rows ? 2 : 4);
     nslab = a->F / (4 * Q);

@@ -9,11 +9,12 @@ enum SavpOptId {
     OPT_THIN,              // RGB-side convolution kernels (1)
     OPT_WGP_CFG,           // developer: force a configuration of the LDS-patch weight gradient (0 = auto)
     OPT_WGP_SPLIT,         // developer: force its number of workgroups (0 = auto)
-    OPT_INORM_MIN_HW,      // smallest plane that takes the coalesced two-kernel instance norm (256)
+    OPT_INORM_MIN_HW,      // smallest plane that takes the coalesced two-kernel instance norm (64: measured 60.28 / 60.47 / 60.92 / 61.83 ms per step at 64 / 256 / 512 / 2048)
     OPT_COLSUM_2STAGE,     // partial rows + reduce launch for large column sums when a workspace is supplied (1)
     OPT_DENSE_LEGACY,      // developer: pre-round-2 few-row dense kernel (0)
     OPT_CDNA_LEGACY,       // developer: pre-round-2 CDNA kernels (0)
     OPT_LSTM_FUSED,        // one-launch ConvLSTM gate block, forward and backward (1)
+    OPT_LSTM_Q,            // developer: force the threads per pixel (channel quads per slab) of the one-launch gate kernels (0 = auto)
     OPT_COUNT
 };
 
