@@ -263,17 +263,27 @@ def main(argv=None):
     start_time = time.time()
     info = None
     # start at one step earlier to log everything without doing any training; step is relative to start_step (train.py:240-242)
+    def have_batch(it_inputs):
+        """End of data (finite num_epochs) must be a collective decision: replicas read different file shards and may run dry at
+        different steps -- a rank that left the loop alone would leave the others blocked in the gradient all-reduce."""
+        ok = it_inputs is not None
+        if dist is not None and getattr(train_dataset, 'num_epochs', None) is not None:     # endless data: no per-step collective / sync
+            flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        return ok
+
     for step in range(-1, max_steps - start_step):
         if step == 1:
             start_time = time.time()            # skip step -1 and 0 for timing purposes (train.py:243-245)
         global_step = model.global_step
         if step >= 0:
+            if step > 0:                        # the batch of step 0 was fetched for build_graph; later ones at the top of their own step,
+                inputs = next(train_iter, None)  # so that the summary / progress / save blocks below always run for the step just trained
+            if not have_batch(inputs):
+                break
             run_start_time = time.time()
             info = model.train_step(inputs)
-            try:
-                inputs = next(train_iter)
-            except StopIteration:
-                break
             if should(step, args.progress_freq, max_steps, start_step):
                 torch.cuda.synchronize()
             run_elapsed_time = time.time() - run_start_time
