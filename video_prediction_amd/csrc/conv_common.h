@@ -40,6 +40,10 @@ struct ConvP {
     int src16;                                // source activations are bf16 (strides in elements)
     int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
     float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
+    // bf16 source staged by LDS-DMA (src16 && dma_patch): the patch as a sequence of 16-byte slots
+    int dma_patch;                            // 1: stage_patch_dma (16-byte aligned bf16 source)
+    const void* zero16;                       // 16 zero bytes in global memory (source of halo / padding slots)
+    unsigned long long s1_magPI8, s1_magP8, s1_magC8;   // fastdiv by slots per image (PH * pitch / 8), per patch row (pitch / 8), per pixel (CP / 8)
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {

@@ -213,6 +213,43 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         }
     };
 
+    // ---- the same patch filled by LDS-DMA (bf16 source, round 3): the patch is a run of 16-byte slots -- [image][patch row][pixel]
+    // [8-channel chunk], row pitch and pixel pitch both multiples of 16 bytes -- so a wave instruction of `global_load_lds_dwordx4`
+    // fills 64 consecutive slots, each lane from its own source address: the pixel's 8 channels, or 16 zero bytes in global memory
+    // for halo pixels, channels beyond Cred, images beyond N and the pad slots.  No VGPR round trip, no conversion, no ds_write (the
+    // VGPR path above is instruction-bound: 12-22 k cycles of a 62-105 k cycle gate convolution).  The DMAs are drained (vmcnt 0)
+    // before the barrier that publishes the patch, so the weight ring's counted waits never see them.
+    auto stage_patch_dma = [&](int cfirst) {
+        const int C8 = CP >> 3, P8 = pitch >> 3;
+        const int used8 = (spp * CKB) >> 3;                   // chunks of a pixel that are read (the last one of CP is pitch padding)
+        const int per_img8 = PH * P8;
+        const int total = ni * per_img8;
+        const unsigned patch_lds = ring_lds + (unsigned)(RING * SLABB);
+        const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src);
+        for (int base = wave * 64; base < (ABL(4) ? 0 : total); base += NT) {
+            const int slot = base + lane;
+            if (slot < total) {
+                const int im = (int)fastdiv((unsigned)slot, p.s1_magPI8);
+                const int rem = slot - im * per_img8;
+                const int pyy = (int)fastdiv((unsigned)rem, p.s1_magP8);
+                const int r = rem - pyy * P8;
+                const int pxx = (int)fastdiv((unsigned)r, p.s1_magC8);
+                const int ch8 = r - pxx * C8;
+                const int iy = org_h + pyy, ix = org_w + pxx;
+                const int cg = cfirst * CKB + ch8 * 8;
+                const int gi = img0 + im;
+                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
+                const bool ok = pxx < PW && ch8 < used8 && (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN &&
+                                cg < Cred && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
+                const long long off = (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg;
+                const void* g = ok ? static_cast<const void*>(src_b + off * 2) : p.zero16;
+                ring_dma16(g, patch_lds + (unsigned)(base * 16));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -305,7 +342,9 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                                  (unsigned)((pu * pitch + pv * CP + sl * CKB) * 2));
         }
         RT(1);
-        if (p.src16) stage_patch(g_first, std::true_type{}); else stage_patch(g_first, std::false_type{});
+        if (p.dma_patch) stage_patch_dma(g_first);
+        else if (p.src16) stage_patch(g_first, std::true_type{});
+        else stage_patch(g_first, std::false_type{});
         __syncthreads();                                   // table + patch visible
         RT(2);
         issue(etab[0], B0{});
@@ -491,6 +530,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned g_ring_zero[4] = {0u, 0u, 0u, 0u};      // source of the DMA-staged patch's zero slots
+
 template <int NW, int WM, int WN, int NKS>
 static hipError_t launch_ring(const ConvP& p, dim3 grid, size_t lds, hipStream_t st) {
     static size_t attr_lds = 0;
@@ -591,6 +632,15 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
     p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
     p.s1_magDm = magic40(Dm);
+    // LDS-DMA patch staging: bf16 source whose pixel rows are 16-byte aligned runs (option "ring_dma" = 0: the VGPR path, for A/B)
+    {
+        const long long ssn = dg ? a->y_sn : a->x_sn, ssd = dg ? a->y_sd : a->x_sd, ssh = dg ? a->y_sh : a->x_sh, ssw = dg ? a->y_sw : a->x_sw;
+        const void* sptr = dg ? a->y : a->x;
+        const int CP = spp * nks * 16 + 8;
+        p.dma_patch = (savp_opt(OPT_RING_DMA) && a->src_bf16 && (ssn % 8 == 0) && (ssd % 8 == 0) && (ssh % 8 == 0) && (ssw % 8 == 0) &&
+                       ((((uintptr_t)sptr) & 15) == 0) && p.zero16 && (long long)ni * PH * (pitch / 8) < (1 << 24) && (long long)PH * (pitch / 8) < 65536 && (pitch % 8 == 0)) ? 1 : 0;
+        p.s1_magPI8 = magic40(PH * (pitch / 8)); p.s1_magP8 = magic40(pitch / 8); p.s1_magC8 = magic40(CP / 8);
+    }
     p.tm = (int)(((long long)a->N * Dm + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
     const long long tiles = (long long)p.tm * p.tn;
     const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
@@ -638,6 +688,9 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
     if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)Nout * a->kh * a->kw * a->kd * Cred >= (1ll << 30))
         return false;
     if ((long long)Hm * Wm < 16) return false;
+    static const void* zero16 = nullptr;                         // address of g_ring_zero (resolved once; a constant of the loaded code object)
+    if (!zero16 && hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16 = nullptr;
+    p.zero16 = zero16;
     RingPlan pl;
     bool ok = false;
     if (wm) {

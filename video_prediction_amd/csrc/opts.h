@@ -14,6 +14,7 @@ enum SavpOptId {
     OPT_DENSE_LEGACY,      // developer: pre-round-2 few-row dense kernel (0)
     OPT_CDNA_LEGACY,       // developer: pre-round-2 CDNA kernels (0)
     OPT_LSTM_FUSED,        // one-launch ConvLSTM gate block, forward and backward (1)
+    OPT_RING_DMA,          // bf16 sources of the ring kernel are staged into the LDS patch by LDS-DMA (1)
     OPT_LSTM_Q,            // developer: force the threads per pixel (channel quads per slab) of the one-launch gate kernels (0 = auto)
     OPT_COUNT
 };
