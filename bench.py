@@ -40,6 +40,10 @@ RECIPE = dict(  # hparams/bair_action_free/ours_savp/model_hparams.json of the r
 #   c4: configs[3] -- KTH 64x64x1, seq 40, context 10 (kth_dataset.py:26-36), nz 32 / kl 0.01 (hparams/kth/ours_savp), batch 16 per GPU
 #   c5: configs[4] -- synthetic 128x128x3, seq 30, context 2, batch 8 per GPU (the >= 128 layer table, savp_model.py:198-210)
 CONFIGS = {
+    # c1: configs[0] -- the reference's CPU-runnable plumbing case (ours_deterministic_l1: nz=0, l1 only), BAIR, context 2 + 10, batch 4
+    'c1': dict(name='BAIR action-free 64x64x3 (deterministic)', shape=(64, 64, 3), seq=12, context=2, batch=4,
+               over=dict(nz=0, lr=0.001, beta1=0.9, l1_weight=1.0, kl_weight=0.0, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                         vae_gan_feature_cdist_weight=0.0)),
     'c2': dict(name='BAIR action-free 64x64x3', shape=(64, 64, 3), seq=30, context=2, batch=16, over={}),
     'c4': dict(name='KTH 64x64x1', shape=(64, 64, 1), seq=40, context=10, batch=16, over=dict(nz=32, kl_weight=0.01)),
     'c5': dict(name='synthetic 128x128x3', shape=(128, 128, 3), seq=30, context=2, batch=8, over={}),
@@ -318,12 +322,14 @@ def main():
                 traffic = None
     frames = world * args.batch * seq * args.steps
     result = {
-        'metric': 'train frames/sec (whole node), %s seq%d SAVP' % ({'c2': 'BAIR 64x64', 'c4': 'KTH 64x64', 'c5': 'synthetic 128x128'}[args.config], seq),
+        'metric': 'train frames/sec (whole node), %s seq%d SAVP' % ({'c1': 'BAIR 64x64 deterministic', 'c2': 'BAIR 64x64', 'c4': 'KTH 64x64', 'c5': 'synthetic 128x128'}[args.config], seq),
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': '%s: SAVP full VAE-GAN (ours_savp recipe), %s, seq=%d, context=%d, nz=%d, '
-                               'batch=%d per GPU, D step + G/E step per train step' % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
+        'config': {'workload': ('%s: SAVP full VAE-GAN (ours_savp recipe), %s, seq=%d, context=%d, nz=%d, batch=%d per GPU, D step + G/E step '
+                                'per train step' if engine.has_d else
+                                '%s: SAVP deterministic generator (ours_deterministic_l1 recipe), %s, seq=%d, context=%d, nz=%d, batch=%d per GPU, '
+                                'one Adam step on the L1 loss per train step') % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
                    'global_batch': world * args.batch, 'seq_len': seq, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt,
                    'submission': mode, 'eager_ms_per_step': eager_ms, 'instrumented_ms_per_step': inst_ms},

@@ -295,6 +295,15 @@ def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
     return out
 
 
+def check_config_c1():
+    """BASELINE configs[0] at its own shape: ours_deterministic_l1 (hparams/bair_action_free/ours_deterministic_l1/model_hparams.json:
+    nz=0, l1 only, lr 1e-3, beta1 0.9), BAIR 64x64x3, context 2 + predict 10 -> T=12, B=4; forward and one train step, fp32 datapath."""
+    res = check_generator_forward(nz=0, B=4, T=12, tag='c1_det_fwd')
+    res += check_train_step(B=4, T=12, nz=0, steps=1, tag='c1_det_train', lr=1e-3, beta1=0.9, beta2=0.999, l1_weight=1.0, l2_weight=0.0,
+                            kl_weight=0.0, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
+    return res
+
+
 def check_config_c4():
     res = check_generator_forward(nz=32, B=2, T=12, C=1, tag='c4_kth_fwd', context_frames=10)
     res += check_train_step(B=1, T=12, C=1, nz=32, steps=1, tag='c4_kth_train', context_frames=10, clip_length=10, kl_weight=0.01)

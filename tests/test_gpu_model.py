@@ -61,6 +61,13 @@ def test_learned_prior_and_recurrent_encoder_vs_oracle():
     _assert_ok(res)
 
 
+def test_config_c1_deterministic_b4_t12_forward_and_train_vs_oracle():
+    """BASELINE configs[0] at its own shape (not scaled): deterministic generator, nz=0, B=4, T=12, 64x64x3, the
+    ours_deterministic_l1 recipe."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_config_c1())
+
+
 def test_config_c4_kth_forward_and_train_vs_oracle():
     """BASELINE configs[3] shapes scaled in batch/time: KTH 64x64x1, nz=32, context 10 (datasets/kth_dataset.py:26-36,
     hparams/kth/ours_savp/model_hparams.json)."""
