@@ -143,6 +143,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='(default on one GPU; kept for older command lines)')
     ap.add_argument('--inst-steps', type=int, default=8, help='instrumented eager steps after the timed region (0: none, roofline objects empty)')
     ap.add_argument('--no-f32', action='store_true', help='skip the second object: the exact-fp32 datapath on the same workload')
+    ap.add_argument('--tuning-table', default=None, help='developer: a tuning table other than the shipped one (A/B of re-tuned entries)')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
     args = ap.parse_args()
@@ -200,7 +201,7 @@ def main():
         K.enable_autotune(not args.no_autotune)      # tile / split-K selection happens during the warm-up steps
         # shipped table of the BASELINE workload (measured on MI355X by an earlier run of this script with --save-tuning):
         # problems found in it are not timed again, anything else is tuned live during the warm-up
-        table = os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % precision)
+        table = args.tuning_table or os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % precision)
         if not args.no_autotune and not args.retune and os.path.exists(table):
             K.load_tuning(table)
         model = make_hparams(args.batch, seq, cfg['context'], cfg['over'])
@@ -236,6 +237,7 @@ def main():
     dt, info = timed_steps(engine, args.warmup, args.steps)
     mode = 'hipGraph replay' if (engine.use_graph and engine.graph is not None) else 'eager launches'
     eager_ms = None
+    host_issue_ms = None
     INST_STEPS = max(0, args.inst_steps)
     engine.use_graph = False
     inst = convlstm_flops(engine)
@@ -260,6 +262,16 @@ def main():
             L['cell_prof'] = None
         e_dt, _ = timed_steps(engine, 1, min(args.steps, 10))
         eager_ms = e_dt / min(args.steps, 10) * 1e3
+        # host time to ISSUE one eager step (GPU idle at the start of each measurement, no sync before the clock stops): the head-room
+        # of launch-by-launch submission -- what a replica of a multi-GPU run, which cannot replay a graph around its collectives, needs
+        acc = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            engine.train_step()
+            acc += time.perf_counter() - th
+        torch.cuda.synchronize()
+        host_issue_ms = acc / 3 * 1e3
         for layer, _ in inst:
             layer.prof = prof_lists[id(layer)]
     # roofline of the dominant kernel family from the live event pairs
@@ -332,7 +344,7 @@ def main():
                                 'one Adam step on the L1 loss per train step') % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
                    'global_batch': world * args.batch, 'seq_len': seq, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt,
-                   'submission': mode, 'eager_ms_per_step': eager_ms, 'instrumented_ms_per_step': inst_ms},
+                   'submission': mode, 'eager_ms_per_step': eager_ms, 'host_issue_ms_per_step': host_issue_ms, 'instrumented_ms_per_step': inst_ms},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic, 'algorithmic_bytes': traffic_alg,
                      'traffic_unit': 'HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '

@@ -13,6 +13,32 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define BKP 36          // padded K row (floats) for the row-major-K LDS layout
 #define NTHREADS 256
 
+struct DimGeom {          // one spatial dimension of the (possibly phase-restricted) problem
+    int Mdim;             // extent of the M-grid along this dim
+    int base, mstep;      // source coord = base + m*mstep + j*jstep
+    int jstep;
+    int nt;               // number of (reduced) taps
+    int t0, tstep;        // full weight tap index = t0 + j*tstep
+    int ob, os;           // destination coord = ob + m*os
+    int srcN;             // source extent (bounds)
+};
+
+__host__ __device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out, int k, int s, int p) {
+    DimGeom g;
+    if (!dgrad) {
+        g.Mdim = Out; g.base = -p; g.mstep = s; g.jstep = 1; g.nt = k; g.t0 = 0; g.tstep = 1;
+        g.ob = 0; g.os = 1; g.srcN = In;
+    } else {
+        int u0 = (f + p) % s;
+        g.nt = (k > u0) ? (k - u0 + s - 1) / s : 0;
+        g.base = (f + p - u0) / s; g.mstep = 1; g.jstep = -1;
+        g.t0 = u0; g.tstep = s;
+        g.Mdim = (In > f) ? (In - f + s - 1) / s : 0;
+        g.ob = f; g.os = s; g.srcN = Out;
+    }
+    return g;
+}
+
 struct ConvP {
     int mode;
     int N, D, H, W, Cx;
@@ -44,11 +70,38 @@ struct ConvP {
     int dma_patch;                            // 1: stage_patch_dma (16-byte aligned bf16 source)
     const void* zero16;                       // 16 zero bytes in global memory (source of halo / padding slots)
     unsigned long long s1_magPI8, s1_magP8, s1_magC8;   // fastdiv by slots per image (PH * pitch / 8), per patch row (pitch / 8), per pixel (CP / 8)
+    // launch constants of conv_ring_kernel, worked out by the launcher (pre = 1: FPROP, or DGRAD with unit H/W strides -- every
+    // workgroup then sees the same geometry; 0: the kernel derives them from blockIdx.y's output phase).  Fifteen scalar integer
+    // divisions leave the kernel's prologue this way (1-2 k of its 8-10 k cycles, profiles/r03_ring_prologue_stamps.log).  The same
+    // change made conv_patch_kernel 10-19 % SLOWER in the step (its main loop's register allocation) and was not kept there.
+    int pre;
+    DimGeom gD, gH, gW;
+    int s1_tih_sh;                            // log2(s1_tih): tile rows per image are a power of two
+    int s1_ngs, s1_itper;                     // slab groups per depth tap, (tap, slab) entries per K split
+    unsigned long long s1_magTm, s1_magTHW, s1_magTW;    // fastdiv by tm, tiles per image (th * tw), tile columns
+    unsigned long long s1_magKw, s1_magSpp, s1_magTail;  // fastdiv by the reduced tap columns, slabs per group, slabs of the last group
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
     // floor(p / d) for p < 2^24, d < 2^16 with magic = ceil(2^40 / d)
     return (unsigned)(((unsigned long long)p * magic) >> 40);
+}
+
+// Touch every 64-byte line of the kernel-argument segment with one scalar load each and wait for all of them once.  The
+// argument block of a launch is always cold (the command processor has just written it) and a miss is an HBM-latency round trip
+// (~2 k cycles); hipcc loads a 500-byte struct field group by field group as the code reaches them, so a long prologue pays
+// that latency three or four times in series (cycle stamps of conv_ring_kernel: ~3 k cycles before the first use of the
+// geometry, 1.2 k more for the next group, ...).  After this call every later s_load of the struct hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    constexpr int LINES = (BYTES + 63) / 64;
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t[LINES];
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) asm volatile("s_load_dword %0, %1, %2" : "=&s"(t[i]) : "s"(ka), "n"(i * 64) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) asm volatile("" :: "s"(t[i]));
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -62,36 +115,33 @@ __device__ __forceinline__ int xcd_logical(int b, int n) {
 }
 
 
-struct DimGeom {          // one spatial dimension of the (possibly phase-restricted) problem
-    int Mdim;             // extent of the M-grid along this dim
-    int base, mstep;      // source coord = base + m*mstep + j*jstep
-    int jstep;
-    int nt;               // number of (reduced) taps
-    int t0, tstep;        // full weight tap index = t0 + j*tstep
-    int ob, os;           // destination coord = ob + m*os
-    int srcN;             // source extent (bounds)
-};
-
-__device__ __forceinline__ DimGeom make_geom(bool dgrad, int f, int In, int Out, int k, int s, int p) {
-    DimGeom g;
-    if (!dgrad) {
-        g.Mdim = Out; g.base = -p; g.mstep = s; g.jstep = 1; g.nt = k; g.t0 = 0; g.tstep = 1;
-        g.ob = 0; g.os = 1; g.srcN = In;
-    } else {
-        int u0 = (f + p) % s;
-        g.nt = (k > u0) ? (k - u0 + s - 1) / s : 0;
-        g.base = (f + p - u0) / s; g.mstep = 1; g.jstep = -1;
-        g.t0 = u0; g.tstep = s;
-        g.Mdim = (In > f) ? (In - f + s - 1) / s : 0;
-        g.ob = f; g.os = s; g.srcN = Out;
-    }
-    return g;
-}
-
 // ceil(2^40 / d): magic number of fastdiv()
 static inline unsigned long long magic40(int d) {
     if (d <= 0) d = 1;
     return ((1ULL << 40) + (unsigned long long)d - 1ULL) / (unsigned long long)d;
+}
+
+// Launch constants of conv_ring_kernel (ConvP::pre and friends) from the launcher's tiling: identical for every workgroup
+// unless a strided DGRAD splits the output into phases (then pre = 0 and the kernel derives them from blockIdx.y).
+static inline void patch_launch_constants(ConvP& p, const SavpConvArgs* a, int phases, int tih, int nch, int spp, int tW, int splitk) {
+    const bool dg = a->mode == SAVP_CONV_DGRAD;
+    int sh_ = 0;
+    while ((1 << sh_) < tih) ++sh_;
+    p.s1_tih_sh = sh_;
+    const int ngs = (nch + spp - 1) / spp;
+    p.s1_ngs = ngs;
+    p.pre = 0;
+    if (phases != 1 || (dg && (a->sh != 1 || a->sw != 1))) return;
+    p.gD = make_geom(dg, 0, a->D, a->Do, a->kd, 1, a->pd);
+    p.gH = make_geom(dg, 0, a->H, a->Ho, a->kh, a->sh, a->ph);
+    p.gW = make_geom(dg, 0, a->W, a->Wo, a->kw, a->sw, a->pw);
+    const long long it_all = (long long)p.gD.nt * p.gH.nt * p.gW.nt * nch;
+    p.s1_itper = (int)((it_all + splitk - 1) / splitk);
+    const int thw = p.s1_th * tW;
+    p.s1_magTm = magic40(p.tm); p.s1_magTHW = magic40(thw); p.s1_magTW = magic40(tW);
+    p.s1_magKw = magic40(p.gW.nt); p.s1_magSpp = magic40(spp); p.s1_magTail = magic40(nch - (ngs - 1) * spp);
+    // fastdiv: numerators < 2^24, divisors < 2^16
+    if ((long long)p.tm * p.tn < (1 << 24) && p.tm < 65536 && thw < 65536 && it_all < (1 << 24) && p.gW.nt >= 1 && p.gH.nt >= 1) p.pre = 1;
 }
 
 // conv_thin.hip: FPROP / WGRAD of a 3x3(x3) stride-1 convolution with Cx <= 4, Cy = 32 (bf16 mode).  true = handled.

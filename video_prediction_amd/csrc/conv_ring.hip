@@ -55,17 +55,35 @@ __device__ __forceinline__ void sched_interleave() {
 
 #ifdef SAVP_CONV_ABLATE
 __device__ unsigned long long g_ring_t[16];       // developer build: s_memtime stamps of workgroup 0, wave 0 (savp_debug_ring_times)
-#define RT(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_ring_t[i] = __builtin_readcyclecounter(); } while (0)
+__constant__ int g_ring_blk = 0;                  // which workgroup stamps
+#define RT(i) do { if (blockIdx.x == g_ring_blk && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_ring_t[i] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_ring_w[2][8];     // per-wave stamps of workgroup 0: kernel entry, arrival at the first barrier
+#define RTW(k) do { if (blockIdx.x == g_ring_blk && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_ring_w[k][threadIdx.x >> 6] = __builtin_readcyclecounter(); } while (0)
+__constant__ int g_ring_kwarm = 1;                // developer A/B of kernarg_warm
+#define savp_kwarm() g_ring_kwarm
 extern "C" int savp_debug_ring_times(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_t), sizeof(g_ring_t)) == hipSuccess ? 0 : -1;
 }
+extern "C" int savp_debug_ring_wave_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_w), sizeof(g_ring_w)) == hipSuccess ? 0 : -1;
+}
+extern "C" int savp_debug_ring_block(int b) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_blk), &b, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+extern "C" int savp_debug_ring_kwarm(int on) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_kwarm), &on, sizeof(int)) == hipSuccess ? 0 : -1;
+}
 #else
 #define RT(i) do {} while (0)
+#define RTW(k) do {} while (0)
+#define savp_kwarm() true
 #endif
 
 template <int NW, int WM, int WN, int NKS>
 __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     RT(0);
+    RTW(0);
+    if (savp_kwarm()) kernarg_warm<sizeof(ConvP)>();
     constexpr int NT = 64 * NW;
     constexpr int BM = 16 * NW * WM, BN = 64 * WN, TW = 8;
     constexpr int CKB = 16 * NKS;
@@ -78,10 +96,18 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const bool dgrad = (p.mode == SAVP_CONV_DGRAD);
-    const int fh = dgrad ? (int)blockIdx.y / p.sw : 0, fw = dgrad ? (int)blockIdx.y % p.sw : 0;
-    const DimGeom gd = make_geom(dgrad, 0, p.D, p.Do, p.kd, 1, p.pd);
-    const DimGeom gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
-    const DimGeom gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
+    // p.pre: the launcher worked the geometry and the index-arithmetic constants out (ConvP); otherwise (strided DGRAD: the geometry
+    // depends on blockIdx.y's output phase) they are derived here with real divisions
+    const bool pre = p.pre != 0;
+    DimGeom gd, gh, gw;
+    if (pre) { gd = p.gD; gh = p.gH; gw = p.gW; }
+    else {
+        const int fh = dgrad ? (int)blockIdx.y / p.sw : 0, fw = dgrad ? (int)blockIdx.y % p.sw : 0;
+        gd = make_geom(dgrad, 0, p.D, p.Do, p.kd, 1, p.pd);
+        gh = make_geom(dgrad, fh, p.H, p.Ho, p.kh, p.sh, p.ph);
+        gw = make_geom(dgrad, fw, p.W, p.Wo, p.kw, p.sw, p.pw);
+    }
+    auto divq = [&](int x, int d, unsigned long long mag) -> int { return pre ? (int)fastdiv((unsigned)x, mag) : x / d; };
     const int Cred = dgrad ? p.Cy : p.Cx;
     const int Nout = dgrad ? p.Cx : p.Cy;
     const int kh = gh.nt, kw = gw.nt;
@@ -92,8 +118,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int tW = p.s1_tw, tH = p.s1_th;
     const int PW = p.s1_pw, PH = p.s1_ph;
     const int tih = p.s1_tih;
-    const int ni = (BM / TW) / tih;
-    const int rpi = tih * TW;
+    const int rsh = p.s1_tih_sh + 3;                       // log2(rows of one image in the tile): tih is a power of two
+    const int ni = (BM / TW) >> p.s1_tih_sh;
     const int nch = p.s1_nch, pitch = p.s1_pitch;
     const int spp = p.s1_spp;
     const int CP = spp * CKB + 8;
@@ -106,11 +132,13 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     if (ABL(16)) return;
     const int split = blockIdx.z;
     const int tlog = xcd_logical(blockIdx.x, p.tm * p.tn);
-    const int mt = tlog % p.tm;
-    const int n0 = (tlog / p.tm) * BN;
-    const int ig = mt / (tH * tW);
+    const int nt_ = divq(tlog, p.tm, p.s1_magTm);
+    const int mt = tlog - nt_ * p.tm;
+    const int n0 = nt_ * BN;
+    const int ig = divq(mt, tH * tW, p.s1_magTHW);
     const int trem = mt - ig * (tH * tW);
-    const int oy0 = (trem / tW) * tih, ox0 = (trem % tW) * TW;
+    const int trow = divq(trem, tW, p.s1_magTW);
+    const int oy0 = trow * tih, ox0 = (trem - trow * tW) * TW;
     const int img0 = ig * ni;
     if (oy0 >= Hm || ox0 >= Wm || kh <= 0 || kw <= 0) return;
     const int org_h = gh.base + oy0 * gh.mstep + (gh.jstep > 0 ? 0 : (kh - 1) * gh.jstep);
@@ -124,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 
     const int it_dep = ntaps * nch;
     const int it_all = gd.nt * it_dep;
-    const int it_per = (it_all + p.splitk - 1) / p.splitk;
+    const int it_per = pre ? p.s1_itper : (it_all + p.splitk - 1) / p.splitk;
     const int it_begin = split * it_per;
     const int it_end = min(it_all, it_begin + it_per);
 
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int row = wm0 + i * 32 + l31;
-        const int im = row / rpi, rr = row - im * rpi;
+        const int im = row >> rsh, rr = row - (im << rsh);
         arow[i] = im * pimg + (rr >> 3) * gh.mstep * pitch + (rr & 7) * gw.mstep * CP + khalf * 8;
     }
     const int brow0 = (wn0 + l31) * BROW + khalf * 8;
@@ -313,12 +341,13 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     // ---- group-outer loop; inside a group the weight slabs stream through the four-deep DMA ring -----------------------------
     // entry e: its slab is DMAed three iterations ahead, its fragments are read one iteration ahead, its MFMAs run in iteration e.
     const int gsz = ntaps * spp;
-    const int ngs = (nch + spp - 1) / spp;
+    const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     Frags F0, F1;
     using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
-    for (int gg = (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
-        g_jd = gg / ngs;
+    for (int gg = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
+        RT(11);
+        g_jd = (gd.nt == 1) ? 0 : gg / ngs;
         const int g = gg - g_jd * ngs;
         g_first = g * spp;
         g_slabs = min(spp, nch - g_first);
@@ -328,12 +357,14 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         const int t_end = ABL(32) ? 0 : min(it_end, e_lo + ntaps * g_slabs) - e_lo;
         if (t_begin >= t_end) continue;
         const int len = t_end - t_begin;
+        RT(12);
+        RTW(1);
         __syncthreads();                                   // previous group's patch, ring and table are dead (no DMA in flight here)
         RT(10);
         for (int e = tid; e < len; e += NT) {              // entry table of this group
             const int ent = t_begin + e;
-            const int tap = ent / g_slabs, sl = ent - tap * g_slabs;
-            const int jh = tap / kw, jw = tap - jh * kw;
+            const int tap = divq(ent, g_slabs, g_slabs == spp ? p.s1_magSpp : p.s1_magTail), sl = ent - tap * g_slabs;
+            const int jh = divq(tap, kw, p.s1_magKw), jw = tap - jh * kw;
             const int f_tap = ((gd.t0 + g_jd * gd.tstep) * p.kh + (gh.t0 + jh * gh.tstep)) * p.kw + (gw.t0 + jw * gw.tstep);
             const int f_cc = g_first + sl;
             const int pu = gh.jstep > 0 ? jh * gh.jstep : (kh - 1 - jh) * -gh.jstep;
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int rowb = wm0 + i * 32;
-            const int im = rowb / rpi;
+            const int im = rowb >> rsh;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 float s = 0.f, q = 0.f;
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         constexpr int CH = BN / 8;                            // 16-byte pieces per tile row
         for (int idx = tid; idx < BM * CH; idx += NT) {
             const int row = idx / CH, c8 = idx - row * CH;
-            const int im = row / rpi, rr = row - im * rpi;
+            const int im = row >> rsh, rr = row - (im << rsh);
             const int gi = img0 + im;
             const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
             const int py = oy0 + (rr >> 3), px = ox0 + (rr & 7);
@@ -483,8 +514,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int rowb = wm0 + i * 32;
-        const int im = rowb / rpi;
-        const int py0 = oy0 + ((rowb - im * rpi) >> 3);
+        const int im = rowb >> rsh;
+        const int py0 = oy0 + ((rowb - (im << rsh)) >> 3);
         const int gi = img0 + im;
         if (gi >= nimg) continue;
         const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
@@ -663,6 +694,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         if (!dense) splitk = 1;
     }
     p.splitk = splitk;
+    patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
     pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
     pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     return true;
