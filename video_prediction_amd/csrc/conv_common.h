@@ -75,6 +75,7 @@ struct ConvP {
     // divisions leave the kernel's prologue this way (1-2 k of its 8-10 k cycles, profiles/r03_ring_prologue_stamps.log).  The same
     // change made conv_patch_kernel 10-19 % SLOWER in the step (its main loop's register allocation) and was not kept there.
     int pre;
+    int wwarm;                                // conv_ring_kernel: warm the L2 with the column tile's weight block first (option ring_wwarm)
     DimGeom gD, gH, gW;
     int s1_tih_sh;                            // log2(s1_tih): tile rows per image are a power of two
     int s1_ngs, s1_itper;                     // slab groups per depth tap, (tap, slab) entries per K split
@@ -85,23 +86,6 @@ struct ConvP {
 __device__ __forceinline__ unsigned fastdiv(unsigned p, unsigned long long magic) {
     // floor(p / d) for p < 2^24, d < 2^16 with magic = ceil(2^40 / d)
     return (unsigned)(((unsigned long long)p * magic) >> 40);
-}
-
-// Touch every 64-byte line of the kernel-argument segment with one scalar load each and wait for all of them once.  The
-// argument block of a launch is always cold (the command processor has just written it) and a miss is an HBM-latency round trip
-// (~2 k cycles); hipcc loads a 500-byte struct field group by field group as the code reaches them, so a long prologue pays
-// that latency three or four times in series (cycle stamps of conv_ring_kernel: ~3 k cycles before the first use of the
-// geometry, 1.2 k more for the next group, ...).  After this call every later s_load of the struct hits the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ void kernarg_warm() {
-    constexpr int LINES = (BYTES + 63) / 64;
-    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned t[LINES];
-#pragma unroll
-    for (int i = 0; i < LINES; ++i) asm volatile("s_load_dword %0, %1, %2" : "=&s"(t[i]) : "s"(ka), "n"(i * 64) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < LINES; ++i) asm volatile("" :: "s"(t[i]));
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }

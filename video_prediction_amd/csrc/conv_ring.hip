@@ -150,6 +150,33 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // ---- L2 warm-up of this column tile's weight block ------------------------------------------------------------------
+    // The block (BN rows x ldb bf16, contiguous in the packed layout) is streamed by every workgroup of the tile through a
+    // four-deep DMA ring: three slabs (~1.5 k cycles) of look-ahead.  Inside the train step the weights are cold (each layer's
+    // are touched once per time step, tens of MB of other traffic in between) and an L2 miss costs more than the look-ahead:
+    // the in-step gate convolutions ran 5-15 us above their back-to-back time (tests/tools/insitu_tune.py).  All workgroups of
+    // a column tile on one XCD (consecutive logical ids, one private L2) therefore split the block between them and pull their
+    // slices in with LDS-DMA instructions issued before anything else -- bandwidth-bound and overlapped with the prologue and
+    // the patch staging.  The data lands in this wave's own slots of the (still unused) ring; the real slab DMAs of the same
+    // wave are ordered behind it.  (Not with split-K: a split reads a tap range of every row, not a contiguous block.)
+    if (p.wwarm && p.splitk == 1) {
+        const int nwg = p.tm * p.tn, qx = nwg >> 3, rx = nwg & 7, xcd = (int)blockIdx.x & 7;
+        const int first = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
+        const int cnt = qx + (xcd < rx ? 1 : 0);
+        const int l_lo = max(first, nt_ * p.tm), l_hi = min(first + cnt, (nt_ + 1) * p.tm);
+        const int share = max(l_hi - l_lo, 1), mine = min(max(tlog - l_lo, 0), share - 1);
+        const int blk = min(BN, Nout - n0) * ldb * 2;                       // bytes of the block (launcher: < 2^31)
+        const int chunk = ((blk + share - 1) / share + 1023) & ~1023;       // bytes per workgroup, whole wave instructions
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w16) + (size_t)n0 * ldb * 2;
+        const int lo = mine * chunk;
+        int slot = 0;
+        for (int off = wave * 1024; off < chunk && lo + off < blk; off += NW * 1024) {
+            const int a = min(lo + off + lane * 16, blk - 16);
+            ring_dma16(wb + a, ring_lds + (unsigned)((wave * LW + slot % LW) * 1024 + (slot / LW % RING) * SLABB));
+            ++slot;
+        }
+    }
+
     const int it_dep = ntaps * nch;
     const int it_all = gd.nt * it_dep;
     const int it_per = pre ? p.s1_itper : (it_all + p.splitk - 1) / p.splitk;
@@ -695,6 +722,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     }
     p.splitk = splitk;
     patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
+    p.wwarm = savp_opt(OPT_RING_WWARM) ? 1 : 0;
     pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
     pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     return true;

@@ -16,7 +16,27 @@ enum SavpOptId {
     OPT_LSTM_FUSED,        // one-launch ConvLSTM gate block, forward and backward (1)
     OPT_RING_DMA,          // bf16 sources of the ring kernel are staged into the LDS patch by LDS-DMA (1)
     OPT_LSTM_Q,            // developer: force the threads per pixel (channel quads per slab) of the one-launch gate kernels (0 = auto)
+    OPT_RING_WWARM,        // ring kernel: workgroups of a column tile pull its weight block into their XCD's L2 first (1)
     OPT_COUNT
 };
 
 int savp_opt(int id);
+
+#ifdef __HIPCC__
+// Touch every 64-byte line of the kernel-argument segment with one scalar load each and wait for all of them once.  The
+// argument block of a launch is always cold (the command processor has just written it) and a miss is an HBM-latency round trip
+// (~2 k cycles); hipcc loads a 500-byte struct field group by field group as the code reaches them, so a long prologue pays
+// that latency three or four times in series (cycle stamps of conv_ring_kernel: ~3 k cycles before the first use of the
+// geometry, 1.2 k more for the next group, ...).  After this call every later s_load of the struct hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    constexpr int LINES = (BYTES + 63) / 64;
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t[LINES];
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) asm volatile("s_load_dword %0, %1, %2" : "=&s"(t[i]) : "s"(ka), "n"(i * 64) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) asm volatile("" :: "s"(t[i]));
+}
+#endif

@@ -50,6 +50,9 @@ def set_conv_precision(name):
 
 AUTOTUNE = {'enabled': False, 'cache': {}, 'log': [], 'dist': None}
 CONV_CALL_LOG = None
+# developer aid (tests/tools/insitu_tune.py): in-step timing of the conv launches of chosen problems and their isolated candidate
+# ranking -- {'mode': 'all' | 'targets' | 'rank', 'targets': set of problem keys, 'events': [(key, e0, e1)], 'ranked': {key: [...]}}
+INSITU = None
 
 
 def save_tuning(path):
@@ -117,10 +120,10 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     return a
 
 
-def _tune(a, mode, dst, w):
-    """Time candidate (tile, splitk) pairs for this problem; returns the fastest."""
+def _tune(a, mode, dst, w, return_all=False):
+    """Time candidate (tile, splitk) pairs for this problem; returns the fastest (return_all: every (ms, tile, splitk), sorted)."""
     if lib.get().savp_conv_special(ctypes.byref(a)):
-        return (0, 0)                    # a problem-specific kernel takes the call under tile 0: nothing to choose
+        return [] if return_all else (0, 0)   # a problem-specific kernel takes the call under tile 0: nothing to choose
     torch.cuda.synchronize()             # nothing else in flight (other streams would distort the timings)
     fn = lib.get().savp_conv
     st = lib.stream()
@@ -156,6 +159,7 @@ def _tune(a, mode, dst, w):
                 a.y = scratch.data_ptr()
             a.beta = 0
     best, best_t = None, 1e30
+    every = []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for tile, sk in cands:
         a.tile, a.splitk = tile, sk
@@ -169,6 +173,7 @@ def _tune(a, mode, dst, w):
             e1.record()
             e1.synchronize()
             t = min(t, e0.elapsed_time(e1))
+        every.append((t, tile, sk))
         if t < best_t:
             best, best_t = (tile, sk), t
     if mode == lib.CONV_WGRAD:
@@ -180,6 +185,8 @@ def _tune(a, mode, dst, w):
             a.x = real_dst
         else:
             a.y = real_dst
+    if return_all:
+        return sorted(every)
     return best or (0, 0)
 
 
@@ -209,6 +216,18 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
             AUTOTUNE['cache'][key] = cfg
             AUTOTUNE['log'].append((key, cfg))
         a.tile, a.splitk = cfg
+        if INSITU is not None:
+            if INSITU['mode'] == 'rank':
+                if key in INSITU['targets'] and key not in INSITU['ranked']:
+                    INSITU['ranked'][key] = _tune(a, mode, x if mode == lib.CONV_DGRAD else y, w, return_all=True)
+                    a.tile, a.splitk = cfg
+            elif INSITU['mode'] == 'all' or key in INSITU['targets']:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
+                e1.record()
+                INSITU['events'].append((key, e0, e1))
+                return
     if CONV_CALL_LOG is not None:      # profiling aid (tests/conv_shape_profile.py): launch order -> problem shape
         CONV_CALL_LOG.append((mode, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, tuple(geom.k), tuple(geom.s), a.tile, a.splitk))
     lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
