@@ -100,15 +100,20 @@ typedef struct SavpConvArgs {
                                       y (output-gradient) operand holds bf16.
                                       This is the ConvLSTM gate convolution (rnn_ops.py:121): the gate tensor makes its round trip to
                                       the gate kernels in half the bytes */
-    float* stats;                  /* with out_bf16: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
-                                      of every (sample, channel) of the destination, taken from the fp32 accumulators before rounding
-                                      = the statistics of the instance norm that follows (rnn_ops.py:148-149); caller zeroes; may be NULL */
+    float* stats;                  /* FPROP / DGRAD: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
+                                      of every (sample, channel) of the destination (conv + bias, fp32 accumulators, before any rounding)
+                                      = the statistics of the instance norm that follows (rnn_ops.py:148-149, normalization.py:146-170);
+                                      caller zeroes; may be NULL.  bf16 precision only (the ring kernel); an fp32 destination additionally
+                                      needs whole tiles (savp_conv_stats_ok() tells), no activation, no beta; SAVP_EINVAL otherwise */
     void* ws; int64_t ws_bytes;    /* optional caller-owned scratch (16-byte aligned; written before it is read, so one buffer can serve
                                       every call on a stream).  savp_conv_workspace_bytes() says how much a call can use; without it
                                       the call takes a kernel that needs none */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
+/* 1: savp_conv would honour args->stats (any non-NULL value) for this problem; 0: it would return SAVP_EINVAL -- the caller then
+ * leaves stats NULL and lets the instance norm take its own statistics.  No launch, no device access. */
+int savp_conv_stats_ok(const SavpConvArgs* args);
 /* bytes of args->ws this call would use (0: none) -- today the RGB-side weight gradient's per-workgroup partial sums */
 int64_t savp_conv_workspace_bytes(const SavpConvArgs* args);
 /* 1 when, with tile bits 8-9 == 0 (automatic algorithm), a problem-specific kernel takes this call and tile / splitk are not
@@ -148,6 +153,8 @@ typedef struct SavpInormArgs {
     int32_t dy_c0[4], dy_nc[4];    /* bwd: gradient k covers channels [dy_c0, dy_c0 + dy_nc) (dy_nc == 0: all C) */
     int32_t out_bf16;              /* fwd: bit k set = output view k is a bf16 tensor (its strides count bf16 elements): a destination
                                       that only feeds convolutions of the bf16 datapath (they round to bf16 anyway) in half the bytes */
+    int32_t stats_ready;           /* fwd: ws already holds the per-(sample, channel) sum / sum of squares of x, UNSHIFTED (savp_conv's
+                                      `stats` epilogue wrote them while it produced x): the statistics pass is skipped -> one launch */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);

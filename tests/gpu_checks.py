@@ -4,6 +4,8 @@ Used by tests/test_gpu_*.py (pytest -m gpu), by __graft_entry__.smoke() and by t
 dumps every result to gpurun_out/ instead of stopping at the first failure).  Each check returns a list of
 (name, err, tol) tuples; err is max|hip - oracle| / max(|oracle|) with the oracle evaluated in float64.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -1164,6 +1166,84 @@ def _taps_ref(mode, x, w, y, k, s, p):
                     xp[sl] += y @ w[a, u, v].t()
     if mode == lib.CONV_DGRAD:
         return xp[:, p[0]:p[0] + D, p[1]:p[1] + H, p[2]:p[2] + W].contiguous()
+    return out
+
+
+def check_conv_stats_fp32(seed=43):
+    """Statistics epilogue of the ring kernel on an fp32 destination (round 3: the generator's down / upsample convolutions leave
+    the sums of the instance norm that follows, conv + bias, behind; the norm then runs its apply pass alone): output, sums, and
+    savp_instnorm_act_fwd(stats_ready) against fused_instance_norm of the fp32 tap-loop convolution; every tile code that accepts the
+    problem; a problem with partial tiles must be refused by savp_conv_stats_ok."""
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32)
+
+    cases = [  # name, mode, N, (H, W, Cx) x-side, (Ho, Wo, Cy) y-side, k, s, p
+        ('pool4x4s2', lib.CONV_FPROP, 4, (32, 32, 40), (16, 16, 64), (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+        ('pool6x6s2', lib.CONV_FPROP, 3, (64, 64, 16), (32, 32, 32), (1, 6, 6), (1, 2, 2), (0, 2, 2)),
+        ('up6x6s2', lib.CONV_DGRAD, 4, (32, 32, 32), (16, 16, 136), (1, 6, 6), (1, 2, 2), (0, 2, 2)),
+        ('up6x6s2_b', lib.CONV_DGRAD, 2, (16, 16, 64), (8, 8, 136), (1, 6, 6), (1, 2, 2), (0, 2, 2)),
+        ('conv3x3', lib.CONV_FPROP, 2, (64, 64, 32), (64, 64, 64), (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ]
+    for name, mode, N, (H, W, Cx), (Ho, Wo, Cy), k, s, p in cases:
+        x32, y32 = rn(N, 1, H, W, Cx), rn(N, 1, Ho, Wo, Cy)
+        w32 = rn(*k, Cx, Cy) * 0.1
+        fprop = mode == lib.CONV_FPROP
+        cdst = Cy if fprop else Cx
+        bias = rn(cdst)
+        ref = _taps_ref(mode, x32, w32, y32, k, s, p) + bias                     # [N, 1, h, w, cdst]
+        ref = ref[:, 0]
+        geom = K.ConvGeom(k, s, p)
+        wp = (pack_wt(w32) if fprop else pack_wd(w32)).contiguous()
+        gam, bet = rn(cdst) * 0.3 + 1, rn(cdst) * 0.3
+        yn = torch.relu(O.fused_instance_norm(ref.cpu().double(), gam.cpu().double(), bet.cpu().double()))
+        ran = 0
+        for tile in (0, 0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721):
+            xv, yv = x32[:, 0].clone(), y32[:, 0].clone()
+            dst = yv if fprop else xv
+            dst.fill_(float('nan'))
+            stats = torch.zeros(N, cdst, 2, device=DEV)
+            try:
+                K.conv(mode, geom, xv, yv, wp, bias=bias, tile=tile, precision=1, w16=wp.to(torch.bfloat16), stats=stats)
+            except RuntimeError:
+                continue                                   # this tile cannot honour the statistics for this problem
+            ran += 1
+            tag = 'convstats_%s_t%x' % (name, tile)
+            out.append((tag + '/out', rel_err(dst, ref), 1e-2))
+            r2 = ref.reshape(N, -1, cdst)
+            out.append((tag + '/sum', rel_err(stats[..., 0], r2.sum(1)), 1e-2))
+            out.append((tag + '/sumsq', rel_err(stats[..., 1], (r2 * r2).sum(1)), 1e-2))
+            o1 = torch.empty_like(dst)
+            mean, rstd = torch.empty(N, cdst, device=DEV), torch.empty(N, cdst, device=DEV)
+            K.instnorm_act_fwd(dst, gam, bet, [o1], mean, rstd, act='relu', stats=stats)
+            out.append((tag + '/inorm_from_stats', rel_err(o1, yn), 1e-2))
+            o2 = torch.empty_like(dst)
+            K.instnorm_act_fwd(dst, gam, bet, [o2], mean, rstd, act='relu')
+            out.append((tag + '/inorm_same_as_own_stats', rel_err(o1, o2), 1e-3))
+        out.append(('convstats_%s/tiles_that_ran>=2' % name, 0.0 if ran >= 2 else float('inf'), 1.0))
+        a = K._fill_conv_args(mode, geom, x32[:, 0], y32[:, 0], wp, bias, 0, 0, 0.0, None, 0, 0, 1, wp.to(torch.bfloat16), None)
+        out.append(('convstats_%s/stats_ok' % name, 0.0 if lib.get().savp_conv_stats_ok(ctypes.byref(a)) == 1 else float('inf'), 1.0))
+    # partial tiles (12 columns: not a multiple of the 8-column tile) and the fp32 datapath: refused, and the probe says so
+    x32, y32, w32 = rn(2, 12, 12, 32), rn(2, 12, 12, 64), rn(1, 3, 3, 32, 64) * 0.1
+    wp = pack_wt(w32).contiguous()
+    geom = K.ConvGeom((1, 3, 3), (1, 1, 1), (0, 1, 1))
+    for prec in (1, 0):
+        a = K._fill_conv_args(lib.CONV_FPROP, geom, x32, y32, wp, None, 0, 0, 0.0, None, 0, 0, prec, wp.to(torch.bfloat16), None)
+        ok = lib.get().savp_conv_stats_ok(ctypes.byref(a))
+        if prec == 0:
+            x32, y32 = rn(2, 16, 16, 32), rn(2, 16, 16, 64)
+            a = K._fill_conv_args(lib.CONV_FPROP, geom, x32, y32, wp, None, 0, 0, 0.0, None, 0, 0, prec, wp.to(torch.bfloat16), None)
+            ok = lib.get().savp_conv_stats_ok(ctypes.byref(a))
+        out.append(('convstats_refused_prec%d/probe' % prec, 0.0 if ok == 0 else float('inf'), 1.0))
+        st = torch.zeros(2, 64, 2, device=DEV)
+        try:
+            K.conv(lib.CONV_FPROP, geom, x32, y32, wp, precision=prec, w16=wp.to(torch.bfloat16), stats=st)
+            out.append(('convstats_refused_prec%d/call' % prec, float('inf'), 1.0))
+        except RuntimeError:
+            out.append(('convstats_refused_prec%d/call' % prec, 0.0, 1.0))
+    torch.cuda.synchronize()
     return out
 
 

@@ -78,6 +78,11 @@ def test_fused_convlstm_cell_bf16():
     _run(gpu_checks.check_conv_cell)
 
 
+def test_conv_epilogue_statistics_feed_the_instance_norm():
+    from tests import gpu_checks
+    _run(gpu_checks.check_conv_stats_fp32)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

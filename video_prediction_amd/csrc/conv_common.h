@@ -163,4 +163,4 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
 // conv_wgrad_patch.hip: LDS patch WGRAD (2-D stride-1, bf16); same contract.
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc);
 // conv_ring.hip: LDS patch + LDS-DMA weight ring (+ fused bf16 / statistics epilogue); same contract.
-bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc);
+bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc, bool dry = false);

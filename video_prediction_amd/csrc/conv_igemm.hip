@@ -764,6 +764,22 @@ extern "C" int savp_conv_special(const SavpConvArgs* a) {
     return (conv_thin_applies(a) || conv_s2dgrad_applies(a)) ? 1 : 0;
 }
 
+extern "C" int savp_conv_stats_ok(const SavpConvArgs* a) {
+    if (!a || (a->mode != SAVP_CONV_FPROP && a->mode != SAVP_CONV_DGRAD) || a->precision != SAVP_PREC_BF16) return 0;
+    if (((a->tile >> 8) & 3) == 0 && (conv_thin_applies(a) || conv_s2dgrad_applies(a))) return 0;     // those kernels take no statistics
+    const bool dg = a->mode == SAVP_CONV_DGRAD;
+    const int Cred = dg ? a->Cy : a->Cx;
+    if (!(a->w_bf16 && (Cred % 8 == 0) && aligned16(a->w_bf16))) return 0;
+    ConvP p;
+    p.bf16 = 1; p.w16 = (const unsigned short*)a->w_bf16; p.src16 = a->src_bf16 ? 1 : 0; p.splitk = 1; p.tm = p.tn = 1;
+    SavpConvArgs b = *a;
+    if (!b.stats) b.stats = (float*)(uintptr_t)16;               // any non-NULL value: only the plan is made
+    int wm = 0, wn = 0;
+    if (b.tile & 0xff) { wm = (b.tile >> 4) & 15; wn = b.tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return 0; }
+    int rc = SAVP_OK;
+    return conv_ring_try(p, &b, wm, wn, nullptr, &rc, true) ? 1 : 0;
+}
+
 extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     if (!a || !a->x || !a->y || !a->w) return SAVP_EINVAL;
     if (a->sd < 1 || a->sh < 1 || a->sw < 1 || a->kd < 1 || a->kh < 1 || a->kw < 1) return SAVP_EINVAL;

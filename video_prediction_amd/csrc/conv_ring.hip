@@ -538,6 +538,42 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int col0 = n0 + wn0 + l31;
     const int px0 = ox0 + 4 * khalf;
     const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
+    bool biased = false;                                      // the bias is already in the accumulators
+    if (p.stats) {
+        // ---- statistics of an fp32 destination (the instance norm behind a generator convolution, normalization.py:146-170): the
+        // per-(image, channel) sum / sum of squares of conv + bias leave with this kernel and the norm's own statistics pass (one more
+        // launch that re-reads the tensor) disappears.  Launcher guarantees: full tiles, every tile row block inside one image,
+        // split-K 1, no activation / beta; one global atomic per (image, channel, workgroup) as in the cell epilogue.
+        float* stat = reinterpret_cast<float*>(smem);         // [ni][BN][2]
+        __syncthreads();                                      // ring and patch are dead
+        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int im = (wm0 + i * 32) >> rsh;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = col0 + 32 * j;
+                const float bias = (p.bias && col < Nout) ? p.bias[col] : 0.f;
+                float sm = 0.f, q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r] + bias; acc[i][j][r] = v; sm += v; q += v * v; }
+                sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
+                if (khalf == 0 && col < Nout) {
+                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
+                    unsafeAtomicAdd(d, sm); unsafeAtomicAdd(d + 1, q);
+                }
+            }
+        }
+        biased = true;
+        __syncthreads();
+        for (int i = tid; i < ni * BN * 2; i += NT) {
+            const int im = i / (BN * 2), rem = i - im * (BN * 2);
+            const int gi = img0 + im;
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            if (n0 + (rem >> 1) < Nout) unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int rowb = wm0 + i * 32;
@@ -554,7 +590,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 if (col0 + 32 * j >= Nout) continue;
-                const float bias = p.bias ? p.bias[col0 + 32 * j] : 0.f;
+                const float bias = (p.bias && !biased) ? p.bias[col0 + 32 * j] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
             }
@@ -564,7 +600,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (col0 + 32 * j >= Nout) continue;
-            const float bias = (p.bias && split == 0) ? p.bias[col0 + 32 * j] : 0.f;
+            const float bias = (p.bias && split == 0 && !biased) ? p.bias[col0 + 32 * j] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
@@ -685,7 +721,15 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     if ((long long)a->N * Dm >= (1 << 24)) return false;
     if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
     p.cell = cell ? 1 : 0;
-    p.stats = cell ? (float*)a->stats : nullptr;
+    p.stats = (float*)a->stats;
+    if (a->stats && !cell) {
+        // statistics of an fp32 destination: whole tiles only (every accumulator is a real output), no split-K, nothing after the bias
+        const long long nimg = (long long)a->N * Dm;
+        const bool even = !dg || (a->H % a->sh == 0 && a->W % a->sw == 0);       // every output phase has the same extent
+        if (a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || !even || (a->splitk > 1) ||
+            (size_t)ni * BN * 2 * 4 > lds)
+            return false;
+    }
     p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
     p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
     p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
@@ -703,7 +747,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     const long long tiles = (long long)p.tm * p.tn;
     const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
     int splitk = a->splitk;
-    if (a->act != SAVP_ACT_NONE || cell) splitk = 1;
+    if (a->act != SAVP_ACT_NONE || cell || a->stats) splitk = 1;
     else if (splitk <= 0) {
         splitk = 1;
         if (tiles <= 192 && iters >= 16) {
@@ -731,7 +775,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
 // Returns true when the ring kernel handled the call (*rc = status); false = not applicable (the caller falls back).
 // SavpConvArgs.out_bf16 selects the cell epilogue: bf16 destination + optional statistics; with an automatic tile the first
 // (waves, tile) choice whose tiling can honour it is taken, a forced tile that cannot is refused (false).
-bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc) {
+bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc, bool dry) {
     const bool dg = a->mode == SAVP_CONV_DGRAD;
     const int Cred = dg ? a->Cy : a->Cx, Nout = dg ? a->Cx : a->Cy;
     const long long ssn = dg ? a->y_sn : a->x_sn, ssh = dg ? a->y_sh : a->x_sh, ssw = dg ? a->y_sw : a->x_sw;
@@ -749,7 +793,7 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
         return false;
     if ((long long)Hm * Wm < 16) return false;
     static const void* zero16 = nullptr;                         // address of g_ring_zero (resolved once; a constant of the loaded code object)
-    if (!zero16 && hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16 = nullptr;
+    if (!dry && !zero16 && hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16 = nullptr;
     p.zero16 = zero16;
     RingPlan pl;
     bool ok = false;
@@ -764,6 +808,7 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
         for (int i = 0; i < 5 && !ok; ++i) ok = ring_plan(p, a, cand[i][0], cand[i][1], cand[i][2], pl);
     }
     if (!ok) return false;
+    if (dry) return true;                                        // savp_conv_stats_ok: the plan exists, nothing is launched
     if (p.splitk > 1 && !a->beta) {
         const int Dm = dg ? a->D : a->Do;
         const long long dW_ = dg ? a->W : a->Wo;

@@ -304,7 +304,7 @@ class ConvLayer(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.kind == 'up':
-            K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16)
+            K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16, stats=stats)
         else:
             K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats)
         if self.prof is not None:
@@ -312,6 +312,14 @@ class ConvLayer(object):
             self.prof.append((e0, e1))
         if self.ktimer is not None:
             self.ktimer.taken()
+
+    def stats_ok(self, x, y):
+        """Can forward(x, y, stats=...) leave the destination's instance-norm statistics behind (kernels.conv_stats_ok)?"""
+        if K.PRECISION['value'] != 1:
+            return False
+        if self.kind == 'up':
+            return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=self.bias, w16=self.wd16)
+        return K.conv_stats_ok(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=self.bias, w16=self.wt16)
 
     def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
         if self.kind == 'up':
@@ -425,6 +433,9 @@ class ConcatConv(object):
 
     def forward(self, x, y, **kw):
         self.inner.forward(x, y, **kw)
+
+    def stats_ok(self, x, y):
+        return self.inner.stats_ok(x, y)
 
     def backward_data(self, dy, dx, **kw):
         self.inner.backward_data(dy, dx, **kw)

@@ -139,8 +139,8 @@ def _tune(a, mode, dst, w, return_all=False):
         # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
         # (0x6xx = patch kernel with 8 waves per workgroup; 0x1000 / 0x2000 = its LDS budget capped at 64 / 96 KB)
         # 0x3xx / 0x7xx = LDS-DMA ring kernel with 4 / 8 waves (the only one for bf16 activations / the cell epilogue)
-        algs = (0x300, 0x700) if (a.src_bf16 or a.out_bf16) else (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600, 0x300, 0x700)
-        if a.out_bf16:
+        algs = (0x300, 0x700) if (a.src_bf16 or a.out_bf16 or a.stats) else (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600, 0x300, 0x700)
+        if a.out_bf16 or a.stats:
             splits = (1,)
         cands = [(alg | t, sk) for alg in algs for t in tiles for sk in splits]
         real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
@@ -231,6 +231,13 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     if CONV_CALL_LOG is not None:      # profiling aid (tests/conv_shape_profile.py): launch order -> problem shape
         CONV_CALL_LOG.append((mode, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, tuple(geom.k), tuple(geom.s), a.tile, a.splitk))
     lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
+
+
+def conv_stats_ok(mode, geom, x, y, w, bias=None, w16=None):
+    """True when savp_conv would honour a `stats` buffer for this FPROP / DGRAD problem (bf16 precision, ring kernel, whole tiles):
+    the instance norm behind the convolution can then skip its own statistics pass (instnorm_act_fwd(stats=...))."""
+    a = _fill_conv_args(mode, geom, x, y, w, bias, 0, 0, 0.0, None, 0, 0, None, w16, None)
+    return bool(lib.get().savp_conv_stats_ok(ctypes.byref(a)))
 
 
 ACT_IDS = {None: 0, 'none': 0, 'relu': 1, 'lrelu': 2}
@@ -358,10 +365,16 @@ def _set_ranges(c0_arr, nc_arr, ranges):
             c0_arr[i], nc_arr[i] = int(r[0]), int(r[1])
 
 
-def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6, out_ranges=None):
-    """out_ranges: per output view the (first channel, count) slice of the normalised tensor it receives (default: all)."""
+def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6, out_ranges=None, stats=None):
+    """out_ranges: per output view the (first channel, count) slice of the normalised tensor it receives (default: all).
+    stats: [N, C, 2] sum / sum of squares of x written by the producing convolution's epilogue (conv(..., stats=...)): the
+    statistics pass is skipped."""
     a = lib.SavpInormArgs()
-    a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
+    if stats is not None:
+        lib.require_device(stats)
+        a.ws, a.ws_clean, a.stats_ready = stats.data_ptr(), 1, 1
+    else:
+        a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)

@@ -93,6 +93,7 @@ def _declare(lib):
     _sig(lib, 'savp_conv', [c_vp, P(SavpConvArgs)])
     _sig(lib, 'savp_conv_workspace_bytes', [P(SavpConvArgs)], restype=c_i64)
     _sig(lib, 'savp_conv_special', [P(SavpConvArgs)])
+    _sig(lib, 'savp_conv_stats_ok', [P(SavpConvArgs)])
     _sig(lib, 'savp_set_option', [ctypes.c_char_p, c_i32])
     _sig(lib, 'savp_get_option', [ctypes.c_char_p, P(c_i32)])
     _sig(lib, 'savp_allreduce_bucket', [c_vp, c_vp, c_vp, c_i64])
@@ -156,6 +157,7 @@ class SavpInormArgs(ctypes.Structure):
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
         ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
         ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4), ('out_bf16', c_i32),
+        ('stats_ready', c_i32),
     ]
 
 

@@ -22,6 +22,7 @@ from .. import lib
 from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_views, prep_layers
 from ..variables import layer_specs, num_masks
 
+CONV_STATS = os.environ.get('SAVP_CONV_STATS', '1') == '1'      # developer A/B switch of the conv-epilogue statistics
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
 
 
@@ -92,6 +93,7 @@ class SAVPGenerator(object):
         self.train = train
         dev = store.device
         self.dev = dev
+        self._cstats = {}                # head name -> the conv's epilogue supplies the instance norm's statistics (decided at first use)
         if hp.nz and not hp.use_tile_concat:
             raise NotImplementedError('use_tile_concat=False')
         if hp.conv_rnn not in ('lstm', 'gru') or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
@@ -399,13 +401,18 @@ class SAVPGenerator(object):
                      [in0.v[t][..., 0:C]] + ([maskin.v[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else []))
             for L in self.layers:
                 f = L['f']
-                L['conv'].forward(L['in'].v[t], L['pre'].v[t])
+                # the conv's epilogue leaves the instance norm's statistics behind where it can (bf16 datapath, whole tiles): the
+                # norm is then ONE launch (SAVP_CONV_STATS=0: the norm takes its own statistics)
+                if 'cstats' not in L:
+                    L['cstats'] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
+                st = K.zero_arena(self.dev).take(N * f * 2) if L['cstats'] else None
+                L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
                     a = L['a']
                     hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN)
+                                       act='relu', eps=EPS_IN, stats=st)
                     n1, n2 = L['n1'], L['n2']
                     hprev = a.v[t][..., hs:hs + f]
                     L['rconv'].forward(a.v[t][..., 0:cin1], L['gates'].v[t], use_bias=False)
@@ -419,7 +426,7 @@ class SAVPGenerator(object):
                 elif L['rnn']:
                     a = L['a']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN)
+                                       act='relu', eps=EPS_IN, stats=st)
                     stats1 = s1 = None
                     if L['fused']:
                         stats1, s1 = K.lstm_stats_ws(self.dev, N, f)
@@ -440,17 +447,16 @@ class SAVPGenerator(object):
                         cp.append((ce0, ce1))
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN)
+                                       act='relu', eps=EPS_IN, stats=st)
             tslot = maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             ngf = self.hp.ngf
             if self.merge_heads:
                 # one conv + one instance norm for every 3x3 head on h_last; outputs routed by channel range
                 hn = self.heads_norm
-                self.heads_conv.forward(self.h_last.v[t], self.heads_pre.v[t])
                 outs = ([self.scratch_h.v[t]] if self.scratch else []) + [maskin.v[t][..., 0:ngf]] + \
                        ([self.tf_h.v[t]] if self.tf != 'cdna' else [])
-                K.instnorm_act_fwd(self.heads_pre.v[t], hn.gamma, hn.beta, outs, hn.mean[t], hn.rstd[t], act='relu', eps=EPS_IN,
-                                   out_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
+                self._conv_norm('heads', self.heads_conv, self.h_last.v[t], self.heads_pre.v[t], hn, outs, t,
+                                out_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
             if self.tf == 'cdna':
                 # CDNA kernels from the smallest layer (savp_model.py:546-559) and their application (:580, :893-923)
                 self.cdna_dense.forward(self.hsmall.v[t].reshape(N, -1), self.cdna_raw.v[t])
@@ -458,10 +464,7 @@ class SAVPGenerator(object):
                 K.cdna_apply_fwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], tslot, self.kh, self.kw, self.nk)
             else:
                 if not self.merge_heads:
-                    self.tf_conv.forward(self.h_last.v[t], self.tf_pre.v[t])
-                    tn = self.tf_norm
-                    K.instnorm_act_fwd(self.tf_pre.v[t], tn.gamma, tn.beta, [self.tf_h.v[t]], tn.mean[t], tn.rstd[t], act='relu',
-                                       eps=EPS_IN)
+                    self._conv_norm('tf', self.tf_conv, self.h_last.v[t], self.tf_pre.v[t], self.tf_norm, [self.tf_h.v[t]], t)
                 self.tf_out.forward(self.tf_h.v[t], self.tf_raw.v[t])
                 if self.tf == 'flow':
                     K.image_warp_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], tslot, self.nk)            # apply_flows :955-965
@@ -469,25 +472,31 @@ class SAVPGenerator(object):
                     K.dna_apply_fwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], tslot, self.kh, self.kw, self.nk)
             # scratch image (savp_model.py:561-572): sigmoid fused into the conv epilogue, written into its mask-conv slot
             if self.scratch and not self.merge_heads:
-                self.scratch_conv.forward(self.h_last.v[t], self.scratch_pre.v[t])
-                sn = self.scratch_norm
-                K.instnorm_act_fwd(self.scratch_pre.v[t], sn.gamma, sn.beta, [self.scratch_h.v[t]], sn.mean[t], sn.rstd[t],
-                                   act='relu', eps=EPS_IN)
+                self._conv_norm('scratch', self.scratch_conv, self.h_last.v[t], self.scratch_pre.v[t], self.scratch_norm,
+                                [self.scratch_h.v[t]], t)
             if self.scratch:
                 self.scratch_out.forward(self.scratch_h.v[t], maskin.v[t][..., self.o_scratch:self.o_scratch + self.Cs],
                                          act=lib.ACT_SIGMOID)
             # masks (savp_model.py:623-646)
             if not self.merge_heads:
-                self.masks_conv.forward(self.h_last.v[t], self.masks_pre.v[t])
-                mn = self.masks_norm
-                K.instnorm_act_fwd(self.masks_pre.v[t], mn.gamma, mn.beta, [maskin.v[t][..., 0:self.hp.ngf]], mn.mean[t], mn.rstd[t],
-                                   act='relu', eps=EPS_IN)
+                self._conv_norm('masks', self.masks_conv, self.h_last.v[t], self.masks_pre.v[t], self.masks_norm,
+                                [maskin.v[t][..., 0:self.hp.ngf]], t)
             self.masks_out.forward(maskin.v[t][..., 0:self.mask_cin], self.logits.v[t])
             K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:self.hp.ngf + self.M * C], self.gen.v[t],
                             self.masks[t] if collect_masks else None, M=self.M)
         return self.gen.v
 
     # ---------------------------------------------------------------------------------------------------------
+    def _conv_norm(self, name, conv, x, pre, nrm, outs, t, **kw):
+        """conv -> instance norm + ReLU of a head; the conv's epilogue supplies the norm's statistics where it can (see forward)."""
+        ok = self._cstats.get(name)
+        if ok is None:
+            c = pre.shape[-1]
+            ok = self._cstats[name] = bool(CONV_STATS and c <= 256 and (c & (c - 1)) == 0 and conv.stats_ok(x, pre))
+        st = K.zero_arena(self.dev).take(self.N * pre.shape[-1] * 2) if ok else None
+        conv.forward(x, pre, stats=st)
+        K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], act='relu', eps=EPS_IN, stats=st, **kw)
+
     def _lstm_ws(self, L):
         """Scratch of the coalesced ConvLSTM gate kernels (one buffer shared by all layers: the launches are serial)."""
         h, w = L['hw']
