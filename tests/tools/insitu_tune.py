@@ -100,6 +100,11 @@ for k in targets: K.AUTOTUNE['cache'][k] = picks[k]
 a2 = step_ms()
 print('eager step: picks %.2f / %.2f ms, shipped %.2f ms' % (a, a2, b))
 d = json.load(open(table))
+new = 0
+for k, v in K.AUTOTUNE['cache'].items():          # problems the shipped table did not know (tuned live during the warm-up steps)
+    if repr(k) not in d:
+        d[repr(k)] = list(v); new += 1
 for k in targets:
     d[repr(k)] = list(picks[k])
+print('table: %d entries, %d new' % (len(d), new))
 json.dump(d, open(out_path, 'w'), indent=0, sort_keys=True)
