@@ -1247,6 +1247,48 @@ def check_conv_stats_fp32(seed=43):
     return out
 
 
+def check_ring_weight_warmup_invisible(seed=47):
+    """Option ring_wwarm only moves bytes into the L2 ahead of time (csrc/conv_ring.hip): outputs with it on and off are bit-identical,
+    for FPROP / DGRAD, one and several column tiles, several slab groups, and a bf16 source (LDS-DMA staged patch)."""
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32)
+
+    cases = [('lstm16', 8, 16, 16, 136, 256, 5, 0x711), ('lstm8', 8, 8, 8, 264, 512, 5, 0x311), ('lstm32', 4, 32, 32, 72, 128, 5, 0x712),
+             ('head3', 4, 64, 64, 32, 64, 3, 0x321)]
+    old = lib.get_option('ring_wwarm')
+    try:
+        for name, N, H, W, Cx, Cy, k, tile in cases:
+            x, y = rn(N, H, W, Cx), rn(N, H, W, Cy)
+            w = rn(k, k, Cx, Cy) * 0.1
+            geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
+            for mode, mname in ((lib.CONV_FPROP, 'fprop'), (lib.CONV_DGRAD, 'dgrad')):
+                wp = (pack_wt(w) if mode == lib.CONV_FPROP else pack_wd(w)).contiguous()
+                w16 = wp.to(torch.bfloat16)
+                for src16 in (False, True):
+                    res = []
+                    for on in (1, 0):
+                        lib.set_option('ring_wwarm', on)
+                        xv, yv = x.clone(), y.clone()
+                        if src16:
+                            if mode == lib.CONV_FPROP:
+                                xv = xv.to(torch.bfloat16)
+                            else:
+                                yv = yv.to(torch.bfloat16)
+                        dst = yv if mode == lib.CONV_FPROP else xv
+                        dst.fill_(float('nan'))
+                        K.conv(mode, geom, xv, yv, wp, tile=tile, splitk=1, precision=1, w16=w16)
+                        res.append(dst.float().clone())
+                    same = torch.equal(res[0], res[1]) and bool(torch.isfinite(res[0]).all())
+                    out.append(('wwarm_%s_%s%s/bit_identical' % (name, mname, '_src16' if src16 else ''), 0.0 if same else float('inf'), 1.0))
+    finally:
+        lib.set_option('ring_wwarm', old)
+    torch.cuda.synchronize()
+    return out
+
+
 def check_tuning_table(precision='bf16', max_entries=None, seed=41):
     """Runs every entry of video_prediction_amd/tuning_gfx950_<precision>.json as that exact savp_conv call (mode, shapes, view
     strides, bias / w16 / act / beta / bf16 source / bf16 destination / statistics epilogue, the table's tile code and split-K)."""

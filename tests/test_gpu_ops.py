@@ -83,6 +83,11 @@ def test_conv_epilogue_statistics_feed_the_instance_norm():
     _run(gpu_checks.check_conv_stats_fp32)
 
 
+def test_ring_kernel_weight_warmup_does_not_change_results():
+    from tests import gpu_checks
+    _run(gpu_checks.check_ring_weight_warmup_invisible)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

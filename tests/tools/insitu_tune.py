@@ -47,7 +47,8 @@ def measured_step(mode, targets=()):
 tot, _ = measured_step('all')
 order = sorted(tot.items(), key=lambda kv: -kv[1][1])
 print('conv launches %d, in-step conv time %.2f ms (events include the hand-over gap in front of each kernel)' % (sum(v[0] for v in tot.values()), sum(v[1] for v in tot.values()) / 1e3))
-targets = [k for k, v in order if k[0] in (lib.CONV_FPROP, lib.CONV_DGRAD) and K.AUTOTUNE['cache'].get(k, (0, 0)) != (0, 0)][:TOP]
+MODES = tuple(int(m) for m in os.environ.get('MODES', '0,1').split(','))        # 0 FPROP, 1 DGRAD, 2 WGRAD
+targets = [k for k, v in order if k[0] in MODES and (K.AUTOTUNE['cache'].get(k, (0, 0)) != (0, 0) or k[0] == lib.CONV_WGRAD)][:TOP]
 _, ranked = measured_step('rank', targets)
 shipped = {k: K.AUTOTUNE['cache'][k] for k in targets}
 plans = {}

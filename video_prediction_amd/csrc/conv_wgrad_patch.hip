@@ -400,7 +400,13 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     const int tH = (a->Ho + 7) / 8;
     q.tW = (a->Wo + 7) / 8; q.tHW = tH * q.tW;
     q.PT = a->N * a->Do * q.tHW;
-    long long s = 768 / ((long long)NB * MC);                      // ~3 rounds of one 8-wave workgroup per CU
+    // Total workgroups: ONE round with eight waves per CU -- 256 eight-wave or 512 four-wave workgroups.  Measured INSIDE the train
+    // step (round 3, `wgp_split` sweep 128 ... 1536 with per-kernel traces): every 8-wave instantiation is fastest at 256 (e.g. the
+    // ConvLSTM gate layers 648 -> 580 us, the 3x3 heads 395 -> 214 us against the former 768), the 4-wave ones at 512 (622 -> 575 us;
+    // 831 us at 256), anything that is not a whole round pays a tail (384 / 640: slower than either neighbour).  In the step the
+    // activations of all 928 images are HBM-cold and a workgroup's fixed costs (prologue, the atomic dW epilogue of its split) count;
+    // back to back on warm caches round 2 had measured the opposite (768 best), which is how 768 got here.
+    long long s = (256LL * (8 / nw)) / ((long long)NB * MC);
     if (s < 1) s = 1;
     {
         const int ovs = savp_opt(OPT_WGP_SPLIT);      // developer override: total workgroups
