@@ -231,6 +231,44 @@ def test_conv_workspace_query_and_special_probe(hip_lib):
     assert hip_lib.savp_conv_special(ctypes.byref(a)) == 0
 
 
+def _conv2d_args(lib, mode, N, H, W, Cx, Ho, Wo, Cy, k, s, p, precision=1):
+    a = lib.SavpConvArgs()
+    a.mode = mode
+    a.N, a.D, a.H, a.W, a.Cx = N, 1, H, W, Cx
+    a.Do, a.Ho, a.Wo, a.Cy = 1, Ho, Wo, Cy
+    a.kd, a.kh, a.kw, a.sd, a.sh, a.sw, a.pd, a.ph, a.pw = 1, k, k, 1, s, s, 0, p, p
+    a.precision = precision
+    a.x, a.y, a.w, a.w_bf16 = 0x100000, 0x200000, 0x300000, 0x400000
+    a.x_sw, a.x_sh, a.x_sd, a.x_sn = Cx, W * Cx, H * W * Cx, H * W * Cx
+    a.y_sw, a.y_sh, a.y_sd, a.y_sn = Cy, Wo * Cy, Ho * Wo * Cy, Ho * Wo * Cy
+    return a
+
+
+def test_conv_statistics_probe_is_a_host_side_predicate(hip_lib):
+    """savp_conv_stats_ok (include/savp_hip.h): answers without a device -- yes for the generator's down / upsample convolutions of
+    the bf16 datapath (whole 8-column tiles), no for the fp32 datapath, for planes that leave partial tiles, for an activation or an
+    accumulating epilogue, and for the problems the RGB-side kernels take."""
+    from video_prediction_amd import lib
+    ok = lambda a: hip_lib.savp_conv_stats_ok(ctypes.byref(a))
+    down = _conv2d_args(lib, lib.CONV_FPROP, 32, 32, 32, 40, 16, 16, 64, 4, 2, 1)              # conv_pool2d 3x3 folded to 4x4 stride 2
+    assert ok(down) == 1
+    up = _conv2d_args(lib, lib.CONV_DGRAD, 32, 32, 32, 32, 16, 16, 136, 6, 2, 2)               # upsample_conv2d as a DGRAD-mode launch
+    assert ok(up) == 1
+    down.precision = 0
+    assert ok(down) == 0                                                                         # exact-fp32 datapath: no ring kernel
+    down.precision, down.act = 1, lib.ACT_LRELU
+    assert ok(down) == 0
+    down.act, down.beta = 0, 1
+    assert ok(down) == 0
+    down.beta, down.w_bf16 = 0, None
+    assert ok(down) == 0                                                                         # no packed bf16 weights
+    ragged = _conv2d_args(lib, lib.CONV_FPROP, 2, 12, 12, 32, 12, 12, 64, 3, 1, 1)             # 12 columns: partial 8-column tiles
+    assert ok(ragged) == 0
+    rgb = _conv2d_args(lib, lib.CONV_FPROP, 32, 64, 64, 3, 64, 64, 32, 3, 1, 1)                # taken by conv_thin.hip under tile 0
+    assert ok(rgb) == 0
+    assert hip_lib.savp_conv_stats_ok(None) == 0
+
+
 def test_allreduce_bucket_entry_point_validates_its_arguments(hip_lib):
     """savp_allreduce_bucket: exported, refuses a missing communicator / buffer, and an empty bucket is a no-op
     that does not even load RCCL.  (The collective itself needs >= 2 GPUs: the driver's scaling run.)"""
