@@ -15,6 +15,9 @@ it eager).  Prints ONE JSON line (rank 0).  Extra objects:
                   of the datapath in use (bf16: 2.5 PFLOP/s; --precision f32: 157.3 TFLOP/s).  `traffic` is read from the
                   committed rocprofv3 PMC pass of the round (profiles/), not collected by this run.
   roofline_cell-- the fused cell (gate conv + ONE gate-block launch) against both roofs, same instrumented steps.
+  config       -- besides the workload: `submission` (hipGraph replay / eager launches), `eager_ms_per_step` (the same step launch by
+                  launch) and `host_issue_ms_per_step` (host time to ISSUE one eager step with an idle GPU: what a replica of a
+                  multi-GPU run, which cannot replay a graph around its collectives, has to sustain).
   f32          -- (N=1) the exact-fp32 datapath, the reference's own arithmetic, on the same workload, timed the same way.
   cpu_baseline -- the CPU oracle (a torch-CPU restatement of the reference step, kind "port") timed on this host's
                   cores on a bounded sample (one sequence), rank 0 at N=1 only.
