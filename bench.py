@@ -7,8 +7,8 @@ HBM.  Workload at every N: configs[1] of BASELINE.json per GPU (full VAE-GAN, ac
 batch 16 per GPU, published ours_savp recipe) -> weak scaling; one process per GPU, gradients all-reduced by RCCL.
 
 Timed region: W untimed + exactly K timed steps between (barrier + synchronize) pairs, MAX over ranks; un-instrumented; on one
-GPU the step body (no host input) is replayed as a captured hipGraph (--eager: launch by launch; with replicas the collectives keep
-it eager).  Prints ONE JSON line (rank 0).  Extra objects:
+GPU the step body (no host input) is replayed as a captured hipGraph (--eager: launch by launch); with replicas it is replayed as
+hipGraph SEGMENTS with the collectives issued by the host between them (models/savp_model.py:_StepProgram).  Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel family (LDS-patch / implicit-GEMM conv on the MFMA pipe): 8 further EAGER steps after the
                   timed region carry HIP events / dispatch stamps around the five ConvLSTM gate-conv FPROP launches; algorithmic
                   FLOPs per launch from SURVEY.md 8(d) (2*M*N*K of each layer) / measured duration, against the dense MFMA peak
@@ -179,7 +179,10 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    # SAVP_FORCE_DIST=1: keep the process group and every collective of the step at world size 1 -- RCCL, the side-stream exchange
+    # and the segmented replay run on a one-GPU box exactly as a rank of the 8-GPU job runs them (tests/test_gpu_dp.py)
+    force_dist = os.environ.get('SAVP_FORCE_DIST', '0') == '1'
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -233,12 +236,15 @@ def main():
 
     engine, hp = build_engine(args.precision)
     # The timed region runs the step the way a training job does: un-instrumented, and on one GPU as a replayed hipGraph (the step
-    # body has no host input; --eager keeps per-launch submission; with replicas the collectives keep it eager).  The roofline
+    # body has no host input; --eager keeps per-launch submission; with replicas: graph segments between the collectives).  The roofline
     # numbers come from INST_STEPS further steps AFTER the timed region, eager, with HIP events / dispatch stamps around the
     # ConvLSTM gate-conv launches and around whole cells -- instrumentation never sits inside the timed region.
-    engine.use_graph = (not args.eager) and world == 1
+    engine.use_graph = not args.eager
     dt, info = timed_steps(engine, args.warmup, args.steps)
-    mode = 'hipGraph replay' if (engine.use_graph and engine.graph is not None) else 'eager launches'
+    mode = 'eager launches'
+    if engine.use_graph and engine.graph is not None:
+        nseg = engine.graph.segments
+        mode = 'hipGraph replay' if nseg == 1 else 'hipGraph replay in %d segments, collectives issued between them' % nseg
     eager_ms = None
     host_issue_ms = None
     INST_STEPS = max(0, args.inst_steps)
@@ -366,6 +372,11 @@ def main():
                                   'algorithmic_bytes_per_cell': (cell_bytes / cell_n) if cell_n else None}},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
+    if dist is not None:
+        st = engine.replicas.stats
+        result['config']['dist'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
+                                    'allreduce_chunks_issued': st['chunks'], 'allreduce_elements': st['elements'], 'aux_broadcasts': st['aux_broadcasts'],
+                                    'side_stream': engine.replicas.comm_stream is not None}
     if dist is not None and os.environ.get('SAVP_BENCH_CHECK_REPLICAS', '0') == '1':
         result['replicas_identical'] = bool(engine.replicas.checksum_identical())      # collective: every rank calls it
     if rank == 0 and args.save_tuning:

@@ -108,9 +108,32 @@ typedef struct SavpConvArgs {
     void* ws; int64_t ws_bytes;    /* optional caller-owned scratch (16-byte aligned; written before it is read, so one buffer can serve
                                       every call on a stream).  savp_conv_workspace_bytes() says how much a call can use; without it
                                       the call takes a kernel that needs none */
+    int32_t dst_gap_at, dst_gap;   /* FPROP / DGRAD, SAVP_PREC_BF16 (ring kernel; SAVP_EINVAL elsewhere): the destination channel count
+                                      (Cy for FPROP, Cx for DGRAD) counts LOGICAL channels; logical channel c >= dst_gap_at is physical
+                                      channel c + dst_gap of the destination tensor, of the bias and of the packed weights (whose row
+                                      count is the logical count + dst_gap).  dst_gap == 0: off.  This is the ConvLSTM gate convolution's
+                                      data gradient without the tiled-z channels of its input [x | z | h] (rnn_ops.py:144-146,
+                                      savp_model.py:436-444): their gradient is a per-sample sum (savp_tiled_z_grad) and leaving them
+                                      out keeps the column count on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256) */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
+
+/* Gradient of a latent vector that is TILED over the plane and concatenated into a stride-1 SAME convolution's input -- the nz
+ * channels [z0, z0 + nz) of the ConvLSTM gate convolution's input [x | tile(z) | h] (rnn_ops.py:144-146 through tile_concat,
+ * savp_model.py:436-444) -- from the convolution's OUTPUT gradient alone, so that the per-pixel data gradient can leave those
+ * channels out (SavpConvArgs.dst_gap):  dz[img, c] = sum_p (F^T dy)[img, p, z0 + c]  computed as
+ * sum_{25 regions r} sum_k R[img, r, k] * weff[r, k, c]  with R = region sums of dy (row class x column class, classes
+ * {0, 1, middle, n-2, n-1}) -- tests/test_tiled_z_gradient_algebra.py pins the identity against autograd.
+ *   savp_tiled_z_weff: weff [25][Cout][8] fp32 from the HWIO kernel w [kh][kw][Cin][Cout] (kh, kw <= 5, pads <= 2, nz <= 8; once per
+ *                      step and layer).
+ *   savp_tiled_z_grad: dy [nimg][H][W][C] contiguous (bf16 if dy_bf16, else fp32; 16-byte aligned), one launch for the gate
+ *                      gradients of all timesteps; dz [nimg][nz] fp32 is overwritten (beta 0) or accumulated into (beta 1).
+ *                      H >= 4, W in {4, 8, 16, 32}, C % 64 == 0; SAVP_EINVAL otherwise.  Deterministic (fixed-order reductions). */
+int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t Cin, int32_t Cout,
+                      int32_t z0, int32_t nz, float* weff);
+int savp_tiled_z_grad(void* stream, const void* dy, int32_t dy_bf16, int64_t nimg, int32_t H, int32_t W, int32_t C,
+                      const float* weff, int32_t nz, float* dz, int32_t beta);
 /* 1: savp_conv would honour args->stats (any non-NULL value) for this problem; 0: it would return SAVP_EINVAL -- the caller then
  * leaves stats NULL and lets the instance norm take its own statistics.  No launch, no device access. */
 int savp_conv_stats_ok(const SavpConvArgs* args);

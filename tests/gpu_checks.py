@@ -1392,3 +1392,67 @@ def check_tuning_table(precision='bf16', max_entries=None, seed=41):
             out.append((tag + '/REFUSED:%s' % str(ex)[:60], float('inf'), 0.0))
     torch.cuda.synchronize()
     return out
+
+
+def check_tiled_z_and_gapped_dgrad(seed=53):
+    """ConvLSTM gate convolution backward without the tiled-z channels (csrc/tiled_z.hip, SavpConvArgs.dst_gap):
+    (1) dz from savp_tiled_z_weff + savp_tiled_z_grad == autograd of conv2d([x | tile(z) | h], W) w.r.t. z (fp64 CPU, both the bf16
+        and the fp32 gate-gradient layouts, planes 8x8 / 16x16 / 32x32 / 4x8, several images);
+    (2) the DGRAD with dst_gap = (f, nz) writes exactly the x and h channels the full DGRAD writes (every ring tile code that takes
+        the problem) and leaves the z channels of the destination untouched."""
+    import torch.nn.functional as F_
+    out = []
+    rng = np.random.default_rng(seed)
+    geom = K.ConvGeom((1, 5, 5), (1, 1, 1), (0, 2, 2))
+    for (IMG, H, W, f, nz, dt) in ((3, 8, 8, 16, 8, torch.bfloat16), (2, 16, 16, 16, 8, torch.float32), (2, 32, 32, 32, 8, torch.bfloat16),
+                                   (5, 4, 8, 16, 3, torch.bfloat16)):
+        Cin, C = f + nz + f, 4 * f
+        w = rnd(rng, 5, 5, Cin, C) * 0.1
+        dy = (rnd(rng, IMG, H, W, C)).to(dt)
+        z = torch.zeros(IMG, nz, dtype=torch.float64, requires_grad=True)
+        a = torch.cat([torch.zeros(IMG, H, W, f, dtype=torch.float64), z[:, None, None, :].expand(IMG, H, W, nz),
+                       torch.zeros(IMG, H, W, f, dtype=torch.float64)], dim=-1)
+        g = F_.conv2d(a.permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=2).permute(0, 2, 3, 1)
+        (g * dy.double()).sum().backward()
+        wd_, dyd = dev(w), dy.to(DEV).contiguous()
+        weff = torch.empty(25, C, 8, device=DEV)
+        dz = torch.full((IMG, nz), 0.5, device=DEV)
+        K.tiled_z_weff(wd_, geom, f, nz, weff)
+        K.tiled_z_grad(dyd, weff, dz, beta=1)
+        out.append(('tiled_z/dz_%dx%d_%s' % (H, W, 'bf16' if dt == torch.bfloat16 else 'f32'), rel_err(dz - 0.5, z.grad), 2e-5))
+        dz2 = torch.full((IMG, nz), 7.0, device=DEV)
+        K.tiled_z_grad(dyd, weff, dz2, beta=0)
+        out.append(('tiled_z/beta0_%dx%d' % (H, W), rel_err(dz2, z.grad), 2e-5))
+        out.append(('tiled_z/ok_%dx%d' % (H, W), 0.0 if K.tiled_z_ok(H, W, C, nz, geom) else 1.0, 0.5))
+    # (2) gapped DGRAD vs the full one, bf16 gate gradient, the recipe's three plane sizes (N kept small)
+    for (N, H, f, nz) in ((4, 32, 32, 8), (4, 16, 64, 8), (8, 8, 128, 8)):
+        Cin, C = f + nz + f, 4 * f
+        w = rnd(rng, 5, 5, Cin, C) * 0.05
+        wd32 = dev(pack_wd(w))
+        wd16 = wd32.to(torch.bfloat16)
+        dy = rnd(rng, N, H, H, C).to(torch.bfloat16).to(DEV).contiguous()
+        full = torch.zeros(N, H, H, Cin, device=DEV)
+        K.conv(lib.CONV_DGRAD, geom, full, dy, wd32, w16=wd16, precision=1)
+        took = 0
+        for tile in (0, 0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721, 0x722):
+            got = torch.full((N, H, H, Cin), 123.0, device=DEV)
+            try:
+                K.conv(lib.CONV_DGRAD, geom, got, dy, wd32, w16=wd16, precision=1, tile=tile, dst_gap=(f, nz))
+            except RuntimeError:
+                continue                      # this tile code does not take the problem
+            took += 1
+            keep = torch.cat([got[..., :f], got[..., f + nz:]], dim=-1)
+            ref = torch.cat([full[..., :f], full[..., f + nz:]], dim=-1)
+            out.append(('zless_dgrad/%dx%d_tile%x' % (H, H, tile), rel_err(keep, ref.double().cpu()), 1e-5))
+            untouched = bool((got[..., f:f + nz] == 123.0).all())
+            out.append(('zless_dgrad/%dx%d_tile%x_gap_untouched' % (H, H, tile), 0.0 if untouched else 1.0, 0.5))
+        out.append(('zless_dgrad/%dx%d_tiles_taken' % (H, H), 0.0 if took >= 3 else 1.0, 0.5))
+    # a gap is refused outside the ring kernel (fp32 precision) instead of being ignored
+    try:
+        K.conv(lib.CONV_DGRAD, geom, torch.zeros(2, 8, 8, 40, device=DEV), torch.zeros(2, 8, 8, 64, device=DEV),
+               torch.zeros(40, 25 * 64, device=DEV), precision=0, dst_gap=(16, 8))
+        out.append(('zless_dgrad/fp32_refused', 1.0, 0.5))
+    except RuntimeError:
+        out.append(('zless_dgrad/fp32_refused', 0.0, 0.5))
+    torch.cuda.synchronize()
+    return out

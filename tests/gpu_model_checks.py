@@ -203,11 +203,19 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
     return out
 
 
-def recipe_case(B, T=30, H=64, W=64, C=3, seed=0):
+# bench.py's workloads (BASELINE.json configs[1], [3], [4]) as recipe_case arguments: the golden steps are taken at exactly these shapes
+BENCH_CASES = {
+    'c2': dict(B=16, T=30, H=64, W=64, C=3, context=2, nz=8, kl_weight=1.0),
+    'c4': dict(B=16, T=40, H=64, W=64, C=1, context=10, nz=32, kl_weight=0.01),      # KTH (kth_dataset.py:26-36, hparams/kth/ours_savp)
+    'c5': dict(B=8, T=30, H=128, W=128, C=3, context=2, nz=8, kl_weight=1.0),        # 128x128: the >= 128 layer table (savp_model.py:198-210)
+}
+
+
+def recipe_case(B, T=30, H=64, W=64, C=3, seed=0, context=2, nz=8, kl_weight=1.0):
     """The benchmarked step's inputs (hparams/bair_action_free/ours_savp recipe: T=30, clip_length=10, nz=8) at batch B, all seeded:
     (hparams, variables (init + perturbed norm parameters / biases so that they matter), images [T,B,H,W,C] fp64, noise)."""
-    hp = make_hparams(context_frames=2, sequence_length=T, clip_length=10, nz=8, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
-                      l2_weight=0.0, kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
+    hp = make_hparams(context_frames=context, sequence_length=T, clip_length=10, nz=nz, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
+                      l2_weight=0.0, kl_weight=kl_weight, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
                       vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
     specs = V.variable_specs(hp, (H, W, C), mode='train')
     vals = V.init_variables(specs, seed=4)

@@ -275,3 +275,23 @@ def test_allreduce_bucket_entry_point_validates_its_arguments(hip_lib):
     assert hip_lib.savp_allreduce_bucket(None, None, 0x1000, 16) != 0
     assert hip_lib.savp_allreduce_bucket(0x1000, None, None, 16) != 0
     assert hip_lib.savp_allreduce_bucket(0x1000, None, 0x2000, 0) == 0
+
+
+def test_action_and_state_inputs_are_refused_not_ignored():
+    """SAVPCell.call consumes inputs['actions'] / ['states'] (reference savp_model.py:413-421,655-658); the HIP path is action-free,
+    so every entry that takes the dataset's inputs dict raises instead of running as if the keys were absent."""
+    import numpy as np
+    import pytest
+    from video_prediction_amd.models import get_model_class
+    from video_prediction_amd.models import savp_model as M
+    images = np.zeros((2, 4, 64, 64, 3), np.float32)
+    model = get_model_class('savp')(mode='test', hparams_dict=dict(context_frames=2, sequence_length=4))
+    for key in ('actions', 'states'):
+        inputs = {'images': images, key: np.zeros((2, 4, 4), np.float32)}
+        with pytest.raises(NotImplementedError, match=key):
+            model.build_graph(inputs)
+        with pytest.raises(NotImplementedError, match=key):
+            M.generator_fn(inputs, 'test', model.hparams)
+        with pytest.raises(NotImplementedError, match=key):
+            M.SAVPEngine.set_images(None, inputs)
+    M.refuse_conditioning_inputs({'images': images, 'actions': None})       # an absent / None entry is the action-free case

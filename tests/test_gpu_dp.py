@@ -203,3 +203,158 @@ def test_live_tuning_choice_is_rank0s_on_every_replica():
         assert p.exitcode == 0
     assert res[0]['cfg'] == res[1]['cfg'] and res[0]['cfg'] != (0x111, 1)
     assert np.array_equal(res[0]['y'], res[1]['y'])
+
+
+# ---- RCCL itself, at world size 1 (the one transport a one-GPU box cannot exercise between ranks) -----------------------------------
+def _rccl_world1_worker(port, q):
+    """One rank, backend 'nccl' (= RCCL), collectives FORCED: attach_process_group(force=True) keeps the rank-0 broadcast, the
+    side-stream chunked all-reduce, the u broadcast and the event chaining in the step although a sum over one replica is the
+    identity.  Engine A: forced collectives + segmented hipGraph replay.  Engine B: plain single-process engine, eager."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from tests import gpu_model_checks as G
+        from video_prediction_amd.models.savp_model import SAVPEngine
+        hp, vals, images, _ = _setup(False)
+        noises = [G.make_noise(hp, B_GLOBAL, seed=100 + i, sampling=True) for i in range(4)]
+        a = SAVPEngine(hp, (HW, HW, C), B_GLOBAL, mode='train', values=vals, device='cuda:0')
+        a.attach_process_group(dist, force=True)
+        a.set_images(images.to('cuda:0'), time_major=True)
+        la = []
+        for n in noises:                                   # step 0 eager, step 1 captured + run, steps 2-3 replayed
+            info = a.train_step(n)
+            la.append((float(info['d_loss']), float(info['g_loss'])))
+        torch.cuda.synchronize()
+        res = {'backend': dist.get_backend(), 'active': a.replicas.active, 'dp': a.dp, 'stats': dict(a.replicas.stats),
+               'side_stream': a.replicas.comm_stream is not None, 'segments': a.graph.segments if a.graph is not None else 0,
+               'host_ops': sum(1 for it in a.graph.items if not isinstance(it, torch.cuda.CUDAGraph)) if a.graph is not None else 0,
+               'same': a.replicas.checksum_identical(), 'la': la, 'pa': a.store.to_numpy()}
+        b = SAVPEngine(hp, (HW, HW, C), B_GLOBAL, mode='train', values=vals, device='cuda:0')
+        b.use_graph = False
+        b.set_images(images.to('cuda:0'), time_major=True)
+        lb = []
+        for n in noises:
+            info = b.train_step(n)
+            lb.append((float(info['d_loss']), float(info['g_loss'])))
+        torch.cuda.synchronize()
+        res['lb'], res['pb'] = lb, b.store.to_numpy()
+        # the tuning table broadcast (kernels.sync_tuning_table) and a barrier also run on RCCL here
+        dist.barrier()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_world_size_one_forced_collectives_and_segmented_replay_equal_the_plain_step():
+    """Everything a rank of the 8-GPU job does that no gloo test reaches: init_process_group('nccl'), the replica broadcast, the
+    chunked all-reduce of arena slices on the side stream, the u broadcast + wait_aux, and the step replayed as hipGraph
+    segments with the RCCL calls between them (tf_utils.py:450-480, base_model.py:590-592,614-616,640-646).  At world size 1
+    every collective is the identity, so four steps must reproduce the plain engine's four steps."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=800)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert r['backend'] == 'nccl' and r['active'] and r['dp'] and r['side_stream'] and r['same']
+    # per step: D step one chunk per discriminator, G step generator cell + encoder => 4 all-reduces, 1 u broadcast
+    assert r['stats']['chunks'] == 4 * 4 and r['stats']['aux_broadcasts'] == 4, r['stats']
+    # wait_aux | D chunk | D chunk | finish D | G chunk | finish G (+ the rest) | sync_aux  => 7 host actions, 8 segments
+    assert r['segments'] == r['host_ops'] + 1 and r['host_ops'] >= 6, (r['segments'], r['host_ops'])
+    hp = _setup(False)[0]
+    for (da, ga), (db, gb) in zip(r['la'], r['lb']):
+        assert abs(da - db) <= 1e-4 * max(abs(db), 1e-3) and abs(ga - gb) <= 1e-4 * max(abs(gb), 1e-3), (r['la'], r['lb'])
+    tot = cnt = 0.0
+    for name, pb in r['pb'].items():
+        d = np.abs(pb.astype(np.float64) - r['pa'][name])
+        tot += float(d.sum())
+        cnt += d.size
+    assert tot / cnt <= 0.02 * hp.lr, tot / cnt          # four Adam steps, fp32 datapath: summation-order noise only
+
+
+def _bucket_worker(q):
+    """savp_allreduce_bucket with a communicator the CALLER owns: ncclGetUniqueId + ncclCommInitRank through ctypes on the RCCL
+    copy the process already holds (torch's), a non-default stream, result == input for one rank."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from video_prediction_amd import lib
+    torch.cuda.set_device(0)
+    rccl = ctypes.CDLL('librccl.so')                       # dlopen by the name common.hip uses: the same handle
+
+    class UID(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_char * 128)]
+    uid = UID()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UID)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0 and comm.value
+    side = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randn(5_000_003, generator=g).cuda()        # an odd-sized 20 MB bucket (one discriminator's chunk)
+    want = buf.clone()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        rc = lib.get().savp_allreduce_bucket(comm, ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(buf.data_ptr()), buf.numel())
+        rc2 = lib.get().savp_allreduce_bucket(comm, ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(buf[7:].data_ptr()), 1000)
+    side.synchronize()
+    ok = bool(torch.equal(buf, want))
+    rccl.ncclCommDestroy(comm)
+    q.put({'rc': rc, 'rc2': rc2, 'equal': ok})
+
+
+@pytest.mark.timeout(300)
+def test_savp_allreduce_bucket_on_a_one_rank_rccl_communicator():
+    """SURVEY.md 8(b)'s `savp_allreduce_bucket(ncclComm_t, hipStream_t, void*, size_t)` with a real ncclComm_t: librccl resolved by
+    the library's dlopen, ncclAllReduce(sum, fp32, in place) ordered on the caller's stream."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_bucket_worker, args=(q,))
+    p.start()
+    r = q.get(timeout=250)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert r == {'rc': 0, 'rc2': 0, 'equal': True}, r
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torchrun_with_rccl_at_world_size_one():
+    """The driver's launch line with N=1 and the collectives forced (SAVP_FORCE_DIST=1): bench.py's rendezvous, RCCL process group,
+    tuning-table broadcast, replica broadcast, side-stream exchange inside the segmented replay, barrier + MAX-over-ranks clock, one
+    JSON line.  The loss of the last step equals the plain one-GPU run's (same seeds, bf16 datapath: run-to-run spread)."""
+    import json
+    import subprocess
+    outs = {}
+    for force in ('1', '0'):
+        env = dict(os.environ, SAVP_FORCE_DIST=force, SAVP_BENCH_CHECK_REPLICAS='1')
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SAVP_DIST_BACKEND'):
+            env.pop(k, None)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2',
+               '--no-cpu-baseline', '--no-f32', '--inst-steps', '0']
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout
+        outs[force] = json.loads(lines[0])
+    d = outs['1']
+    assert d['n_gpus'] == 1 and d['config']['dist']['backend'].startswith('nccl') and d['config']['dist']['forced_at_world_1']
+    assert d['config']['dist']['side_stream'] and d['config']['dist']['allreduce_chunks_issued'] == 4 * 5
+    assert 'segments' in d['config']['submission'], d['config']['submission']
+    assert d['replicas_identical'] is True
+    assert 'dist' not in outs['0']['config'] and outs['0']['config']['submission'] == 'hipGraph replay'
+    for k in ('d_loss', 'g_loss'):
+        a, b = d['losses'][k], outs['0']['losses'][k]
+        assert abs(a - b) <= 2e-2 * max(abs(b), 1e-3), (k, a, b)
+    # issuing the collectives from the host between graph segments must not cost the step more than a few percent
+    assert d['ms_per_step'] <= 1.10 * outs['0']['ms_per_step'] + 1.0, (d['ms_per_step'], outs['0']['ms_per_step'])

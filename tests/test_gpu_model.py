@@ -324,28 +324,26 @@ def test_train_and_generate_scripts(tmp_path):
     assert len(pngs) == 2 * 2 * 10 and 'gen_image_00001_01_09.png' in pngs          # 2 sequences x 2 samples x 10 future frames
 
 
-def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
-    """EXACTLY the benchmarked problem (BASELINE.json configs[1]: B=16, T=30, 64x64x3, nz=8, clip_length=10, recipe weights) on the
-    bf16 datapath with the shipped tuning table, i.e. the (problem, tile, split-K) instantiations bench.py launches, against one
-    step of the CPU oracle committed as tests/golden/b16_step_golden.npz (tests/golden/make_b16_step_golden.py; inputs re-created
-    here from the same seeds).  Tolerances = the bf16 gates of check_train_recipe_shapes: losses within 2e-2 (6e-2 per term) of
-    max(|ref|, 0.05), sampled frames within 5e-2, per-variable gradient (a seeded sample of <= 4096 elements) within 0.25 relative L2
-    unless its absolute error is below 2e-3 of the group's largest gradient."""
+GRAD_REL_L2 = 0.22      # bf16 datapath, per-variable gradient vs the oracle (measured worst on MI355X: 0.19; run-to-run spread 0.02)
+
+
+def _golden_step_check(fname, case):
+    """One bf16 train step at a bench shape with the shipped tuning table vs a committed oracle step (tests/golden/<fname>)."""
     from tests import gpu_model_checks as G
     from tests.golden.make_b16_step_golden import sample_index
     from video_prediction_amd import kernels as K
     from video_prediction_amd.models.savp_model import SAVPEngine
-    gold = np.load(os.path.join(HERE, 'golden', 'b16_step_golden.npz'))
+    gold = np.load(os.path.join(HERE, 'golden', fname))
     B, T = int(gold['B']), int(gold['T'])
-    assert (B, T) == (16, 30)
-    hp, vals, images, noise = G.recipe_case(B, T)
+    assert (B, T) == (case['B'], case['T'])
+    hp, vals, images, noise = G.recipe_case(**case)
     K.set_conv_precision('bf16')
     saved = dict(K.AUTOTUNE, cache=dict(K.AUTOTUNE['cache']))
     try:
         K.enable_autotune(True)
         n = K.load_tuning(os.path.join(os.path.dirname(HERE), 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
         assert n >= 200
-        eng = SAVPEngine(hp, (64, 64, 3), B, mode='train', values=vals, device='cuda:0')
+        eng = SAVPEngine(hp, (case['H'], case['W'], case['C']), B, mode='train', values=vals, device='cuda:0')
         eng.set_images(images.float().cuda(), time_major=True)
         info = eng.train_step(noise, return_grads=True)
         torch.cuda.synchronize()
@@ -365,28 +363,64 @@ def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
     gen = eng.gen.gen.v
     ts, bs = torch.as_tensor(gold['gen_t']), torch.as_tensor(gold['gen_b'])
     for key, half in (('gen_images_enc', gen[:, :B]), ('gen_images', gen[:, B:])):
-        got = half[ts][:, bs].float().cpu().numpy()
+        got = half[ts][:, bs].float().cpu().numpy()[..., :case['C']]
         err = float(np.abs(got - gold[key]).max())
         if err > 5e-2:
             bad.append((key, err))
-    checked = 0
+    checked, projected, worst = 0, 0, (0.0, None)
     for key in ('d_grads', 'g_grads'):
         names = [k.split('/', 1)[1].rsplit('/', 1)[0] for k in gold.files if k.startswith(key + '/') and k.endswith('/norm')]
         gmax = max(float(gold['%s/%s/max' % (key, nme)]) for nme in names)
         for nme in names:
-            g = info[key][nme].detach().reshape(-1)
+            g = info[key][nme].detach()
             ref = gold['%s/%s/sample' % (key, nme)].astype(np.float64)
-            got = g[torch.from_numpy(sample_index(nme, g.numel())).to(g.device)].double().cpu().numpy()
+            got = g.reshape(-1)[torch.from_numpy(sample_index(nme, g.numel())).to(g.device)].double().cpu().numpy()
             checked += 1
             if float(gold['%s/%s/max' % (key, nme)]) < 1e-9 * gmax:
                 if float(np.abs(got).max()) / gmax > 1e-2:
                     bad.append((nme, 'analytically zero gradient', float(np.abs(got).max()) / gmax))
                 continue
             e = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
-            if e > 0.25 and float(np.abs(got - ref).max()) > 2e-3 * gmax:
+            small = float(np.abs(got - ref).max()) <= 2e-3 * gmax
+            if not small and e > worst[0]:
+                worst = (e, nme)
+            if e > GRAD_REL_L2 and not small:
                 bad.append((nme, 'rel L2 %.3f' % e, 'abs/gmax %.2e' % (float(np.abs(got - ref).max()) / gmax)))
+            ck = '%s/%s/colnorm' % (key, nme)
+            if ck in gold.files:
+                # whole-tensor projections: L2 norm per output channel and per (tap, input channel) row of the full gradient
+                g2 = g.double().reshape(-1, g.shape[-1])
+                for proj, want in ((g2.norm(dim=0), gold[ck]), (g2.norm(dim=1), gold['%s/%s/rownorm' % (key, nme)])):
+                    want = want.astype(np.float64)
+                    pe = float(np.linalg.norm(proj.cpu().numpy() - want) / max(np.linalg.norm(want), 1e-30))
+                    projected += 1
+                    if pe > 0.10 and float(np.abs(proj.cpu().numpy() - want).max()) > 2e-3 * gmax * np.sqrt(g2.numel() / want.size):
+                        bad.append((nme, 'projection rel L2 %.3f' % pe))
     assert checked >= 100
-    assert not bad, bad
+    assert not bad, (bad, 'worst per-variable gradient rel L2 %.3f at %s' % worst)
+    return checked, projected, worst
+
+
+def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
+    """EXACTLY the benchmarked problem (BASELINE.json configs[1]: B=16, T=30, 64x64x3, nz=8, clip_length=10, recipe weights) on the
+    bf16 datapath with the shipped tuning table, i.e. the (problem, tile, split-K) instantiations bench.py launches, against one
+    step of the CPU oracle committed as tests/golden/b16_step_golden.npz (tests/golden/make_b16_step_golden.py; inputs re-created
+    here from the same seeds).  Tolerances: losses within 2e-2 (6e-2 per term) of max(|ref|, 0.05), sampled frames within 5e-2,
+    per-variable gradient (a seeded sample of <= 4096 elements) within GRAD_REL_L2 relative L2 unless its absolute error is below
+    2e-3 of the group's largest gradient; the assertion names the worst variable."""
+    from tests import gpu_model_checks as G
+    _golden_step_check('b16_step_golden.npz', G.BENCH_CASES['c2'])
+
+
+@pytest.mark.parametrize('config', ['c4', 'c5'])
+def test_bench_workloads_c4_c5_bf16_step_at_bench_shape_vs_oracle_golden(config):
+    """bench.py --config c4 / c5 at THEIR bench shapes (BASELINE.json configs[3]: KTH 64x64x1, B=16, T=40, context 10, nz=32;
+    configs[4]: 128x128x3, B=8, T=30), bf16 datapath, shipped table + live tuning of the rest, vs committed oracle steps
+    (CONFIG=c4|c5 tests/golden/make_b16_step_golden.py).  Same gates as the c2 golden, plus whole-tensor projections (per output
+    channel / per row L2 norms of every gradient above 4096 elements) within 10 %."""
+    from tests import gpu_model_checks as G
+    checked, projected, worst = _golden_step_check('%s_step_golden.npz' % config, G.BENCH_CASES[config])
+    assert projected >= 40
 
 
 def test_bf16_loss_curve_tracks_fp32_over_50_steps():

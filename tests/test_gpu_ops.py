@@ -151,3 +151,8 @@ def test_every_shipped_tuning_table_instantiation_vs_fp64(precision):
     assert len(res) >= 90
     bad = gpu_checks.failures(res)
     assert not bad, 'parity failures (name, rel err, tol): %r' % bad[:20]
+
+
+def test_tiled_z_gradient_and_gapped_gate_dgrad():
+    from tests import gpu_checks
+    _run(gpu_checks.check_tiled_z_and_gapped_dgrad)

@@ -772,6 +772,8 @@ extern "C" int savp_conv_stats_ok(const SavpConvArgs* a) {
     if (!(a->w_bf16 && (Cred % 8 == 0) && aligned16(a->w_bf16))) return 0;
     ConvP p;
     p.bf16 = 1; p.w16 = (const unsigned short*)a->w_bf16; p.src16 = a->src_bf16 ? 1 : 0; p.splitk = 1; p.tm = p.tn = 1;
+    p.gap_at = 0x7fffffff; p.gap = 0;
+    if (a->dst_gap) return 0;                                   // statistics of a gapped destination: not offered
     SavpConvArgs b = *a;
     if (!b.stats) b.stats = (float*)(uintptr_t)16;               // any non-NULL value: only the plan is made
     int wm = 0, wn = 0;
@@ -799,6 +801,9 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.splitk = 1; p.tm = p.tn = 1;
     p.src16 = a->src_bf16 ? 1 : 0; p.cell = 0; p.stats = nullptr;
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
+    const bool gapped = a->dst_gap != 0;
+    if (gapped && (a->dst_gap < 0 || a->dst_gap_at < 0 || a->mode == SAVP_CONV_WGRAD)) return SAVP_EINVAL;
+    p.gap_at = gapped ? a->dst_gap_at : 0x7fffffff; p.gap = gapped ? a->dst_gap : 0;
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
     const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel, 3 = LDS-DMA ring kernel
@@ -809,12 +814,12 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
     // problem-specific kernels, taken only when the caller leaves the algorithm to the library (tile bits 8-9 == 0): a forced
     // algorithm gets exactly that kernel or EINVAL
-    if (algo == 0) {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first
+    if (algo == 0 && !gapped) {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first
         // layer (FPROP, WGRAD) and the data gradient of the generator's scratch-image head
         int rc = SAVP_OK;
         if (conv_thin_try(a, st, &rc)) return rc;
     }
-    if (algo == 0 && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
+    if (algo == 0 && !gapped && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
         int rc = SAVP_OK;
         if (conv_s2dgrad_try(a, st, &rc)) return rc;
     }
@@ -835,7 +840,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         }
         if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
         // ---- LDS patch kernel (conv_patch.hip): 2-D stride-1 convs in bf16 with pre-packed bf16 weights --------------
-        const bool needs_ring = a->out_bf16 || a->src_bf16 || a->stats;       // only the ring kernel reads / writes bf16 activations
+        const bool needs_ring = a->out_bf16 || a->src_bf16 || a->stats || gapped;   // only the ring kernel reads / writes bf16 activations / skips destination channels
         if (algo == 3 || needs_ring || (algo == 0 && ring_default())) {
             int rc = SAVP_OK;
             if (conv_ring_try(p, a, wm, wn, st, &rc)) return rc;

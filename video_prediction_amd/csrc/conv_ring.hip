@@ -165,9 +165,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         const int cnt = qx + (xcd < rx ? 1 : 0);
         const int l_lo = max(first, nt_ * p.tm), l_hi = min(first + cnt, (nt_ + 1) * p.tm);
         const int share = max(l_hi - l_lo, 1), mine = min(max(tlog - l_lo, 0), share - 1);
-        const int blk = min(BN, Nout - n0) * ldb * 2;                       // bytes of the block (launcher: < 2^31)
+        // (with a column gap the physical rows of the tile's first .. last logical column are warmed, gap rows included)
+        const int r_lo = n0 + (n0 >= p.gap_at ? p.gap : 0), c_hi = min(n0 + BN, Nout) - 1, r_hi = c_hi + (c_hi >= p.gap_at ? p.gap : 0);
+        const int blk = (r_hi - r_lo + 1) * ldb * 2;                        // bytes of the block (launcher: < 2^31)
         const int chunk = ((blk + share - 1) / share + 1023) & ~1023;       // bytes per workgroup, whole wave instructions
-        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w16) + (size_t)n0 * ldb * 2;
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w16) + (size_t)r_lo * ldb * 2;
         const int lo = mine * chunk;
         int slot = 0;
         for (int off = wave * 1024; off < chunk && lo + off < blk; off += NW * 1024) {
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         const int r = min(slot / RS, BN - 1);                  // slots >= SLOTS land in the buffer's tail, never read
         int j = slot % RS;
         if (j == 2 * NKS) j = 0;                               // pad slot of the row: any valid address
-        const int row = min(n0 + r, Nout - 1);                 // columns >= Nout are computed on valid data, never stored
+        int row = min(n0 + r, Nout - 1);                       // columns >= Nout are computed on valid data, never stored
+        if (row >= p.gap_at) row += p.gap;                     // logical output column -> physical weight row (ConvP::gap)
         const bool okL = (nch - 1) * CKB + j * 8 < Cred;       // beyond Cred the patch holds zeros: any FINITE weights do
         goffF[q] = (unsigned)(row * ldb + j * 8) * 2u;
         goffL[q] = (unsigned)(row * ldb + (okL ? j * 8 : 0)) * 2u;
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int gsz = ntaps * spp;
     const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     Frags F0, F1;
+    bool first_group = true;
     using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
     for (int gg = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
@@ -386,7 +390,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         const int len = t_end - t_begin;
         RT(12);
         RTW(1);
-        __syncthreads();                                   // previous group's patch, ring and table are dead (no DMA in flight here)
+        // previous group's patch, ring and table are dead (no DMA in flight here).  Not for the first group: nothing to protect, and
+        // __syncthreads() = s_waitcnt vmcnt(0) + s_barrier would put the whole latency of the weight warm-up DMAs (issued a few
+        // hundred cycles ago) in front of the table fill and the patch staging
+        if (!first_group) __syncthreads();
+        first_group = false;
         RT(10);
         for (int e = tid; e < len; e += NT) {              // entry table of this group
             const int ent = t_begin + e;
@@ -423,18 +431,22 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         constexpr int KH = (NKS + 1) / 2;
         // `steady`: entries e+1 .. e+3 exist -- no branch in the step (a conditional load / DMA merges hipcc's wait-count states
         // at the join and it falls back to lgkmcnt(0) in front of the MFMAs again)
+        // Table entries travel one step ahead of their use in a three-deep register queue (tq0 = entry e+1: fragments read in step e,
+        // tq2 = entry e+3: its slab DMA is issued in step e): the one table read of a step (entry e+4) is issued behind the barrier
+        // and consumed a whole step later, so neither the DMA address nor the A-fragment address waits for an LDS round trip there.
+        uint2 tq0 = etab[min(1, len - 1)], tq1 = etab[min(2, len - 1)], tq2 = etab[min(3, len - 1)];
         auto step = [&](int e, Frags& cur, Frags& nxt, auto bn, auto bd, auto steadyc) {
             constexpr bool STEADY = decltype(steadyc)::value;
             const bool more = STEADY || e + 1 < len;
             if (more) {
-                const uint2 tn = etab[e + 1];
-                uint2 td = tn;
-                if (STEADY || e + 3 < len) td = etab[e + 3];
+                const uint2 tn = tq0, td = tq2;
                 if (STEADY || e + 2 < len) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                const uint2 t4 = etab[min(e + 4, len - 1)];
                 if (STEADY || e + 3 < len) issue(td, bd);
                 load_a(nxt, tn);
+                tq0 = tq1; tq1 = tq2; tq2 = t4;
             }
             if constexpr (STEADY) {
                 load_b(nxt, bn);
@@ -536,6 +548,9 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     // ---- plain epilogue (as conv_patch.hip) -------------------------------------------------------------------------------------
     const int e_sh = d_sh * gh.os, e_sw = d_sw * gw.os;
     const int col0 = n0 + wn0 + l31;
+    int pcol[WN];                                             // physical destination channel of this lane's column j (ConvP::gap)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) pcol[j] = col0 + 32 * j + ((col0 + 32 * j) >= p.gap_at ? p.gap : 0);
     const int px0 = ox0 + 4 * khalf;
     const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
     bool biased = false;                                      // the bias is already in the accumulators
@@ -584,15 +599,15 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
         float* __restrict__ dst = p.out + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
                                   (long long)(gh.ob + py0 * gh.os) * d_sh +
-                                  (long long)(gw.ob + px0 * gw.os) * d_sw + col0;
+                                  (long long)(gw.ob + px0 * gw.os) * d_sw;
         const bool full = (py0 + 4 <= Hm) && (ox0 + TW <= Wm);
         if (plain && full) {
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 if (col0 + 32 * j >= Nout) continue;
-                const float bias = (p.bias && !biased) ? p.bias[col0 + 32 * j] : 0.f;
+                const float bias = (p.bias && !biased) ? p.bias[pcol[j]] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + 32 * j] = acc[i][j][r] + bias;
+                for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + pcol[j]] = acc[i][j][r] + bias;
             }
             continue;
         }
@@ -600,11 +615,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (col0 + 32 * j >= Nout) continue;
-            const float bias = (p.bias && split == 0 && !biased) ? p.bias[col0 + 32 * j] : 0.f;
+            const float bias = (p.bias && split == 0 && !biased) ? p.bias[pcol[j]] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
-                const int off = (r >> 2) * e_sh + (r & 3) * e_sw + 32 * j;
+                const int off = (r >> 2) * e_sh + (r & 3) * e_sw + pcol[j];
                 float v = acc[i][j][r] + bias;
                 if (p.splitk > 1) {
                     unsafeAtomicAdd(dst + off, v);
@@ -789,8 +804,9 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
     const int Hm = dg ? (a->H + a->sh - 1) / a->sh : a->Ho, Wm = dg ? (a->W + a->sw - 1) / a->sw : a->Wo;
     const long long dH = dg ? a->H : a->Ho;
     const long long d_sh = dg ? a->x_sh : a->y_sh;
-    if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)Nout * a->kh * a->kw * a->kd * Cred >= (1ll << 30))
+    if (ssh * (a->H + a->kh) >= (1ll << 30) || d_sh * (dH + 16) >= (1ll << 30) || (long long)(Nout + p.gap) * a->kh * a->kw * a->kd * Cred >= (1ll << 30))
         return false;
+    if (p.gap && (a->out_bf16 || a->stats)) return false;        // the gap lives in the plain epilogue only
     if ((long long)Hm * Wm < 16) return false;
     static const void* zero16 = nullptr;                         // address of g_ring_zero (resolved once; a constant of the loaded code object)
     if (!dry && !zero16 && hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16 = nullptr;

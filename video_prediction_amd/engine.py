@@ -321,11 +321,12 @@ class ConvLayer(object):
             return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=self.bias, w16=self.wd16)
         return K.conv_stats_ok(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=self.bias, w16=self.wt16)
 
-    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None):
+    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None, skip=None):
+        """skip = (first, count): input channels whose data gradient is not needed per pixel (left unwritten in dx)."""
         if self.kind == 'up':
-            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16)
+            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16, dst_gap=skip)
         else:
-            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16)
+            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16, dst_gap=skip)
 
     def backward_weights(self, x, dy):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may

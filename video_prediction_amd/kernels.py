@@ -70,14 +70,29 @@ def load_tuning(path):
         d = json.load(f)
     for k, v in d.items():
         AUTOTUNE['cache'][ast.literal_eval(k)] = (int(v[0]), int(v[1]))
+    sync_tuning_table()
     return len(d)
 
 
-def set_tuning_group(dist_module):
+def set_tuning_group(dist_module, force=False):
     """Data-parallel runs: every replica executes the same launch sequence, so all of them meet an unknown conv problem at the
     same call; each times the candidates on its own GPU, then rank 0's choice is broadcast and used by everyone (identical
     kernels -> identical per-rank step time; without this the ranks could settle on different tiles)."""
-    AUTOTUNE['dist'] = dist_module if (dist_module is not None and dist_module.get_world_size() > 1) else None
+    AUTOTUNE['dist'] = dist_module if (dist_module is not None and (dist_module.get_world_size() > 1 or force)) else None
+    sync_tuning_table()
+
+
+def sync_tuning_table():
+    """Make every replica's (problem -> tile) cache a copy of rank 0's.  The broadcast inside conv() fires on a LOCAL cache miss,
+    so caches that differ between ranks (a table file readable on some ranks only, --retune on one rank) would make the ranks
+    disagree on the number of collectives; identical caches + identical launch sequences keep the misses collective."""
+    d = AUTOTUNE['dist']
+    if d is None:
+        return
+    box = [dict(AUTOTUNE['cache']) if d.get_rank() == 0 else None]
+    d.broadcast_object_list(box, src=0)
+    AUTOTUNE['cache'].clear()
+    AUTOTUNE['cache'].update(box[0])
 
 
 def enable_autotune(flag=True):
@@ -86,7 +101,7 @@ def enable_autotune(flag=True):
     AUTOTUNE['enabled'] = bool(flag)
 
 
-def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None):
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, dst_gap=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -95,6 +110,15 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
         raise ValueError('batch mismatch %d vs %d' % (N, N2))
     a.N, a.D, a.H, a.W, a.Cx = N, D, H, W, Cx
     a.Do, a.Ho, a.Wo, a.Cy = Do, Ho, Wo, Cy
+    if dst_gap is not None and dst_gap[1]:
+        # the destination view spans ALL physical channels; the kernel computes the logical ones (SavpConvArgs.dst_gap)
+        a.dst_gap_at, a.dst_gap = int(dst_gap[0]), int(dst_gap[1])
+        if mode == lib.CONV_DGRAD:
+            a.Cx = Cx - a.dst_gap
+        elif mode == lib.CONV_FPROP:
+            a.Cy = Cy - a.dst_gap
+        else:
+            raise ValueError('dst_gap: FPROP / DGRAD only')
     a.kd, a.kh, a.kw = geom.k
     a.sd, a.sh, a.sw = geom.s
     a.pd, a.ph, a.pw = geom.p
@@ -190,13 +214,15 @@ def _tune(a, mode, dst, w, return_all=False):
     return best or (0, 0)
 
 
-def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None):
+def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
+         dst_gap=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
     destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] fp32 (zeroed by the caller)
-    receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only)."""
+    receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only); dst_gap = (first, count):
+    `count` destination channels from `first` on are left out (neither computed nor written)."""
     lib.require_device(w, bias, aux, stats)
     lib.require_device_any(x, y)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap)
     if mode == lib.CONV_WGRAD:           # caller-owned scratch (today: the RGB-side weight gradient's partial sums)
         need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
         if need:
@@ -205,6 +231,8 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
+        if a.dst_gap:
+            key = key + ((a.dst_gap_at, a.dst_gap),)
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
@@ -511,6 +539,35 @@ def tile_channels(z, out, scale=1.0, beta=0):
         return
     lib.check(_L().savp_tile_channels(lib.stream(), _p(z), R, _hw(out), C, float(scale), view(out), int(beta)),
               'savp_tile_channels')
+
+
+def tiled_z_weff(w_hwio, geom, z0, nz, weff):
+    """Effective weights [25, Cout, 8] of the tiled-z gradient from the master HWIO kernel (csrc/tiled_z.hip)."""
+    lib.require_device(w_hwio, weff)
+    kh, kw, cin, cout = w_hwio.shape[-4:]
+    if not w_hwio.is_contiguous() or weff.numel() < 25 * cout * 8:
+        raise ValueError('tiled_z_weff: contiguous HWIO kernel and a [25, Cout, 8] buffer expected')
+    lib.check(lib.get().savp_tiled_z_weff(lib.stream(), w_hwio.data_ptr(), kh, kw, geom.p[1], geom.p[2], cin, cout, int(z0), int(nz),
+                                          weff.data_ptr()), 'savp_tiled_z_weff')
+
+
+def tiled_z_grad(dy, weff, dz, beta=1):
+    """dz [IMG, nz] (+)= gradient of a latent tiled over the plane from the conv output gradient dy [IMG, H, W, C] (fp32 / bf16,
+    contiguous) and tiled_z_weff's effective weights: the per-pixel data gradient of those channels is never formed."""
+    lib.require_device(weff, dz)
+    lib.require_device_any(dy)
+    if not dy.is_contiguous() or not dz.is_contiguous() or dy.dim() != 4:
+        raise ValueError('tiled_z_grad: contiguous dy [IMG, H, W, C] and dz [IMG, nz] expected')
+    img, H, W, C = dy.shape
+    lib.check(lib.get().savp_tiled_z_grad(lib.stream(), dy.data_ptr(), int(dy.dtype == torch.bfloat16), img, H, W, C, weff.data_ptr(),
+                                          dz.shape[-1], dz.data_ptr(), int(beta)), 'savp_tiled_z_grad')
+
+
+def tiled_z_ok(H, W, C, nz, geom):
+    """Does csrc/tiled_z.hip cover this plane / kernel (else the data gradient keeps the z channels)?"""
+    k, p = geom.k, geom.p
+    return (H >= 4 and 4 <= W <= 32 and (W & (W - 1)) == 0 and C % 64 == 0 and 1 <= nz <= 8 and k[0] == 1 and
+            p[1] <= 2 and p[2] <= 2 and k[1] - 1 - p[1] <= 2 and k[2] - 1 - p[2] <= 2 and tuple(geom.s) == (1, 1, 1))
 
 
 def colsum(x, out, scale=1.0, per_row=False):

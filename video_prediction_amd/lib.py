@@ -32,6 +32,7 @@ class SavpConvArgs(ctypes.Structure):
         ('w', c_vp), ('bias', c_vp), ('aux', c_vp), ('w_bf16', c_vp),
         ('src_bf16', c_i32), ('out_bf16', c_i32), ('stats', c_vp),
         ('ws', c_vp), ('ws_bytes', c_i64),
+        ('dst_gap_at', c_i32), ('dst_gap', c_i32),
     ]
 
 
@@ -97,6 +98,8 @@ def _declare(lib):
     _sig(lib, 'savp_set_option', [ctypes.c_char_p, c_i32])
     _sig(lib, 'savp_get_option', [ctypes.c_char_p, P(c_i32)])
     _sig(lib, 'savp_allreduce_bucket', [c_vp, c_vp, c_vp, c_i64])
+    _sig(lib, 'savp_tiled_z_weff', [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp])
+    _sig(lib, 'savp_tiled_z_grad', [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32])
     for name, argtypes in _EXTRA_SIGS.items():
         _sig(lib, name, argtypes)
 

@@ -186,6 +186,13 @@ class SAVPGenerator(object):
                 L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
                 L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
                 L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
+                # The data gradient of the gate convolution leaves the tiled-z channels of [x | z | h] out (their gradient is a per-sample
+                # sum, taken once over all timesteps from region sums of the gate gradient: csrc/tiled_z.hip), which keeps its column count
+                # on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256).  bf16 datapath (the ring kernel owns the column gap).
+                L['zless'] = bool(g and zr and L['fused'] and os.environ.get('SAVP_ZLESS_DGRAD', '1') == '1' and
+                                  K.tiled_z_ok(h_, w_, 4 * f, zr, L['rconv'].geom))
+                if L['zless']:
+                    L['weff'] = torch.empty(25, 4 * f, 8, device=dev)
             else:
                 L['out'] = None
             self.layers.append(L)
@@ -591,7 +598,7 @@ class SAVPGenerator(object):
                                          n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
                                          dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L),
                                          dgates_raw=L.get('dg_raw'))
-                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
+                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=(f, L['zr']) if L['zless'] else None)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
                                        [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
                 else:
@@ -643,7 +650,12 @@ class SAVPGenerator(object):
             b = L['in']
             if L['zc']:
                 K.colsum(b.flat(b.g)[..., L['zoff_in']:L['zoff_in'] + nz], drz, per_row=True)
-            if L['rnn'] and L['zr']:
+            if L['rnn'] and L['zr'] and L.get('zless'):
+                # z gradient of the gate convolution from the gate gradients of all timesteps (the DGRADs left those channels out)
+                gt = L['gates']
+                K.tiled_z_weff(L['rconv'].W, L['rconv'].geom, L['f'], nz, L['weff'])
+                K.tiled_z_grad(gt.flat(gt.g), L['weff'], drz.reshape(T1 * N, nz), beta=1)
+            elif L['rnn'] and L['zr']:
                 a = L['a']
                 K.colsum(a.flat(a.g)[..., L['f']:L['f'] + nz], drz, per_row=True)
         if self.use_rnn_z:

@@ -32,6 +32,79 @@ def _image_shape(images):
 IDX_KEYS = ('enc_real', 'enc_fake', 'real', 'fake')
 
 
+class _StepProgram(object):
+    """One train step as a sequence of hipGraph segments and host actions.
+
+    The launch sequence of a step has no host input, so on one GPU it is one hipGraph.  With data-parallel replicas the step
+    also contains collectives (base_model.py:590-592,614-616: gradient sums; here chunked onto a side stream, parallel.py) that
+    must stay outside a capture: RCCL calls are issued by the host, in the same order on every rank.  The program therefore
+    cuts the launch sequence at every host action: [graph 0] action [graph 1] action ... [graph n].  Replaying it costs a
+    handful of hipGraphLaunch + torch.distributed calls per step, so eight replica processes on one host no longer each need
+    tens of milliseconds of Python per step to keep their GPU busy.  All segments share one private memory pool (they are
+    always replayed in capture order)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device=device)
+        self.cur = None
+
+    def _begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        # thread_local: ProcessGroupNCCL's watchdog thread may query events while this thread captures
+        self.cur.capture_begin(pool=self.pool, capture_error_mode='thread_local')
+
+    def _end(self):
+        g, self.cur = self.cur, None
+        g.capture_end()
+        self.items.append(g)
+
+    def host_op(self, fn):
+        self._end()
+        self.items.append(fn)
+        self._begin()
+
+    def capture(self, engine, body):
+        """Run body() once under capture (nothing executes; host actions are recorded, not performed).  Returns body's value."""
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        main = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(main)
+        try:
+            with torch.cuda.stream(self.stream):
+                self._begin()
+                engine._rec = self
+                out = body()
+                self._end()
+        except Exception:
+            if self.cur is not None:
+                try:
+                    self.cur.capture_end()
+                except Exception:
+                    pass
+                self.cur = None
+            raise
+        finally:
+            engine._rec = None
+        main.wait_stream(self.stream)
+        return out
+
+    @property
+    def segments(self):
+        return sum(1 for it in self.items if isinstance(it, torch.cuda.CUDAGraph))
+
+    def run(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+    replay = run
+
+
 class SAVPEngine(object):
     """All device state of one SAVP replica: variables, generator unroll (batch 2B: posterior + prior), posterior
     encoder, the two video discriminators; implements one training step and inference."""
@@ -104,6 +177,8 @@ class SAVPEngine(object):
         self.loss_buf = torch.zeros(getattr(self, 'loss_buf_size', 16), device=self.device)
         self.step = 0
         self.world = 1
+        self.dp = False
+        self._rec = None
         self.dist = None
         # per-step inputs drawn on the host are staged into these persistent device buffers BEFORE the kernels of the step
         # are launched, so that the launch sequence itself has no host input and can be captured into a hipGraph
@@ -122,32 +197,57 @@ class SAVPEngine(object):
         self.eager_steps = 0
 
     # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
-    def attach_process_group(self, dist_module):
-        """One process per GPU; see parallel.ReplicaGroup."""
+    def attach_process_group(self, dist_module, force=None):
+        """One process per GPU; see parallel.ReplicaGroup.  force (default: SAVP_FORCE_DIST=1): keep every collective of the
+        step even in a group of one rank -- RCCL / the side stream / the segmented replay exercised on a one-GPU box."""
         from ..parallel import ReplicaGroup
-        self.replicas = ReplicaGroup(self.store, dist_module, overlap=os.environ.get('SAVP_DP_OVERLAP', '1') == '1')
+        if force is None:
+            force = os.environ.get('SAVP_FORCE_DIST', '0') == '1'
+        self.replicas = ReplicaGroup(self.store, dist_module, overlap=os.environ.get('SAVP_DP_OVERLAP', '1') == '1', force=force)
         self.dist = dist_module
         self.world = self.replicas.world
+        self.dp = self.replicas.active          # the step carries collectives (world > 1, or forced)
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
-        K.set_tuning_group(dist_module)         # rank 0's tile choice for every conv problem tuned live
+        self.graph = None                       # a step captured without the collectives is not this engine's step any more
+        K.set_tuning_group(dist_module, force=self.dp)     # rank 0's tuning table, and rank 0's choice for problems tuned live
+
+    def wait_aux(self):
+        """Order the compute stream behind the side-stream broadcast of the spectral-norm u vectors (ReplicaGroup.sync_aux):
+        called by every entry point that reads or writes the 'aux' arena outside the train step (discriminator_fn, restore,
+        save, variable loads)."""
+        if self.dp:
+            self.replicas.wait_aux()
+
+    def _host_op(self, fn):
+        """A host-side action between launches of the step (a collective on the side stream, an event wait).  Eager step: done
+        now.  While the step is being captured (_StepProgram): closes the current hipGraph segment, is recorded as the action
+        to perform between this segment and the next one, and a new segment is opened."""
+        if self._rec is not None:
+            self._rec.host_op(fn)
+        else:
+            fn()
 
     def _begin_allreduce(self, group, prefix):
         """Start the exchange of the gradients of the variables under `prefix` (one network = one contiguous chunk)."""
-        if self.world > 1:
+        if self.dp:
             try:
                 lo, hi = self.store.chunk_of(group, prefix)
             except ValueError:          # scope not contiguous in the arena: left to finish_allreduce (exchanged at the end)
                 return
-            self.replicas.begin_allreduce(group, lo, hi)
+            self._host_op(lambda: self.replicas.begin_allreduce(group, lo, hi))
 
     def _allreduce(self, group):
         """Complete the exchange of the group's gradient bucket (chunks not started yet are exchanged now)."""
-        if self.world > 1:
-            self.replicas.finish_allreduce(group)
+        if self.dp:
+            self._host_op(lambda: self.replicas.finish_allreduce(group))
 
     # -- input staging -------------------------------------------------------------------------------------------------
     def set_images(self, images, time_major=False):
-        """images: device fp32 [B,T,H,W,C] (reference layout) or [T,B,H,W,C] if time_major."""
+        """images: device fp32 [B,T,H,W,C] (reference layout) or [T,B,H,W,C] if time_major; or the dataset's inputs dict
+        (its 'images' entry is taken; 'actions' / 'states' are refused, see refuse_conditioning_inputs)."""
+        if isinstance(images, dict):
+            refuse_conditioning_inputs(images)
+            images = images['images']
         T = self.T
         if time_major:
             self.images_tm.copy_(images[:T])
@@ -294,9 +394,10 @@ class SAVPEngine(object):
         device scalars (losses) -- nothing is synchronised unless the caller reads them.
 
         The step = (a) host part: draw / stage the random inputs and the step-dependent scalars into device buffers,
-        (b) the launch sequence _step_body(), which has no host input.  On one GPU (b) is captured into a hipGraph after
-        the first eager steps and replayed afterwards (SAVP_GRAPH=0 keeps it eager): ~3.5k launches per step otherwise
-        cost more host time than the GPU needs for the small per-timestep kernels."""
+        (b) the launch sequence _step_body(), which has no host input.  (b) is captured after the first eager step(s) and
+        replayed afterwards (SAVP_GRAPH=0 keeps it eager): on one GPU as ONE hipGraph; with replicas as a _StepProgram of
+        hipGraph segments with the collectives issued by the host between them (a replica issues ~10 host calls per step
+        instead of ~2.5k launches: 39 ms of Python / ctypes per 55 ms step otherwise)."""
         hp = self.hp
         if noise is None:
             noise = self.default_noise()
@@ -307,18 +408,16 @@ class SAVPEngine(object):
         lr_d = store.groups['d'].next_lr_t(lr, hp.beta1, hp.beta2) if self.discs else 0.0
         lr_g = store.groups['g'].next_lr_t(lr, hp.beta1, hp.beta2)
         self.d_scal.copy_(torch.tensor([lr_d, lr_g, klw or 0.0, 0.0], dtype=torch.float32))
-        graph_ok = self.use_graph and self.world == 1 and not return_grads
+        graph_ok = self.use_graph and not return_grads
         if graph_ok and self.graph is not None:
-            self.graph.replay()
+            self.graph.run()
             info = self._fresh_info(self.graph_info, klw)
         elif graph_ok and self.eager_steps >= 1:
             # capture: every conv problem has been tuned and every kernel launched once by the eager step(s)
-            torch.cuda.synchronize()
+            prog = _StepProgram(self.device)
             try:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    info = self._step_body(klw, False)
-                self.graph, self.graph_info = g, info
+                info = prog.capture(self, lambda: self._step_body(klw, False))
+                self.graph, self.graph_info = prog, info
             except Exception as ex:        # capture refused (e.g. an untuned conv problem wanted to time itself): stay eager
                 import warnings
                 warnings.warn('hipGraph capture of the train step failed (%r); continuing eagerly' % (ex,))
@@ -326,7 +425,7 @@ class SAVPEngine(object):
                 torch.cuda.synchronize()
                 info = self._step_body(klw, False)
             else:
-                g.replay()
+                prog.run()
         else:
             info = self._step_body(klw, return_grads)
             self.eager_steps += 1
@@ -360,8 +459,8 @@ class SAVPEngine(object):
         # generator forward; the D step joins it with an event.  Off by default (SAVP_SIDE_PREP=1 enables): measured 74.4 vs 74.3 ms
         # per step -- the side stream's launches compete with the forward chain for the same CUs, like every other overlap tried.
         d_prep_done = None
-        if discs and self.world > 1:
-            self.replicas.wait_aux()               # last step's u broadcast (side stream) before anything touches u again
+        if discs and self.dp:
+            self._host_op(self.replicas.wait_aux)  # last step's u broadcast (side stream) before anything touches u again
         if discs and self.side_prep:
             if self._prep_stream is None:
                 self._prep_stream = torch.cuda.Stream(device=self.device)
@@ -490,8 +589,8 @@ class SAVPEngine(object):
             store.groups['d'].adam_apply(0.0, hp.beta1, hp.beta2, gscale=1.0 / self.world, lr_t_dev=self.d_scal[0:1])
         for D in {id(d['D']): d['D'] for d in discs}.values():
             D.commit_u()
-        if discs and self.world > 1:
-            self.replicas.sync_aux()          # u vectors: bit-identical replicas (parallel.ReplicaGroup.sync_aux)
+        if discs and self.dp:
+            self._host_op(self.replicas.sync_aux)    # u vectors: bit-identical replicas (parallel.ReplicaGroup.sync_aux)
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
         d_losses, g_losses = OrderedDict(), OrderedDict()
         for d in discs:
@@ -604,7 +703,19 @@ class SAVPEngine(object):
 _ENGINES = {}
 
 
+def refuse_conditioning_inputs(inputs):
+    """SAVPCell.call concatenates inputs['actions'] / inputs['states'] into every layer and predicts the next state
+    (savp_model.py:413-421,655-658; generator_fn slices them at :702-703).  The HIP path is the action-free one of
+    BASELINE.json's north_star: a batch that carries them is refused instead of being run as if they were not there."""
+    if isinstance(inputs, dict):
+        for k in ('actions', 'states'):
+            if inputs.get(k) is not None:
+                raise NotImplementedError("inputs[%r] given: action- / state-conditioned SAVP cells (reference savp_model.py:413-421,"
+                                          "655-658) are not on the MI355X hot path; drop the key (action-free model) to proceed" % k)
+
+
 def _engine_for(inputs, mode, hparams, engine=None):
+    refuse_conditioning_inputs(inputs)
     images = inputs['images']
     if engine is not None:
         return engine
@@ -685,6 +796,7 @@ def discriminator_fn(inputs, outputs, mode, hparams, engine=None, noise=None):
     if noise is None:
         noise = eng.default_noise()
     eng._stage_noise(noise)
+    eng.wait_aux()                 # D.prep_weights reads u: order behind a u broadcast still in flight on the side stream
     B = eng.B
     out = OrderedDict()
     for d in eng.discs:
@@ -723,6 +835,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
 
     def build_graph(self, inputs, values=None, seed=4, device='cuda:0'):
         """inputs: {'images': [B,T,H,W,C] device tensor} (batch-major like the reference's dataset iterator)."""
+        refuse_conditioning_inputs(inputs)
         super(SAVPVideoPredictionModel, self).build_graph(inputs)
         images = inputs['images']
         B = images.shape[0]
@@ -740,6 +853,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
     def train_step(self, inputs=None, noise=None):
         """One ``sess.run(model.train_op)``."""
         if inputs is not None:
+            refuse_conditioning_inputs(inputs)
             self.inputs = inputs
         self.engine.set_images(self.inputs['images'])
         info = self.engine.train_step(noise)
@@ -750,6 +864,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
     def generate(self, inputs=None, noise=None):
         """Fills self.outputs['gen_images'] batch-major [B,T-1,H,W,C] (scripts/generate.py:166)."""
         if inputs is not None:
+            refuse_conditioning_inputs(inputs)
             self.inputs = inputs
         self.engine.set_images(self.inputs['images'])
         gen = self.engine.generate(noise)
@@ -780,6 +895,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         """savp_model.py:848-855 / base_model.py:229-247: `checkpoints` is a TensorFlow V2 checkpoint directory or prefix (or a
         list of them, each holding a subset of the variables), read by video_prediction_amd.checkpoint without TensorFlow; a
         {variable name: array} dict is accepted as well.  Names fall back from `savp_cell` to `dna_cell` like the reference."""
+        self.engine.wait_aux()                    # a u broadcast of the last step may still be writing the 'aux' arena
         if isinstance(checkpoints, dict):
             self.engine.store.load(checkpoints)
             return
@@ -858,8 +974,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         powers of both optimizers) as a V2 checkpoint at `prefix`."""
         from .. import checkpoint as CK
         store, hp = self.engine.store, self.hparams
-        if self.engine.world > 1:
-            self.engine.replicas.wait_aux()        # the u broadcast of the last step runs on the side stream
+        self.engine.wait_aux()                     # the u broadcast of the last step runs on the side stream
         vals = store.to_numpy()
         vals['global_step'] = np.asarray(self.engine.step, dtype=np.int64)
         if self.mode == 'train':

@@ -25,18 +25,24 @@ import torch
 
 
 class ReplicaGroup(object):
-    def __init__(self, store, dist_module=None, overlap=True):
+    def __init__(self, store, dist_module=None, overlap=True, force=False):
+        """force: run every collective even in a group of ONE rank (SAVP_FORCE_DIST=1).  A sum over one replica is the identity,
+        so the step's numbers do not change, but process-group creation, the rank-0 broadcast, the side-stream chunked
+        all-reduce, the u broadcast and the event chaining all execute on the real transport -- the way to exercise RCCL on a
+        one-GPU box before a multi-GPU lease does (tests/test_gpu_dp.py)."""
         self.store = store
         self.dist = dist_module
         self.world = dist_module.get_world_size() if dist_module is not None else 1
         self.rank = dist_module.get_rank() if dist_module is not None else 0
+        self.active = dist_module is not None and (self.world > 1 or bool(force))
         dev = torch.device(store.device)
         self.on_gpu = dev.type == 'cuda'
         # side stream of the gradient exchange (None on the CPU: gloo reduces host tensors synchronously)
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and overlap and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and overlap and self.active) else None
         self.pending = {}          # group -> list of (lo, hi, done event | None)
-        self.stats = {'chunks': 0, 'elements': 0}
-        if self.world > 1:
+        self.stats = {'chunks': 0, 'elements': 0, 'aux_broadcasts': 0}
+        self.aux_done = None
+        if self.active:
             for g in store.groups.values():            # post_init_ops: every replica starts from rank 0's variables
                 dist_module.broadcast(g.p, src=0)
 
@@ -49,7 +55,7 @@ class ReplicaGroup(object):
         """Start summing elements lo:hi of the group's flat gradient arena over all replicas.  Everything launched on the
         current stream so far (the backward pass that produced the chunk) is waited for by the side stream; later launches on
         the current stream run concurrently with the exchange until finish_allreduce(group)."""
-        if self.world == 1:
+        if not self.active:
             return
         g = self.store.groups[group].g
         hi = g.numel() if hi is None else hi
@@ -75,7 +81,7 @@ class ReplicaGroup(object):
     def finish_allreduce(self, group):
         """Exchange whatever part of the group's arena no begin_allreduce covered, then make the current stream wait for every
         chunk: after this call the arena holds the sum over replicas (divide by world in Adam)."""
-        if self.world == 1:
+        if not self.active:
             return
         n = self.store.groups[group].g.numel()
         covered = sorted((lo, hi) for lo, hi, _ in self.pending.get(group, []))
@@ -102,11 +108,12 @@ class ReplicaGroup(object):
         stream does NOT wait here: the next reader of u is the discriminators' weight preparation of the NEXT step, a whole
         generator forward later -- wait_aux() in front of it finds the broadcast long finished, so the collective is off the
         critical path of every step."""
-        if self.world == 1:
+        if not self.active:
             return
         aux = self.store.groups.get('aux')
         if aux is None or aux.p.numel() == 0:
             return
+        self.stats['aux_broadcasts'] += 1
         if self.comm_stream is not None:
             cur = torch.cuda.current_stream(aux.p.device)
             ready = torch.cuda.Event()
@@ -122,7 +129,7 @@ class ReplicaGroup(object):
 
     def wait_aux(self):
         """Order the current stream behind the last sync_aux() broadcast (call before anything reads or writes the 'aux' arena)."""
-        done = getattr(self, 'aux_done', None)
+        done = self.aux_done
         if done is not None:
             aux = self.store.groups['aux']
             torch.cuda.current_stream(aux.p.device).wait_event(done)
@@ -130,7 +137,7 @@ class ReplicaGroup(object):
 
     def allreduce_grads(self, group, async_op=False):
         """Sum the whole flat gradient bucket of one optimiser group (blocking with respect to the current stream)."""
-        if self.world > 1:
+        if self.active:
             self.finish_allreduce(group)
         return None
 
@@ -144,7 +151,7 @@ class ReplicaGroup(object):
 
     def checksum_identical(self):
         """True iff every replica holds bit-identical variables (they must: identical averaged grads, identical Adam)."""
-        if self.world == 1:
+        if not self.active:
             return True
         self.wait_aux()
         ok = True
