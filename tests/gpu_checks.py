@@ -1247,9 +1247,11 @@ def check_conv_stats_fp32(seed=43):
     return out
 
 
-def check_ring_weight_warmup_invisible(seed=47):
+def check_ring_weight_warmup_invisible(seed=47, option='ring_wwarm'):
     """Option ring_wwarm only moves bytes into the L2 ahead of time (csrc/conv_ring.hip): outputs with it on and off are bit-identical,
-    for FPROP / DGRAD, one and several column tiles, several slab groups, and a bf16 source (LDS-DMA staged patch)."""
+    for FPROP / DGRAD, one and several column tiles, several slab groups, and a bf16 source (LDS-DMA staged patch).  Likewise
+    option ring_roles (round 4: waves 4-7 of an 8-wave workgroup multiply first and issue their slab DMA afterwards): it changes when
+    a slab is requested, never what is summed in which order."""
     out = []
     rng = torch.Generator(device=DEV).manual_seed(seed)
 
@@ -1258,7 +1260,7 @@ def check_ring_weight_warmup_invisible(seed=47):
 
     cases = [('lstm16', 8, 16, 16, 136, 256, 5, 0x711), ('lstm8', 8, 8, 8, 264, 512, 5, 0x311), ('lstm32', 4, 32, 32, 72, 128, 5, 0x712),
              ('head3', 4, 64, 64, 32, 64, 3, 0x321)]
-    old = lib.get_option('ring_wwarm')
+    old = lib.get_option(option)
     try:
         for name, N, H, W, Cx, Cy, k, tile in cases:
             x, y = rn(N, H, W, Cx), rn(N, H, W, Cy)
@@ -1270,7 +1272,7 @@ def check_ring_weight_warmup_invisible(seed=47):
                 for src16 in (False, True):
                     res = []
                     for on in (1, 0):
-                        lib.set_option('ring_wwarm', on)
+                        lib.set_option(option, on)
                         xv, yv = x.clone(), y.clone()
                         if src16:
                             if mode == lib.CONV_FPROP:
@@ -1282,9 +1284,9 @@ def check_ring_weight_warmup_invisible(seed=47):
                         K.conv(mode, geom, xv, yv, wp, tile=tile, splitk=1, precision=1, w16=w16)
                         res.append(dst.float().clone())
                     same = torch.equal(res[0], res[1]) and bool(torch.isfinite(res[0]).all())
-                    out.append(('wwarm_%s_%s%s/bit_identical' % (name, mname, '_src16' if src16 else ''), 0.0 if same else float('inf'), 1.0))
+                    out.append(('%s_%s_%s%s/bit_identical' % (option[5:], name, mname, '_src16' if src16 else ''), 0.0 if same else float('inf'), 1.0))
     finally:
-        lib.set_option('ring_wwarm', old)
+        lib.set_option(option, old)
     torch.cuda.synchronize()
     return out
 

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     Frags F0, F1;
     bool first_group = true;
+    const bool late_role = p.roles && wave >= 4;               // see "ROLES" below
     using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
     for (int gg = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
@@ -434,46 +435,69 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // Table entries travel one step ahead of their use in a three-deep register queue (tq0 = entry e+1: fragments read in step e,
         // tq2 = entry e+3: its slab DMA is issued in step e): the one table read of a step (entry e+4) is issued behind the barrier
         // and consumed a whole step later, so neither the DMA address nor the A-fragment address waits for an LDS round trip there.
-        uint2 tq0 = etab[min(1, len - 1)], tq1 = etab[min(2, len - 1)], tq2 = etab[min(3, len - 1)];
-        auto step = [&](int e, Frags& cur, Frags& nxt, auto bn, auto bd, auto steadyc) {
-            constexpr bool STEADY = decltype(steadyc)::value;
-            const bool more = STEADY || e + 1 < len;
-            if (more) {
-                const uint2 tn = tq0, td = tq2;
-                if (STEADY || e + 2 < len) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const uint2 t4 = etab[min(e + 4, len - 1)];
-                if (STEADY || e + 3 < len) issue(td, bd);
-                load_a(nxt, tn);
-                tq0 = tq1; tq1 = tq2; tq2 = t4;
+        //
+        // ROLES (8-wave workgroups, option "ring_roles"): all waves leave the per-entry barrier together, and a wave's DMA issue
+        // (LW instructions of ~100 cycles each) used to come before its MFMAs -- so both waves of a SIMD issued DMAs while the matrix
+        // pipe idled, then both multiplied (measured: a step costs the SUM of the two phases, 690 + 640 cycles at 32x32).  Waves w
+        // and w + 4 share a SIMD (waves are placed round-robin over the four SIMDs): waves 4-7 are LATE -- MFMAs of entry e first
+        // (their fragments are in registers when the barrier opens), DMA of slab e+3 afterwards -- so one wave of every SIMD
+        // multiplies while the other issues, and they swap.  Ring safety is unchanged: slab e+3 overwrites the buffer slab e-1 left
+        // before barrier e either way, and the counted waits see the same number of outstanding DMAs per wave at every barrier.
+        auto run = [&](auto latec) {
+            constexpr bool LATE = decltype(latec)::value;
+            uint2 tq0 = etab[min(1, len - 1)], tq1 = etab[min(2, len - 1)], tq2 = etab[min(3, len - 1)];
+            auto step = [&](int e, Frags& cur, Frags& nxt, auto bn, auto bd, auto steadyc) {
+                constexpr bool STEADY = decltype(steadyc)::value;
+                const bool more = STEADY || e + 1 < len;
+                const bool dma = STEADY || e + 3 < len;
+                uint2 td = tq2;
+                if (more) {
+                    const uint2 tn = tq0;
+                    if (STEADY || e + 2 < len) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const uint2 t4 = etab[min(e + 4, len - 1)];
+                    if (!LATE && dma) issue(td, bd);
+                    load_a(nxt, tn);
+                    tq0 = tq1; tq1 = tq2; tq2 = t4;
+                }
+                if constexpr (STEADY) {
+                    load_b(nxt, bn);
+                    mma(cur, 0, NKS);
+                    sched_interleave<NKS * (WM + WN), NKS * WM * WN, 0>();
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(cur, 0, KH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) load_b(nxt, bn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(cur, KH, NKS);
+                }
+                if (LATE && more && dma) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(td, bd);
+                }
+            };
+            int e = 0;
+            for (; e + 6 < len; e += 4) {
+                step(e, F0, F1, B1{}, B3{}, std::true_type{});
+                step(e + 1, F1, F0, B2{}, B0{}, std::true_type{});
+                step(e + 2, F0, F1, B3{}, B1{}, std::true_type{});
+                step(e + 3, F1, F0, B0{}, B2{}, std::true_type{});
             }
-            if constexpr (STEADY) {
-                load_b(nxt, bn);
-                mma(cur, 0, NKS);
-                sched_interleave<NKS * (WM + WN), NKS * WM * WN, 0>();
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-                mma(cur, 0, KH);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) load_b(nxt, bn);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(cur, KH, NKS);
+            for (; e < len; e += 4) {
+                step(e, F0, F1, B1{}, B3{}, std::false_type{});
+                if (e + 1 < len) step(e + 1, F1, F0, B2{}, B0{}, std::false_type{});
+                if (e + 2 < len) step(e + 2, F0, F1, B3{}, B1{}, std::false_type{});
+                if (e + 3 < len) step(e + 3, F1, F0, B0{}, B2{}, std::false_type{});
             }
         };
         RT(3);
-        int e = 0;
-        for (; e + 6 < len; e += 4) {
-            step(e, F0, F1, B1{}, B3{}, std::true_type{});
-            step(e + 1, F1, F0, B2{}, B0{}, std::true_type{});
-            step(e + 2, F0, F1, B3{}, B1{}, std::true_type{});
-            step(e + 3, F1, F0, B0{}, B2{}, std::true_type{});
-        }
-        for (; e < len; e += 4) {
-            step(e, F0, F1, B1{}, B3{}, std::false_type{});
-            if (e + 1 < len) step(e + 1, F1, F0, B2{}, B0{}, std::false_type{});
-            if (e + 2 < len) step(e + 2, F0, F1, B3{}, B1{}, std::false_type{});
-            if (e + 3 < len) step(e + 3, F1, F0, B0{}, B2{}, std::false_type{});
+        if constexpr (NW == 8) {
+            if (late_role) run(std::true_type{});
+            else run(std::false_type{});
+        } else {
+            run(std::false_type{});
         }
         RT(4);
     }
@@ -782,6 +806,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     p.splitk = splitk;
     patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
     p.wwarm = savp_opt(OPT_RING_WWARM) ? 1 : 0;
+    p.roles = savp_opt(OPT_RING_ROLES) ? 1 : 0;
     pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
     pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     return true;

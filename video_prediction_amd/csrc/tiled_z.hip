@@ -33,28 +33,28 @@ __device__ __forceinline__ bool tz_tap_valid(int cls, int off) {
     return y + off >= 0 && y + off < 8;
 }
 
-// Weff[r = ry*5 + rx][k][c] (c padded to TZ_NZ) from the HWIO kernel W[kh][kw][Cin][Cout], z channels z0 .. z0+nz-1
+// Weff[r = ry*5 + rx][k][c] (c padded to TZ_NZ) from the HWIO kernel W[kh][kw][Cin][Cout], z channels z0 .. z0+nz-1.
+// One thread per (r, c, k): up to 25 independent loads (invalid taps read a valid address and are multiplied by zero, so that all of
+// them are in flight together), coalesced over k.
 __global__ void tiled_z_weff_kernel(const float* __restrict__ w, int kh, int kw, int ph, int pw, int Cin, int Cout, int z0, int nz,
                                     float* __restrict__ weff) {
     const int r = blockIdx.y, ry = r / 5, rx = r - ry * 5;
+    const int c = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Cout) return;
-    float s[TZ_NZ];
-#pragma unroll
-    for (int c = 0; c < TZ_NZ; ++c) s[c] = 0.f;
-    for (int u = 0; u < kh; ++u) {
-        if (!tz_tap_valid(ry, u - ph)) continue;
-        for (int v = 0; v < kw; ++v) {
-            if (!tz_tap_valid(rx, v - pw)) continue;
-            const float* p = w + ((long long)(u * kw + v) * Cin + z0) * Cout + k;
-#pragma unroll
-            for (int c = 0; c < TZ_NZ; ++c)
-                if (c < nz) s[c] += p[(long long)c * Cout];
+    float s = 0.f;
+    if (c < nz) {
+        const float* base = w + (long long)(z0 + c) * Cout + k;
+        for (int u = 0; u < kh; ++u) {
+            const float mu = tz_tap_valid(ry, u - ph) ? 1.f : 0.f;
+#pragma unroll 5
+            for (int v = 0; v < kw; ++v) {
+                const float m = tz_tap_valid(rx, v - pw) ? mu : 0.f;
+                s = fmaf(base[(long long)(u * kw + v) * Cin * Cout], m, s);
+            }
         }
     }
-    float* o = weff + ((long long)r * Cout + k) * TZ_NZ;
-#pragma unroll
-    for (int c = 0; c < TZ_NZ; ++c) o[c] = s[c];
+    weff[((long long)r * Cout + k) * TZ_NZ + c] = s;
 }
 
 extern "C" int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t Cin,
@@ -62,8 +62,8 @@ extern "C" int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32
     if (!w || !weff || nz < 1 || nz > TZ_NZ || z0 < 0 || z0 + nz > Cin || Cout < 1) return SAVP_EINVAL;
     // the class construction needs every tap offset within +-2 of the pixel
     if (kh < 1 || kw < 1 || ph < 0 || pw < 0 || ph > 2 || pw > 2 || kh - 1 - ph > 2 || kw - 1 - pw > 2) return SAVP_EINVAL;
-    dim3 grid((unsigned)((Cout + 127) / 128), 25);
-    hipLaunchKernelGGL(tiled_z_weff_kernel, grid, dim3(128), 0, (hipStream_t)stream, w, kh, kw, ph, pw, Cin, Cout, z0, nz, weff);
+    dim3 grid((unsigned)((Cout + 63) / 64), 25, TZ_NZ);
+    hipLaunchKernelGGL(tiled_z_weff_kernel, grid, dim3(64), 0, (hipStream_t)stream, w, kh, kw, ph, pw, Cin, Cout, z0, nz, weff);
     return LAUNCH_OK();
 }
 
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restric
     const long long img = blockIdx.x;
     const int tid = threadIdx.x, lane8 = tid & 7, slot = tid >> 3;
     const int HW = H * W;
+    const int wsh = 31 - __builtin_clz((unsigned)W);     // W is a power of two
     const int xcls = tz_class(slot & (W - 1), W);
     float dzp[TZ_NZ];
 #pragma unroll
@@ -88,26 +89,43 @@ __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restric
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
         const int ch = c0 + lane8 * 8;
-        for (int p = slot; p < HW; p += 32) {
-            const int y = p / W;                         // W is a power of two: a shift
-            const int yc = tz_class(y, H);
-            float v[8];
-            const long long off = (img * HW + p) * (long long)C + ch;
-            if (BF16) {
-                const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dy_) + off);
-                const unsigned u[4] = {q.x, q.y, q.z, q.w};
+        // U pixels per trip, all U loads issued before the first is used (one load per trip would make the walk a chain of HBM round
+        // trips: 131 us per launch on MI355X for 243 MB = 1.8 TB/s); trips past the end re-read the last pixel with weight zero
+        constexpr int U = 4;
+        for (int p0 = slot; p0 < HW; p0 += 32 * U) {
+            uint4 q[U];
+            float4 a0[U], a1[U];
+            float live[U];
+            int ycls[U];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(u[j] << 16); v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
-            } else {
-                const float4 a0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + off);
-                const float4 a1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + off + 4);
-                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + 32 * u;
+                live[u] = p < HW ? 1.f : 0.f;
+                const int pc = min(p, HW - 1);
+                ycls[u] = tz_class(pc >> wsh, H);
+                const long long off = (img * HW + pc) * (long long)C + ch;
+                if (BF16) q[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dy_) + off);
+                else {
+                    a0[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + off);
+                    a1[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + off + 4);
+                }
             }
 #pragma unroll
-            for (int a = 0; a < 5; ++a) {
-                const float m = (a == yc) ? 1.f : 0.f;
+            for (int u = 0; u < U; ++u) {
+                float v[8];
+                if (BF16) {
+                    const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[a][j] = fmaf(v[j], m, acc[a][j]);
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w4[j] << 16); v[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u); }
+                } else {
+                    v[0] = a0[u].x; v[1] = a0[u].y; v[2] = a0[u].z; v[3] = a0[u].w; v[4] = a1[u].x; v[5] = a1[u].y; v[6] = a1[u].z; v[7] = a1[u].w;
+                }
+#pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    const float m = (a == ycls[u]) ? live[u] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[a][j] = fmaf(v[j], m, acc[a][j]);
+                }
             }
         }
         __syncthreads();                                 // previous chunk's readers are done
