@@ -28,8 +28,7 @@ const char* savp_version(void);
 
 /* Kernel-selection switches (process-wide; SAVP_EINVAL for an unknown name).  Names and defaults: "conv_ring" 0 (auto algorithm
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1, "ring_dma" 1 (problem-specific kernels / LDS-DMA patch staging of bf16 sources on), "ring_wwarm" 1 (the ring kernel's
- * workgroups pull their column tile's weight block into the XCD's L2 first), "ring_roles" 1 (ring kernel, 8-wave workgroups: the two
- * waves of a SIMD issue their weight DMAs and their MFMAs in opposite order), "colsum_2stage" 1,
+ * workgroups pull their column tile's weight block into the XCD's L2 first), "colsum_2stage" 1,
  * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
@@ -179,6 +178,9 @@ typedef struct SavpInormArgs {
                                       that only feeds convolutions of the bf16 datapath (they round to bf16 anyway) in half the bytes */
     int32_t stats_ready;           /* fwd: ws already holds the per-(sample, channel) sum / sum of squares of x, UNSHIFTED (savp_conv's
                                       `stats` epilogue wrote them while it produced x): the statistics pass is skipped -> one launch */
+    int32_t dx_bf16;               /* bwd: dx is a bf16 tensor (strides in bf16 elements, multiples of 4; dx_beta must be 0): the gradient of
+                                      a convolution's output, whose only readers are that convolution's DGRAD / WGRAD on the bf16
+                                      datapath (they round it to bf16 when they stage it anyway) -- half the bytes, identical numbers */
 } SavpInormArgs;
 int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a);
 int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a);

@@ -1249,9 +1249,7 @@ def check_conv_stats_fp32(seed=43):
 
 def check_ring_weight_warmup_invisible(seed=47, option='ring_wwarm'):
     """Option ring_wwarm only moves bytes into the L2 ahead of time (csrc/conv_ring.hip): outputs with it on and off are bit-identical,
-    for FPROP / DGRAD, one and several column tiles, several slab groups, and a bf16 source (LDS-DMA staged patch).  Likewise
-    option ring_roles (round 4: waves 4-7 of an 8-wave workgroup multiply first and issue their slab DMA afterwards): it changes when
-    a slab is requested, never what is summed in which order."""
+    for FPROP / DGRAD, one and several column tiles, several slab groups, and a bf16 source (LDS-DMA staged patch)."""
     out = []
     rng = torch.Generator(device=DEV).manual_seed(seed)
 

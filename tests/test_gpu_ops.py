@@ -157,8 +157,3 @@ def test_tiled_z_gradient_and_gapped_gate_dgrad():
     from tests import gpu_checks
     _run(gpu_checks.check_tiled_z_and_gapped_dgrad)
 
-
-def test_ring_kernel_wave_roles_do_not_change_results():
-    """conv_ring_kernel with 8 waves: the late-DMA role of waves 4-7 (option ring_roles) is invisible in the output, bit for bit."""
-    from tests import gpu_checks
-    _run(lambda: gpu_checks.check_ring_weight_warmup_invisible(seed=59, option='ring_roles'))

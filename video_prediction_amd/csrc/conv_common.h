@@ -76,7 +76,6 @@ struct ConvP {
     // change made conv_patch_kernel 10-19 % SLOWER in the step (its main loop's register allocation) and was not kept there.
     int pre;
     int gap_at, gap;                          // conv_ring_kernel: logical output column c >= gap_at is physical weight row / destination channel c + gap (SavpConvArgs.dst_gap)
-    int roles;                                // conv_ring_kernel, 8 waves: waves 4-7 multiply first and issue their slab DMA afterwards (option ring_roles)
     int wwarm;                                // conv_ring_kernel: warm the L2 with the column tile's weight block first (option ring_wwarm)
     DimGeom gD, gH, gW;
     int s1_tih_sh;                            // log2(s1_tih): tile rows per image are a power of two

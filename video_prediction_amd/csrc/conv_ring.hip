@@ -56,7 +56,8 @@ __device__ __forceinline__ void sched_interleave() {
 #ifdef SAVP_CONV_ABLATE
 __device__ unsigned long long g_ring_t[16];       // developer build: s_memtime stamps of workgroup 0, wave 0 (savp_debug_ring_times)
 __constant__ int g_ring_blk = 0;                  // which workgroup stamps
-#define RT(i) do { if (blockIdx.x == g_ring_blk && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_ring_t[i] = __builtin_readcyclecounter(); } while (0)
+__constant__ int g_ring_wv = 0;                   // which wave of it
+#define RT(i) do { if (blockIdx.x == g_ring_blk && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == g_ring_wv * 64) g_ring_t[i] = __builtin_readcyclecounter(); } while (0)
 __device__ unsigned long long g_ring_w[2][8];     // per-wave stamps of workgroup 0: kernel entry, arrival at the first barrier
 #define RTW(k) do { if (blockIdx.x == g_ring_blk && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_ring_w[k][threadIdx.x >> 6] = __builtin_readcyclecounter(); } while (0)
 __constant__ int g_ring_kwarm = 1;                // developer A/B of kernarg_warm
@@ -69,6 +70,13 @@ extern "C" int savp_debug_ring_wave_times(unsigned long long* out) {
 }
 extern "C" int savp_debug_ring_block(int b) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_blk), &b, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+extern "C" int savp_debug_ring_wave(int w) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_wv), &w, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+extern "C" int savp_debug_ring_ablate(int bits) {          // same bits as SAVP_ABLATE, changeable between launches
+    ablate_init();
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
 }
 extern "C" int savp_debug_ring_kwarm(int on) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_kwarm), &on, sizeof(int)) == hipSuccess ? 0 : -1;
@@ -374,7 +382,6 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     Frags F0, F1;
     bool first_group = true;
-    const bool late_role = p.roles && wave >= 4;               // see "ROLES" below
     using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
     for (int gg = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
@@ -436,16 +443,23 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // tq2 = entry e+3: its slab DMA is issued in step e): the one table read of a step (entry e+4) is issued behind the barrier
         // and consumed a whole step later, so neither the DMA address nor the A-fragment address waits for an LDS round trip there.
         //
-        // ROLES (8-wave workgroups, option "ring_roles"): all waves leave the per-entry barrier together, and a wave's DMA issue
-        // (LW instructions of ~100 cycles each) used to come before its MFMAs -- so both waves of a SIMD issued DMAs while the matrix
-        // pipe idled, then both multiplied (measured: a step costs the SUM of the two phases, 690 + 640 cycles at 32x32).  Waves w
-        // and w + 4 share a SIMD (waves are placed round-robin over the four SIMDs): waves 4-7 are LATE -- MFMAs of entry e first
-        // (their fragments are in registers when the barrier opens), DMA of slab e+3 afterwards -- so one wave of every SIMD
-        // multiplies while the other issues, and they swap.  Ring safety is unchanged: slab e+3 overwrites the buffer slab e-1 left
-        // before barrier e either way, and the counted waits see the same number of outstanding DMAs per wave at every barrier.
-        auto run = [&](auto latec) {
-            constexpr bool LATE = decltype(latec)::value;
-            uint2 tq0 = etab[min(1, len - 1)], tq1 = etab[min(2, len - 1)], tq2 = etab[min(3, len - 1)];
+        // DMA LAST (round 4): all waves leave the per-entry barrier together, and a wave's slab DMA issue (LW instructions of ~100
+        // cycles each: M0 set-up, address arithmetic, the request itself) used to come before its MFMAs -- the matrix pipe idled while
+        // every wave issued, and a step cost the SUM of the two phases (measured 690 + 640 cycles at 32x32).  The fragments of entry
+        // e are in registers when the barrier opens, so the MFMAs go first and the DMA of slab e+3 is issued behind them, in their
+        // shadow.  Ring safety is unchanged: slab e+3 overwrites the buffer slab e-1 left before barrier e either way, and the
+        // counted waits see the same number of outstanding DMAs per wave at every barrier.  Measured in the step on MI355X (one
+        // call, runtime switch, twice): DMA first 56.84 / 56.77 ms, waves 4-7 last 56.46 / 56.47, every wave last 55.95 / 55.85;
+        // gate conv FPROP 32.2 -> 28.9 us on that box.  -DSAVP_RING_EARLY_DMA restores the old order for A/B builds.
+#ifdef SAVP_RING_EARLY_DMA
+        constexpr bool LATE = false;
+#else
+        constexpr bool LATE = true;
+#endif
+        // (the table entries are wave-uniform: kept in scalar registers)
+        auto sld = [&](int i) { const uint2 t = etab[i]; return make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)t.x), (unsigned)__builtin_amdgcn_readfirstlane((int)t.y)); };
+        {
+            uint2 tq0 = sld(min(1, len - 1)), tq1 = sld(min(2, len - 1)), tq2 = sld(min(3, len - 1));
             auto step = [&](int e, Frags& cur, Frags& nxt, auto bn, auto bd, auto steadyc) {
                 constexpr bool STEADY = decltype(steadyc)::value;
                 const bool more = STEADY || e + 1 < len;
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                     if (STEADY || e + 2 < len) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    const uint2 t4 = etab[min(e + 4, len - 1)];
+                    const uint2 t4 = sld(min(e + 4, len - 1));
                     if (!LATE && dma) issue(td, bd);
                     load_a(nxt, tn);
                     tq0 = tq1; tq1 = tq2; tq2 = t4;
@@ -478,6 +492,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                     issue(td, bd);
                 }
             };
+            RT(3);
             int e = 0;
             for (; e + 6 < len; e += 4) {
                 step(e, F0, F1, B1{}, B3{}, std::true_type{});
@@ -491,13 +506,6 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 if (e + 2 < len) step(e + 2, F0, F1, B3{}, B1{}, std::false_type{});
                 if (e + 3 < len) step(e + 3, F1, F0, B0{}, B2{}, std::false_type{});
             }
-        };
-        RT(3);
-        if constexpr (NW == 8) {
-            if (late_role) run(std::true_type{});
-            else run(std::false_type{});
-        } else {
-            run(std::false_type{});
         }
         RT(4);
     }
@@ -806,7 +814,6 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     p.splitk = splitk;
     patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
     p.wwarm = savp_opt(OPT_RING_WWARM) ? 1 : 0;
-    p.roles = savp_opt(OPT_RING_ROLES) ? 1 : 0;
     pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
     pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     return true;

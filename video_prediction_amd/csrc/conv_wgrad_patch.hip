@@ -349,6 +349,14 @@ static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
+// operand dtypes picked at run time: both fp32, both bf16, or dy alone in bf16
+template <int NW, int MTW, int NPF>
+static hipError_t launch_wgp_dt(const WgP& q, dim3 grid, size_t lds, hipStream_t st, bool x16, bool y16) {
+    if (x16 && y16) return launch_wgp<NW, MTW, NPF, true, true>(q, grid, lds, st);
+    if (y16) return launch_wgp<NW, MTW, NPF, false, true>(q, grid, lds, st);
+    return launch_wgp<NW, MTW, NPF, false, false>(q, grid, lds, st);
+}
+
 // Returns true when the call was handled (2-D, stride 1, bf16 precision, channel counts % 4, <= 8 taps per side).
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
@@ -425,21 +433,18 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     dim3 grid((unsigned)(q.S * NB * MC), 1u, 1u);
     hipError_t err;
     const bool x16 = a->src_bf16 != 0, y16 = a->out_bf16 != 0;     // WGRAD: src = x, "out" = the dy operand
-    if (x16 || y16) {
-        // bf16 operand tensors: instantiated for the 8-wave x 8-tile shape only (the ConvLSTM gate convolutions' weight gradients,
-        // the one place the engine keeps bf16 activations); anything else is refused, never read as fp32
-        if (!(nw == 8 && mtw == 8)) { *rc = SAVP_EINVAL; return true; }
-        if (x16 && y16) err = (npf <= 4) ? launch_wgp<8, 8, 4, true, true>(q, grid, lds, st) : launch_wgp<8, 8, 8, true, true>(q, grid, lds, st);
-        else if (x16) err = (npf <= 4) ? launch_wgp<8, 8, 4, true, false>(q, grid, lds, st) : launch_wgp<8, 8, 8, true, false>(q, grid, lds, st);
-        else err = (npf <= 4) ? launch_wgp<8, 8, 4, false, true>(q, grid, lds, st) : launch_wgp<8, 8, 8, false, true>(q, grid, lds, st);
-        *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
-        return true;
+    // bf16 operand tensors (round 3: the ConvLSTM gate convolutions; round 4: every generator convolution whose input / output
+    // gradient is stored in bf16): both operands bf16, or dy alone (layer 0: the input image stays fp32), for every workgroup shape;
+    // x alone only for the 8 x 8 shape.  A combination that is not instantiated is refused, never read as fp32.
+    if (x16 && !y16 && !(nw == 8 && mtw == 8)) { *rc = SAVP_EINVAL; return true; }
+    if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp_dt<8, 4, 4>(q, grid, lds, st, x16, y16) : launch_wgp_dt<8, 4, 8>(q, grid, lds, st, x16, y16);
+    else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp_dt<8, 2, 4>(q, grid, lds, st, x16, y16) : launch_wgp_dt<8, 2, 8>(q, grid, lds, st, x16, y16);
+    else if (nw == 8) {
+        if (x16 && !y16) err = (npf <= 4) ? launch_wgp<8, 8, 4, true, false>(q, grid, lds, st) : launch_wgp<8, 8, 8, true, false>(q, grid, lds, st);
+        else err = (npf <= 4) ? launch_wgp_dt<8, 8, 4>(q, grid, lds, st, x16, y16) : launch_wgp_dt<8, 8, 8>(q, grid, lds, st, x16, y16);
     }
-    if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp<8, 4, 4>(q, grid, lds, st) : launch_wgp<8, 4, 8>(q, grid, lds, st);
-    else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp<8, 2, 4>(q, grid, lds, st) : launch_wgp<8, 2, 8>(q, grid, lds, st);
-    else if (nw == 8) err = (npf <= 4) ? launch_wgp<8, 8, 4>(q, grid, lds, st) : launch_wgp<8, 8, 8>(q, grid, lds, st);
-    else if (mtw == 8) err = (npf <= 8) ? launch_wgp<4, 8, 8>(q, grid, lds, st) : launch_wgp<4, 8, 16>(q, grid, lds, st);
-    else err = (npf <= 8) ? launch_wgp<4, 4, 8>(q, grid, lds, st) : launch_wgp<4, 4, 16>(q, grid, lds, st);
+    else if (mtw == 8) err = (npf <= 8) ? launch_wgp_dt<4, 8, 8>(q, grid, lds, st, x16, y16) : launch_wgp_dt<4, 8, 16>(q, grid, lds, st, x16, y16);
+    else err = (npf <= 8) ? launch_wgp_dt<4, 4, 8>(q, grid, lds, st, x16, y16) : launch_wgp_dt<4, 4, 16>(q, grid, lds, st, x16, y16);
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
     return true;
 }

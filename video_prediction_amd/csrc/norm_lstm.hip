@@ -94,6 +94,7 @@ struct InormP {
     int ndy; const float* dy[4]; long long dy_sn[4], dy_sp[4];
     int dy_c0[4], dy_c1[4];         // gradient k covers channels [dy_c0, dy_c1) of the output (default: all C)
     float* dx; long long dx_sn, dx_sp; int dx_beta;
+    int dx16;                       // dx is a bf16 tensor (strides in bf16 elements; no dx_beta)
     float* dgamma; float* dbeta;
 };
 
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
         unsafeAtomicAdd(p.dgamma + c0 + threadIdx.x, s[4 + threadIdx.x]);
     }
     const float inv = 1.f / (float)p.HW;
-    float* dx = p.dx + (long long)n * p.dx_sn + c0;
+    float* dx = p.dx + (p.dx16 ? 0 : (long long)n * p.dx_sn + c0);
     for (int px = threadIdx.x; px < p.HW; px += NT) {
         float4 xh; float4 d = load_dz(px, xh);
         float4 o;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
         o.y = g.y * r.y * (d.y - s[1] * inv - xh.y * s[5] * inv);
         o.z = g.z * r.z * (d.z - s[2] * inv - xh.z * s[6] * inv);
         o.w = g.w * r.w * (d.w - s[3] * inv - xh.w * s[7] * inv);
+        if (p.dx16) { st4x(dx, (long long)n * p.dx_sn + (long long)px * p.dx_sp + c0, o, 1); continue; }
         float* q = dx + (long long)px * p.dx_sp;
         if (p.dx_beta) { float4 t = ld4(q); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
         st4(q, o);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[e] *= inv; s2[e] *= inv; }
     const float4 g = ld4(p.gamma + c4 * 4), bt = ld4(p.beta + c4 * 4);
-    float* dx = p.dx + (long long)n * p.dx_sn + c4 * 4;
+    float* dx = p.dx + (p.dx16 ? 0 : (long long)n * p.dx_sn + c4 * 4);
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
     for (int px = p0 + prow; px < p1; px += rows) {
         float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, x, m, r, g, bt, xh);
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
         o.y = g.y * r[1] * (d.y - s1[1] - xh.y * s2[1]);
         o.z = g.z * r[2] * (d.z - s1[2] - xh.z * s2[2]);
         o.w = g.w * r[3] * (d.w - s1[3] - xh.w * s2[3]);
+        if (p.dx16) { st4x(dx, (long long)n * p.dx_sn + (long long)px * p.dx_sp + c4 * 4, o, 1); continue; }
         float* qq = dx + (long long)px * p.dx_sp;
         if (p.dx_beta) { float4 t = ld4(qq); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
         st4(qq, o);
@@ -405,6 +408,8 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
         if ((p.dy_c0[i] & 3) || (p.dy_c1[i] & 3) || p.dy_c0[i] < 0 || p.dy_c1[i] > a->C) return SAVP_EINVAL;
     }
     p.dx = (float*)a->dx.p; p.dx_sn = a->dx.sn; p.dx_sp = a->dx.sp; p.dx_beta = a->dx_beta;
+    p.dx16 = a->dx_bf16 ? 1 : 0;
+    if (p.dx16 && (a->dx_beta || (a->dx.sn & 3) || (a->dx.sp & 3) || (((uintptr_t)a->dx.p) & 7))) return SAVP_EINVAL;
     p.dgamma = a->dgamma; p.dbeta = a->dbeta;
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;

@@ -335,7 +335,11 @@ class ConvLayer(object):
         if self.kind == 'up':
             K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
             bias_src = dy
-            if self.dbias is not None:
+            # A bf16 dy is the gradient an instance norm's backward wrote (SAVPGenerator.act16): every upsample convolution is followed by
+            # fused_instance_norm (savp_model.py:486-500), whose input gradient sums to zero over each (sample, channel) plane --
+            # gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) with sum(xhat) = 0 -- so the bias gradient is identically zero (the
+            # reference's value is that zero plus rounding noise) and the column-sum pass is left out
+            if self.dbias is not None and bias_src.dtype != torch.bfloat16:
                 K.colsum(bias_src, self.dbias)
         else:       # bias gradient = column sums of dy: fused into the WGRAD pass (include/savp_hip.h, SavpConvArgs.bias)
             K.conv(lib.CONV_WGRAD, self.geom, x, dy, target, bias=self.dbias)

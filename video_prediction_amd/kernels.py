@@ -430,7 +430,8 @@ def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, d
     a.ndy = len(dys)
     _set_views(a.dy, dys)
     _set_ranges(a.dy_c0, a.dy_nc, dy_ranges)
-    a.dx = view(dx)
+    a.dx = view(dx, any_dtype=True)
+    a.dx_bf16 = _bf16_mask([dx])
     a.dx_beta = int(dx_beta)
     a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
     lib.check(lib.get().savp_instnorm_act_bwd(lib.stream(), ctypes.byref(a)), 'savp_instnorm_act_bwd')

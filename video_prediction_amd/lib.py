@@ -58,7 +58,7 @@ def get():
 # Kernel-selection switches of the library (include/savp_hip.h: savp_set_option).  The library itself never reads the environment;
 # for A/B runs the host forwards SAVP_<NAME>=<int> here, once, when the library is loaded.
 OPTION_NAMES = ('conv_ring', 's2dgrad', 'thin', 'wgp_cfg', 'wgp_split', 'inorm_min_hw', 'colsum_2stage', 'dense_legacy', 'cdna_legacy',
-                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm', 'ring_roles')
+                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm')
 
 
 def set_option(name, value):
@@ -167,7 +167,7 @@ class SavpInormArgs(ctypes.Structure):
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
         ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
         ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4), ('out_bf16', c_i32),
-        ('stats_ready', c_i32),
+        ('stats_ready', c_i32), ('dx_bf16', c_i32),
     ]
 
 

@@ -114,6 +114,14 @@ class SAVPGenerator(object):
         # every conv-RNN; 'input' = the first encoder conv only; 'middle' = the first decoder conv only
         zr = nz if hp.where_add == 'all' else 0                         # z channels in a conv-RNN's input [x | z | h]
         g = train
+        # bf16 storage of tensors whose ONLY readers are convolutions of the bf16 datapath (round 4; the cell input [x | z | h] and the
+        # gate gradient have been stored this way since round 3): the inputs of the down / upsample convolutions behind layer 0, the
+        # last decoder layer's output (read by the 3x3 heads) and the gradient of every conv_pool / upsample / head convolution's output
+        # (written by the instance norm's backward, read by that convolution's DGRAD / WGRAD).  Those kernels round their operands to
+        # bf16 while staging anyway: identical numbers, half the bytes of the batched weight gradients' activation stream, and the
+        # ring kernel stages a bf16 source by LDS-DMA.  SAVP_BF16_CONVIO=0 keeps fp32 tensors.
+        self.act16 = bool(K.PRECISION['value'] == 1 and hp.conv_rnn == 'lstm' and os.environ.get('SAVP_BF16_CONVIO', '1') == '1')
+        a16 = torch.bfloat16 if self.act16 else torch.float32
         enc_specs, dec_specs = layer_specs(hp.ngf, H, W)
         self.ne, self.nd = len(enc_specs), len(dec_specs)
 
@@ -130,7 +138,8 @@ class SAVPGenerator(object):
             if i < self.ne:
                 cx = 2 * C if i == 0 else prev_f
                 k = 5 if i == 0 else 3
-                L['in'] = Act((T1, N, h_, w_, ceil4(cx + zc)), dev, grad=g)      # pad channels stay zero
+                L['in'] = Act((T1, N, h_, w_, ceil4(cx + zc)), dev, grad=g,      # pad channels stay zero
+                              dtype=a16 if (i > 0 and ceil4(cx + zc) % 8 == 0) else torch.float32)     # layer 0 holds the input image: fp32
                 L['zoff_in'] = cx
                 L['conv'] = ConvLayer(store, s + 'conv_pool2d/kernel', s + 'conv_pool2d/bias', 'pool', (k, k), (2, 2),
                                       (same_pad_before(k + 1, 2, h_), same_pad_before(k + 1, 2, w_)),
@@ -140,14 +149,14 @@ class SAVPGenerator(object):
                 j = i - self.ne
                 skip = 0 if j == 0 else self.layers[self.ne - j - 1]['f']
                 cx = prev_f + skip
-                L['in'] = Act((T1, N, h_, w_, cx + zc), dev, grad=g)
+                L['in'] = Act((T1, N, h_, w_, cx + zc), dev, grad=g, dtype=a16 if (cx + zc) % 8 == 0 else torch.float32)
                 L['zoff_in'] = cx
                 L['skip_off'] = prev_f
                 h_, w_ = h_ * 2, w_ * 2
                 L['conv'] = ConvLayer(store, s + 'upsample_conv2d/kernel', s + 'upsample_conv2d/bias', 'up', (3, 3), (2, 2),
                                       (same_pad_before(6, 2, h_), same_pad_before(6, 2, w_)))
             L['hw'] = (h_, w_)
-            L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g)
+            L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g, grad_dtype=a16 if f % 8 == 0 else torch.float32)
             L['norm'] = Norm(store, s + 'InstanceNorm/', T1, N, f, dev)
             if use_rnn and hp.conv_rnn == 'gru':
                 # Conv2DGRUCell (rnn_ops.py:174-267): a = [x | z | h_prev | r*h_prev]; the gates conv reads the first
@@ -207,7 +216,7 @@ class SAVPGenerator(object):
 
         # ---- heads ------------------------------------------------------------------------------------------
         self.tf = hp.transformation
-        self.h_last = Act((T1, N, H, W, last['f']), dev, grad=g)
+        self.h_last = Act((T1, N, H, W, last['f']), dev, grad=g, dtype=a16 if last['f'] % 8 == 0 else torch.float32)
         tf_convs = []
         if self.tf == 'cdna':
             sh_, sw_ = H // 2 ** self.ne, W // 2 ** self.ne
@@ -311,7 +320,7 @@ class SAVPGenerator(object):
             self.nheads = len(parts)
             self.heads_conv = ConcatConv(store, parts, (3, 3), (1, 1), (1, 1))
             self.heads_norm = ConcatNorm(norms, T1, N, dev)
-            self.heads_pre = Act((T1, N, H, W, self.nheads * ngf), dev, grad=g)
+            self.heads_pre = Act((T1, N, H, W, self.nheads * ngf), dev, grad=g, grad_dtype=a16 if (self.nheads * ngf) % 8 == 0 else torch.float32)
             head_convs = [self.heads_conv]
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
                      [L['cconv'] for L in self.layers if L['rnn'] and self.gru] + \
