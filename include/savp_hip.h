@@ -288,6 +288,12 @@ typedef struct SavpCompositeArgs {
     SavpView drow;                 /* bwd: gradient of the WHOLE mask-conv input row [N,HW,row_channels]: channels
                                       [timgs_offset, timgs_offset+M*C) get mask_k*dgen, all others are written as 0 */
     int32_t timgs_offset, row_channels;
+    /* fwd, optional (nnext > 0): the NEXT time step's input image, image = tf.where(ground_truth[t+1], inputs['images'][t+1], gen_image)
+       (savp_model.py:406), written by the kernel that produces gen_image: next[k] [N,HW,C] receives gt_img where gt_mask[n] != 0 and
+       the composited image elsewhere -- the separate select launch of every autoregressive step disappears */
+    int32_t nnext; SavpView next[2];
+    const int32_t* gt_mask;        /* [N] */
+    SavpView gt_img;               /* [N,HW,C] */
 } SavpCompositeArgs;
 int savp_composite_fwd(void* stream, const SavpCompositeArgs* a);
 int savp_composite_bwd(void* stream, const SavpCompositeArgs* a);

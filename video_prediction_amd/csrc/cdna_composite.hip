@@ -704,6 +704,8 @@ struct CompP {
     float* dlogits;                        // [N*HW, ls] (pad columns written as 0)
     float* drow; long long dr_sn, dr_sp;   // gradient row of the whole mask-conv input buffer [N,HW,rowc]
     int toff, rowc;                        // timgs live at channels [toff, toff+M*C); everything else is written as 0
+    int nnext; float* next[2]; long long n_sn[2], n_sp[2];      // fwd: the next step's input image slots (SavpCompositeArgs.next)
+    const int* gt_mask; const float* gt_img; long long gi_sn, gi_sp;
 };
 
 template <int TM, int TC>
@@ -734,6 +736,18 @@ __global__ void composite_fwd_kernel(CompP p) {
     float* go = p.gen + (long long)n * p.g_sn + (long long)px * p.g_sp;
 #pragma unroll
     for (int c = 0; c < C; ++c) go[c] = g[c];
+    if (p.nnext) {        // image of step t+1 = ground truth where scheduled sampling says so, this step's prediction elsewhere
+        if (p.gt_mask[n]) {
+            const float* gi = p.gt_img + (long long)n * p.gi_sn + (long long)px * p.gi_sp;
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[c] = gi[c];
+        }
+        for (int k = 0; k < p.nnext; ++k) {
+            float* o = p.next[k] + (long long)n * p.n_sn[k] + (long long)px * p.n_sp[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = g[c];
+        }
+    }
     if (p.masks) {
 #pragma unroll
         for (int k = 0; k < M; ++k) p.masks[i * M + k] = m[k];
@@ -872,6 +886,13 @@ static int fill_comp(CompP& p, const SavpCompositeArgs* a) {
     p.dlogits = a->dlogits;
     p.drow = (float*)a->drow.p; p.dr_sn = a->drow.sn; p.dr_sp = a->drow.sp;
     p.toff = a->timgs_offset; p.rowc = a->row_channels;
+    p.nnext = a->nnext;
+    if (a->nnext < 0 || a->nnext > 2 || (a->nnext && (!a->gt_mask || !a->gt_img.p))) return SAVP_EINVAL;
+    for (int k = 0; k < a->nnext; ++k) {
+        if (!a->next[k].p) return SAVP_EINVAL;
+        p.next[k] = (float*)a->next[k].p; p.n_sn[k] = a->next[k].sn; p.n_sp[k] = a->next[k].sp;
+    }
+    p.gt_mask = a->gt_mask; p.gt_img = (const float*)a->gt_img.p; p.gi_sn = a->gt_img.sn; p.gi_sp = a->gt_img.sp;
     return SAVP_OK;
 }
 

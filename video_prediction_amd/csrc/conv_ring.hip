@@ -477,8 +477,18 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 }
                 if constexpr (STEADY) {
                     load_b(nxt, bn);
+#ifdef SAVP_RING_DMA_MID
+                    // developer A/B: the slab DMA between the two halves of the entry's MFMAs (fragment reads around the first half)
+                    mma(cur, 0, KH);
+                    sched_interleave<NKS * (WM + WN), KH * WM * WN, 0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma) issue(td, bd);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(cur, KH, NKS);
+#else
                     mma(cur, 0, NKS);
                     sched_interleave<NKS * (WM + WN), NKS * WM * WN, 0>();
+#endif
                 } else {
                     __builtin_amdgcn_sched_barrier(0);
                     mma(cur, 0, KH);
@@ -487,7 +497,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                     __builtin_amdgcn_sched_barrier(0);
                     mma(cur, KH, NKS);
                 }
+#ifdef SAVP_RING_DMA_MID
+                if (LATE && more && dma && !STEADY) {
+#else
                 if (LATE && more && dma) {
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     issue(td, bd);
                 }

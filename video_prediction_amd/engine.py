@@ -332,17 +332,19 @@ class ConvLayer(object):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may
         carry folded leading (time, batch) dims: [R, (D,) H, W, C]."""
         target = self.dwfp if self.padded else (self.dwf if self.dwf is not None else self.dW)
+        # A bf16 dy is the gradient an instance norm's backward wrote (SAVPGenerator.act16).  The convolution in front of a
+        # fused_instance_norm (every conv_pool2d / upsample_conv2d / 3x3 head of the cell, savp_model.py:449-500,522-567,625-631) has an
+        # identically zero bias gradient: the norm's input gradient gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) sums to zero
+        # over each (sample, channel) plane because sum(xhat) = 0.  The reference's value is that zero plus fp32 rounding noise; column
+        # sums of the bf16-ROUNDED gradient would be noise 2^-9 / 2^-24 times larger (measured 2e-3 of the group's largest gradient at
+        # T = 40), so with a bf16 dy the bias gradient is left at its exact value, zero.
+        db = self.dbias if dy.dtype != torch.bfloat16 else None
         if self.kind == 'up':
             K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
-            bias_src = dy
-            # A bf16 dy is the gradient an instance norm's backward wrote (SAVPGenerator.act16): every upsample convolution is followed by
-            # fused_instance_norm (savp_model.py:486-500), whose input gradient sums to zero over each (sample, channel) plane --
-            # gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) with sum(xhat) = 0 -- so the bias gradient is identically zero (the
-            # reference's value is that zero plus rounding noise) and the column-sum pass is left out
-            if self.dbias is not None and bias_src.dtype != torch.bfloat16:
-                K.colsum(bias_src, self.dbias)
+            if db is not None:
+                K.colsum(dy, db)
         else:       # bias gradient = column sums of dy: fused into the WGRAD pass (include/savp_hip.h, SavpConvArgs.bias)
-            K.conv(lib.CONV_WGRAD, self.geom, x, dy, target, bias=self.dbias)
+            K.conv(lib.CONV_WGRAD, self.geom, x, dy, target, bias=db)
 
     def finish_weight_grad(self, sn_done=False):
         """Map the folded / spectrally-normalised kernel gradient back to the master variable and clear it."""

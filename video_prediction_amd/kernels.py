@@ -677,12 +677,23 @@ def _comp_args(logits, timgs, C, M):
     return a
 
 
-def composite_fwd(logits, timgs, gen, masks=None, M=None):
-    """logits [N,H,W,ls] (first M columns used), timgs view [N,H,W,M*C]."""
+def composite_fwd(logits, timgs, gen, masks=None, M=None, next_inputs=None):
+    """logits [N,H,W,ls] (first M columns used), timgs view [N,H,W,M*C].  next_inputs = (gt_mask [N] int32, gt_image [N,H,W,C],
+    [destination views]): also writes the NEXT step's input image (ground truth where gt_mask, else this step's composite)."""
     M = M or logits.shape[-1]
     a = _comp_args(logits, timgs, gen.shape[-1], M)
     a.gen = view(gen)
     a.masks = _p(masks)
+    if next_inputs is not None:
+        gt_mask, gt_img, dsts = next_inputs
+        lib.require_device(gt_mask, gt_img)
+        if gt_mask.dtype != torch.int32 or len(dsts) > 2:
+            raise ValueError('composite_fwd: int32 gt_mask and at most two next-input views')
+        a.nnext = len(dsts)
+        for i, d in enumerate(dsts):
+            a.next[i] = view(d)
+        a.gt_mask = gt_mask.data_ptr()
+        a.gt_img = view(gt_img)
     lib.check(_L().savp_composite_fwd(lib.stream(), ctypes.byref(a)), 'savp_composite_fwd')
 
 

@@ -204,6 +204,7 @@ class SavpCompositeArgs(ctypes.Structure):
         ('N', c_i32), ('HW', c_i32), ('M', c_i32), ('C', c_i32),
         ('logits', c_vp), ('logits_stride', c_i32), ('timgs', SavpView), ('gen', SavpView), ('masks', c_vp),
         ('dgen', SavpView), ('dlogits', c_vp), ('drow', SavpView), ('timgs_offset', c_i32), ('row_channels', c_i32),
+        ('nnext', c_i32), ('next', SavpView * 2), ('gt_mask', c_vp), ('gt_img', SavpView),
     ]
 
 

@@ -410,11 +410,16 @@ class SAVPGenerator(object):
                 copy_view(images[:n].reshape(n, NH, self.W, C), [mflat[:n][..., off:off + C]])
                 if T1 > n:
                     K.select(self._ones, frame_all_steps(cf - 1, n), None, [mflat[n:][..., off:off + C]])
+        fuse_select = os.environ.get('SAVP_FUSE_SELECT', '1') == '1'
+
+        def image_slots(t):         # where step t's input image goes: the first conv's input and the 'prev' background slot
+            return [in0.v[t][..., 0:C]] + ([maskin.v[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else [])
         for t in range(T1):
-            # image = tf.where(ground_truth[t], inputs['images'], states['gen_image'])     (savp_model.py:406)
-            prev_gen = self.gen.v[t - 1] if t > 0 else None
-            K.select(gt_mask[t], images[t], prev_gen,
-                     [in0.v[t][..., 0:C]] + ([maskin.v[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else []))
+            # image = tf.where(ground_truth[t], inputs['images'], states['gen_image'])     (savp_model.py:406); from step 1 on the
+            # compositing kernel of step t-1 has already written it (composite_fwd(next_inputs=...))
+            if t == 0 or not fuse_select:
+                prev_gen = self.gen.v[t - 1] if t > 0 else None
+                K.select(gt_mask[t], images[t], prev_gen, image_slots(t))
             for L in self.layers:
                 f = L['f']
                 # the conv's epilogue leaves the instance norm's statistics behind where it can (bf16 datapath, whole tiles): the
@@ -498,8 +503,9 @@ class SAVPGenerator(object):
                 self._conv_norm('masks', self.masks_conv, self.h_last.v[t], self.masks_pre.v[t], self.masks_norm,
                                 [maskin.v[t][..., 0:self.hp.ngf]], t)
             self.masks_out.forward(maskin.v[t][..., 0:self.mask_cin], self.logits.v[t])
+            nxt = (gt_mask[t + 1], images[t + 1], image_slots(t + 1)) if (fuse_select and t + 1 < T1) else None
             K.composite_fwd(self.logits.v[t], maskin.v[t][..., self.hp.ngf:self.hp.ngf + self.M * C], self.gen.v[t],
-                            self.masks[t] if collect_masks else None, M=self.M)
+                            self.masks[t] if collect_masks else None, M=self.M, next_inputs=nxt)
         return self.gen.v
 
     # ---------------------------------------------------------------------------------------------------------
