@@ -254,10 +254,12 @@ def main():
     prof_lists = {id(layer): [] for layer, _ in inst}
     ktimers = {id(layer): K.KernelTimer() for layer, _ in inst}       # kernel-only durations of the same launches
     cell_lists = {id(L): [] for L in cells}
+    gate_timers = {id(L): K.KernelTimer() for L in cells}              # the gate-block launch of every cell, kernel-only clock
     for layer, _ in inst:
         layer.prof, layer.ktimer = prof_lists[id(layer)], ktimers[id(layer)]
     for L in cells:
         L['cell_prof'] = cell_lists[id(L)]
+        L['gate_ktimer'] = gate_timers[id(L)]
     sync()
     t1 = time.perf_counter()
     for _ in range(INST_STEPS):
@@ -269,6 +271,7 @@ def main():
             layer.prof = layer.ktimer = None
         for L in cells:
             L['cell_prof'] = None
+            L['gate_ktimer'] = None
         e_dt, _ = timed_steps(engine, 1, min(args.steps, 10))
         eager_ms = e_dt / min(args.steps, 10) * 1e3
         # host time to ISSUE one eager step (GPU idle at the start of each measurement, no sync before the clock stops): the head-room
@@ -291,12 +294,14 @@ def main():
     # fp32 datapath) fall back to (2).
     tot_flops, tot_s, launches = 0.0, 0.0, 0
     k_flops, k_s, k_launches = 0.0, 0.0, 0
+    conv_us_of = {}                               # gate conv layer -> its kernel-only durations (for the cell's kernel-only clock)
     for layer, fl in inst:
         for e0, e1 in prof_lists[id(layer)]:
             tot_s += e0.elapsed_time(e1) * 1e-3
             tot_flops += fl
             launches += 1
-        for us in ktimers[id(layer)].durations_us():
+        conv_us_of[id(layer)] = ktimers[id(layer)].durations_us()
+        for us in conv_us_of[id(layer)]:
             k_s += us * 1e-6
             k_flops += fl
             k_launches += 1
@@ -313,6 +318,7 @@ def main():
     # Algorithmic bytes (read x, h, c and W once, write c', h'; fp32 activations, bf16
     # weights in bf16 mode) and FLOPs (2*M*N*K of the gate conv) per cell launch-set, against both roofs.
     cell_s, cell_flops, cell_bytes, cell_n = 0.0, 0.0, 0.0, 0
+    ck_s, ck_flops, ck_bytes, ck_n = 0.0, 0.0, 0.0, 0          # the same cells on the kernel-only clock: gate conv + gate block durations
     for L in cells:
         h_, w_ = L['hw']
         cin, f = L['a'].v.shape[-1], L['f']
@@ -325,16 +331,32 @@ def main():
             cell_flops += fl
             cell_bytes += wbytes + abytes
             cell_n += 1
+        g_us = gate_timers[id(L)].durations_us() if L.get('gate_ktimer') is not None else []
+        c_us = conv_us_of.get(id(L['rconv']), [])
+        if g_us and len(g_us) == len(c_us):
+            ck_s += (sum(g_us) + sum(c_us)) * 1e-6
+            ck_flops += fl * len(g_us)
+            ck_bytes += (wbytes + abytes) * len(g_us)
+            ck_n += len(g_us)
+        gate_timers[id(L)].close()
         L['cell_prof'] = None
+        L['gate_ktimer'] = None
     # HBM traffic of the same kernel / shapes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (FETCH_SIZE x2 on gfx950 per
     # MI355X_MICROARCH.md).  bench.py cannot collect counters itself: the number is read from the committed PMC pass of the
     # round (profiles/, written by tests/tools/collect_profiles.sh on the same build) and labelled with its source.
-    traffic, traffic_src, traffic_alg = None, None, None
-    for rnd in ('r03', 'r02'):
+    traffic, traffic_src, traffic_alg, traffic_note = None, None, None, None
+    from video_prediction_amd import lib as _lib
+    src_id = _lib.source_id()
+    for rnd in ('r04', 'r03', 'r02'):
         pmc_path = os.path.join(ROOT, 'profiles', '%s_convlstm_cell_pmc_%s.json' % (rnd, args.precision))
         if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
             try:
                 pmc = json.load(open(pmc_path))
+                if pmc.get('source_id') != src_id:
+                    # a counter profile of OTHER kernel sources / tuning tables is not this build's traffic: say so instead of quoting it
+                    traffic_note = ('no counter profile of this build: %s was taken on source id %s, this checkout is %s (re-run '
+                                    'tests/tools/collect_profiles.sh)' % (os.path.basename(pmc_path), pmc.get('source_id'), src_id))
+                    break
                 traffic = pmc['avg_hbm_bytes_per_launch_five_layers']
                 traffic_alg = pmc.get('avg_algorithmic_bytes_five_layers')
                 traffic_src = 'profiles/' + os.path.basename(pmc_path)
@@ -356,8 +378,9 @@ def main():
                    'submission': mode, 'eager_ms_per_step': eager_ms, 'host_issue_ms_per_step': host_issue_ms, 'instrumented_ms_per_step': inst_ms},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic, 'algorithmic_bytes': traffic_alg,
-                     'traffic_unit': 'HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
-                                     'read from %s, not collected by this run); algorithmic bytes: avg_algorithmic_bytes_five_layers of the same file' % traffic_src,
+                     'traffic_unit': ('HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
+                                     'read from %s -- a counter pass of the same kernel sources + tuning tables (source id %s), not collected by this '
+                                     'run); algorithmic bytes: avg_algorithmic_bytes_five_layers of the same file' % (traffic_src, src_id)) if traffic is not None else traffic_note,
                      'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None, 'clock': clock,
                      'avg_launch_us_with_gaps': gaps_us,
@@ -365,6 +388,11 @@ def main():
         'roofline_cell': {'what': 'fused ConvLSTM cell = gate conv (instance-norm statistics + bf16 gates in its epilogue) + ONE gate-block launch, '
                                   'five layers, HIP events around each cell of the instrumented steps',
                           'avg_cell_us': (cell_s / cell_n * 1e6) if cell_n else None, 'cells_timed': cell_n,
+                          'clock': 'HIP event markers around the cell (two launches, three markers: half of it is marker / hand-over gaps)',
+                          'kernel_only': {'what': 'the same cells, sum of the two launches\' own begin / end stamps (gate conv + gate block)',
+                                          'avg_cell_us': (ck_s / ck_n * 1e6) if ck_n else None, 'cells_timed': ck_n,
+                                          'mfma_frac': (ck_flops / ck_s / 1e12 / PEAK_TFLOPS[args.precision]) if ck_s else None,
+                                          'hbm_frac': (ck_bytes / ck_s / 1e9 / 8000.0) if ck_s else None},
                           'mfma': {'achieved': (cell_flops / cell_s / 1e12) if cell_s else None, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                                    'frac': (cell_flops / cell_s / 1e12 / PEAK_TFLOPS[args.precision]) if cell_s else None},
                           'hbm': {'achieved': (cell_bytes / cell_s / 1e9) if cell_s else None, 'peak': 8000.0, 'unit': 'GB/s',
@@ -372,6 +400,13 @@ def main():
                                   'algorithmic_bytes_per_cell': (cell_bytes / cell_n) if cell_n else None}},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
+    # whole step against the conv roofline (algorithmic FLOPs per sequence and train step, fwd + data-grad + weight-grad)
+    step_tflop = {'c2': 0.684, 'c4': 1.004, 'c5': 4.81}.get(args.config)
+    if step_tflop:
+        tf = step_tflop * world * args.batch * args.steps / dt
+        result['roofline_step'] = {'what': 'whole train step: SURVEY.md 8(d) algorithmic TFLOP per sequence x sequences / measured time',
+                                   'tflop_per_sequence': step_tflop, 'achieved': tf, 'peak': PEAK_TFLOPS[args.precision] * world, 'unit': 'TFLOP/s',
+                                   'frac': tf / (PEAK_TFLOPS[args.precision] * world)}
     if dist is not None:
         st = engine.replicas.stats
         result['config']['dist'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),

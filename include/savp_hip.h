@@ -115,6 +115,18 @@ typedef struct SavpConvArgs {
                                       data gradient without the tiled-z channels of its input [x | z | h] (rnn_ops.py:144-146,
                                       savp_model.py:436-444): their gradient is a per-sample sum (savp_tiled_z_grad) and leaving them
                                       out keeps the column count on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256) */
+    /* FPROP / DGRAD, SAVP_PREC_BF16, fp32 destination, unit strides (ring kernel; savp_conv_stats_ok() with nb_ws set tells whether the
+       tiling can honour it, SAVP_EINVAL otherwise): the destination's logical channels [nb_c0, nb_c0 + nb_nc) are the output gradient
+       dy of a fused_instance_norm + activation whose input is nb_x (layers/normalization.py:146-170 differentiated; the ConvLSTM layer's
+       conv_pool / upsample convolution in front of the cell input's x slice, savp_model.py:449-464).  The epilogue then also leaves the
+       two per-(sample, channel) sums that norm's backward needs -- sum(dy') and sum(dy' * xhat), dy' = dy * act'(gamma * xhat + beta),
+       xhat = (x - mean) * rstd -- in nb_ws [N][nb_nc][2] (fp32, caller zeroes, atomically accumulated), so that
+       savp_instnorm_act_bwd(stats_ready) runs its apply pass alone. */
+    const float* nb_x; int64_t nb_x_sn, nb_x_sp;     /* the norm's input [N][pixels][nb_nc], addressed like a SavpView (pixel = y * W + x) */
+    const float *nb_mean, *nb_rstd;                  /* [N][nb_nc] saved by the forward pass */
+    const float *nb_gamma, *nb_beta;                 /* [nb_nc] */
+    float* nb_ws;
+    int32_t nb_c0, nb_nc, nb_act; float nb_alpha;    /* nb_act: 0 none, 1 relu, 2 leaky relu (nb_alpha) */
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
@@ -177,7 +189,9 @@ typedef struct SavpInormArgs {
     int32_t out_bf16;              /* fwd: bit k set = output view k is a bf16 tensor (its strides count bf16 elements): a destination
                                       that only feeds convolutions of the bf16 datapath (they round to bf16 anyway) in half the bytes */
     int32_t stats_ready;           /* fwd: ws already holds the per-(sample, channel) sum / sum of squares of x, UNSHIFTED (savp_conv's
-                                      `stats` epilogue wrote them while it produced x): the statistics pass is skipped -> one launch */
+                                      `stats` epilogue wrote them while it produced x): the statistics pass is skipped -> one launch.
+                                      bwd: ws already holds sum(dy'), sum(dy' * xhat) per (sample, channel) (savp_conv's nb_ws epilogue wrote
+                                      them while it produced dy): the statistics pass is skipped -> one launch */
     int32_t dx_bf16;               /* bwd: dx is a bf16 tensor (strides in bf16 elements, multiples of 4; dx_beta must be 0): the gradient of
                                       a convolution's output, whose only readers are that convolution's DGRAD / WGRAD on the bf16
                                       datapath (they round it to bf16 when they stage it anyway) -- half the bytes, identical numbers */

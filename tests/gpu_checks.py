@@ -1456,3 +1456,52 @@ def check_tiled_z_and_gapped_dgrad(seed=53):
         out.append(('zless_dgrad/fp32_refused', 0.0, 0.5))
     torch.cuda.synchronize()
     return out
+
+
+def check_norm_bwd_stats_epilogue(seed=61):
+    """savp_conv's nb_* epilogue (round 4): a DGRAD whose destination channels [0, C) are the output gradient of an instance norm + ReLU
+    leaves that norm's backward sums sum(dy'), sum(dy' * xhat) behind.  Checked: the data gradient itself is unchanged (bit for bit),
+    the sums equal an fp64 evaluation on the kernel's own output, and savp_instnorm_act_bwd(stats_ready) gives the dx / dgamma / dbeta
+    of the two-launch path.  Cases: the gate convolution's DGRAD with the z gap (x slice = the first f channels) and a 3x3 head DGRAD
+    (all channels)."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for (name, N, H, k, Cin, Cout, f, gap) in (('gate16', 4, 16, 5, 136, 256, 64, (64, 8)), ('gate32', 2, 32, 5, 72, 128, 32, (32, 8)),
+                                              ('head64', 2, 64, 3, 32, 64, 32, None)):
+        geom = K.ConvGeom((1, k, k), (1, 1, 1), (0, k // 2, k // 2))
+        w = rnd(rng, k, k, Cin, Cout) * 0.05
+        wd32 = dev(pack_wd(w))
+        wd16 = wd32.to(torch.bfloat16)
+        dy = rnd(rng, N, H, H, Cout).to(torch.bfloat16).to(DEV).contiguous()
+        x = dev(rnd(rng, N, H, H, f))                                    # the norm's input
+        gamma, beta = dev(rnd(rng, f) * 0.3 + 1), dev(rnd(rng, f) * 0.3)
+        mean, rstd = torch.empty(N, f, device=DEV), torch.empty(N, f, device=DEV)
+        y = torch.empty(N, H, H, f, device=DEV)
+        K.instnorm_act_fwd(x, gamma, beta, [y], mean, rstd, act='relu')
+        plain = torch.zeros(N, H, H, Cin, device=DEV)
+        K.conv(lib.CONV_DGRAD, geom, plain, dy, wd32, w16=wd16, precision=1, dst_gap=gap)
+        ws = torch.zeros(N, f, 2, device=DEV)
+        nb = dict(x=x, mean=mean, rstd=rstd, gamma=gamma, beta=beta, ws=ws, c0=0, act='relu')
+        ok = K.conv_stats_ok(lib.CONV_DGRAD, geom, plain, dy, wd32, w16=wd16, dst_gap=gap, norm_bwd=dict(nb, ws=None))
+        out.append(('nbstats/%s_offered' % name, 0.0 if ok else 1.0, 0.5))
+        if not ok:
+            continue
+        got = torch.zeros(N, H, H, Cin, device=DEV)
+        K.conv(lib.CONV_DGRAD, geom, got, dy, wd32, w16=wd16, precision=1, dst_gap=gap, norm_bwd=nb)
+        out.append(('nbstats/%s_dx_bit_identical' % name, 0.0 if torch.equal(got, plain) else 1.0, 0.5))
+        g = got[..., :f].double().cpu()
+        xh = (x.double().cpu() - mean.double().cpu()[:, None, None, :]) * rstd.double().cpu()[:, None, None, :]
+        mask = ((x.cpu() - mean.cpu()[:, None, None, :]) * rstd.cpu()[:, None, None, :] * gamma.cpu() + beta.cpu() > 0).double()
+        d = g * mask
+        ref = torch.stack([d.sum(dim=(1, 2)), (d * xh).sum(dim=(1, 2))], dim=-1)
+        out.append(('nbstats/%s_sums' % name, rel_err(ws, ref), 2e-5))
+        res = []
+        for st in (None, ws):
+            dx = torch.empty(N, H, H, f, device=DEV)
+            dg, db = torch.zeros(f, device=DEV), torch.zeros(f, device=DEV)
+            K.instnorm_act_bwd(x, gamma, beta, y, mean, rstd, [got[..., :f]], dx, dg, db, act='relu', stats=st)
+            res.append((dx, dg, db))
+        for nm, a_, b_ in zip(('dx', 'dgamma', 'dbeta'), res[1], res[0]):
+            out.append(('nbstats/%s_%s' % (name, nm), rel_err(a_, b_.double().cpu()), 2e-5))
+    torch.cuda.synchronize()
+    return out

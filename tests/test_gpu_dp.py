@@ -21,6 +21,25 @@ HP = dict(context_frames=2, sequence_length=T, clip_length=4, nz=8, lr=2e-4, bet
           vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
 
 
+def _get(q, procs, timeout):
+    """q.get that gives up as soon as a worker has died without delivering (a crashed worker used to cost the full timeout)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            dead = [p for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            late = time.time() - t0 > timeout
+            if dead or late:
+                for p in procs:                    # the surviving ranks wait in a collective for the one that died: stop exactly those
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError('worker exited with code %s before reporting' % dead[0].exitcode if dead else
+                                     'no result from the workers within %d s' % timeout)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -102,7 +121,7 @@ def test_two_replicas_on_one_gpu_match_the_global_batch_step(joint):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, joint)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=500) for _ in range(2)]
+    results = [_get(q, procs, 500) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -197,7 +216,7 @@ def test_live_tuning_choice_is_rank0s_on_every_replica():
     procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=250) for _ in range(2)], key=lambda r: r['rank'])
+    res = sorted([_get(q, procs, 250) for _ in range(2)], key=lambda r: r['rank'])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -261,7 +280,7 @@ def test_rccl_world_size_one_forced_collectives_and_segmented_replay_equal_the_p
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
     p.start()
-    r = q.get(timeout=800)
+    r = _get(q, [p], 800)
     p.join(timeout=120)
     assert p.exitcode == 0
     assert r['backend'] == 'nccl' and r['active'] and r['dp'] and r['side_stream'] and r['same']
@@ -324,7 +343,7 @@ def test_savp_allreduce_bucket_on_a_one_rank_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_bucket_worker, args=(q,))
     p.start()
-    r = q.get(timeout=250)
+    r = _get(q, [p], 250)
     p.join(timeout=60)
     assert p.exitcode == 0
     assert r == {'rc': 0, 'rc2': 0, 'equal': True}, r

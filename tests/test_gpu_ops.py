@@ -157,3 +157,8 @@ def test_tiled_z_gradient_and_gapped_gate_dgrad():
     from tests import gpu_checks
     _run(gpu_checks.check_tiled_z_and_gapped_dgrad)
 
+
+
+def test_norm_backward_sums_from_the_dgrad_epilogue():
+    from tests import gpu_checks
+    _run(gpu_checks.check_norm_bwd_stats_epilogue)

@@ -54,6 +54,10 @@ for name, (H, W, Cx, Cy) in shapes.items():
 L = out['layers']
 L['lstm_h3'] = dict(L['lstm_h1'])
 L['lstm_h4'] = dict(L['lstm_h0'])
+import sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from video_prediction_amd import lib as _lib  # noqa: E402
+out['source_id'] = _lib.source_id()            # bench.py quotes this file only for the same kernel sources + tuning tables
 out['avg_hbm_bytes_per_launch_five_layers'] = sum(v['hbm_bytes_corrected'] for v in L.values()) / 5
 out['avg_algorithmic_bytes_five_layers'] = sum(v['algorithmic_bytes'] for v in L.values()) / 5
 print(json.dumps(out, indent=1))

@@ -75,6 +75,9 @@ struct ConvP {
     // divisions leave the kernel's prologue this way (1-2 k of its 8-10 k cycles, profiles/r03_ring_prologue_stamps.log).  The same
     // change made conv_patch_kernel 10-19 % SLOWER in the step (its main loop's register allocation) and was not kept there.
     int pre;
+    // conv_ring_kernel: backward statistics of the instance norm whose output gradient this convolution produces (SavpConvArgs.nb_*)
+    const float* nb_x; long long nb_x_sn, nb_x_sp; const float *nb_mean, *nb_rstd, *nb_gamma, *nb_beta; float* nb_ws;
+    int nb_c0, nb_nc, nb_act; float nb_alpha;
     int gap_at, gap;                          // conv_ring_kernel: logical output column c >= gap_at is physical weight row / destination channel c + gap (SavpConvArgs.dst_gap)
     int wwarm;                                // conv_ring_kernel: warm the L2 with the column tile's weight block first (option ring_wwarm)
     DimGeom gD, gH, gW;

@@ -772,10 +772,11 @@ extern "C" int savp_conv_stats_ok(const SavpConvArgs* a) {
     if (!(a->w_bf16 && (Cred % 8 == 0) && aligned16(a->w_bf16))) return 0;
     ConvP p;
     p.bf16 = 1; p.w16 = (const unsigned short*)a->w_bf16; p.src16 = a->src_bf16 ? 1 : 0; p.splitk = 1; p.tm = p.tn = 1;
-    p.gap_at = 0x7fffffff; p.gap = 0;
-    if (a->dst_gap) return 0;                                   // statistics of a gapped destination: not offered
+    p.gap_at = a->dst_gap ? a->dst_gap_at : 0x7fffffff; p.gap = a->dst_gap;
+    p.nb_ws = a->nb_ws; p.nb_c0 = a->nb_c0; p.nb_nc = a->nb_nc;
+    if (a->dst_gap && !a->nb_ws) return 0;                      // forward statistics of a gapped destination: not offered
     SavpConvArgs b = *a;
-    if (!b.stats) b.stats = (float*)(uintptr_t)16;               // any non-NULL value: only the plan is made
+    if (!b.stats && !b.nb_ws) b.stats = (float*)(uintptr_t)16;   // any non-NULL value: only the plan is made
     int wm = 0, wn = 0;
     if (b.tile & 0xff) { wm = (b.tile >> 4) & 15; wn = b.tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return 0; }
     int rc = SAVP_OK;
@@ -804,6 +805,14 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     const bool gapped = a->dst_gap != 0;
     if (gapped && (a->dst_gap < 0 || a->dst_gap_at < 0 || a->mode == SAVP_CONV_WGRAD)) return SAVP_EINVAL;
     p.gap_at = gapped ? a->dst_gap_at : 0x7fffffff; p.gap = gapped ? a->dst_gap : 0;
+    p.nb_ws = a->nb_ws;
+    if (a->nb_ws) {
+        if (a->mode == SAVP_CONV_WGRAD || !a->nb_x || !a->nb_mean || !a->nb_rstd || !a->nb_gamma || !a->nb_beta || a->nb_c0 < 0 || a->nb_nc < 1 ||
+            a->nb_act < 0 || a->nb_act > 2)
+            return SAVP_EINVAL;
+        p.nb_x = a->nb_x; p.nb_x_sn = a->nb_x_sn; p.nb_x_sp = a->nb_x_sp; p.nb_mean = a->nb_mean; p.nb_rstd = a->nb_rstd;
+        p.nb_gamma = a->nb_gamma; p.nb_beta = a->nb_beta; p.nb_c0 = a->nb_c0; p.nb_nc = a->nb_nc; p.nb_act = a->nb_act; p.nb_alpha = a->nb_alpha;
+    }
     p.magW = magic40(a->Wo); p.magHW = magic40(a->Ho * a->Wo); p.magDHW = magic40(a->Do * a->Ho * a->Wo);
     int wm = 0, wn = 0;
     const int algo = (a->tile >> 8) & 3;               // 0 = auto, 1 = generic gather kernel, 2 = LDS patch kernel, 3 = LDS-DMA ring kernel
@@ -814,12 +823,12 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
     // problem-specific kernels, taken only when the caller leaves the algorithm to the library (tile bits 8-9 == 0): a forced
     // algorithm gets exactly that kernel or EINVAL
-    if (algo == 0 && !gapped) {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first
+    if (algo == 0 && !gapped && !a->nb_ws) {   // convolutions between an RGB / grey image and 32 feature channels (conv_thin.hip): the discriminators' first
         // layer (FPROP, WGRAD) and the data gradient of the generator's scratch-image head
         int rc = SAVP_OK;
         if (conv_thin_try(a, st, &rc)) return rc;
     }
-    if (algo == 0 && !gapped && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
+    if (algo == 0 && !gapped && !a->nb_ws && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
         int rc = SAVP_OK;
         if (conv_s2dgrad_try(a, st, &rc)) return rc;
     }
@@ -840,7 +849,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         }
         if (Mmax <= 0 || Nout <= 0) return SAVP_EINVAL;
         // ---- LDS patch kernel (conv_patch.hip): 2-D stride-1 convs in bf16 with pre-packed bf16 weights --------------
-        const bool needs_ring = a->out_bf16 || a->src_bf16 || a->stats || gapped;   // only the ring kernel reads / writes bf16 activations / skips destination channels
+        const bool needs_ring = a->out_bf16 || a->src_bf16 || a->stats || gapped || a->nb_ws;   // only the ring kernel reads / writes bf16 activations / skips destination channels
         if (algo == 3 || needs_ring || (algo == 0 && ring_default())) {
             int rc = SAVP_OK;
             if (conv_ring_try(p, a, wm, wn, st, &rc)) return rc;

@@ -635,6 +635,59 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             if (n0 + (rem >> 1) < Nout) unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
         }
     }
+    if (p.nb_ws) {
+        // ---- backward statistics of the instance norm whose OUTPUT gradient this kernel produces (SavpConvArgs.nb_*): the destination's
+        // logical channels [nb_c0, nb_c0 + nb_nc) are dy of y = act(gamma * xhat + beta), xhat = (x - mean) * rstd; the two sums that norm's
+        // backward needs, sum(dy') and sum(dy' * xhat) with dy' = dy * act'(gamma * xhat + beta), leave with the accumulators -- the norm's
+        // statistics launch (one more pass over x and dy) disappears.  The mask is the forward apply pass's expression, bit for bit.
+        // Launcher guarantees: whole tiles, a row block inside one image, unit destination strides per pixel, split-K 1, no act / beta.
+        float* stat = reinterpret_cast<float*>(smem);         // [ni][BN][2]
+        __syncthreads();                                      // ring and patch are dead
+        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int rowb = wm0 + i * 32;
+            const int im = rowb >> rsh;
+            const int gi = img0 + im;
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int py0 = oy0 + ((rowb - (im << rsh)) >> 3);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int cc = col0 + 32 * j - p.nb_c0;         // channel of the norm
+                const bool in = cc >= 0 && cc < p.nb_nc && col0 + 32 * j < Nout;
+                const int cq = in ? cc : 0;
+                const float mu = p.nb_mean[(long long)n * p.nb_nc + cq], rs = p.nb_rstd[(long long)n * p.nb_nc + cq];
+                const float ga = p.nb_gamma[cq], be = p.nb_beta[cq];
+                const float* xp = p.nb_x + (long long)n * p.nb_x_sn + ((long long)py0 * Wm + px0) * p.nb_x_sp + cq;
+                float xv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = xp[((r >> 2) * Wm + (r & 3)) * p.nb_x_sp];      // all 16 loads in flight
+                float sm = 0.f, q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xh = (xv[r] - mu) * rs;
+                    const float y = xh * ga + be;
+                    const float gr = p.nb_act == 1 ? (y > 0.f ? 1.f : 0.f) : (p.nb_act == 2 ? (y > 0.f ? 1.f : p.nb_alpha) : 1.f);
+                    const float d = acc[i][j][r] * gr;
+                    sm += d; q += d * xh;
+                }
+                sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
+                if (khalf == 0 && in) {
+                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
+                    unsafeAtomicAdd(d, sm); unsafeAtomicAdd(d + 1, q);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < ni * BN * 2; i += NT) {
+            const int im = i / (BN * 2), rem = i - im * (BN * 2);
+            const int gi = img0 + im;
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int cc = n0 + (rem >> 1) - p.nb_c0;
+            if (cc >= 0 && cc < p.nb_nc && n0 + (rem >> 1) < Nout) unsafeAtomicAdd(p.nb_ws + ((long long)n * p.nb_nc + cc) * 2 + (rem & 1), stat[i]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int rowb = wm0 + i * 32;
@@ -791,6 +844,14 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
             (size_t)ni * BN * 2 * 4 > lds)
             return false;
     }
+    if (a->nb_ws) {
+        // norm-backward statistics: whole tiles (every accumulator is a real output of one image), unit strides (destination pixel (y, x)
+        // is pixel y * Wm + x of nb_x), depth 1, no split-K, nothing after the accumulators, an fp32 destination
+        const long long nimg = (long long)a->N * Dm;
+        if (cell || a->stats || a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || phases != 1 || Dm != 1 || (a->splitk > 1) ||
+            a->sh != 1 || a->sw != 1 || a->nb_c0 + a->nb_nc > Nout || (size_t)ni * BN * 2 * 4 > lds)
+            return false;
+    }
     p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
     p.s1_pitch = pitch; p.s1_nch = nch; p.s1_spp = spp;
     p.s1_magPI = magic40(PH * PW * spp * nks * 4); p.s1_magPW = magic40(PW); p.s1_magC4 = magic40(spp * nks * 4);
@@ -808,7 +869,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     const long long tiles = (long long)p.tm * p.tn;
     const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
     int splitk = a->splitk;
-    if (a->act != SAVP_ACT_NONE || cell || a->stats) splitk = 1;
+    if (a->act != SAVP_ACT_NONE || cell || a->stats || a->nb_ws) splitk = 1;
     else if (splitk <= 0) {
         splitk = 1;
         if (tiles <= 192 && iters >= 16) {

@@ -7,9 +7,11 @@
 // so both per-sample reductions are workgroup-local (no grid sync, no atomics except the per-channel
 // gamma/beta gradients which are summed over samples and timesteps).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "savp_hip.h"
+extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
 #include "opts.h"
 
 #define NT 256
@@ -411,6 +413,14 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
     p.dx16 = a->dx_bf16 ? 1 : 0;
     if (p.dx16 && (a->dx_beta || (a->dx.sn & 3) || (a->dx.sp & 3) || (((uintptr_t)a->dx.p) & 7))) return SAVP_EINVAL;
     p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+    if (a->stats_ready) {                      // sum(dy'), sum(dy' * xhat) from the convolution that produced dy: the apply pass alone
+        if (!a->ws || a->C > 256 || (NT % (a->C / 4)) != 0) return SAVP_EINVAL;
+        hipStream_t st = (hipStream_t)stream;
+        p.chunk = inorm_chunk(a);
+        dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
+        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws);
+        return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+    }
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
         if (!a->ws_clean) hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
@@ -1464,7 +1474,14 @@ static bool lstm_fused_cfg(const SavpLstmArgs* a, bool fwd, int& Q, int& PPT, in
             else { if (PPT == 1) KERNEL(4, 1, false, __VA_ARGS__); else if (PPT == 2) KERNEL(4, 2, false, __VA_ARGS__); else KERNEL(4, 4, false, __VA_ARGS__); } \
         }                                                                                                                  \
     } while (0)
-#define LSTM_FWD_LAUNCH(Q_, P_, G_, ...) hipLaunchKernelGGL((lstm_fused_fwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, __VA_ARGS__)
+// (bench.py's roofline_cell: a launch armed with savp_prof_arm stamps its own begin / end, like the ring convolution's)
+#define LSTM_FWD_LAUNCH(Q_, P_, G_, ...)                                                                                      \
+    do {                                                                                                                   \
+        if (g_savp_prof_start) {                                                                                           \
+            hipExtLaunchKernelGGL((lstm_fused_fwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, g_savp_prof_start, g_savp_prof_stop, 0, __VA_ARGS__); \
+            g_savp_prof_start = g_savp_prof_stop = nullptr;                                                                \
+        } else hipLaunchKernelGGL((lstm_fused_fwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, __VA_ARGS__);                \
+    } while (0)
 #define LSTM_BWD_LAUNCH(Q_, P_, G_, ...) hipLaunchKernelGGL((lstm_fused_bwd_kernel<Q_, P_, G_>), grid, dim3(NT), 0, st, __VA_ARGS__)
 
 static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {

@@ -321,12 +321,25 @@ class ConvLayer(object):
             return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=self.bias, w16=self.wd16)
         return K.conv_stats_ok(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=self.bias, w16=self.wt16)
 
-    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None, skip=None):
-        """skip = (first, count): input channels whose data gradient is not needed per pixel (left unwritten in dx)."""
+    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None, skip=None, norm_bwd=None):
+        """skip = (first, count): input channels whose data gradient is not needed per pixel (left unwritten in dx).  norm_bwd: dx's
+        channels [c0, c0 + C) are the output gradient of an instance norm over norm_bwd['x']; its backward sums leave with this launch
+        (kernels.conv)."""
         if self.kind == 'up':
-            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16, dst_gap=skip)
+            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16, dst_gap=skip,
+                   norm_bwd=norm_bwd)
         else:
-            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16, dst_gap=skip)
+            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16, dst_gap=skip,
+                   norm_bwd=norm_bwd)
+
+    def norm_bwd_ok(self, dy, dx, norm_bwd, skip=None):
+        """Can backward_data(dy, dx, norm_bwd=...) leave the norm-backward sums behind (bf16 datapath, ring kernel, whole tiles)?"""
+        if K.PRECISION['value'] != 1:
+            return False
+        nb = dict(norm_bwd, ws=None)
+        if self.kind == 'up':
+            return K.conv_stats_ok(lib.CONV_FPROP, self.geom, dy, dx, self.wt, w16=self.wt16, dst_gap=skip, norm_bwd=nb)
+        return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, w16=self.wd16, dst_gap=skip, norm_bwd=nb)
 
     def backward_weights(self, x, dy):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may
@@ -446,6 +459,9 @@ class ConcatConv(object):
 
     def backward_data(self, dy, dx, **kw):
         self.inner.backward_data(dy, dx, **kw)
+
+    def norm_bwd_ok(self, dy, dx, norm_bwd, skip=None):
+        return self.inner.norm_bwd_ok(dy, dx, norm_bwd, skip)
 
     def backward_weights(self, x, dy):
         self.inner.backward_weights(x, dy)

@@ -101,7 +101,8 @@ def enable_autotune(flag=True):
     AUTOTUNE['enabled'] = bool(flag)
 
 
-def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, dst_gap=None):
+def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, dst_gap=None,
+                    norm_bwd=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -119,6 +120,17 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
             a.Cy = Cy - a.dst_gap
         else:
             raise ValueError('dst_gap: FPROP / DGRAD only')
+    if norm_bwd is not None:
+        # the destination's channels [c0, c0 + C) are the output gradient of an instance norm (+ activation) over nb['x']: the epilogue
+        # leaves that norm's backward sums in nb['ws'] (SavpConvArgs.nb_*); instnorm_act_bwd(stats=ws) then runs its apply pass alone
+        nb = norm_bwd
+        xv = view(nb['x'])
+        a.nb_x, a.nb_x_sn, a.nb_x_sp = xv.p, xv.sn, xv.sp
+        a.nb_mean, a.nb_rstd = nb['mean'].data_ptr(), nb['rstd'].data_ptr()
+        a.nb_gamma, a.nb_beta = nb['gamma'].data_ptr(), nb['beta'].data_ptr()
+        a.nb_ws = nb['ws'].data_ptr() if nb.get('ws') is not None else 16        # 16: plan query only (conv_stats_ok)
+        a.nb_c0, a.nb_nc = int(nb.get('c0', 0)), nb['x'].shape[-1]
+        a.nb_act, a.nb_alpha = ACT_IDS[nb.get('act', 'relu')], float(nb.get('alpha', 0.0))
     a.kd, a.kh, a.kw = geom.k
     a.sd, a.sh, a.sw = geom.s
     a.pd, a.ph, a.pw = geom.p
@@ -215,14 +227,14 @@ def _tune(a, mode, dst, w, return_all=False):
 
 
 def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
-         dst_gap=None):
+         dst_gap=None, norm_bwd=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
     destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] fp32 (zeroed by the caller)
     receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only); dst_gap = (first, count):
     `count` destination channels from `first` on are left out (neither computed nor written)."""
     lib.require_device(w, bias, aux, stats)
     lib.require_device_any(x, y)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd)
     if mode == lib.CONV_WGRAD:           # caller-owned scratch (today: the RGB-side weight gradient's partial sums)
         need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
         if need:
@@ -233,6 +245,8 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
         if a.dst_gap:
             key = key + ((a.dst_gap_at, a.dst_gap),)
+        if norm_bwd is not None:
+            key = key + (('nb', a.nb_c0, a.nb_nc),)
         cfg = AUTOTUNE['cache'].get(key)
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
@@ -261,10 +275,11 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
 
 
-def conv_stats_ok(mode, geom, x, y, w, bias=None, w16=None):
+def conv_stats_ok(mode, geom, x, y, w, bias=None, w16=None, dst_gap=None, norm_bwd=None):
     """True when savp_conv would honour a `stats` buffer for this FPROP / DGRAD problem (bf16 precision, ring kernel, whole tiles):
-    the instance norm behind the convolution can then skip its own statistics pass (instnorm_act_fwd(stats=...))."""
-    a = _fill_conv_args(mode, geom, x, y, w, bias, 0, 0, 0.0, None, 0, 0, None, w16, None)
+    the instance norm behind the convolution can then skip its own statistics pass (instnorm_act_fwd(stats=...)).  With norm_bwd
+    (ws absent): the same question for the norm-backward statistics epilogue."""
+    a = _fill_conv_args(mode, geom, x, y, w, bias, 0, 0, 0.0, None, 0, 0, None, w16, None, dst_gap, norm_bwd)
     return bool(lib.get().savp_conv_stats_ok(ctypes.byref(a)))
 
 
@@ -416,11 +431,16 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
 
 
 def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, dx_beta=0, act='relu', alpha=0.0,
-                     eps=1e-6, dy_ranges=None):
+                     eps=1e-6, dy_ranges=None, stats=None):
     """out0 is not read (the activation mask is recomputed from x, mean, rstd, gamma, beta); dy_ranges: per gradient view the
-    (first channel, count) slice of the output it is the gradient of (default: all channels)."""
+    (first channel, count) slice of the output it is the gradient of (default: all channels).  stats: [N, C, 2] sums written by the
+    convolution that produced dy (conv(..., norm_bwd=...)): the statistics pass is skipped."""
     a = lib.SavpInormArgs()
-    a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
+    if stats is not None:
+        lib.require_device(stats)
+        a.ws, a.ws_clean, a.stats_ready = stats.data_ptr(), 1, 1
+    else:
+        a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]
     a.act, a.alpha, a.eps = ACT_IDS[act], float(alpha), float(eps)
     a.x = view(x)
@@ -686,9 +706,10 @@ def composite_fwd(logits, timgs, gen, masks=None, M=None, next_inputs=None):
     a.masks = _p(masks)
     if next_inputs is not None:
         gt_mask, gt_img, dsts = next_inputs
-        lib.require_device(gt_mask, gt_img)
-        if gt_mask.dtype != torch.int32 or len(dsts) > 2:
-            raise ValueError('composite_fwd: int32 gt_mask and at most two next-input views')
+        lib.require_device(gt_img)
+        _require_i32(gt_mask)
+        if len(dsts) > 2:
+            raise ValueError('composite_fwd: at most two next-input views')
         a.nnext = len(dsts)
         for i, d in enumerate(dsts):
             a.next[i] = view(d)

@@ -33,6 +33,8 @@ class SavpConvArgs(ctypes.Structure):
         ('src_bf16', c_i32), ('out_bf16', c_i32), ('stats', c_vp),
         ('ws', c_vp), ('ws_bytes', c_i64),
         ('dst_gap_at', c_i32), ('dst_gap', c_i32),
+        ('nb_x', c_vp), ('nb_x_sn', c_i64), ('nb_x_sp', c_i64), ('nb_mean', c_vp), ('nb_rstd', c_vp), ('nb_gamma', c_vp), ('nb_beta', c_vp),
+        ('nb_ws', c_vp), ('nb_c0', c_i32), ('nb_nc', c_i32), ('nb_act', c_i32), ('nb_alpha', c_f32),
     ]
 
 
@@ -119,6 +121,25 @@ def register(name, argtypes):
     _EXTRA_SIGS[name] = argtypes
     if _lib is not None:
         _sig(_lib, name, argtypes)
+
+
+def source_id():
+    """16 hex digits identifying the kernel sources + shipped tuning tables of this checkout (sha256 over csrc/*, include/*.h and
+    tuning_gfx950_*.json in name order).  Measurement files under profiles/ carry it, and bench.py only quotes a counter profile
+    (roofline.traffic) whose id equals the running checkout's: a profile of another build cannot pass for this one."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = []
+    for d, pat in ((os.path.join(_HERE, 'csrc'), ('.hip', '.h')), (os.path.join(root, 'include'), ('.h',)), (_HERE, ('.json',))):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(pat) and (d != _HERE or f.startswith('tuning_gfx950_')):
+                files.append(os.path.join(d, f))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def stream():

@@ -23,6 +23,7 @@ from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_view
 from ..variables import layer_specs, num_masks
 
 CONV_STATS = os.environ.get('SAVP_CONV_STATS', '1') == '1'      # developer A/B switch of the conv-epilogue statistics
+NORM_BWD_STATS = os.environ.get('SAVP_NORM_BWD_STATS', '1') == '1'      # ... and of the norm-backward sums from the DGRAD that produces dy
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
 
 
@@ -460,9 +461,14 @@ class SAVPGenerator(object):
                     if t + 1 < T1:
                         outs.append(a.v[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
+                    gk = L.get('gate_ktimer')                # bench.py: the gate-block launch's own begin / end stamps
+                    if gk is not None:
+                        gk.arm()
                     K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
                                          n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
                                          eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
+                    if gk is not None:
+                        gk.taken()
                     if cp is not None:
                         ce1.record()
                         cp.append((ce0, ce1))
@@ -519,6 +525,21 @@ class SAVPGenerator(object):
         conv.forward(x, pre, stats=st)
         K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], act='relu', eps=EPS_IN, stats=st, **kw)
 
+    def _norm_bwd(self, key, holder, conv, dy, dx, nrm, x, skip=None):
+        """The instance norm (over x, parameters nrm) whose OUTPUT gradient is the channels [0, C) that conv.backward_data(dy, dx) is
+        about to write: where the ring kernel can, its epilogue leaves that norm's backward sums behind (SavpConvArgs.nb_*), and the
+        norm's backward is then ONE launch.  Returns the norm_bwd dict for backward_data (None: the norm takes its own sums); its 'ws'
+        is what instnorm_act_bwd(stats=...) gets.  The decision is made once per layer (holder[key])."""
+        t_ = dict(x=x, mean=nrm.mean[0], rstd=nrm.rstd[0], gamma=nrm.gamma, beta=nrm.beta, c0=0, act='relu')
+        ok = holder.get(key)
+        if ok is None:
+            ok = holder[key] = bool(NORM_BWD_STATS and dx.dtype == torch.float32 and x.shape[-1] <= 256 and
+                                    conv.norm_bwd_ok(dy, dx, t_, skip))
+        if not ok:
+            return None
+        t_['ws'] = K.zero_arena(self.dev).take(self.N * x.shape[-1] * 2)
+        return t_
+
     def _lstm_ws(self, L):
         """Scratch of the coalesced ConvLSTM gate kernels (one buffer shared by all layers: the launches are serial)."""
         h, w = L['hw']
@@ -564,7 +585,15 @@ class SAVPGenerator(object):
                       ([self.tf_h.g[t]] if self.tf != 'cdna' else [])
                 K.instnorm_act_bwd(self.heads_pre.v[t], hn.gamma, hn.beta, None, hn.mean[t], hn.rstd[t], dys, self.heads_pre.g[t],
                                    hn.dgamma, hn.dbeta, act='relu', eps=EPS_IN, dy_ranges=[(i * ngf, ngf) for i in range(self.nheads)])
-                self.heads_conv.backward_data(self.heads_pre.g[t], self.h_last.g[t], beta=0)
+                Ll = self.layers[-1]
+                nb_last = None
+                if not Ll['rnn']:          # h_last is the output of the last layer's instance norm: its backward sums leave with this DGRAD
+                    nl_ = Ll['norm']
+                    nb_last = self._norm_bwd('nb_heads', self._cstats, self.heads_conv, self.heads_pre.g[t], self.h_last.g[t], nl_,
+                                             Ll['pre'].v[t])
+                    if nb_last is not None:
+                        nb_last['mean'], nb_last['rstd'] = nl_.mean[t], nl_.rstd[t]
+                self.heads_conv.backward_data(self.heads_pre.g[t], self.h_last.g[t], beta=0, norm_bwd=nb_last)
             else:
                 mn = self.masks_norm
                 K.instnorm_act_bwd(self.masks_pre.v[t], mn.gamma, mn.beta, maskin.v[t][..., 0:ngf], mn.mean[t], mn.rstd[t],
@@ -580,6 +609,8 @@ class SAVPGenerator(object):
                     K.instnorm_act_bwd(self.tf_pre.v[t], tn.gamma, tn.beta, self.tf_h.v[t], tn.mean[t], tn.rstd[t], [self.tf_h.g[t]],
                                        self.tf_pre.g[t], tn.dgamma, tn.dbeta, act='relu', eps=EPS_IN)
                     self.tf_conv.backward_data(self.tf_pre.g[t], self.h_last.g[t], beta=1)
+            if not self.merge_heads:
+                nb_last = None
             # decoder / encoder ladder in reverse
             for L in reversed(self.layers):
                 f = L['f']
@@ -613,13 +644,19 @@ class SAVPGenerator(object):
                                          n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
                                          dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L),
                                          dgates_raw=L.get('dg_raw'))
-                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=(f, L['zr']) if L['zless'] else None)
+                    skip = (f, L['zr']) if L['zless'] else None
+                    nb = self._norm_bwd('nbstats', L, L['rconv'], L['gates'].g[t], a.g[t], nrm, L['pre'].v[t], skip)
+                    if nb is not None:
+                        nb['mean'], nb['rstd'] = nrm.mean[t], nrm.rstd[t]
+                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=skip, norm_bwd=nb)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
-                                       [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                                       [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN,
+                                       stats=nb['ws'] if nb is not None else None)
                 else:
                     y0 = self._out_views(L, t)[0]
+                    st_ = nb_last['ws'] if (L is self.layers[-1] and nb_last is not None and len(dys) == 1) else None
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, y0, nrm.mean[t], nrm.rstd[t], dys, L['pre'].g[t],
-                                       nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                                       nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN, stats=st_)
                 L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0)
             # d image -> previous step's generated frame where it was fed back (not ground truth)
             if t > 0:
