@@ -331,7 +331,7 @@ def main():
             cell_flops += fl
             cell_bytes += wbytes + abytes
             cell_n += 1
-        g_us = gate_timers[id(L)].durations_us() if L.get('gate_ktimer') is not None else []
+        g_us = gate_timers[id(L)].durations_us()
         c_us = conv_us_of.get(id(L['rconv']), [])
         if g_us and len(g_us) == len(c_us):
             ck_s += (sum(g_us) + sum(c_us)) * 1e-6

@@ -141,11 +141,14 @@ int savp_conv(void* stream, const SavpConvArgs* args);
  *                      step and layer).
  *   savp_tiled_z_grad: dy [nimg][H][W][C] contiguous (bf16 if dy_bf16, else fp32; 16-byte aligned), one launch for the gate
  *                      gradients of all timesteps; dz [nimg][nz] fp32 is overwritten (beta 0) or accumulated into (beta 1).
- *                      H >= 4, W in {4, 8, 16, 32}, C % 64 == 0; SAVP_EINVAL otherwise.  Deterministic (fixed-order reductions). */
+ *                      H >= 4, W in {4, 8, 16, 32}, C % 64 == 0; SAVP_EINVAL otherwise.  Two launches (per-chunk partials into ws, then
+ *                      their sum in chunk order).  Deterministic (fixed-order reductions). */
 int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t Cin, int32_t Cout,
                       int32_t z0, int32_t nz, float* weff);
 int savp_tiled_z_grad(void* stream, const void* dy, int32_t dy_bf16, int64_t nimg, int32_t H, int32_t W, int32_t C,
-                      const float* weff, int32_t nz, float* dz, int32_t beta);
+                      const float* weff, int32_t nz, float* dz, int32_t beta, void* ws, int64_t ws_bytes);
+/* bytes of the caller-owned scratch `ws` of savp_tiled_z_grad (per-(image, 64-channel chunk) partial sums; written before it is read) */
+int64_t savp_tiled_z_workspace_bytes(int64_t nimg, int32_t C);
 /* 1: savp_conv would honour args->stats (any non-NULL value) for this problem; 0: it would return SAVP_EINVAL -- the caller then
  * leaves stats NULL and lets the instance norm take its own statistics.  No launch, no device access. */
 int savp_conv_stats_ok(const SavpConvArgs* args);

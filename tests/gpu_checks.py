@@ -1466,6 +1466,7 @@ def check_norm_bwd_stats_epilogue(seed=61):
     (all channels)."""
     out = []
     rng = np.random.default_rng(seed)
+    K.set_conv_precision('bf16')              # conv_stats_ok answers for the datapath in use
     for (name, N, H, k, Cin, Cout, f, gap) in (('gate16', 4, 16, 5, 136, 256, 64, (64, 8)), ('gate32', 2, 32, 5, 72, 128, 32, (32, 8)),
                                               ('head64', 2, 64, 3, 32, 64, 32, None)):
         geom = K.ConvGeom((1, k, k), (1, 1, 1), (0, k // 2, k // 2))
@@ -1495,6 +1496,17 @@ def check_norm_bwd_stats_epilogue(seed=61):
         d = g * mask
         ref = torch.stack([d.sum(dim=(1, 2)), (d * xh).sum(dim=(1, 2))], dim=-1)
         out.append(('nbstats/%s_sums' % name, rel_err(ws, ref), 2e-5))
+        # split-K: both sums are linear in the accumulators, every split adds its share (the 8x8 gate DGRAD needs the splits to fill the chip)
+        ws2 = torch.zeros(N, f, 2, device=DEV)
+        got2 = torch.full((N, H, H, Cin), 123.0, device=DEV)
+        try:
+            K.conv(lib.CONV_DGRAD, geom, got2, dy, wd32, w16=wd16, precision=1, tile=0x311, splitk=2, dst_gap=gap, norm_bwd=dict(nb, ws=ws2))
+            keep = [got2[..., :f]] + ([got2[..., gap[0] + gap[1]:]] if gap else [got2[..., f:]])
+            refk = [plain[..., :f]] + ([plain[..., gap[0] + gap[1]:]] if gap else [plain[..., f:]])
+            out.append(('nbstats/%s_splitk2_dx' % name, rel_err(torch.cat(keep, -1), torch.cat(refk, -1).double().cpu()), 1e-5))
+            out.append(('nbstats/%s_splitk2_sums' % name, rel_err(ws2, ref), 2e-5))
+        except RuntimeError as ex:
+            out.append(('nbstats/%s_splitk2_refused_%s' % (name, str(ex)[-40:]), 1.0, 0.5))
         res = []
         for st in (None, ws):
             dx = torch.empty(N, H, H, f, device=DEV)
@@ -1503,5 +1515,6 @@ def check_norm_bwd_stats_epilogue(seed=61):
             res.append((dx, dg, db))
         for nm, a_, b_ in zip(('dx', 'dgamma', 'dbeta'), res[1], res[0]):
             out.append(('nbstats/%s_%s' % (name, nm), rel_err(a_, b_.double().cpu()), 2e-5))
+    K.set_conv_precision('f32')
     torch.cuda.synchronize()
     return out

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     // for halo pixels, channels beyond Cred, images beyond N and the pad slots.  No VGPR round trip, no conversion, no ds_write (the
     // VGPR path above is instruction-bound: 12-22 k cycles of a 62-105 k cycle gate convolution).  The DMAs are drained (vmcnt 0)
     // before the barrier that publishes the patch, so the weight ring's counted waits never see them.
-    auto stage_patch_dma = [&](int cfirst) {
+    auto stage_patch_dma = [&](int cfirst, auto drainc) {
         const int C8 = CP >> 3, P8 = pitch >> 3;
         const int used8 = (spp * CKB) >> 3;                   // chunks of a pixel that are read (the last one of CP is pitch padding)
         const int per_img8 = PH * P8;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 ring_dma16(g, patch_lds + (unsigned)(base * 16));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (decltype(drainc)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     f32x16 acc[WM][WN];
@@ -404,31 +404,53 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         if (!first_group) __syncthreads();
         first_group = false;
         RT(10);
-        for (int e = tid; e < len; e += NT) {              // entry table of this group
-            const int ent = t_begin + e;
+        auto entry_of = [&](int ent) {                     // (tap, slab) entry -> {weight byte offset | last-slab flag, patch byte offset}
             const int tap = divq(ent, g_slabs, g_slabs == spp ? p.s1_magSpp : p.s1_magTail), sl = ent - tap * g_slabs;
             const int jh = divq(tap, kw, p.s1_magKw), jw = tap - jh * kw;
             const int f_tap = ((gd.t0 + g_jd * gd.tstep) * p.kh + (gh.t0 + jh * gh.tstep)) * p.kw + (gw.t0 + jw * gw.tstep);
             const int f_cc = g_first + sl;
             const int pu = gh.jstep > 0 ? jh * gh.jstep : (kh - 1 - jh) * -gh.jstep;
             const int pv = gw.jstep > 0 ? jw * gw.jstep : (kw - 1 - jw) * -gw.jstep;
-            etab[e] = make_uint2((unsigned)((f_tap * Cred + f_cc * CKB) * 2) | (f_cc == nch - 1 ? 0x80000000u : 0u),
-                                 (unsigned)((pu * pitch + pv * CP + sl * CKB) * 2));
-        }
+            return make_uint2((unsigned)((f_tap * Cred + f_cc * CKB) * 2) | (f_cc == nch - 1 ? 0x80000000u : 0u),
+                              (unsigned)((pu * pitch + pv * CP + sl * CKB) * 2));
+        };
+        for (int e = tid; e < len; e += NT) etab[e] = entry_of(t_begin + e);      // entry table of this group
         RT(1);
-        if (p.dma_patch) stage_patch_dma(g_first);
-        else if (p.src16) stage_patch(g_first, std::true_type{});
-        else stage_patch(g_first, std::false_type{});
-        __syncthreads();                                   // table + patch visible
-        RT(2);
-        issue(etab[0], B0{});
-        if (len > 1) issue(etab[1], B1{});
-        if (len > 2) issue(etab[2], B2{});
-        // slab 0 of every wave has landed (up to two more stay in flight)
-        if (len > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LW) : "memory");
-        else if (len > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+#ifdef SAVP_RING_NO_SLAB_OVERLAP
+        constexpr bool SLAB_OVERLAP = false;               // developer A/B build: the old order
+#else
+        constexpr bool SLAB_OVERLAP = true;
+#endif
+        if (SLAB_OVERLAP && p.dma_patch) {
+            // DMA-staged patch: the first three weight slabs are requested right behind the patch's DMAs (their table entries worked out
+            // here in scalar registers -- the LDS table is not published yet), so the slabs' L2 round trip overlaps the patch's instead of
+            // starting after it (the old order: patch DMAs, vmcnt(0), barrier, slab DMAs, wait, barrier)
+            stage_patch_dma(g_first, std::false_type{});
+            const int wl = wave * 0;                         // (wave-uniform zero: keeps the entries in SGPRs)
+            issue(entry_of(t_begin + wl), B0{});
+            if (len > 1) issue(entry_of(t_begin + 1 + wl), B1{});
+            if (len > 2) issue(entry_of(t_begin + 2 + wl), B2{});
+            // everything but the two (one, no) youngest slabs has landed: the patch and slab 0
+            if (len > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * LW) : "memory");
+            else if (len > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(LW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // table, patch and slab 0 visible
+            RT(2);
+        } else {
+            if (p.dma_patch) stage_patch_dma(g_first, std::true_type{});
+            else if (p.src16) stage_patch(g_first, std::true_type{});
+            else stage_patch(g_first, std::false_type{});
+            __syncthreads();                                   // table + patch visible
+            RT(2);
+            issue(etab[0], B0{});
+            if (len > 1) issue(etab[1], B1{});
+            if (len > 2) issue(etab[2], B2{});
+            // slab 0 of every wave has landed (up to two more stay in flight)
+            if (len > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LW) : "memory");
+            else if (len > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         load_a(F0, etab[0]);
         load_b(F0, B0{});
         // step e (cur holds the fragments of entry e): wait for slab e+1, barrier, DMA slab e+3 into the buffer slab e-1 just left,
@@ -443,18 +465,14 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // tq2 = entry e+3: its slab DMA is issued in step e): the one table read of a step (entry e+4) is issued behind the barrier
         // and consumed a whole step later, so neither the DMA address nor the A-fragment address waits for an LDS round trip there.
         //
-        // DMA LAST (round 4): all waves leave the per-entry barrier together, and a wave's slab DMA issue (LW instructions of ~100
-        // cycles each: M0 set-up, address arithmetic, the request itself) used to come before its MFMAs -- the matrix pipe idled while
-        // every wave issued, and a step cost the SUM of the two phases (measured 690 + 640 cycles at 32x32).  The fragments of entry
-        // e are in registers when the barrier opens, so the MFMAs go first and the DMA of slab e+3 is issued behind them, in their
-        // shadow.  Ring safety is unchanged: slab e+3 overwrites the buffer slab e-1 left before barrier e either way, and the
-        // counted waits see the same number of outstanding DMAs per wave at every barrier.  Measured in the step on MI355X (one
-        // call, runtime switch, twice): DMA first 56.84 / 56.77 ms, waves 4-7 last 56.46 / 56.47, every wave last 55.95 / 55.85;
-        // gate conv FPROP 32.2 -> 28.9 us on that box.  -DSAVP_RING_EARLY_DMA restores the old order for A/B builds.
-#ifdef SAVP_RING_EARLY_DMA
-        constexpr bool LATE = false;
-#else
+        // Where the slab DMA of a step is issued (round 4, measured in the step on MI355X with three builds side by side in one call,
+        // twice each): right behind the barrier, before the entry's MFMAs (this order) 53.38 / 53.52 ms; between the two halves of the
+        // MFMAs (-DSAVP_RING_DMA_MID) 54.26 / 54.36; behind the MFMAs (-DSAVP_RING_LATE_DMA) 54.01 / 54.01.  A slab requested late
+        // lands late: the three-slab look-ahead is worth more than the MFMA issue slots the request sequence occupies.
+#ifdef SAVP_RING_LATE_DMA
         constexpr bool LATE = true;
+#else
+        constexpr bool LATE = false;
 #endif
         // (the table entries are wave-uniform: kept in scalar registers)
         auto sld = [&](int i) { const uint2 t = etab[i]; return make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)t.x), (unsigned)__builtin_amdgcn_readfirstlane((int)t.y)); };
@@ -848,7 +866,8 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         // norm-backward statistics: whole tiles (every accumulator is a real output of one image), unit strides (destination pixel (y, x)
         // is pixel y * Wm + x of nb_x), depth 1, no split-K, nothing after the accumulators, an fp32 destination
         const long long nimg = (long long)a->N * Dm;
-        if (cell || a->stats || a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || phases != 1 || Dm != 1 || (a->splitk > 1) ||
+        // (split-K is fine: both sums are linear in the accumulators -- the mask depends on x only -- so every split adds its share)
+        if (cell || a->stats || a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || phases != 1 || Dm != 1 ||
             a->sh != 1 || a->sw != 1 || a->nb_c0 + a->nb_nc > Nout || (size_t)ni * BN * 2 * 4 > lds)
             return false;
     }
@@ -869,7 +888,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     const long long tiles = (long long)p.tm * p.tn;
     const long long iters = (long long)(dg ? (a->kh / a->sh) * (a->kw / a->sw) : a->kh * a->kw) * nch * a->kd;
     int splitk = a->splitk;
-    if (a->act != SAVP_ACT_NONE || cell || a->stats || a->nb_ws) splitk = 1;
+    if (a->act != SAVP_ACT_NONE || cell || a->stats) splitk = 1;
     else if (splitk <= 0) {
         splitk = 1;
         if (tiles <= 192 && iters >= 16) {
@@ -882,8 +901,10 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     if (splitk > iters) splitk = (int)iters;
     if (splitk > 1 && !a->beta) {
         const long long dD = Dm;
-        const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (dD == 1 || d_sd == dH * dW_ * Nout) &&
-                           (d_sn == dD * dH * dW_ * Nout);
+        // one dense block (cleared with a single memset; a column gap's channels are cleared with it: nobody reads them)
+        const long long Cd = Nout + p.gap;
+        const bool dense = (d_sw == Cd) && (d_sh == dW_ * Cd) && (dD == 1 || d_sd == dH * dW_ * Cd) &&
+                           (d_sn == dD * dH * dW_ * Cd);
         if (!dense) splitk = 1;
     }
     p.splitk = splitk;
@@ -935,7 +956,7 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
     if (p.splitk > 1 && !a->beta) {
         const int Dm = dg ? a->D : a->Do;
         const long long dW_ = dg ? a->W : a->Wo;
-        hipMemsetAsync(p.out, 0, (size_t)a->N * Dm * dH * dW_ * Nout * sizeof(float), st);
+        hipMemsetAsync(p.out, 0, (size_t)a->N * Dm * dH * dW_ * (Nout + p.gap) * sizeof(float), st);
     }
     ablate_init();
     hipError_t err = (pl.nw == 8) ? launch_ring_tile<8>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st)

@@ -14,7 +14,8 @@
 // resident ([T-1, N, H, W, 4F], the batched weight gradient reads them anyway), and dz is only needed after BPTT (z is an input of
 // the unroll, not a recurrent state), so ONE launch per layer walks the whole history: a workgroup owns an image, streams its
 // plane once (full 16-byte pieces on consecutive lanes), keeps 5 row-class sums per lane, folds them into the 25 x 64 region sums
-// of a 64-channel chunk in LDS and multiplies those with Weff on the spot.  Every reduction is a fixed-order tree: deterministic.
+// of its 64-channel chunk in LDS and multiplies those with Weff on the spot (one workgroup per image and chunk; a second, tiny launch
+// adds the chunks' partial dz in chunk order).  Every reduction is a fixed-order tree: deterministic.
 // The per-timestep DGRAD then leaves the z channels out (SavpConvArgs.dst_gap).  HBM-bound: reads H*W*4F*2 B per image once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -69,9 +70,11 @@ extern "C" int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32
 
 // One workgroup (256 threads = 32 pixel slots x 8 lanes of 8 channels) per image.  W divides 32, so a thread's column (and its
 // column class) is fixed: it keeps one sum per ROW class (5 x 8 channels).
+// (grid.y = the 64-channel chunk: C / 64 times the workgroups of an image-only grid, every one with a quarter to an eighth of the
+// serial walk -- 113 -> measured below; the chunk partials are folded in chunk order by tiled_z_reduce_kernel: deterministic)
 template <bool BF16>
 __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restrict__ dy_, int H, int W, int C, const float* __restrict__ weff,
-                                                           int nz, float* __restrict__ dz, int beta) {
+                                                           int nz, float* __restrict__ part_out) {
     __shared__ float part[32][5][64];          // per pixel slot: row-class sums of the chunk's 64 channels
     __shared__ float red[4][TZ_NZ];
     const long long img = blockIdx.x;
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restric
     float dzp[TZ_NZ];
 #pragma unroll
     for (int c = 0; c < TZ_NZ; ++c) dzp[c] = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 64) {
+    {
+        const int c0 = blockIdx.y * 64;
         float acc[5][8];
 #pragma unroll
         for (int a = 0; a < 5; ++a)
@@ -156,23 +160,37 @@ __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restric
         if ((tid & 63) == 0) red[tid >> 6][c] = v;
     }
     __syncthreads();
-    if (tid < nz) {
-        const float s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        float* d = dz + img * nz + tid;
-        *d = beta ? *d + s : s;
-    }
+    if (tid < TZ_NZ) part_out[(img * gridDim.y + blockIdx.y) * TZ_NZ + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
+__global__ void tiled_z_reduce_kernel(const float* __restrict__ part, long long nimg, int nchunk, int nz, float* __restrict__ dz, int beta) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= nimg * nz) return;
+    const long long img = i / nz;
+    const int c = (int)(i - img * nz);
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[(img * nchunk + k) * TZ_NZ + c];
+    dz[i] = beta ? dz[i] + s : s;
+}
+
+extern "C" int64_t savp_tiled_z_workspace_bytes(int64_t nimg, int32_t C) { return nimg * (int64_t)((C + 63) / 64) * TZ_NZ * 4; }
+
 extern "C" int savp_tiled_z_grad(void* stream, const void* dy, int32_t dy_bf16, int64_t nimg, int32_t H, int32_t W, int32_t C,
-                                 const float* weff, int32_t nz, float* dz, int32_t beta) {
+                                 const float* weff, int32_t nz, float* dz, int32_t beta, void* ws, int64_t ws_bytes) {
     if (!dy || !weff || !dz || nimg < 0 || nz < 1 || nz > TZ_NZ) return SAVP_EINVAL;
+    if (!ws || ws_bytes < savp_tiled_z_workspace_bytes(nimg, C)) return SAVP_EINVAL;
     // W a power of two dividing 32 (a thread's column is fixed), >= 4 rows and columns (disjoint classes), whole 64-channel chunks
     if (H < 4 || W < 4 || W > 32 || (W & (W - 1)) || (C % 64) || nimg >= (1ll << 31)) return SAVP_EINVAL;
     if ((((uintptr_t)dy) & 15) || (((uintptr_t)weff) & 15)) return SAVP_EINVAL;
     if (nimg == 0) return SAVP_OK;
+    const int nchunk = C / 64;
+    if (nchunk > 65535) return SAVP_EINVAL;
+    const dim3 grid((unsigned)nimg, (unsigned)nchunk);
     if (dy_bf16)
-        hipLaunchKernelGGL(tiled_z_grad_kernel<true>, dim3((unsigned)nimg), dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, dz, beta);
+        hipLaunchKernelGGL(tiled_z_grad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, (float*)ws);
     else
-        hipLaunchKernelGGL(tiled_z_grad_kernel<false>, dim3((unsigned)nimg), dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, dz, beta);
+        hipLaunchKernelGGL(tiled_z_grad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, (float*)ws);
+    hipLaunchKernelGGL(tiled_z_reduce_kernel, dim3((unsigned)((nimg * nz + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (long long)nimg,
+                       nchunk, nz, dz, beta);
     return LAUNCH_OK();
 }

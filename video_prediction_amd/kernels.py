@@ -175,7 +175,7 @@ def _tune(a, mode, dst, w, return_all=False):
         # 0x1xx = generic gather kernel, 0x2xx = LDS patch kernel (rejected with EINVAL where it does not apply)
         # (0x6xx = patch kernel with 8 waves per workgroup; 0x1000 / 0x2000 = its LDS budget capped at 64 / 96 KB)
         # 0x3xx / 0x7xx = LDS-DMA ring kernel with 4 / 8 waves (the only one for bf16 activations / the cell epilogue)
-        algs = (0x300, 0x700) if (a.src_bf16 or a.out_bf16 or a.stats) else (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600, 0x300, 0x700)
+        algs = (0x300, 0x700) if (a.src_bf16 or a.out_bf16 or a.stats or a.nb_ws or a.dst_gap) else (0x100, 0x200, 0x600, 0x1200, 0x1600, 0x2200, 0x2600, 0x300, 0x700)
         if a.out_bf16 or a.stats:
             splits = (1,)
         cands = [(alg | t, sk) for alg in algs for t in tiles for sk in splits]
@@ -185,6 +185,10 @@ def _tune(a, mode, dst, w, return_all=False):
         if a.stats:                      # tuning runs must not accumulate into the real statistics
             stats_scratch = torch.zeros(a.N * (a.Cx if mode == lib.CONV_DGRAD else a.Cy) * 2, device=dst.device)
             a.stats = stats_scratch.data_ptr()
+        real_nb = a.nb_ws
+        if a.nb_ws:                      # ... nor into the real norm-backward sums
+            nb_scratch = torch.zeros(a.N * a.nb_nc * 2, device=dst.device)
+            a.nb_ws = nb_scratch.data_ptr()
         if a.beta:                       # never accumulate tuning runs into the real destination
             scratch = torch.empty_like(dst)
             if scratch.stride() != dst.stride():
@@ -217,6 +221,7 @@ def _tune(a, mode, dst, w, return_all=False):
     else:
         a.beta = real_beta
         a.stats = real_stats
+        a.nb_ws = real_nb
         if mode == lib.CONV_DGRAD:
             a.x = real_dst
         else:
@@ -580,8 +585,10 @@ def tiled_z_grad(dy, weff, dz, beta=1):
     if not dy.is_contiguous() or not dz.is_contiguous() or dy.dim() != 4:
         raise ValueError('tiled_z_grad: contiguous dy [IMG, H, W, C] and dz [IMG, nz] expected')
     img, H, W, C = dy.shape
+    need = lib.get().savp_tiled_z_workspace_bytes(img, C)
+    ws = scratch(dy.device, (need + 3) // 4)
     lib.check(lib.get().savp_tiled_z_grad(lib.stream(), dy.data_ptr(), int(dy.dtype == torch.bfloat16), img, H, W, C, weff.data_ptr(),
-                                          dz.shape[-1], dz.data_ptr(), int(beta)), 'savp_tiled_z_grad')
+                                          dz.shape[-1], dz.data_ptr(), int(beta), ws.data_ptr(), ws.numel() * 4), 'savp_tiled_z_grad')
 
 
 def tiled_z_ok(H, W, C, nz, geom):

@@ -108,7 +108,8 @@ def _declare(lib):
     _sig(lib, 'savp_get_option', [ctypes.c_char_p, P(c_i32)])
     _sig(lib, 'savp_allreduce_bucket', [c_vp, c_vp, c_vp, c_i64])
     _sig(lib, 'savp_tiled_z_weff', [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp])
-    _sig(lib, 'savp_tiled_z_grad', [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32])
+    _sig(lib, 'savp_tiled_z_grad', [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64])
+    _sig(lib, 'savp_tiled_z_workspace_bytes', [c_i64, c_i32], restype=c_i64)
     for name, argtypes in _EXTRA_SIGS.items():
         _sig(lib, name, argtypes)
 
