@@ -111,7 +111,8 @@ typedef struct SavpConvArgs {
     int32_t dst_gap_at, dst_gap;   /* FPROP / DGRAD, SAVP_PREC_BF16 (ring kernel; SAVP_EINVAL elsewhere): the destination channel count
                                       (Cy for FPROP, Cx for DGRAD) counts LOGICAL channels; logical channel c >= dst_gap_at is physical
                                       channel c + dst_gap of the destination tensor, of the bias and of the packed weights (whose row
-                                      count is the logical count + dst_gap).  dst_gap == 0: off.  This is the ConvLSTM gate convolution's
+                                      count is the logical count + dst_gap); the gap's channels are not computed (they keep their contents, or are cleared
+                                      with the rest of the block when the launch splits K).  dst_gap == 0: off.  This is the ConvLSTM gate convolution's
                                       data gradient without the tiled-z channels of its input [x | z | h] (rnn_ops.py:144-146,
                                       savp_model.py:436-444): their gradient is a per-sample sum (savp_tiled_z_grad) and leaving them
                                       out keeps the column count on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256) */
