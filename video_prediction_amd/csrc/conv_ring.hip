@@ -416,27 +416,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         };
         for (int e = tid; e < len; e += NT) etab[e] = entry_of(t_begin + e);      // entry table of this group
         RT(1);
-#ifdef SAVP_RING_NO_SLAB_OVERLAP
-        constexpr bool SLAB_OVERLAP = false;               // developer A/B build: the old order
-#else
-        constexpr bool SLAB_OVERLAP = true;
-#endif
-        if (SLAB_OVERLAP && p.dma_patch) {
-            // DMA-staged patch: the first three weight slabs are requested right behind the patch's DMAs (their table entries worked out
-            // here in scalar registers -- the LDS table is not published yet), so the slabs' L2 round trip overlaps the patch's instead of
-            // starting after it (the old order: patch DMAs, vmcnt(0), barrier, slab DMAs, wait, barrier)
-            stage_patch_dma(g_first, std::false_type{});
-            const int wl = wave * 0;                         // (wave-uniform zero: keeps the entries in SGPRs)
-            issue(entry_of(t_begin + wl), B0{});
-            if (len > 1) issue(entry_of(t_begin + 1 + wl), B1{});
-            if (len > 2) issue(entry_of(t_begin + 2 + wl), B2{});
-            // everything but the two (one, no) youngest slabs has landed: the patch and slab 0
-            if (len > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * LW) : "memory");
-            else if (len > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(LW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // table, patch and slab 0 visible
-            RT(2);
-        } else {
+        // (Requesting the first three weight slabs right behind the DMA-staged patch's requests -- their L2 round trips overlapped instead
+        // of back to back -- was built and measured in the step: 54.57 / 54.37 ms against 53.93 / 53.91 for this order, two builds of the
+        // same source in one call.  The slab requests queue behind ~40 patch requests per workgroup either way; issued early they only
+        // delay the patch, which everything waits for.  Removed.)
+        {
             if (p.dma_patch) stage_patch_dma(g_first, std::true_type{});
             else if (p.src16) stage_patch(g_first, std::true_type{});
             else stage_patch(g_first, std::false_type{});
