@@ -85,7 +85,8 @@ typedef struct SavpConvArgs {
     int32_t tile;                  /* 0 = auto; low byte (WM<<4)|WN with tile = 64*WM x 64*WN; bits 8-9 pick the FPROP/DGRAD
                                       algorithm: 0 auto, 1 generic gather kernel, 2 LDS patch kernel, 3 LDS-DMA ring kernel (EINVAL if
                                       not applicable); bit 10: patch / ring kernel with 8 waves; bits 12-13: LDS budget of the patch
-                                      kernel (0 = 160 KB, 1 = 64 KB, 2 = 96 KB) */
+                                      kernel (0 = 160 KB, 1 = 64 KB, 2 = 96 KB); ring kernel: bit 12 = wide weight slabs (8 / 9 k-steps per
+                                      entry, tile 0x11 only) */
     int32_t precision;             /* SAVP_PREC_F32: exact fp32 MFMA; SAVP_PREC_BF16: operands rounded to bf16 in LDS */
     void* x; int64_t x_sn, x_sd, x_sh, x_sw;
     void* y; int64_t y_sn, y_sd, y_sh, y_sw;

@@ -948,6 +948,16 @@ def check_conv_cell(seed=21):
             ws.zero_()
             K.conv(lib.CONV_FPROP, geom, xd, yd, wt, precision=1, w16=wt.to(torch.bfloat16), stats=s1)
             out.append((t2 + '/gates_bf16', rel_err(yd.float(), gates), 1e-2))
+            if Cx > 96:        # wide weight slabs (tile bit 0x1000: 8 / 9 k-steps per entry): same sums in another slab order
+                for wide in (0x1311, 0x1711):
+                    yw = torch.empty_like(yd)
+                    sw = torch.zeros_like(s1)
+                    try:
+                        K.conv(lib.CONV_FPROP, geom, xd, yw, wt, precision=1, w16=wt.to(torch.bfloat16), stats=sw, tile=wide)
+                    except RuntimeError:
+                        continue                       # this workgroup size cannot hold the wider ring (LDS)
+                    out.append((t2 + '/wide%x_gates_bf16' % wide, rel_err(yw.float(), gates), 1e-2))
+                    out.append((t2 + '/wide%x_stats_sum' % wide, rel_err(sw[..., 0], torch.stack([gates.sum(dim=(1, 2))], dim=-1)[..., 0]), 1e-2))
             ref_s = torch.stack([gates.sum(dim=(1, 2)), (gates ** 2).sum(dim=(1, 2))], dim=-1)         # [N, 4F, 2]
             out.append((t2 + '/stats_sum', rel_err(s1[..., 0], ref_s[..., 0]), 1e-2))
             out.append((t2 + '/stats_sumsq', rel_err(s1[..., 1], ref_s[..., 1]), 1e-2))
@@ -1434,7 +1444,7 @@ def check_tiled_z_and_gapped_dgrad(seed=53):
         full = torch.zeros(N, H, H, Cin, device=DEV)
         K.conv(lib.CONV_DGRAD, geom, full, dy, wd32, w16=wd16, precision=1)
         took = 0
-        for tile in (0, 0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721, 0x722):
+        for tile in (0, 0x311, 0x312, 0x321, 0x322, 0x711, 0x712, 0x721, 0x722, 0x1311, 0x1711):
             got = torch.full((N, H, H, Cin), 123.0, device=DEV)
             try:
                 K.conv(lib.CONV_DGRAD, geom, got, dy, wd32, w16=wd16, precision=1, tile=tile, dst_gap=(f, nz))

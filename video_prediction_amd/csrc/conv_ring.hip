@@ -775,6 +775,10 @@ static hipError_t launch_ring_tile(const ConvP& p, int wm, int wn, int nks, dim3
     if (wm == 2 && wn == 2) return launch_ring_nks<NW, 2, 2>(p, nks, grid, lds, st);
     if (wm == 2 && wn == 1) return launch_ring_nks<NW, 2, 1>(p, nks, grid, lds, st);
     if (wm == 1 && wn == 2) return launch_ring_nks<NW, 1, 2>(p, nks, grid, lds, st);
+    // wide slabs (tile bit 0x1000): 8 / 9 k-steps per entry, instantiated for the 32 x 32 wave tile only (two fragment sets of a wider
+    // wave tile would not fit 256 VGPRs)
+    if (nks == 8) return launch_ring<NW, 1, 1, 8>(p, grid, lds, st);
+    if (nks == 9) return launch_ring<NW, 1, 1, 9>(p, grid, lds, st);
     return launch_ring_nks<NW, 1, 1>(p, nks, grid, lds, st);
 }
 
@@ -793,15 +797,20 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     const int tW = (Wm + 7) / 8;
     // channel slabs: with the DMA ring a slab costs (k-steps + ~0.5), so exact fits beat fewer, wider slabs
     const int Cp16 = (Cred + 15) & ~15;
+    // Wide slabs (tile bit 0x1000, 32 x 32 wave tile): up to 9 k-steps per (tap, slab) entry -- 144 channels are ONE slab (25 entries
+    // instead of 75 for the 16x16 gate convolution), 256 / 512 channels split 2 x 8 / 4 x 8 without padding.  The per-entry costs that
+    // do not scale with the slab (barrier, table, address arithmetic) are paid a third as often; the ring needs more LDS per slot.
+    const int kmax = ((a->tile & 0x1000) && wm == 1 && wn == 1) ? 9 : 6;
     int nch = 0, nks = 0;
     double best = 1e30;
-    for (int c = (Cp16 + 95) / 96; c <= (Cp16 + 95) / 96 + 3; ++c) {
+    for (int c = (Cp16 + 16 * kmax - 1) / (16 * kmax); c <= (Cp16 + 95) / 96 + 3; ++c) {
         const int k = (Cp16 / 16 + c - 1) / c;
-        if (k < 1 || k > 6) continue;
+        if (k < 1 || k > kmax || k == 7) continue;
         const double cost = c * (k + 0.5);
         if (cost < best) { best = cost; nch = c; nks = k; }
     }
     if (!nch) return false;
+    if ((a->tile & 0x1000) && nks <= 6) return false;          // nothing wide to offer: let the tuner's plain candidate stand for it
     const int TH = 2 * nw * wm;
     int tih = 4;
     while (tih < TH && tih < Hm) tih *= 2;

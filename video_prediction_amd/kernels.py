@@ -179,6 +179,8 @@ def _tune(a, mode, dst, w, return_all=False):
         if a.out_bf16 or a.stats:
             splits = (1,)
         cands = [(alg | t, sk) for alg in algs for t in tiles for sk in splits]
+        # ring kernel with wide slabs (8 / 9 k-steps per entry; 32 x 32 wave tile only; refused where the channel count offers none)
+        cands += [(alg | 0x1000 | 0x11, sk) for alg in algs if (alg & 0x300) == 0x300 for sk in splits]
         real_dst, real_beta = (a.x if mode == lib.CONV_DGRAD else a.y), a.beta
         scratch = None
         real_stats = a.stats
