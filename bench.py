@@ -400,6 +400,18 @@ def main():
                                   'algorithmic_bytes_per_cell': (cell_bytes / cell_n) if cell_n else None}},
         'losses': {'d_loss': float(info['d_loss']), 'g_loss': float(info['g_loss'])},
     }
+    # kernel time by family: not measurable from inside the run; quoted from the committed rocprofv3 kernel stats of the SAME kernel
+    # sources + tuning tables (tests/tools/kernel_families.py stamps the source id), else left out
+    if args.config == 'c2' and args.batch == 16:
+        fam_path = os.path.join(ROOT, 'profiles', 'r04_kernel_families.json')
+        try:
+            fam = json.load(open(fam_path))
+            if fam.get('source_id') == src_id:
+                result['kernel_families_ms'] = {'source': 'profiles/r04_kernel_families.json (rocprofv3 --kernel-trace --stats, 6 eager steps, same source id)',
+                                                'launches_per_step': fam['launches_per_step'], 'kernel_ms_per_step': fam['kernel_ms_per_step'],
+                                                'families': {k: v['ms_per_step'] for k, v in fam['families'].items()}}
+        except Exception:
+            pass
     # whole step against the conv roofline (algorithmic FLOPs per sequence and train step, fwd + data-grad + weight-grad)
     step_tflop = {'c2': 0.684, 'c4': 1.004, 'c5': 4.81}.get(args.config)
     if step_tflop:

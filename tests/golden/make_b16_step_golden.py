@@ -1,4 +1,5 @@
-"""tests/golden/b16_step_golden.npz: ONE train step of the CPU oracle at exactly the benchmarked problem (BASELINE.json configs[1]:
+"""tests/golden/c2_step_golden.npz (CONFIG=c2; round 3's b16_step_golden.npz without projections is what a run without CONFIG writes):
+ONE train step of the CPU oracle at exactly the benchmarked problem (BASELINE.json configs[1]:
 B=16, T=30, 64x64x3, nz=8, clip_length=10, recipe loss weights), reduced to what a parity test needs -- every loss term, sampled
 generated pixels, and per variable the gradient's L2 norm + a seeded sample of its elements (the full gradients are 70 MB).
 The GPU test (tests/test_gpu_model.py::test_bench_problem_b16_t30_bf16_step_vs_oracle_golden) re-creates the inputs from the same

@@ -196,8 +196,20 @@ def test_hipgraph_replay_matches_eager_steps(monkeypatch):
     le, _, ge = _run_steps(monkeypatch, False, 4)
     lg, _, gg = _run_steps(monkeypatch, True, 4)
     assert gg and not ge
-    for (d0, g0), (d1, g1) in zip(le, lg):
-        assert abs(d0 - d1) <= 5e-2 * max(1.0, abs(d0)) and abs(g0 - g1) <= 5e-2 * max(1.0, abs(g0)), (le, lg)
+    # gate (round 4): the FIRST step sees identical variables and noise, so replay and eager differ by fp32 summation order only
+    # (atomically accumulated statistics): 1e-3 of max(1, |loss|); the later steps carry that noise through Adam's sign-like first
+    # updates at lr = 1e-3 and the GAN terms: 5e-2 as before.  The measured spread is written next to the other evidence so that the
+    # gate can follow the measurement (profiles/r04_graph_vs_eager_spread.json).
+    spread = [max(abs(d0 - d1) / max(1.0, abs(d0)), abs(g0 - g1) / max(1.0, abs(g0))) for (d0, g0), (d1, g1) in zip(le, lg)]
+    out_dir = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, 'r04_graph_vs_eager_spread.json'), 'w') as f:
+            json.dump({'what': 'max over (d_loss, g_loss) of |replay - eager| / max(1, |eager|) per step, fp32 datapath, B=2, T=12, lr=1e-3',
+                       'per_step': spread, 'eager': le, 'replay': lg}, f, indent=1)
+    assert spread[0] <= 1e-3, (spread, le, lg)
+    for sp in spread[1:]:
+        assert sp <= 5e-2, (spread, le, lg)
     # scalars: rebuild the engine in graph mode and watch d_scal
     from tests.gpu_model_checks import make_hparams
     from video_prediction_amd.models.savp_model import SAVPEngine
@@ -409,12 +421,13 @@ def _golden_step_check(fname, case):
 def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
     """EXACTLY the benchmarked problem (BASELINE.json configs[1]: B=16, T=30, 64x64x3, nz=8, clip_length=10, recipe weights) on the
     bf16 datapath with the shipped tuning table, i.e. the (problem, tile, split-K) instantiations bench.py launches, against one
-    step of the CPU oracle committed as tests/golden/b16_step_golden.npz (tests/golden/make_b16_step_golden.py; inputs re-created
+    step of the CPU oracle committed as tests/golden/c2_step_golden.npz (CONFIG=c2 tests/golden/make_b16_step_golden.py; inputs re-created
     here from the same seeds).  Tolerances: losses within 2e-2 (6e-2 per term) of max(|ref|, 0.05), sampled frames within 5e-2,
     per-variable gradient (a seeded sample of <= 4096 elements) within GRAD_REL_L2 relative L2 unless its absolute error is below
     2e-3 of the group's largest gradient; the assertion names the worst variable."""
     from tests import gpu_model_checks as G
-    _golden_step_check('b16_step_golden.npz', G.BENCH_CASES['c2'])
+    checked, projected, worst = _golden_step_check('c2_step_golden.npz', G.BENCH_CASES['c2'])
+    assert projected >= 40        # round 4: the golden also carries whole-tensor projections of every gradient above 4096 elements
 
 
 @pytest.mark.parametrize('config', ['c4', 'c5'])

@@ -12,6 +12,7 @@ cd $R; export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG; mkdir -p $O
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; cut -c1-300 $O/${TAG}_bench.json
 bash tests/tools/prof_step.sh $TAG/$TAG > $O/${TAG}_prof.log 2>&1; tail -1 $O/${TAG}_prof.log
+python tests/tools/kernel_families.py $O/${TAG}_kernel_stats.csv 6 > $O/${TAG}_kernel_families.json
 cd /tmp
 for name in lstm_h0 lstm_h1 lstm_h2; do
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
