@@ -102,7 +102,8 @@ typedef struct SavpConvArgs {
                                       This is the ConvLSTM gate convolution (rnn_ops.py:121): the gate tensor makes its round trip to
                                       the gate kernels in half the bytes */
     float* stats;                  /* FPROP / DGRAD: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
-                                      of every (sample, channel) of the destination (conv + bias, fp32 accumulators, before any rounding)
+                                      of every (sample, channel) of the destination's distance from the bias (y - bias = the fp32 accumulators,
+                                      before any rounding: a large bias does not enter the one-pass variance; SavpInormArgs.stats_shift)
                                       = the statistics of the instance norm that follows (rnn_ops.py:148-149, normalization.py:146-170);
                                       caller zeroes; may be NULL.  bf16 precision only (the ring kernel); an fp32 destination additionally
                                       needs whole tiles (savp_conv_stats_ok() tells), no activation, no beta; SAVP_EINVAL otherwise */
@@ -197,6 +198,8 @@ typedef struct SavpInormArgs {
                                       `stats` epilogue wrote them while it produced x): the statistics pass is skipped -> one launch.
                                       bwd: ws already holds sum(dy'), sum(dy' * xhat) per (sample, channel) (savp_conv's nb_ws epilogue wrote
                                       them while it produced dy): the statistics pass is skipped -> one launch */
+    const float* stats_shift;      /* fwd with stats_ready: per-channel value the producer took its sums around -- savp_conv's `stats` epilogue
+                                      sums the accumulators WITHOUT the bias, so this is that convolution's bias (NULL: sums around 0) */
     int32_t dx_bf16;               /* bwd: dx is a bf16 tensor (strides in bf16 elements, multiples of 4; dx_beta must be 0): the gradient of
                                       a convolution's output, whose only readers are that convolution's DGRAD / WGRAD on the bf16
                                       datapath (they round it to bf16 when they stage it anyway) -- half the bytes, identical numbers */

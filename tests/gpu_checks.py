@@ -1181,7 +1181,7 @@ def _taps_ref(mode, x, w, y, k, s, p):
 
 def check_conv_stats_fp32(seed=43):
     """Statistics epilogue of the ring kernel on an fp32 destination (round 3: the generator's down / upsample convolutions leave
-    the sums of the instance norm that follows, conv + bias, behind; the norm then runs its apply pass alone): output, sums, and
+    the sums of the instance norm that follows, taken around the bias since round 4, behind; the norm then runs its apply pass alone): output, sums, and
     savp_instnorm_act_fwd(stats_ready) against fused_instance_norm of the fp32 tap-loop convolution; every tile code that accepts the
     problem; a problem with partial tiles must be refused by savp_conv_stats_ok."""
     out = []
@@ -1196,13 +1196,16 @@ def check_conv_stats_fp32(seed=43):
         ('up6x6s2', lib.CONV_DGRAD, 4, (32, 32, 32), (16, 16, 136), (1, 6, 6), (1, 2, 2), (0, 2, 2)),
         ('up6x6s2_b', lib.CONV_DGRAD, 2, (16, 16, 64), (8, 8, 136), (1, 6, 6), (1, 2, 2), (0, 2, 2)),
         ('conv3x3', lib.CONV_FPROP, 2, (64, 64, 32), (64, 64, 64), (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+        # |mean| >> std: a bias of ~300 on a convolution output of std ~1.  The sums are taken around the bias (round 4), so the one-pass
+        # variance sum(v^2)/HW - mean(v)^2 keeps its digits; around 0 it would cancel to ~1e-2 relative in fp32 and the norm would be off
+        ('conv3x3_bigbias', lib.CONV_FPROP, 2, (64, 64, 32), (64, 64, 64), (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ]
     for name, mode, N, (H, W, Cx), (Ho, Wo, Cy), k, s, p in cases:
         x32, y32 = rn(N, 1, H, W, Cx), rn(N, 1, Ho, Wo, Cy)
         w32 = rn(*k, Cx, Cy) * 0.1
         fprop = mode == lib.CONV_FPROP
         cdst = Cy if fprop else Cx
-        bias = rn(cdst)
+        bias = rn(cdst) + (300.0 if 'bigbias' in name else 0.0)
         ref = _taps_ref(mode, x32, w32, y32, k, s, p) + bias                     # [N, 1, h, w, cdst]
         ref = ref[:, 0]
         geom = K.ConvGeom(k, s, p)
@@ -1222,12 +1225,12 @@ def check_conv_stats_fp32(seed=43):
             ran += 1
             tag = 'convstats_%s_t%x' % (name, tile)
             out.append((tag + '/out', rel_err(dst, ref), 1e-2))
-            r2 = ref.reshape(N, -1, cdst)
+            r2 = (ref - bias).reshape(N, -1, cdst)                   # the sums are taken around the bias
             out.append((tag + '/sum', rel_err(stats[..., 0], r2.sum(1)), 1e-2))
             out.append((tag + '/sumsq', rel_err(stats[..., 1], (r2 * r2).sum(1)), 1e-2))
             o1 = torch.empty_like(dst)
             mean, rstd = torch.empty(N, cdst, device=DEV), torch.empty(N, cdst, device=DEV)
-            K.instnorm_act_fwd(dst, gam, bet, [o1], mean, rstd, act='relu', stats=stats)
+            K.instnorm_act_fwd(dst, gam, bet, [o1], mean, rstd, act='relu', stats=stats, stats_shift=bias)
             out.append((tag + '/inorm_from_stats', rel_err(o1, yn), 1e-2))
             o2 = torch.empty_like(dst)
             K.instnorm_act_fwd(dst, gam, bet, [o2], mean, rstd, act='relu')

@@ -271,7 +271,12 @@ def check_train_recipe_shapes(B=2, T=30, H=64, W=64, C=3, seed=0):
         for nm, (l, w) in info['g_losses'].items():
             # bf16 datapath: 3 * ltol = 6e-2 of max(|ref|, 0.05) per term -- besides the operand rounding, the ConvLSTM gate
             # pre-activations make their HBM round trip in bf16 (fused cell epilogue), measured 4.7e-2 on the LSGAN generator term
-            out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm]), 2 * ltol if prec == 'f32' else 3 * ltol))
+            # fp32 datapath: 2e-3 relative, or 20 x the distance of the fp32 CPU oracle from the fp64 one on that very term if that is
+            # more (the yardstick of the gradient gates below): the LSGAN generator terms are taken AFTER the discriminator's first Adam
+            # update, which moves a weight by +-lr according to the SIGN of its gradient -- an element whose fp32 gradient has the other
+            # sign than the fp64 one shifts (D(fake) - 1)^2 by more than any rounding (measured on MI355X: 3.6e-3 in one run of several)
+            tol32 = max(2 * ltol, 20.0 * lrel(ref32['g_losses'][nm], ref['g_losses'][nm])) if nm in ref32.get('g_losses', {}) else 2 * ltol
+            out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm]), tol32 if prec == 'f32' else 3 * ltol))
         gen = eng.gen.gen.v
         out.append((t + '/gen_images_enc_abs', float((gen[:, :B].double().cpu() - ref['gen_images_enc']).abs().max()),
                     1e-3 if prec == 'f32' else 5e-2))

@@ -197,8 +197,8 @@ def test_hipgraph_replay_matches_eager_steps(monkeypatch):
     lg, _, gg = _run_steps(monkeypatch, True, 4)
     assert gg and not ge
     # gate (round 4): the FIRST step sees identical variables and noise, so replay and eager differ by fp32 summation order only
-    # (atomically accumulated statistics): 1e-3 of max(1, |loss|); the later steps carry that noise through Adam's sign-like first
-    # updates at lr = 1e-3 and the GAN terms: 5e-2 as before.  The measured spread is written next to the other evidence so that the
+    # (atomically accumulated statistics): 3e-3 of max(1, |loss|); the later steps carry that noise through Adam's sign-like first
+    # updates at lr = 1e-3 and the GAN terms: 1e-2 (round 3: 5e-2 for all four).  The measured spread is written next to the other evidence so that the
     # gate can follow the measurement (profiles/r04_graph_vs_eager_spread.json).
     spread = [max(abs(d0 - d1) / max(1.0, abs(d0)), abs(g0 - g1) / max(1.0, abs(g0))) for (d0, g0), (d1, g1) in zip(le, lg)]
     out_dir = os.path.join(os.path.dirname(HERE), 'gpurun_out')
@@ -207,9 +207,9 @@ def test_hipgraph_replay_matches_eager_steps(monkeypatch):
         with open(os.path.join(out_dir, 'r04_graph_vs_eager_spread.json'), 'w') as f:
             json.dump({'what': 'max over (d_loss, g_loss) of |replay - eager| / max(1, |eager|) per step, fp32 datapath, B=2, T=12, lr=1e-3',
                        'per_step': spread, 'eager': le, 'replay': lg}, f, indent=1)
-    assert spread[0] <= 1e-3, (spread, le, lg)
+    assert spread[0] <= 3e-3, (spread, le, lg)           # measured on MI355X (profiles/r04_graph_vs_eager_spread.json): 8.2e-4
     for sp in spread[1:]:
-        assert sp <= 5e-2, (spread, le, lg)
+        assert sp <= 1e-2, (spread, le, lg)              # measured: 4.3e-4 ... 7.6e-4 (round 3 gated all four steps at 5e-2)
     # scalars: rebuild the engine in graph mode and watch d_scal
     from tests.gpu_model_checks import make_hparams
     from video_prediction_amd.models.savp_model import SAVPEngine

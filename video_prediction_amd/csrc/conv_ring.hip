@@ -618,9 +618,12 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             for (int j = 0; j < WN; ++j) {
                 const int col = col0 + 32 * j;
                 const float bias = (p.bias && col < Nout) ? p.bias[col] : 0.f;
+                // the sums are taken AROUND THE BIAS (of the accumulators alone): sum(y - b), sum((y - b)^2).  One-pass variance
+                // E[v^2] - E[v]^2 cancels when |mean| >> std; a large bias -- the usual reason for a large mean -- no longer enters it
+                // (savp_instnorm_act_fwd(stats_ready, stats_shift = this bias) adds it back to the mean)
                 float sm = 0.f, q = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r] + bias; acc[i][j][r] = v; sm += v; q += v * v; }
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sm += v; q += v * v; acc[i][j][r] = v + bias; }
                 sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
                 if (khalf == 0 && col < Nout) {
                     float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
@@ -929,9 +932,14 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
         return false;
     if (p.gap && (a->out_bf16 || a->stats)) return false;        // the gap lives in the plain epilogue only
     if ((long long)Hm * Wm < 16) return false;
-    static const void* zero16 = nullptr;                         // address of g_ring_zero (resolved once; a constant of the loaded code object)
-    if (!dry && !zero16 && hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16 = nullptr;
-    p.zero16 = zero16;
+    // address of g_ring_zero: a device symbol has one address PER DEVICE, so the cache is indexed by the current device's ordinal (a
+    // process that drives several GPUs -- SAVP_DIST_BACKEND=gloo with differing device indices, library users outside the
+    // one-process-per-GPU runners -- must not hand device 0's pointer to a kernel on device 1)
+    static const void* zero16_of[64] = {nullptr};
+    int dev_ord = 0;
+    if (hipGetDevice(&dev_ord) != hipSuccess || dev_ord < 0 || dev_ord >= 64) dev_ord = 0;
+    if (!dry && !zero16_of[dev_ord] && hipGetSymbolAddress((void**)&zero16_of[dev_ord], HIP_SYMBOL(g_ring_zero)) != hipSuccess) zero16_of[dev_ord] = nullptr;
+    p.zero16 = zero16_of[dev_ord];
     RingPlan pl;
     bool ok = false;
     if (wm) {

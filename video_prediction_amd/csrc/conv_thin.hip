@@ -389,10 +389,12 @@ bool conv_thin_applies(const SavpConvArgs* a) {
 // Returns true when the call was handled (rc set); false = not this kernel's problem, the caller goes on to the general kernels.
 bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     if (!conv_thin_applies(a)) return false;
-    static const float* zero = nullptr;
-    if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
+    static const float* zero_of[64] = {nullptr};               // per device ordinal: a device symbol has one address per device
+    int dev_ord = 0;
+    if (hipGetDevice(&dev_ord) != hipSuccess || dev_ord < 0 || dev_ord >= 64) dev_ord = 0;
+    if (!zero_of[dev_ord] && hipGetSymbolAddress((void**)&zero_of[dev_ord], HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     ThinP p;
-    p.zero = zero;
+    p.zero = zero_of[dev_ord];
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         thin_fill(p, a, TF_R, TF_C, 1024);                    // four resident workgroups per CU: one full wave of them
         p.w = (const float*)a->w; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;

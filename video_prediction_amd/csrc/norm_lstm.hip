@@ -227,13 +227,14 @@ __global__ __launch_bounds__(NT) void inorm_stats_kernel(InormP p, float* ws) {
     }
 }
 
-__global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* ws, int unshifted) {
+__global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* ws, int unshifted, const float* shift) {
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
     if (prow >= rows) return;
     const float* x = p.x + (long long)n * p.x_sn;
-    // unshifted: the sums came out of the producing convolution's epilogue (SavpInormArgs.stats_ready), taken around 0
-    const float4 k = unshifted ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(x + c4 * 4);
+    // unshifted: the sums came out of the producing convolution's epilogue (SavpInormArgs.stats_ready), taken around that convolution's
+    // bias (`shift`, per channel; NULL = around 0); otherwise around the sample's first pixel
+    const float4 k = unshifted ? (shift ? ld4(shift + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f)) : ld4(x + c4 * 4);
     const float inv = 1.f / (float)p.HW;
     float m[4], r[4];
     const float kk[4] = {k.x, k.y, k.z, k.w};
@@ -379,7 +380,7 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
         hipStream_t st = (hipStream_t)stream;
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
-        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 1);
+        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 1, a->stats_shift);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     if (use_large_plane_path(a)) {
@@ -389,7 +390,7 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
         hipLaunchKernelGGL(inorm_stats_kernel, grid, dim3(NT), lds, st, p, a->ws);
-        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 0);
+        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 0, (const float*)nullptr);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     hipLaunchKernelGGL(inorm_fwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);

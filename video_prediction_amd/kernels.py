@@ -415,14 +415,15 @@ def _set_ranges(c0_arr, nc_arr, ranges):
             c0_arr[i], nc_arr[i] = int(r[0]), int(r[1])
 
 
-def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6, out_ranges=None, stats=None):
+def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, eps=1e-6, out_ranges=None, stats=None, stats_shift=None):
     """out_ranges: per output view the (first channel, count) slice of the normalised tensor it receives (default: all).
     stats: [N, C, 2] sum / sum of squares of x written by the producing convolution's epilogue (conv(..., stats=...)): the
-    statistics pass is skipped."""
+    statistics pass is skipped.  stats_shift: that convolution's bias [C] (its sums are taken around the bias); None: no bias."""
     a = lib.SavpInormArgs()
     if stats is not None:
-        lib.require_device(stats)
+        lib.require_device(stats, stats_shift)
         a.ws, a.ws_clean, a.stats_ready = stats.data_ptr(), 1, 1
+        a.stats_shift = stats_shift.data_ptr() if stats_shift is not None else None
     else:
         a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
     a.N, a.HW, a.C = x.shape[0], _hw(x), x.shape[-1]

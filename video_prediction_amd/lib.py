@@ -189,7 +189,7 @@ class SavpInormArgs(ctypes.Structure):
         ('ndy', c_i32), ('dy', SavpView * 4), ('dx', SavpView), ('dx_beta', c_i32),
         ('dgamma', c_vp), ('dbeta', c_vp), ('ws', c_vp), ('ws_clean', c_i32),
         ('out_c0', c_i32 * 4), ('out_nc', c_i32 * 4), ('dy_c0', c_i32 * 4), ('dy_nc', c_i32 * 4), ('out_bf16', c_i32),
-        ('stats_ready', c_i32), ('dx_bf16', c_i32),
+        ('stats_ready', c_i32), ('stats_shift', c_vp), ('dx_bf16', c_i32),
     ]
 
 

@@ -425,16 +425,17 @@ class SAVPGenerator(object):
                 f = L['f']
                 # the conv's epilogue leaves the instance norm's statistics behind where it can (bf16 datapath, whole tiles): the
                 # norm is then ONE launch (SAVP_CONV_STATS=0: the norm takes its own statistics)
-                if 'cstats' not in L:
-                    L['cstats'] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
-                st = K.zero_arena(self.dev).take(N * f * 2) if L['cstats'] else None
+                ck = ('cstats', K.PRECISION['value'])          # the answer depends on the datapath in use: decided once per precision
+                if ck not in L:
+                    L[ck] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
+                st = K.zero_arena(self.dev).take(N * f * 2) if L[ck] else None
                 L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
                     a = L['a']
                     hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN, stats=st)
+                                       act='relu', eps=EPS_IN, stats=st, stats_shift=L['conv'].bias if st is not None else None)
                     n1, n2 = L['n1'], L['n2']
                     hprev = a.v[t][..., hs:hs + f]
                     L['rconv'].forward(a.v[t][..., 0:cin1], L['gates'].v[t], use_bias=False)
@@ -448,7 +449,7 @@ class SAVPGenerator(object):
                 elif L['rnn']:
                     a = L['a']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN, stats=st)
+                                       act='relu', eps=EPS_IN, stats=st, stats_shift=L['conv'].bias if st is not None else None)
                     stats1 = s1 = None
                     if L['fused']:
                         stats1, s1 = K.lstm_stats_ws(self.dev, N, f)
@@ -474,7 +475,7 @@ class SAVPGenerator(object):
                         cp.append((ce0, ce1))
                 else:
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN, stats=st)
+                                       act='relu', eps=EPS_IN, stats=st, stats_shift=L['conv'].bias if st is not None else None)
             tslot = maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             ngf = self.hp.ngf
             if self.merge_heads:
@@ -517,13 +518,15 @@ class SAVPGenerator(object):
     # ---------------------------------------------------------------------------------------------------------
     def _conv_norm(self, name, conv, x, pre, nrm, outs, t, **kw):
         """conv -> instance norm + ReLU of a head; the conv's epilogue supplies the norm's statistics where it can (see forward)."""
-        ok = self._cstats.get(name)
+        ok = self._cstats.get((name, K.PRECISION['value']))
         if ok is None:
             c = pre.shape[-1]
-            ok = self._cstats[name] = bool(CONV_STATS and c <= 256 and (c & (c - 1)) == 0 and conv.stats_ok(x, pre))
+            ok = self._cstats[(name, K.PRECISION['value'])] = bool(CONV_STATS and c <= 256 and (c & (c - 1)) == 0 and conv.stats_ok(x, pre))
         st = K.zero_arena(self.dev).take(self.N * pre.shape[-1] * 2) if ok else None
         conv.forward(x, pre, stats=st)
-        K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], act='relu', eps=EPS_IN, stats=st, **kw)
+        bias = getattr(conv, 'inner', conv).bias          # ConcatConv keeps the concatenated bias in its inner layer
+        K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], act='relu', eps=EPS_IN, stats=st,
+                           stats_shift=bias if st is not None else None, **kw)
 
     def _norm_bwd(self, key, holder, conv, dy, dx, nrm, x, skip=None):
         """The instance norm (over x, parameters nrm) whose OUTPUT gradient is the channels [0, C) that conv.backward_data(dy, dx) is
@@ -531,6 +534,7 @@ class SAVPGenerator(object):
         norm's backward is then ONE launch.  Returns the norm_bwd dict for backward_data (None: the norm takes its own sums); its 'ws'
         is what instnorm_act_bwd(stats=...) gets.  The decision is made once per layer (holder[key])."""
         t_ = dict(x=x, mean=nrm.mean[0], rstd=nrm.rstd[0], gamma=nrm.gamma, beta=nrm.beta, c0=0, act='relu')
+        key = (key, K.PRECISION['value'])
         ok = holder.get(key)
         if ok is None:
             ok = holder[key] = bool(NORM_BWD_STATS and dx.dtype == torch.float32 and x.shape[-1] <= 256 and
