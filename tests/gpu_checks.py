@@ -1338,6 +1338,17 @@ def check_tuning_table(precision='bf16', max_entries=None, seed=41):
         src16, out16, has_stats = (key[20:23] if len(key) >= 23 else (0, 0, False))
         if pr != prec:
             continue
+        # round 4 key extensions: ((gap_at, gap),) = data gradient without `gap` destination channels (the keyed Cx counts the
+        # LOGICAL ones); ('nb', c0, nc) = the norm-backward sums epilogue (same tiling question; run here without the sums, which
+        # check_norm_bwd_stats_epilogue covers)
+        gap = None
+        for extra in key[23:]:
+            if isinstance(extra, tuple) and len(extra) == 2 and not isinstance(extra[0], str):
+                gap = (int(extra[0]), int(extra[1]))
+        if gap is not None:
+            if mode != lib.CONV_DGRAD:
+                continue
+            Cx = Cx + gap[1]                         # physical channel count of the destination and of the packed weights
         tag = 'table_%s/m%d_N%d_%dx%dx%dx%d->%dx%dx%dx%d_k%s_s%s_t%x_sk%d%s' % (
             precision, mode, N, D, H, W, Cx, Do, Ho, Wo, Cy, 'x'.join(map(str, k)), 'x'.join(map(str, s)), tile, sk,
             ('_a%d' % act if act else '') + ('_beta' if beta else '') + ('_s16' if src16 else '') + ('_o16' if out16 else ''))
@@ -1394,11 +1405,15 @@ def check_tuning_table(precision='bf16', max_entries=None, seed=41):
             wp = (pack_wt(w32) if fprop else pack_wd(w32)).contiguous()
             stats = torch.zeros(N, cdst, 2, device=DEV) if has_stats else None
             K.conv(mode, geom, xv, yv, wp, bias=bias, beta=beta, act=act, alpha=alpha, aux=aux, splitk=sk, tile=tile, precision=prec,
-                   w16=wp.to(bf) if has_w16 else None, stats=stats)
+                   w16=wp.to(bf) if has_w16 else None, stats=stats, dst_gap=gap)
             got = dst.float().reshape(dst_shape)
-            out.append((tag + ('/fprop' if fprop else '/dgrad'), rel_err(got, ref.reshape(dst_shape)), 1e-2 if prec else 2e-5))
+            refd = ref.reshape(dst_shape)
+            if gap is not None:                      # the gap's channels are not computed: compare the logical ones
+                keep = [c for c in range(dst_shape[-1]) if not (gap[0] <= c < gap[0] + gap[1])]
+                got, refd = got[..., keep], refd[..., keep]
+            out.append((tag + ('/fprop' if fprop else '/dgrad') + ('_gap' if gap else ''), rel_err(got, refd), 1e-2 if prec else 2e-5))
             if has_stats:
-                r2 = ref.reshape(N, -1, cdst)
+                r2 = (ref - bias.to(rdt) if bias is not None else ref).reshape(N, -1, cdst)        # sums are taken around the bias
                 out.append((tag + '/stats_sum', rel_err(stats[..., 0], r2.sum(1)), 1e-2))
                 out.append((tag + '/stats_sumsq', rel_err(stats[..., 1], (r2 * r2).sum(1)), 1e-2))
         except RuntimeError as ex:
