@@ -321,6 +321,26 @@ int savp_composite_fwd(void* stream, const SavpCompositeArgs* a);
 int savp_composite_bwd(void* stream, const SavpCompositeArgs* a);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * One entry per FUSED operator of the cell: the launches above with their workspace hand-overs checked
+ * inside the library instead of being a caller convention (csrc/fused_ops.hip).  Each is two launches on the stream
+ * (convolution, then the per-sample pass that needs whole-plane sums) and ONE host call.
+ *   savp_convlstm_cell_fwd  BasicConv2DLSTMCell.call (rnn_ops.py:137-171): conv.mode FPROP with y = gates.gates; conv.stats (if
+ *                           set) must be the head of gates.ws_stats and gates.stats1_ready must say so.
+ *   savp_convlstm_cell_bwd  the gate block's backward, then conv (mode DGRAD, y = gates.dgates; dst_gap / nb_* as set).
+ *   savp_conv_in_act_fwd    conv_pool2d / upsample_conv2d / conv2d + fused_instance_norm + activation (savp_model.py:449-464,
+ *                           486-500,562-567,625-631): conv FPROP (or DGRAD mode for upsample_conv2d) whose destination is norm.x;
+ *                           conv.stats (if set) == norm.ws with norm.stats_ready and norm.stats_shift == conv.bias.
+ *   savp_conv_in_act_bwd    the norm's backward, then the convolution's data gradient reading norm.dx.
+ * SAVP_EINVAL when the two halves do not fit together; otherwise the first failing half's code.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct SavpConvLstmCellArgs { SavpConvArgs conv; SavpLstmArgs gates; } SavpConvLstmCellArgs;
+typedef struct SavpConvNormArgs { SavpConvArgs conv; SavpInormArgs norm; } SavpConvNormArgs;
+int savp_convlstm_cell_fwd(void* stream, const SavpConvLstmCellArgs* a);
+int savp_convlstm_cell_bwd(void* stream, const SavpConvLstmCellArgs* a);
+int savp_conv_in_act_fwd(void* stream, const SavpConvNormArgs* a);
+int savp_conv_in_act_bwd(void* stream, const SavpConvNormArgs* a);
+
+/* ------------------------------------------------------------------------------------------------------------
  * small_ops.hip: z-LSTM over all timesteps (savp_model.py:354-362), reparameterisation + KL
  * (savp_model.py:45-49,711-712; losses.py:57-60), image / GAN / feature-matching losses (losses.py:6-54).
  * Loss entries accumulate the (unweighted) loss value into *loss_out and the weighted gradient into d*.

@@ -295,3 +295,30 @@ def test_action_and_state_inputs_are_refused_not_ignored():
         with pytest.raises(NotImplementedError, match=key):
             M.SAVPEngine.set_images(None, inputs)
     M.refuse_conditioning_inputs({'images': images, 'actions': None})       # an absent / None entry is the action-free case
+
+
+def test_fused_operator_entries_refuse_halves_that_do_not_fit(hip_lib):
+    """csrc/fused_ops.hip (one entry per fused op): the hand-overs between the two launches of a fused operator are
+    checked by the library -- a convolution that does not write what the per-sample pass reads, or a statistics buffer only one half
+    knows about, is SAVP_EINVAL before anything is launched (no GPU needed)."""
+    import ctypes
+    from video_prediction_amd import lib
+    c = lib.SavpConvLstmCellArgs()
+    c.conv.mode = lib.CONV_DGRAD                                   # forward wants an FPROP
+    assert hip_lib.savp_convlstm_cell_fwd(None, ctypes.byref(c)) == -1
+    c.conv.mode = lib.CONV_FPROP
+    c.conv.y, c.gates.gates = 0x1000, 0x2000                        # the gate block would not read the conv's output
+    assert hip_lib.savp_convlstm_cell_fwd(None, ctypes.byref(c)) == -1
+    c.gates.gates = 0x1000
+    c.conv.Cy, c.gates.F, c.conv.N, c.gates.N, c.conv.Do, c.conv.Ho, c.conv.Wo, c.gates.HW = 128, 32, 2, 2, 1, 8, 8, 64
+    c.conv.stats = 0x3000                                           # statistics written, but the gate block not told
+    assert hip_lib.savp_convlstm_cell_fwd(None, ctypes.byref(c)) == -1
+    c.gates.stats1_ready, c.gates.ws_stats = 1, 0x4000              # ... or told about another buffer
+    assert hip_lib.savp_convlstm_cell_fwd(None, ctypes.byref(c)) == -1
+    assert hip_lib.savp_convlstm_cell_bwd(None, ctypes.byref(c)) == -1          # backward wants the DGRAD
+    n = lib.SavpConvNormArgs()
+    n.conv.mode = lib.CONV_WGRAD
+    assert hip_lib.savp_conv_in_act_fwd(None, ctypes.byref(n)) == -1 and hip_lib.savp_conv_in_act_bwd(None, ctypes.byref(n)) == -1
+    n.conv.mode, n.conv.y, n.norm.x.p = lib.CONV_FPROP, 0x1000, 0x2000
+    assert hip_lib.savp_conv_in_act_fwd(None, ctypes.byref(n)) == -1
+    assert hip_lib.savp_convlstm_cell_fwd(None, None) == -1 and hip_lib.savp_conv_in_act_bwd(None, None) == -1

@@ -291,13 +291,25 @@ class ConvLayer(object):
             self.u.copy_(self.u_next)
 
     # -- execution ----------------------------------------------------------------------------------------------
-    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True, stats=None):
-        """stats: see kernels.conv (bf16 destination only: the fused ConvLSTM gate convolution)."""
+    def forward(self, x, y, beta=0, act=0, alpha=0.0, use_bias=True, stats=None, defer=False):
+        """stats: see kernels.conv (bf16 destination only: the fused ConvLSTM gate convolution).  defer: return the filled
+        SavpConvArgs instead of launching (for a fused-operator entry point, kernels.convlstm_cell_fwd / conv_in_act_fwd); None when this
+        call is instrumented or takes the few-row dense kernel -- the caller then issues the halves apart."""
         b = self.bias if use_bias else None
         if self.kind == 'conv' and x.dim() == 2 and x.shape[0] <= 64 and not act and not beta and y.is_contiguous():
+            if defer:
+                return None
             # dense layer on a handful of rows: split-K kernel on the master weights (ops.py:5-16)
             K.dense_fwd(x, self.W.reshape(-1, self.cy), b, y, scale=self.sn_ws[1:2] if self.sn_u_name else None)
             return
+        if defer:
+            if self.ktimer is not None or self.prof is not None:
+                return None
+            if self.kind == 'up':
+                return K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16, stats=stats,
+                              defer=True)
+            return K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats,
+                          defer=True)
         if self.ktimer is not None:
             self.ktimer.arm()
         if self.prof is not None:
@@ -321,16 +333,15 @@ class ConvLayer(object):
             return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=self.bias, w16=self.wd16)
         return K.conv_stats_ok(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=self.bias, w16=self.wt16)
 
-    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None, skip=None, norm_bwd=None):
+    def backward_data(self, dy, dx, beta=0, act=0, alpha=0.0, aux=None, skip=None, norm_bwd=None, defer=False):
         """skip = (first, count): input channels whose data gradient is not needed per pixel (left unwritten in dx).  norm_bwd: dx's
         channels [c0, c0 + C) are the output gradient of an instance norm over norm_bwd['x']; its backward sums leave with this launch
         (kernels.conv)."""
         if self.kind == 'up':
-            K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16, dst_gap=skip,
-                   norm_bwd=norm_bwd)
-        else:
-            K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16, dst_gap=skip,
-                   norm_bwd=norm_bwd)
+            return K.conv(lib.CONV_FPROP, self.geom, dy, dx, self.wt, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wt16, dst_gap=skip,
+                          norm_bwd=norm_bwd, defer=defer)
+        return K.conv(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, beta=beta, act=act, alpha=alpha, aux=aux, w16=self.wd16, dst_gap=skip,
+                      norm_bwd=norm_bwd, defer=defer)
 
     def norm_bwd_ok(self, dy, dx, norm_bwd, skip=None):
         """Can backward_data(dy, dx, norm_bwd=...) leave the norm-backward sums behind (bf16 datapath, ring kernel, whole tiles)?"""
@@ -452,13 +463,13 @@ class ConcatConv(object):
         self.inner.prep(defer_pack=defer_pack)
 
     def forward(self, x, y, **kw):
-        self.inner.forward(x, y, **kw)
+        return self.inner.forward(x, y, **kw)
 
     def stats_ok(self, x, y):
         return self.inner.stats_ok(x, y)
 
     def backward_data(self, dy, dx, **kw):
-        self.inner.backward_data(dy, dx, **kw)
+        return self.inner.backward_data(dy, dx, **kw)
 
     def norm_bwd_ok(self, dy, dx, norm_bwd, skip=None):
         return self.inner.norm_bwd_ok(dy, dx, norm_bwd, skip)

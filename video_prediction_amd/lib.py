@@ -207,6 +207,18 @@ class SavpLstmArgs(ctypes.Structure):
     ]
 
 
+class SavpConvLstmCellArgs(ctypes.Structure):
+    _fields_ = [('conv', SavpConvArgs), ('gates', SavpLstmArgs)]
+
+
+class SavpConvNormArgs(ctypes.Structure):
+    _fields_ = [('conv', SavpConvArgs), ('norm', SavpInormArgs)]
+
+
+register('savp_convlstm_cell_fwd', [c_vp, ctypes.POINTER(SavpConvLstmCellArgs)])
+register('savp_convlstm_cell_bwd', [c_vp, ctypes.POINTER(SavpConvLstmCellArgs)])
+register('savp_conv_in_act_fwd', [c_vp, ctypes.POINTER(SavpConvNormArgs)])
+register('savp_conv_in_act_bwd', [c_vp, ctypes.POINTER(SavpConvNormArgs)])
 register('savp_instnorm_act_fwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
 register('savp_instnorm_act_bwd', [c_vp, ctypes.POINTER(SavpInormArgs)])
 register('savp_convlstm_gates_fwd', [c_vp, ctypes.POINTER(SavpLstmArgs)])

@@ -23,6 +23,7 @@ from ..engine import ConcatConv, ConvLayer, same_pad_before, copy_view, add_view
 from ..variables import layer_specs, num_masks
 
 CONV_STATS = os.environ.get('SAVP_CONV_STATS', '1') == '1'      # developer A/B switch of the conv-epilogue statistics
+FUSED_ENTRIES = os.environ.get('SAVP_FUSED_ENTRIES', '1') == '1'      # one host call per fused operator (csrc/fused_ops.hip); 0: the halves apart
 NORM_BWD_STATS = os.environ.get('SAVP_NORM_BWD_STATS', '1') == '1'      # ... and of the norm-backward sums from the DGRAD that produces dy
 EPS_IN = 1e-6   # fused_instance_norm epsilon (layers/normalization.py:37)
 
@@ -429,9 +430,9 @@ class SAVPGenerator(object):
                 if ck not in L:
                     L[ck] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
                 st = K.zero_arena(self.dev).take(N * f * 2) if L[ck] else None
-                L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
+                    L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
                     a = L['a']
                     hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
                     K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
@@ -448,8 +449,7 @@ class SAVPGenerator(object):
                     K.convgru_out_fwd(L['cand'].v[t], hprev, n2.gamma, n2.beta, n2.mean[t], n2.rstd[t], L['u'][t], outs, eps=EPS_IN)
                 elif L['rnn']:
                     a = L['a']
-                    K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, [a.v[t][..., 0:f]], nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN, stats=st, stats_shift=L['conv'].bias if st is not None else None)
+                    self._conv_in_act(L['conv'], L['in'].v[t], L['pre'].v[t], st, nrm, [a.v[t][..., 0:f]], t)
                     stats1 = s1 = None
                     if L['fused']:
                         stats1, s1 = K.lstm_stats_ws(self.dev, N, f)
@@ -457,25 +457,30 @@ class SAVPGenerator(object):
                     if cp is not None:
                         ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         ce0.record()
-                    L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                     outs = self._out_views(L, t)
                     if t + 1 < T1:
                         outs.append(a.v[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
                     gk = L.get('gate_ktimer')                # bench.py: the gate-block launch's own begin / end stamps
-                    if gk is not None:
-                        gk.arm()
-                    K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
-                                         n2.beta, L['c'].v[t], outs, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]],
-                                         eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
-                    if gk is not None:
-                        gk.taken()
+                    gargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma, n2.beta, L['c'].v[t], outs,
+                             [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]])
+                    # the whole cell as ONE host call (savp_convlstm_cell_fwd) unless a measurement wants the two launches apart
+                    ca = (L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1, defer=True)
+                          if (FUSED_ENTRIES and cp is None and gk is None and K.fused_ok()) else None)
+                    if ca is not None:
+                        K.convlstm_cell_fwd(ca, K.convlstm_gates_fwd(*gargs, eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1, defer=True))
+                    else:
+                        L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
+                        if gk is not None:
+                            gk.arm()
+                        K.convlstm_gates_fwd(*gargs, eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1)
+                        if gk is not None:
+                            gk.taken()
                     if cp is not None:
                         ce1.record()
                         cp.append((ce0, ce1))
                 else:
-                    K.instnorm_act_fwd(L['pre'].v[t], nrm.gamma, nrm.beta, self._out_views(L, t), nrm.mean[t], nrm.rstd[t],
-                                       act='relu', eps=EPS_IN, stats=st, stats_shift=L['conv'].bias if st is not None else None)
+                    self._conv_in_act(L['conv'], L['in'].v[t], L['pre'].v[t], st, nrm, self._out_views(L, t), t)
             tslot = maskin.v[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             ngf = self.hp.ngf
             if self.merge_heads:
@@ -523,10 +528,19 @@ class SAVPGenerator(object):
             c = pre.shape[-1]
             ok = self._cstats[(name, K.PRECISION['value'])] = bool(CONV_STATS and c <= 256 and (c & (c - 1)) == 0 and conv.stats_ok(x, pre))
         st = K.zero_arena(self.dev).take(self.N * pre.shape[-1] * 2) if ok else None
-        conv.forward(x, pre, stats=st)
+        self._conv_in_act(conv, x, pre, st, nrm, outs, t, **kw)
+
+    def _conv_in_act(self, conv, x, pre, st, nrm, outs, t, **kw):
+        """conv -> fused_instance_norm + ReLU as ONE host call (savp_conv_in_act_fwd) where nothing instruments the conv; st = the
+        statistics slice the conv's epilogue fills for the norm (None: the norm takes its own)."""
         bias = getattr(conv, 'inner', conv).bias          # ConcatConv keeps the concatenated bias in its inner layer
-        K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], act='relu', eps=EPS_IN, stats=st,
-                           stats_shift=bias if st is not None else None, **kw)
+        nkw = dict(act='relu', eps=EPS_IN, stats=st, stats_shift=bias if st is not None else None, **kw)
+        ca = conv.forward(x, pre, stats=st, defer=True) if (FUSED_ENTRIES and K.fused_ok()) else None
+        if ca is not None:
+            K.conv_in_act_fwd(ca, K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], defer=True, **nkw))
+        else:
+            conv.forward(x, pre, stats=st)
+            K.instnorm_act_fwd(pre, nrm.gamma, nrm.beta, outs, nrm.mean[t], nrm.rstd[t], **nkw)
 
     def _norm_bwd(self, key, holder, conv, dy, dx, nrm, x, skip=None):
         """The instance norm (over x, parameters nrm) whose OUTPUT gradient is the channels [0, C) that conv.backward_data(dy, dx) is
@@ -543,6 +557,18 @@ class SAVPGenerator(object):
             return None
         t_['ws'] = K.zero_arena(self.dev).take(self.N * x.shape[-1] * 2)
         return t_
+
+    def _in_act_conv_bwd(self, L, t, y0, dys, st):
+        """Backward of a ladder layer's instance norm + ReLU and of its conv_pool / upsample convolution's data path: one host call
+        (savp_conv_in_act_bwd).  st: the norm-backward sums a data gradient's epilogue has already left (None: the norm takes them)."""
+        nrm = L['norm']
+        nargs = (L['pre'].v[t], nrm.gamma, nrm.beta, y0, nrm.mean[t], nrm.rstd[t], dys, L['pre'].g[t], nrm.dgamma, nrm.dbeta)
+        if FUSED_ENTRIES and K.fused_ok():
+            K.conv_in_act_bwd(L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0, defer=True),
+                              K.instnorm_act_bwd(*nargs, act='relu', eps=EPS_IN, stats=st, defer=True))
+        else:
+            K.instnorm_act_bwd(*nargs, act='relu', eps=EPS_IN, stats=st)
+            L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0)
 
     def _lstm_ws(self, L):
         """Scratch of the coalesced ConvLSTM gate kernels (one buffer shared by all layers: the launches are serial)."""
@@ -644,23 +670,26 @@ class SAVPGenerator(object):
                     n1, n2 = L['n1'], L['n2']
                     dc_new = L['dc'][(t + 1) & 1] if t + 1 < T1 else None
                     dc_prev = L['dc'][t & 1] if t > 0 else None
-                    K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma,
-                                         n2.beta, [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t],
-                                         dc_prev, [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta], eps=EPS_IN, ws=self._lstm_ws(L),
-                                         dgates_raw=L.get('dg_raw'))
+                    bargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma, n2.beta,
+                             [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t], dc_prev,
+                             [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta])
                     skip = (f, L['zr']) if L['zless'] else None
                     nb = self._norm_bwd('nbstats', L, L['rconv'], L['gates'].g[t], a.g[t], nrm, L['pre'].v[t], skip)
                     if nb is not None:
                         nb['mean'], nb['rstd'] = nrm.mean[t], nrm.rstd[t]
-                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=skip, norm_bwd=nb)
-                    K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
-                                       [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN,
-                                       stats=nb['ws'] if nb is not None else None)
+                    if FUSED_ENTRIES and K.fused_ok():       # gate block backward + the gate convolution's DGRAD: one host call
+                        K.convlstm_cell_bwd(L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=skip, norm_bwd=nb, defer=True),
+                                            K.convlstm_gates_bwd(*bargs, eps=EPS_IN, ws=self._lstm_ws(L), dgates_raw=L.get('dg_raw'), defer=True))
+                    else:
+                        K.convlstm_gates_bwd(*bargs, eps=EPS_IN, ws=self._lstm_ws(L), dgates_raw=L.get('dg_raw'))
+                        L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0, skip=skip, norm_bwd=nb)
+                    self._in_act_conv_bwd(L, t, a.v[t][..., 0:f], [a.g[t][..., 0:f]], nb['ws'] if nb is not None else None)
+                    continue
                 else:
                     y0 = self._out_views(L, t)[0]
                     st_ = nb_last['ws'] if (L is self.layers[-1] and nb_last is not None and len(dys) == 1) else None
-                    K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, y0, nrm.mean[t], nrm.rstd[t], dys, L['pre'].g[t],
-                                       nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN, stats=st_)
+                    self._in_act_conv_bwd(L, t, y0, dys, st_)
+                    continue
                 L['conv'].backward_data(L['pre'].g[t], L['in'].g[t], beta=0)
             # d image -> previous step's generated frame where it was fed back (not ground truth)
             if t > 0:
