@@ -15,9 +15,13 @@ hipGraph SEGMENTS with the collectives issued by the host between them (models/s
                   of the datapath in use (bf16: 2.5 PFLOP/s; --precision f32: 157.3 TFLOP/s).  `traffic` is read from the
                   committed rocprofv3 PMC pass of the round (profiles/), not collected by this run.
   roofline_cell-- the fused cell (gate conv + ONE gate-block launch) against both roofs, same instrumented steps.
-  config       -- besides the workload: `submission` (hipGraph replay / eager launches), `eager_ms_per_step` (the same step launch by
-                  launch) and `host_issue_ms_per_step` (host time to ISSUE one eager step with an idle GPU: what a replica of a
-                  multi-GPU run, which cannot replay a graph around its collectives, has to sustain).
+  roofline_step-- the whole train step: SURVEY.md 8(d)'s algorithmic TFLOP per sequence x sequences / measured time, against the same peak.
+  roofline_cell-- also `kernel_only`: the same cells on the two launches' own begin / end stamps (gate conv + gate block).
+  kernel_families_ms -- kernel time per step by family, quoted from profiles/r04_kernel_families.json (like `roofline.traffic` from the
+                  PMC file) ONLY when that file's source id equals this checkout's (video_prediction_amd.lib.source_id).
+  config       -- besides the workload: `submission` (hipGraph replay / ... in N segments with replicas / eager launches), `eager_ms_per_step`
+                  (the same step launch by launch), `host_issue_ms_per_step` (host time to ISSUE one eager step with an idle GPU) and, with a
+                  process group, `dist` (backend, world, chunks issued, side stream; SAVP_FORCE_DIST=1 keeps the collectives at world size 1).
   f32          -- (N=1) the exact-fp32 datapath, the reference's own arithmetic, on the same workload, timed the same way.
   cpu_baseline -- the CPU oracle (a torch-CPU restatement of the reference step, kind "port") timed on this host's
                   cores on a bounded sample (one sequence), rank 0 at N=1 only.
@@ -27,6 +31,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on these hosts: RCCL / tensor sharing across processes needs it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
