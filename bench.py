@@ -242,10 +242,11 @@ def main():
 
     engine, hp = build_engine(args.precision)
     # The timed region runs the step the way a training job does: un-instrumented, and on one GPU as a replayed hipGraph (the step
-    # body has no host input; --eager keeps per-launch submission; with replicas: graph segments between the collectives).  The roofline
+    # body has no host input; --eager keeps per-launch submission; with replicas over RCCL: graph segments between the
+    # collectives; over gloo, whose collectives block the host, the engine keeps launch-by-launch submission).  The roofline
     # numbers come from INST_STEPS further steps AFTER the timed region, eager, with HIP events / dispatch stamps around the
     # ConvLSTM gate-conv launches and around whole cells -- instrumentation never sits inside the timed region.
-    engine.use_graph = not args.eager
+    engine.use_graph = engine.use_graph and not args.eager     # the engine's own choice stands (eager under a host-blocking backend)
     dt, info = timed_steps(engine, args.warmup, args.steps)
     mode = 'eager launches'
     if engine.use_graph and engine.graph is not None:

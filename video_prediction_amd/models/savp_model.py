@@ -209,6 +209,15 @@ class SAVPEngine(object):
         self.dp = self.replicas.active          # the step carries collectives (world > 1, or forced)
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
         self.graph = None                       # a step captured without the collectives is not this engine's step any more
+        # Segmented replay pays when the collectives are stream-ordered (RCCL).  Under a backend whose collectives block the host
+        # on device tensors (gloo) every segment boundary is a full drain; measured with two ranks time-slicing one MI355X:
+        # 146 ms/step launch by launch against 213 ms/step replayed in 8 segments (profiles/r04_ab_calls.md, call 13).
+        try:
+            backend = str(dist_module.get_backend())
+        except Exception:
+            backend = None
+        if self.dp and backend != 'nccl' and 'SAVP_GRAPH' not in os.environ:
+            self.use_graph = False
         K.set_tuning_group(dist_module, force=self.dp)     # rank 0's tuning table, and rank 0's choice for problems tuned live
 
     def wait_aux(self):
