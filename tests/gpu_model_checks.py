@@ -329,6 +329,33 @@ def check_config_c5():
     return res
 
 
+# Loss weights of the SAVP recipes the reference ships besides ours_savp / ours_deterministic_l1 (which C2 / C4 and C1 cover): the VALUES of
+# hparams/<dataset>/<name>/model_hparams.json (bair_action_free: nz = 8, 64x64x3, context 2; kth: nz = 32, 64x64x1, context 10)
+SHIPPED_RECIPES = {
+    'bair_ours_gan': dict(C=3, nz=8, context_frames=2, lr=2e-4, beta1=0.5, l1_weight=100.0, l2_weight=0.0, kl_weight=0.0,
+                          video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=0.0, gan_feature_cdist_weight=10.0),
+    'bair_ours_vae_l1': dict(C=3, nz=8, context_frames=2, lr=1e-3, beta1=0.9, l1_weight=1.0, l2_weight=0.0, kl_weight=0.001,
+                             video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0),
+    'bair_ours_deterministic_l2': dict(C=3, nz=0, context_frames=2, lr=1e-3, beta1=0.9, l1_weight=0.0, l2_weight=1.0, kl_weight=0.0,
+                                       video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0),
+    'kth_ours_gan': dict(C=1, nz=32, context_frames=10, lr=2e-4, beta1=0.5, l1_weight=100.0, l2_weight=0.0, kl_weight=0.0,
+                         video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=0.0, gan_feature_cdist_weight=10.0),
+    'kth_ours_vae_l1': dict(C=1, nz=32, context_frames=10, lr=1e-3, beta1=0.9, l1_weight=1.0, l2_weight=0.0, kl_weight=1e-5,
+                            video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0),
+}
+
+
+def check_shipped_recipes(names=None):
+    """One train step (losses, per-variable gradients, Adam) per shipped SAVP recipe against the fp64 oracle, at the recipe's clip
+    length (10 -> T = 12) and batch 1."""
+    res = []
+    for name in (names or sorted(SHIPPED_RECIPES)):
+        r = dict(SHIPPED_RECIPES[name])
+        C = r.pop('C')
+        res += check_train_step(B=1, T=12, C=C, steps=1, tag='recipe_' + name, clip_length=10, **r)
+    return res
+
+
 def check_model_small():
     res = []
     res += check_generator_forward(nz=0, B=2, T=5)
@@ -349,6 +376,9 @@ def check_model_small():
     # mask conv on h_masks alone (dependent_mask=False, savp_model.py:631-632) / no scratch image (:561-572, 6 masks)
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_independent_mask', dependent_mask=False)
     res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_no_scratch', generate_scratch_image=False)
+    # latent added as dense(z) behind the convolutions instead of tiled into their inputs (savp_model.py:983-993, rnn_ops.py:145-146):
+    # cancelled by the instance norms (tests/test_untiled_latent_is_cancelled.py); the oracle computes it literally
+    res += check_generator_forward(nz=8, B=1, T=4, tag='gen_fwd_untiled_latent', use_tile_concat=False)
     return res
 
 
@@ -373,6 +403,8 @@ def check_train_small():
     res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_no_scratch_independent_mask', generate_scratch_image=False,
                             dependent_mask=False, transformation='flow', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0)
+    res += check_train_step(B=1, T=4, nz=8, steps=1, tag='train_untiled_latent', use_tile_concat=False, video_sn_vae_gan_weight=0.0,
+                            video_sn_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)
     res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_det', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
                             vae_gan_feature_cdist_weight=0.0, kl_weight=0.0, l1_weight=1.0)
     return res

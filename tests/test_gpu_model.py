@@ -29,6 +29,14 @@ def test_train_step_vs_oracle():
     _assert_ok(G.check_train_small())
 
 
+def test_every_other_shipped_savp_recipe_trains_with_parity():
+    """hparams/{bair_action_free,kth}/ours_{gan,vae_l1,deterministic_l2}: the loss structures the reference ships besides ours_savp
+    (C2 / C4) and ours_deterministic_l1 (C1) -- GAN without the VAE terms (gan_feature_cdist on the prior unroll), VAE without a
+    discriminator, L2 reconstruction."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_shipped_recipes())
+
+
 def test_train_step_recipe_shapes_fp32_and_bf16_vs_oracle():
     """The benchmarked step at the recipe's shapes scaled only in batch (B=2, T=30, clip_length=10, nz=8, 64x64x3): the fp32
     datapath AND the bf16 datapath (bench default) against the fp64 oracle -- losses, per-variable gradients, Adam."""
@@ -228,6 +236,60 @@ def test_hipgraph_replay_matches_eager_steps(monkeypatch):
         assert abs(got[0] - lr_t) <= 1e-6 * lr_t and abs(got[1] - lr_t) <= 1e-6 * lr_t
         assert abs(got[2] - (kl_weight(hp, step) or 0.0)) <= 1e-6
     assert eng.graph is not None
+
+
+def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_train_replay(monkeypatch):
+    """(a) SAVPEngine.generate(): from the second call on the weight preparation + unroll is ONE hipGraph replay; same frames as the
+    eager launches (fp32 datapath: summation order of the atomically accumulated statistics only), also when train-step replays run
+    in between.  (b) The pre-zeroed reduction arena (kernels.ZeroArena) is shared by every launch sequence on the device: a replayed
+    step leaves its sums in the arena's head whatever the host-side offset says, so eager callers between two replays -- the eval
+    summary of scripts/train.py -- must continue behind the replay's mark (ZeroArena.replayed), never inside it."""
+    from tests.gpu_model_checks import make_hparams
+    from video_prediction_amd import kernels as K
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    monkeypatch.setenv('SAVP_GRAPH', '1')
+    saved = K._ARENAS.pop('cuda:0', None)
+    K._ARENAS['cuda:0'] = K.ZeroArena(torch.device('cuda:0'), floats=1 << 20)      # small: eager takes wrap within the test
+    try:
+        hp = make_hparams(context_frames=2, sequence_length=4, nz=8, lr=0.0, l1_weight=100.0, kl_weight=1.0, video_sn_gan_weight=0.0,
+                          video_sn_vae_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)        # lr = 0: the variables stay put
+        eng = SAVPEngine(hp, (64, 64, 3), 1, mode='train', seed=4)
+        eng.set_images(torch.rand(4, 1, 64, 64, 3).cuda(), time_major=True)
+        arena = K.zero_arena(eng.device)
+        assert arena is K._ARENAS['cuda:0']
+        noise = eng.default_noise()
+        eng.infer_graph = False
+        ref = eng.generate(noise).clone()
+        for _ in range(3):
+            eng.train_step()
+        assert eng.graph is not None and 0 < eng.graph.arena_mark < arena.buf.numel()
+        mark = eng.graph.arena_mark
+        for i in range(12):
+            eng.train_step()                                   # replay
+            assert arena.off == mark
+            if i == 0:
+                torch.cuda.synchronize()
+                assert float(arena.buf[:mark].abs().sum()) > 0.0 and float(arena.buf[mark:].abs().sum()) == 0.0
+            got = eng.generate(noise)                           # eager takes: behind the mark, wrapping (reset) when the arena is full
+            assert float((got - ref).abs().max()) <= 1e-4, i
+        # (a) replayed unroll
+        eng.infer_graph = True
+        for i in range(4):
+            got = eng.generate(noise)
+            assert float((got - ref).abs().max()) <= 1e-4, i
+            eng.train_step()
+        assert eng.gen_graph is not None and eng.gen_graph.segments == 1
+        other = eng.default_noise(torch.Generator().manual_seed(123))
+        eng.set_images(torch.rand(4, 1, 64, 64, 3, generator=torch.Generator().manual_seed(7)).cuda(), time_major=True)
+        a = eng.generate(other).clone()                          # replay on freshly staged images and noise ...
+        eng.infer_graph = False
+        b = eng.generate(other)                                  # ... against eager launches
+        assert float((a - ref).abs().max()) > 1e-2               # the staged inputs are what the replay reads
+        assert float((a - b).abs().max()) <= 1e-4
+    finally:
+        K._ARENAS.pop('cuda:0', None)
+        if saved is not None:
+            K._ARENAS['cuda:0'] = saved
 
 
 def test_bf16_patch_kernels_match_generic_kernels_on_a_train_step(monkeypatch):

@@ -379,6 +379,7 @@ class ZeroArena(object):
     def __init__(self, device, floats=16 << 20):
         self.buf = torch.zeros(floats, device=device)
         self.off = 0
+        self.hi = 0          # high-water mark of `off` since the owner last cleared it (see replayed())
 
     def reset(self):
         self.buf.zero_()
@@ -392,7 +393,15 @@ class ZeroArena(object):
             self.reset()
         v = self.buf[self.off:self.off + n]
         self.off += n
+        self.hi = max(self.hi, self.off)
         return v
+
+    def replayed(self, mark):
+        """A captured launch sequence that begins with reset() and took slices up to `mark` (the value of `hi` at the end of its
+        capture, `hi` cleared at its start) has just been replayed: the device memory is zero from `mark` on and used below it, whatever
+        the host-side offset said -- eager takes continue at `mark`.  (Without this an eager caller between two replays -- the eval
+        summary of a training loop -- could be handed slices the replay had left its sums in.)"""
+        self.off = int(mark)
 
 
 _ARENAS = {}

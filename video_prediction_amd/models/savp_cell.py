@@ -96,8 +96,6 @@ class SAVPGenerator(object):
         dev = store.device
         self.dev = dev
         self._cstats = {}                # head name -> the conv's epilogue supplies the instance norm's statistics (decided at first use)
-        if hp.nz and not hp.use_tile_concat:
-            raise NotImplementedError('use_tile_concat=False')
         if hp.conv_rnn not in ('lstm', 'gru') or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
             raise NotImplementedError('HIP path covers conv_rnn in (lstm, gru) with instance norm')
         if hp.downsample_layer != 'conv_pool2d' or hp.upsample_layer != 'upsample_conv2d' or hp.activation_layer != 'relu':
@@ -114,7 +112,14 @@ class SAVPGenerator(object):
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
         # every conv-RNN; 'input' = the first encoder conv only; 'middle' = the first decoder conv only
-        zr = nz if hp.where_add == 'all' else 0                         # z channels in a conv-RNN's input [x | z | h]
+        # use_tile_concat=False (savp_model.py:458-460,470-471,495-496,506-507 -> _maybe_tile_concat_layer :983-993, rnn_ops.py:128-135,
+        # 145-146): the latent enters as dense(z)[:, None, None, :] ADDED to the convolution's output instead of as tiled input channels.
+        # Every such sum sits directly in front of an instance norm here (norm_layer / conv_rnn_norm_layer == 'instance' are required
+        # above), and a per-(sample, channel) constant is removed exactly by the norm's mean subtraction: the outputs do not depend on
+        # z, the `dense/kernel` / `weights` variables and z itself get zero gradients.  The layers therefore run without z channels and
+        # those variables keep their (zero-initialised) gradients; pinned against the oracle, which computes the sums literally.
+        tile = bool(hp.use_tile_concat)
+        zr = nz if (hp.where_add == 'all' and tile) else 0              # z channels in a conv-RNN's input [x | z | h]
         g = train
         # bf16 storage of tensors whose ONLY readers are convolutions of the bf16 datapath (round 4; the cell input [x | z | h] and the
         # gate gradient have been stored this way since round 3): the inputs of the down / upsample convolutions behind layer 0, the
@@ -135,7 +140,8 @@ class SAVPGenerator(object):
             L = {'f': f, 'rnn': use_rnn, 'idx': i, 'dec': i >= self.ne}
             s = prefix + 'h%d/' % i
             j_dec = i - len(enc_specs)
-            zc = nz if (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0) or (hp.where_add == 'middle' and j_dec == 0)) else 0
+            zc = nz if (tile and (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0) or
+                                  (hp.where_add == 'middle' and j_dec == 0))) else 0
             L['zc'], L['zr'] = zc, zr
             if i < self.ne:
                 cx = 2 * C if i == 0 else prev_f

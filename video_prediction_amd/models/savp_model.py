@@ -49,6 +49,7 @@ class _StepProgram(object):
         self.pool = torch.cuda.graph_pool_handle()
         self.stream = torch.cuda.Stream(device=device)
         self.cur = None
+        self.arena_mark = 0
 
     def _begin(self):
         self.cur = torch.cuda.CUDAGraph()
@@ -72,6 +73,8 @@ class _StepProgram(object):
         gc.collect()
         main = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(main)
+        arena = K.zero_arena(self.device)
+        arena.hi = 0
         try:
             with torch.cuda.stream(self.stream):
                 self._begin()
@@ -89,6 +92,7 @@ class _StepProgram(object):
         finally:
             engine._rec = None
         main.wait_stream(self.stream)
+        self.arena_mark = arena.hi          # the body starts with arena.reset(): see ZeroArena.replayed
         return out
 
     @property
@@ -101,6 +105,7 @@ class _StepProgram(object):
                 it.replay()
             else:
                 it()
+        K.zero_arena(self.device).replayed(self.arena_mark)
 
     replay = run
 
@@ -195,6 +200,8 @@ class SAVPEngine(object):
         self.side_prep = os.environ.get('SAVP_SIDE_PREP', '0') == '1' and self.device.type == 'cuda'
         self._prep_stream = None
         self.eager_steps = 0
+        self.infer_graph = os.environ.get('SAVP_INFER_GRAPH', '1') == '1' and self.device.type == 'cuda'
+        self.gen_graph, self.gen_graph_out, self.gen_eager = None, None, 0
 
     # -- data-parallel replicas (base_model.py:517-692 / tf_utils.allreduce_grads) ---------------------------------
     def attach_process_group(self, dist_module, force=None):
@@ -628,11 +635,39 @@ class SAVPEngine(object):
 
     # -- inference (scripts/generate.py:166: model.outputs['gen_images']) ------------------------------------------------------
     def generate(self, noise=None, collect_masks=False):
+        """One prior (and posterior) unroll of the generator on the staged images: gen [T1, N, H, W, C] (a buffer of the engine: the
+        next call overwrites it).  Like the train step, the launch sequence (weight preparation + unroll, ~1 k launches) has no host
+        input once the noise is staged, so from the second call on it is replayed as ONE hipGraph (SAVP_INFER_GRAPH=0: eager): the
+        100 unrolls of an evaluation (eval_outputs_and_metrics) cost 100 graph launches instead of ~10^5 host calls."""
         if noise is None:
             noise = self.default_noise()
-        self.prep_generator_weights()
-        gen = self.forward_generator(noise, collect_masks=collect_masks)
-        return gen
+        if not (self.infer_graph and not collect_masks and K.fused_ok()):
+            self.prep_generator_weights()
+            return self.forward_generator(noise, collect_masks=collect_masks)
+        self._stage_noise(noise)
+
+        def body():
+            K.zero_arena(self.device).reset()
+            self.prep_generator_weights()
+            return self.forward_generator(None)
+        if self.gen_graph is not None:
+            self.gen_graph.run()
+            return self.gen_graph_out
+        if self.gen_eager >= 1:              # every conv problem tuned and every kernel loaded by the eager call(s)
+            prog = _StepProgram(self.device)
+            try:
+                out = prog.capture(self, body)
+            except Exception as ex:
+                import warnings
+                warnings.warn('hipGraph capture of the generator unroll failed (%r); continuing eagerly' % (ex,))
+                self.infer_graph = False
+                torch.cuda.synchronize()
+                return body()
+            self.gen_graph, self.gen_graph_out = prog, out
+            prog.run()
+            return out
+        self.gen_eager += 1
+        return body()
 
     # -- evaluation: metrics_fn / eval_outputs_and_metrics_fn (base_model.py:113-227; SURVEY.md 8(f1)) ------------------------
     METRICS = ('psnr', 'mse', 'ssim')            # base_model.py:119-124 without lpips (external AlexNet weights)
