@@ -4,7 +4,7 @@
 #   collect_profiles.sh r04   default bench line (f32 object, cpu_baseline), rocprofv3 kernel stats + last-step trace, gate-conv PMC (c2)
 #   the whole GPU suite
 #   bench lines of c4 / c5 / c1, the forced-RCCL world-1 line under torch.distributed.run, the two-rank line over gloo
-#   gate-conv PMC of c4 / c5
+#   gate-conv PMC of c4 / c5; inference throughput (bench_generate.py); the hipGraph memset-node probe
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 TAG=r04
@@ -20,6 +20,11 @@ timeout 600 python bench.py --config c5 --steps 40 --warmup 5 --no-f32 --no-cpu-
 timeout 600 python bench.py --config c1 --steps 100 --warmup 5 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_c1_det.json 2> $O/c1.err; echo "c1 rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-200 $O/${TAG}_bench_c1_det.json
 SAVP_FORCE_DIST=1 SAVP_BENCH_CHECK_REPLICAS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 1 --steps 20 --warmup 5 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_rccl_world1_forced.json 2> $O/rccl.err; echo "rccl rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-300 $O/${TAG}_bench_rccl_world1_forced.json
 SAVP_DIST_BACKEND=gloo SAVP_BENCH_CHECK_REPLICAS=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $O/dp.err; echo "dp2 rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-300 $O/${TAG}_bench_2ranks_one_gpu_gloo.json
+for c in c2 c4 c5 c1; do
+  timeout 300 python tests/tools/bench_generate.py --config $c > $O/${TAG}_generate_$c.json 2> $O/generate_$c.err || tail -5 $O/generate_$c.err
+done
+echo "generate $(( $(date +%s)-t0 ))s"; cut -c1-200 $O/${TAG}_generate_c2.json
+timeout 300 python tests/tools/ab_calls/graph_memset_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_graph_memset_probe.log
 cd /tmp
 for set in c4 c5; do
   names="c4_h0 c4_h1 c4_h2"; [ $set = c5 ] && names="c5_h4 c5_h5"

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 #include "opts.h"
 
 #define NT 256
@@ -662,7 +663,7 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
             else hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, v2);
         }
         if (p.dkern) {
-            if (!p.dimg) hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            if (!p.dimg) savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(float), st);
             dim3 grid(tiles_x * tiles_y, a->N);
             if (kind == 3) hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
             else hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
@@ -679,7 +680,7 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
     if (p.dkern) {
         if (fast) {
             const int chunk = 512;
-            hipMemsetAsync(p.dkern, 0, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(float), st);
             dim3 gk((a->H * a->W + chunk - 1) / chunk, a->N);
             if (fast == 3) hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 3>), gk, dim3(NT), 0, st, p, chunk);
             else hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 1>), gk, dim3(NT), 0, st, p, chunk);

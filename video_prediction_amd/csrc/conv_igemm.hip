@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 
 #include "conv_common.h"
 #include <stdlib.h>
@@ -885,7 +886,7 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
                             s_w = dg ? a->x_sw : a->y_sw;
             const bool dense = (s_w == Nout) && (s_h == dW_ * Nout) && (dD == 1 || s_d == dH * dW_ * Nout) &&
                                (s_n == dD * dH * dW_ * Nout);
-            if (dense) hipMemsetAsync(p.out, 0, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
+            if (dense) savp_zero_async(p.out, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
             else splitk = 1;
         }
         p.splitk = splitk;

@@ -17,6 +17,7 @@
 // LDS layouts: pixel stride CP = Cpad + 8 elements (16 B x odd), patch row pitch = 8 (mod 16) 16-byte slots, weight
 // rows 16 B x odd -> every ds_read_b128 lane group of the MFMA fragments is bank-conflict-free.
 #include "conv_common.h"
+#include "zero_fill.h"
 #include <type_traits>
 
 
@@ -442,7 +443,7 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         const long long dD = Dm;
         const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (dD == 1 || d_sd == dH * dW_ * Nout) &&
                            (d_sn == dD * dH * dW_ * Nout);
-        if (dense) hipMemsetAsync(p.out, 0, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
+        if (dense) savp_zero_async(p.out, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
         else splitk = 1;
     }
     p.splitk = splitk;

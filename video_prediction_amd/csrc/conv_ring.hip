@@ -19,6 +19,7 @@
 // Applies to stride-1 and strided 2-D / 3-D FPROP and DGRAD problems in SAVP_PREC_BF16 exactly like conv_patch.hip (same ConvP
 // geometry fields, filled by conv_ring_try); the plain fp32 epilogue (bias / LeakyReLU / sigmoid / beta / split-K) is kept.
 #include "conv_common.h"
+#include "zero_fill.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -957,7 +958,7 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
     if (p.splitk > 1 && !a->beta) {
         const int Dm = dg ? a->D : a->Do;
         const long long dW_ = dg ? a->W : a->Wo;
-        hipMemsetAsync(p.out, 0, (size_t)a->N * Dm * dH * dW_ * (Nout + p.gap) * sizeof(float), st);
+        savp_zero_async(p.out, (size_t)a->N * Dm * dH * dW_ * (Nout + p.gap) * sizeof(float), st);
     }
     ablate_init();
     hipError_t err = (pl.nw == 8) ? launch_ring_tile<8>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 
 #define NT 256
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
@@ -133,7 +134,7 @@ extern "C" int savp_frame_ssim(void* stream, const float* a, int64_t a_st, int64
     const size_t lds = (size_t)2 * H * W * sizeof(float);
     if (lds > 64 * 1024) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(out, 0, (size_t)T * B * sizeof(float), st);
+    savp_zero_async(out, (size_t)T * B * sizeof(float), st);
     hipLaunchKernelGGL(frame_ssim_kernel, dim3((unsigned)(T * B * C)), dim3(NT), lds, st, a, (long long)a_st, (long long)a_sb, b,
                        (long long)b_st, (long long)b_sb, B, H, W, C, out);
     return LAUNCH_OK();

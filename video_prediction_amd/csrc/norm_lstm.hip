@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
 #include "opts.h"
 
@@ -385,7 +386,7 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
     }
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        if (!a->ws_clean) hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(float), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
@@ -424,7 +425,7 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
     }
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        if (!a->ws_clean) hipMemsetAsync(a->ws, 0, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(float), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
@@ -1534,7 +1535,7 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
         w.so = a->ws_stats ? a->ws : w.k2 + (size_t)N * F;
         if (a->stats1_ready && !a->ws_stats) return SAVP_EINVAL;
         if (!a->stats1_ready) {
-        if (!(a->ws_stats && a->ws_stats_clean)) hipMemsetAsync(w.s1, 0, (size_t)N * F * 10 * sizeof(float), st);
+        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.s1, (size_t)N * F * 10 * sizeof(float), st);
         if (a->gates_bf16) return SAVP_EINVAL;             // bf16 gates come with their statistics from the conv epilogue
         // pass 1: shifted sums of the gate tensor, the instance-norm statistics kernel with C = 4F
         InormP q;
@@ -1582,7 +1583,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
         w.r2 = a->ws_stats ? a->ws_stats : a->ws;
         w.r1 = w.r2 + (size_t)N * F * 2;
         w.dz2 = a->ws_stats ? a->ws : w.r1 + (size_t)N * 4 * F * 2;
-        if (!(a->ws_stats && a->ws_stats_clean)) hipMemsetAsync(w.r2, 0, (size_t)N * F * 10 * sizeof(float), st);
+        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.r2, (size_t)N * F * 10 * sizeof(float), st);
         const int rows = NT / (F / 4);
         long long c = ((long long)HW * N + 511) / 512;
         if (c < rows) c = rows;

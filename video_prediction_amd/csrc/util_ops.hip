@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 #include "opts.h"
 
 #define NT 256
@@ -760,7 +761,7 @@ extern "C" int savp_dense_fwd(void* stream, const float* x, int64_t x_row_stride
                            out);
         return LAUNCH_OK();
     }
-    hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
+    savp_zero_async(out, (size_t)M * C * sizeof(float), st);
     size_t lds = (size_t)(M * DKC + DKC * C + M * C) * sizeof(float);
     const long long chunks = (K + DKC - 1) / DKC;
     int nsub = (int)((chunks + 255) / 256);                    // at most ~256 workgroups (fewer atomics for very long K)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 
 #define NT 256
 #define RELU_SHIFT 1e-12f
@@ -96,7 +97,7 @@ extern "C" int savp_image_warp_bwd(void* stream, const SavpWarpArgs* a) {
     int rc = fill_warp(p, a);
     if (rc || !p.dout || !p.dflows) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (p.dimg) hipMemsetAsync(p.dimg, 0, (size_t)a->N * a->H * a->W * a->C * sizeof(float), st);
+    if (p.dimg) savp_zero_async(p.dimg, (size_t)a->N * a->H * a->W * a->C * sizeof(float), st);
     long long total = (long long)a->N * a->H * a->W * a->K;
     hipLaunchKernelGGL((image_warp_kernel<true>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, st, p);
     return LAUNCH_OK();

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "savp_hip.h"
+#include "zero_fill.h"
 
 #define NT 256
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
@@ -403,7 +404,7 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
     // ws must hold 8 + 2C + 2K floats.  On return ws[1] = 1/sigma (device scalar for pack_weights), u_new = u_final.
     if (!W || !u || !ws || K < 1 || C < 1) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, (size_t)(8 + C) * sizeof(float), st);
+    savp_zero_async(ws, (size_t)(8 + C) * sizeof(float), st);
     float* a = ws + 8 + 2 * C;
     unsigned nb = (unsigned)((K + 3) / 4);
     if (nb > 2048) nb = 2048;
@@ -473,7 +474,7 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
     // ws as left by savp_sn_fwd for the same (W, u).  G = dL/dW_bar [K,C]; dW = dL/dW.
     if (!W || !u || !ws || !G || !dW) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws + 5, 0, 2 * sizeof(float), st);
+    savp_zero_async(ws + 5, 2 * sizeof(float), st);
     long long n = (long long)K * C;
     unsigned nb = (unsigned)((n + NT - 1) / NT);
     if (nb > 2048) nb = 2048;
