@@ -243,16 +243,16 @@ def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_tra
     eager launches (fp32 datapath: summation order of the atomically accumulated statistics only), also when train-step replays run
     in between.  (b) The pre-zeroed reduction arena (kernels.ZeroArena) is shared by every launch sequence on the device: a replayed
     step leaves its sums in the arena's head whatever the host-side offset says, so eager callers between two replays -- the eval
-    summary of scripts/train.py -- must continue behind the replay's mark (ZeroArena.replayed), never inside it.  (c) Nothing here
-    synchronizes the host between a replay and the eager launches around it (except once, to look at the arena): on the legacy
-    default stream that sequence put NaNs into the variables before _StepProgram.run() moved replays onto the program's own stream
-    (tests/tools/ab_calls/r04_call15.py; profiles/r04_ab_calls.md, calls 15-16)."""
+    summary of scripts/train.py -- must continue behind the replay's mark (ZeroArena.replayed), never inside it.  (c) Twenty replayed steps of this
+    small fp32 model with stream-level host synchronization only: before csrc/zero_fill.h the variables went NaN after ~8 of them (memset
+    NODES of a replayed hipGraph are not ordered with their neighbours on this ROCm build; DESIGN.md section 3, profiles/r04_ab_calls.md
+    calls 14-22)."""
     from tests.gpu_model_checks import make_hparams
     from video_prediction_amd import kernels as K
     from video_prediction_amd.models.savp_model import SAVPEngine
     monkeypatch.setenv('SAVP_GRAPH', '1')
     saved = K._ARENAS.pop('cuda:0', None)
-    K._ARENAS['cuda:0'] = K.ZeroArena(torch.device('cuda:0'), floats=1 << 20)      # small: eager takes wrap within the test
+    K._ARENAS['cuda:0'] = K.ZeroArena(torch.device('cuda:0'), floats=1 << 20)      # small: looking at the whole arena below stays cheap
     try:
         hp = make_hparams(context_frames=2, sequence_length=4, nz=8, lr=0.0, l1_weight=100.0, kl_weight=1.0, video_sn_gan_weight=0.0,
                           video_sn_vae_gan_weight=0.0, vae_gan_feature_cdist_weight=0.0)        # lr = 0: the variables stay put
@@ -273,7 +273,7 @@ def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_tra
             if i == 0:
                 torch.cuda.synchronize()
                 assert float(arena.buf[:mark].abs().sum()) > 0.0 and float(arena.buf[mark:].abs().sum()) == 0.0
-            got = eng.generate(noise)                           # eager takes: behind the mark, wrapping (reset) when the arena is full
+            got = eng.generate(noise)                           # eager takes: behind the replay's mark
             assert float((got - ref).abs().max()) <= 1e-4, i
         # (a) replayed unroll
         eng.infer_graph = True
