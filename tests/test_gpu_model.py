@@ -238,6 +238,54 @@ def test_hipgraph_replay_matches_eager_steps(monkeypatch):
     assert eng.graph is not None
 
 
+def _adam_moments_after(monkeypatch, graph, precision, steps):
+    """Adam moments of both groups after `steps` train steps at lr = 0 (the variables never move, so every step's gradient is a fixed
+    function of that step's seeded noise: replayed and eager runs must accumulate the same m and v), plus the per-step losses."""
+    from tests.gpu_model_checks import make_hparams
+    from video_prediction_amd import kernels as K
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    monkeypatch.setenv('SAVP_GRAPH', '1' if graph else '0')
+    K.set_conv_precision(precision)
+    try:
+        hp = make_hparams(context_frames=2, sequence_length=6, clip_length=4, nz=8, lr=0.0, beta1=0.5, l1_weight=100.0, kl_weight=1.0,
+                          kl_anneal='none', video_sn_gan_weight=0.1, video_sn_vae_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0)
+        eng = SAVPEngine(hp, (64, 64, 3), 2, mode='train', seed=4)
+        eng.set_images(torch.rand(6, 2, 64, 64, 3, generator=torch.Generator().manual_seed(1)).cuda(), time_major=True)
+        losses = []
+        for _ in range(steps):
+            info = eng.train_step()
+            losses.append(torch.stack([info['d_loss'].reshape(()), info['g_loss'].reshape(())]).clone())      # no host sync here
+        G = eng.store.groups
+        out = {g: (G[g].m.detach().double().cpu(), G[g].v.detach().double().cpu()) for g in ('g', 'd')}
+        return out, torch.stack(losses).cpu(), eng.graph is not None
+    finally:
+        K.set_conv_precision('f32')
+
+
+@pytest.mark.parametrize('precision,tol', [('f32', 2e-3), ('bf16', 5e-2)])
+def test_replayed_steps_accumulate_the_same_adam_moments_as_eager_steps(monkeypatch, precision, tol):
+    """Gradient-level statement of "the replay IS the step", over more replays than any other test makes: 16 steps at lr = 0, replayed
+    against launched one by one, from identical seeds; Adam's m (beta1 = 0.5: the last few gradients) and v (beta2 = 0.999: all of them)
+    of the generator / encoder and discriminator groups must agree -- fp32 datapath to summation-order noise, bf16 datapath to its
+    run-to-run spread (atomically summed statistics feed bf16 roundings).  Before csrc/zero_fill.h the replayed run
+    of such a model went non-finite after ~8 steps (memset nodes of a replayed hipGraph)."""
+    steps = 16
+    me, le, ge = _adam_moments_after(monkeypatch, False, precision, steps)
+    mg, lg, gg = _adam_moments_after(monkeypatch, True, precision, steps)
+    assert gg and not ge
+    assert torch.isfinite(lg).all() and torch.isfinite(le).all()
+    worst = 0.0
+    for grp in ('g', 'd'):
+        for which, name in ((0, 'm'), (1, 'v')):
+            a, b = me[grp][which], mg[grp][which]
+            assert torch.isfinite(b).all(), (grp, name)
+            e = float((a - b).norm() / max(float(a.norm()), 1e-30))
+            worst = max(worst, e)
+            assert e <= tol, (precision, grp, name, e)
+    rel = ((lg - le).abs() / le.abs().clamp_min(1.0)).max()
+    assert float(rel) <= (2e-3 if precision == 'f32' else 5e-2), (precision, float(rel))
+
+
 def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_train_replay(monkeypatch):
     """(a) SAVPEngine.generate(): from the second call on the weight preparation + unroll is ONE hipGraph replay; same frames as the
     eager launches (fp32 datapath: summation order of the atomically accumulated statistics only), also when train-step replays run
