@@ -335,3 +335,35 @@ def test_fused_operator_entries_refuse_halves_that_do_not_fit(hip_lib):
     n.conv.mode, n.conv.y, n.norm.x.p = lib.CONV_FPROP, 0x1000, 0x2000
     assert hip_lib.savp_conv_in_act_fwd(None, ctypes.byref(n)) == -1
     assert hip_lib.savp_convlstm_cell_fwd(None, None) == -1 and hip_lib.savp_conv_in_act_bwd(None, None) == -1
+
+
+def test_zero_arena_offsets_after_a_replay():
+    """kernels.ZeroArena on the host side (CPU tensors: no launch involved): fresh slices are disjoint and zero, the high-water mark
+    follows the takes, a full arena wraps through reset(), and replayed(mark) puts eager takes behind a captured sequence's slices
+    whatever the host offset said (models/savp_model._StepProgram.run)."""
+    import torch
+    from video_prediction_amd import kernels as K
+    a = K.ZeroArena(torch.device('cpu'), floats=1024)
+    s1, s2 = a.take(100), a.take(1)
+    assert s1.numel() == 128 and s2.numel() == 64 and a.off == 192 and a.hi == 192          # rounded up to 64 floats
+    assert s1.data_ptr() + 128 * 4 == s2.data_ptr()
+    s1.fill_(3.0)
+    a.hi = 0                                  # what a capture does before it runs the body
+    a.reset()
+    assert a.off == 0 and float(a.buf.abs().sum()) == 0.0
+    a.take(300)
+    a.take(200)
+    mark = a.hi
+    assert mark == 320 + 256 and a.off == mark
+    # an eager caller runs on, wraps (reset: memset + rewind) and leaves a small offset behind ...
+    for _ in range(3):
+        a.take(256).fill_(1.0)
+    assert a.off < mark
+    # ... then the captured sequence is replayed: device memory is zero from `mark` on and used below it
+    a.buf.zero_()
+    a.buf[:mark].fill_(7.0)
+    a.replayed(mark)
+    nxt = a.take(64)
+    assert a.off == mark + 64 and float(nxt.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        a.take(4096)
