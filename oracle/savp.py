@@ -243,8 +243,13 @@ def _conv_rnn(vs, inputs, state, filters, hp):
     raise NotImplementedError
 
 
-def savp_cell_zero_state(images, hp, zs=None):
-    """SAVPCell.zero_state, savp_model.py:263-293,344-352 (learn_initial_state=False)."""
+def savp_cell_zero_state(images, hp, zs=None, vs=None):
+    """SAVPCell.zero_state, savp_model.py:263-308,344-352.
+
+    learn_initial_state (:295-307): the conv-RNN states and the rnn_z state are variables `initial_state_<i>/initial_state`, i = position in
+    nest.flatten of {'conv_rnn_states': [...], 'rnn_z_state': ...} (dict keys in sorted order, LSTM state tuples as (c, h)), zero-initialised,
+    created in the scope the cell is constructed in (vs = that scope: `generator/`, savp_model.py:689-693) and tiled over the batch (:346-348);
+    both unrolls of generator_fn share them (the second one reuses the scope, :730-732)."""
     T, B, H, W, C = images.shape
     enc, dec = layer_specs(hp, H, W)
     dt = images.dtype
@@ -258,15 +263,33 @@ def savp_cell_zero_state(images, hp, zs=None):
         h_, w_ = h_ * 2, w_ * 2
         if use_conv_rnn:
             states.append((h_, w_, out_channels))
+    learn = bool(getattr(hp, 'learn_initial_state', False))
+    if learn and vs is None:
+        raise ValueError('learn_initial_state needs the scope the initial-state variables live in')
+    counter = [0]
+
+    def initial(shape):
+        if not learn:
+            return torch.zeros((B,) + shape, dtype=dt)
+        v = vs['initial_state_%d/initial_state' % counter[0]]
+        counter[0] += 1
+        assert tuple(v.shape) == shape, (tuple(v.shape), shape)
+        return v.to(dt)[None].expand((B,) + shape)                              # tf.tile(x[None], [batch_size, 1, ...]) (:346-348)
+
     conv_rnn_states = []
     for (sh, sw, sc) in states:
-        z = torch.zeros(B, sh, sw, sc, dtype=dt)
-        conv_rnn_states.append((z, z) if hp.conv_rnn == 'lstm' else z)
+        if hp.conv_rnn == 'lstm':
+            c0 = initial((sh, sw, sc))                                           # LSTMStateTuple(c, h): c first in nest.flatten
+            h0 = initial((sh, sw, sc))
+            conv_rnn_states.append((c0, h0))
+        else:
+            conv_rnn_states.append(initial((sh, sw, sc)))
     st = {'time': 0, 'gen_image': torch.zeros(B, H, W, C, dtype=dt),
           'last_images': [images[0]] * hp.last_frames, 'conv_rnn_states': conv_rnn_states}
     if zs is not None and hp.use_rnn_z:
-        zz = torch.zeros(B, hp.nz, dtype=dt)
-        st['rnn_z_state'] = (zz, zz)
+        c0 = initial((hp.nz,))
+        h0 = initial((hp.nz,))
+        st['rnn_z_state'] = (c0, h0)
     return st
 
 
@@ -465,7 +488,7 @@ def generator_given_z_fn(vs, inputs, mode, hp, ground_truth_sampling=None):
     ground_truth = torch.cat([torch.ones(hp.context_frames, B, dtype=torch.bool),
                               torch.as_tensor(ground_truth_sampling, dtype=torch.bool)], dim=0)   # :333-334
     cell_vs = vs.sub('rnn').sub('savp_cell')
-    states = savp_cell_zero_state(images, hp, zs)
+    states = savp_cell_zero_state(images, hp, zs, vs)
     outs = []
     for t in range(T1):
         step_in = {'images': images[t]}

@@ -225,6 +225,23 @@ def generator_variable_specs(hp, image_shape):
         cin = hp.ngf + (nm * C if hp.dependent_mask else 0)
         specs[p + 'masks/conv2d/kernel'] = ((3, 3, cin, nm), 'tn0.02')
         specs[p + 'masks/conv2d/bias'] = ((nm,), 'zeros')
+    if getattr(hp, 'learn_initial_state', False):
+        # savp_model.py:295-307: one variable per entry of nest.flatten({'conv_rnn_states': [...], 'rnn_z_state': ...}) -- dict keys sorted,
+        # LSTM state tuples as (c, h) -- created where the cell is constructed (scope `generator/`, not `generator/rnn/savp_cell/`)
+        shapes = []
+        h_, w_ = H, W
+        for f, use_rnn in enc:
+            h_, w_ = h_ // 2, w_ // 2
+            if use_rnn:
+                shapes += [(h_, w_, f)] * (2 if hp.conv_rnn == 'lstm' else 1)
+        for f, use_rnn in dec:
+            h_, w_ = h_ * 2, w_ * 2
+            if use_rnn:
+                shapes += [(h_, w_, f)] * (2 if hp.conv_rnn == 'lstm' else 1)
+        if nz and hp.use_rnn_z:
+            shapes += [(nz,)] * (2 if hp.rnn == 'lstm' else 1)
+        for i, shp in enumerate(shapes):
+            specs['generator/initial_state_%d/initial_state' % i] = (shp, 'zeros')
     return specs
 
 
