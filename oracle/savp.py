@@ -287,9 +287,12 @@ def savp_cell_zero_state(images, hp, zs=None, vs=None):
     st = {'time': 0, 'gen_image': torch.zeros(B, H, W, C, dtype=dt),
           'last_images': [images[0]] * hp.last_frames, 'conv_rnn_states': conv_rnn_states}
     if zs is not None and hp.use_rnn_z:
-        c0 = initial((hp.nz,))
-        h0 = initial((hp.nz,))
-        st['rnn_z_state'] = (c0, h0)
+        if hp.rnn == 'lstm':
+            c0 = initial((hp.nz,))
+            h0 = initial((hp.nz,))
+            st['rnn_z_state'] = (c0, h0)
+        else:                                                                    # GRUCell: the state is h (:288-291)
+            st['rnn_z_state'] = initial((hp.nz,))
     return st
 
 
@@ -313,11 +316,16 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
     rnn_z_state = None
     if 'zs' in inputs:
         if hp.use_rnn_z:
-            if hp.rnn != 'lstm':
-                raise NotImplementedError
-            v = vs.sub('lstm_z').sub('basic_lstm_cell')
-            c0, h0 = states['rnn_z_state']
-            rnn_z, rnn_z_state = tf_ops.lstm_cell(inputs['zs'], c0, h0, v['kernel'], v['bias'])  # :431
+            if hp.rnn == 'lstm':
+                v = vs.sub('lstm_z').sub('basic_lstm_cell')
+                c0, h0 = states['rnn_z_state']
+                rnn_z, rnn_z_state = tf_ops.lstm_cell(inputs['zs'], c0, h0, v['kernel'], v['bias'])  # :431
+            elif hp.rnn == 'gru':                                                # _rnn_func, :358-359: tf.contrib.rnn.GRUCell
+                v = vs.sub('gru_z').sub('gru_cell')
+                rnn_z, rnn_z_state = tf_ops.gru_cell(inputs['zs'], states['rnn_z_state'], v['gates/kernel'], v['gates/bias'],
+                                                     v['candidate/kernel'], v['candidate/bias'])
+            else:
+                raise NotImplementedError(hp.rnn)                                 # :360-361
             state_action_z = rnn_z
         else:
             state_action_z = inputs['zs']
@@ -619,10 +627,18 @@ def _e_rnn(vs, h, hp):
     T, B = h.shape[:2]
     s = vs.sub('layer_%d' % (hp.n_layers + 1))
     h = ops.dense(h.reshape(T * B, -1), s['dense/kernel'], s['dense/bias']).reshape(T, B, -1)
-    if hp.rnn != 'lstm':
-        raise NotImplementedError('rnn=%s (GRUCell) is not restated' % hp.rnn)
     r = vs.sub(hp.rnn)
-    return basic_lstm_unroll(r['rnn/basic_lstm_cell/kernel'], r['rnn/basic_lstm_cell/bias'], h)
+    if hp.rnn == 'lstm':
+        return basic_lstm_unroll(r['rnn/basic_lstm_cell/kernel'], r['rnn/basic_lstm_cell/bias'], h)
+    if hp.rnn == 'gru':                                                          # :38-39: tf.contrib.rnn.GRUCell, zero initial state
+        g = r.sub('rnn').sub('gru_cell')
+        state = torch.zeros(B, g['candidate/bias'].shape[0], dtype=h.dtype)
+        out = []
+        for t in range(T):
+            o, state = tf_ops.gru_cell(h[t], state, g['gates/kernel'], g['gates/bias'], g['candidate/kernel'], g['candidate/bias'])
+            out.append(o)
+        return torch.stack(out)
+    raise NotImplementedError(hp.rnn)
 
 
 def _z_heads(vs, h):

@@ -144,6 +144,18 @@ def lstm_cell(x, c, h, kernel, bias, forget_bias=1.0):
     return h_new, (c_new, h_new)
 
 
+def gru_cell(x, h, gates_kernel, gates_bias, candidate_kernel, candidate_bias):
+    """tf.contrib.rnn.GRUCell (= tf.nn.rnn_cell.GRUCell, TensorFlow 1.x rnn_cell_impl.GRUCell.call; un-vendored dependency
+    tensorflow>=1.9, algorithm restated from its published source):
+      [r, u] = sigmoid([x, h] @ gates_kernel + gates_bias)   (r first);  c = tanh([x, r*h] @ candidate_kernel + candidate_bias);
+      h' = u*h + (1-u)*c.   Call sites: savp_model.py:38-41 (encoder tail), :358-362 (_rnn_func: rnn_z)."""
+    ru = torch.sigmoid(torch.cat([x, h], dim=-1) @ gates_kernel + gates_bias)
+    r, u = torch.chunk(ru, 2, dim=-1)
+    c = torch.tanh(torch.cat([x, r * h], dim=-1) @ candidate_kernel + candidate_bias)
+    h_new = u * h + (1.0 - u) * c
+    return h_new, h_new
+
+
 def adam_update(p, g, m, v, lr, beta1, beta2, t, epsilon=1e-8):
     """tf.train.AdamOptimizer step t (1-based): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
     m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2; p -= lr_t*m/(sqrt(v)+eps).  Call site: base_model.py:486-487."""

@@ -165,6 +165,26 @@ def test_lstm_cell_gate_order_and_forget_bias_by_hand():
     assert nz == 1
 
 
+def test_gru_cell_gate_order_and_update_convention_by_hand():
+    """tf.contrib.rnn.GRUCell: [r, u] = sigmoid([x, h] @ gates_kernel + gates_bias) with r FIRST; the candidate sees [x, r * h];
+    h' = u * h + (1 - u) * c (the update gate keeps the OLD state, unlike some other GRU write-ups)."""
+    x, h = torch.tensor([[0.5]]), torch.tensor([[-0.25]])
+    gk = torch.tensor([[0.3, -0.7], [1.1, 0.4]])            # rows: x, h; columns: r, u
+    gb = torch.tensor([1.0, 1.0])                            # GRUCell's gate bias is initialised to 1
+    ck = torch.tensor([[0.9], [-1.3]])
+    cb = torch.tensor([0.05])
+    h1, state = T.gru_cell(x, h, gk, gb, ck, cb)
+    sig = lambda v: 1.0 / (1.0 + math.exp(-v))
+    r = sig(0.5 * 0.3 - 0.25 * 1.1 + 1.0)
+    u = sig(0.5 * -0.7 - 0.25 * 0.4 + 1.0)
+    c = math.tanh(0.5 * 0.9 + (r * -0.25) * -1.3 + 0.05)
+    assert abs(float(h1) - (u * -0.25 + (1.0 - u) * c)) < 1e-7 and state is h1
+    # zero input, zero state, zero candidate bias: the state stays zero whatever the gates say
+    z = torch.zeros(2, 3)
+    h2, _ = T.gru_cell(z, z, torch.randn(6, 6), torch.ones(6), torch.randn(6, 3), torch.zeros(3))
+    assert float(h2.abs().max()) == 0.0
+
+
 def test_adam_first_two_steps_by_hand():
     """tf.train.AdamOptimizer docs: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m, v EMA; var -= lr_t m / (sqrt(v) + eps) -- epsilon
     OUTSIDE the bias correction (differs from torch.optim.Adam)."""

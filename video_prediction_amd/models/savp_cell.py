@@ -104,6 +104,8 @@ class SAVPGenerator(object):
             raise NotImplementedError('HIP path covers transformation in (cdna, flow, dna) with last_frames=1')
         if tuple(hp.dilation_rate) != (1, 1):
             raise NotImplementedError('dilation_rate != (1, 1)')
+        if hp.nz and hp.use_rnn_z and hp.rnn != 'lstm':
+            raise NotImplementedError("rnn=%r: the latent's recurrent cell is built as an LSTMCell only (savp_model.py:354-362)" % (hp.rnn,))
         if hp.where_add not in ('input', 'all', 'middle'):
             raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
         if hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:

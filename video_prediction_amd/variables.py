@@ -72,6 +72,21 @@ def generator_variable_specs(hp, image_shape):
     H, W, C = image_shape
     specs = OrderedDict()
     nz = hp.nz
+    def rnn_cell_specs(scope, n_in, u):
+        """savp_model.py:36-41,354-362: 'lstm' = BasicLSTMCell / LSTMCell(name='basic_lstm_cell') -- kernel [in + u, 4u] with get_variable's
+        default initializer (glorot-uniform), zero bias; 'gru' = tf.contrib.rnn.GRUCell (default name 'gru_cell') -- gates/{kernel [in + u,
+        2u], bias = 1}, candidate/{kernel [in + u, u], bias = 0} (rnn_cell_impl.GRUCell.build)."""
+        if hp.rnn == 'lstm':
+            specs[scope + 'basic_lstm_cell/kernel'] = ((n_in + u, 4 * u), 'glorot')
+            specs[scope + 'basic_lstm_cell/bias'] = ((4 * u,), 'zeros')
+        elif hp.rnn == 'gru':
+            specs[scope + 'gru_cell/gates/kernel'] = ((n_in + u, 2 * u), 'glorot')
+            specs[scope + 'gru_cell/gates/bias'] = ((2 * u,), 'ones')
+            specs[scope + 'gru_cell/candidate/kernel'] = ((n_in + u, u), 'glorot')
+            specs[scope + 'gru_cell/candidate/bias'] = ((u,), 'zeros')
+        else:
+            raise NotImplementedError(hp.rnn)                                       # savp_model.py:361-362
+
     def encoder_specs(p, recurrent):
         """networks.encoder + the optional recurrent tail + the two heads under scope p (savp_model.py:21-51 posterior_fn with
         use_e_rnn, :54-85 prior_fn which always has the tail)."""
@@ -86,17 +101,12 @@ def generator_variable_specs(hp, image_shape):
                 specs[s + 'InstanceNorm/gamma'] = ((cout,), 'ones')
             cin = cout
         if recurrent:
-            if hp.rnn != 'lstm':
-                raise NotImplementedError('rnn=%r: only the BasicLSTMCell tail is built (savp_model.py:36-41)' % (hp.rnn,))
             u = hp.nef * 4
             s = p + 'layer_%d/' % (hp.n_layers + 1)
             specs[s + 'dense/kernel'] = ((cin, u), 'tn0.02')
             specs[s + 'dense/bias'] = ((u,), 'zeros')
-            # tf_utils.unroll_rnn = tf.nn.dynamic_rnn under scope hparams.rnn: '<rnn>/rnn/basic_lstm_cell/{kernel,bias}';
-            # BasicLSTMCell creates its kernel with get_variable's default initializer (glorot-uniform)
-            s = p + '%s/rnn/basic_lstm_cell/' % hp.rnn
-            specs[s + 'kernel'] = ((2 * u, 4 * u), 'glorot')
-            specs[s + 'bias'] = ((4 * u,), 'zeros')
+            # tf_utils.unroll_rnn = tf.nn.dynamic_rnn under scope hparams.rnn: '<rnn>/rnn/<cell name>/...'
+            rnn_cell_specs(p + '%s/rnn/' % hp.rnn, u, u)
             cin = u
         for head in ('z_mu', 'z_log_sigma_sq'):
             specs[p + head + '/dense/kernel'] = ((cin, nz), 'tn0.02')
@@ -109,8 +119,7 @@ def generator_variable_specs(hp, image_shape):
 
     p = 'generator/rnn/savp_cell/'
     if nz and hp.use_rnn_z:
-        specs[p + 'lstm_z/basic_lstm_cell/kernel'] = ((2 * nz, 4 * nz), 'glorot')
-        specs[p + 'lstm_z/basic_lstm_cell/bias'] = ((4 * nz,), 'zeros')
+        rnn_cell_specs(p + '%s_z/' % hp.rnn, nz, nz)                                # scope '%s_z' % rnn (savp_model.py:426)
     tile = hp.use_tile_concat
     zc = nz if tile else 0          # channels added by tile_concat
     enc, dec = layer_specs(hp.ngf, H, W)
