@@ -232,15 +232,38 @@ def _upsample(vs, h, hp):
 
 
 def _conv_rnn(vs, inputs, state, filters, hp):
-    """SAVPCell._conv_rnn_func, savp_model.py:364-391 (ablation_conv_rnn_norm=False)."""
+    """SAVPCell._conv_rnn_func, savp_model.py:364-391.  ablation_conv_rnn_norm (:380-384): the cell is built WITHOUT a normalizer (bias
+    path of the cells) and the layer's output h -- not the state handed to the next step -- goes through normalizer_fn, whose variables
+    live in its default scope `InstanceNorm` beside the cell's."""
     normalized = hp.conv_rnn_norm_layer != 'none'
     if normalized and hp.conv_rnn_norm_layer != 'instance':
         raise NotImplementedError(hp.conv_rnn_norm_layer)
     if hp.conv_rnn == 'lstm':
-        return conv_lstm_cell(vs, inputs, state, filters, normalized)
+        cell = conv_lstm_cell
     elif hp.conv_rnn == 'gru':
-        return conv_gru_cell(vs, inputs, state, filters, normalized)
-    raise NotImplementedError
+        cell = conv_gru_cell
+    else:
+        raise NotImplementedError
+    if getattr(hp, 'ablation_conv_rnn_norm', False):
+        if not normalized:
+            raise TypeError("ablation_conv_rnn_norm with conv_rnn_norm_layer='none': the reference calls normalizer_fn = None (:384)")
+        h, state = cell(vs, inputs, state, filters, False)
+        return ops.fused_instance_norm(h, vs['InstanceNorm/gamma'], vs['InstanceNorm/beta']), state
+    return cell(vs, inputs, state, filters, normalized)
+
+
+def _conv_rnn_layer(vs, idx, conv_rnn_h, conv_rnn_states, new_conv_rnn_states, filters, hp):
+    """The `if use_conv_rnn:` block of SAVPCell.call (savp_model.py:465-482 / :501-517).  ablation_rnn: the recurrent cell is replaced by
+    conv2d 5x5 -> norm_layer -> activation under scope `conv_h<idx>` and there is no state."""
+    if getattr(hp, 'ablation_rnn', False):
+        s = vs.sub('conv_h%d' % idx)
+        h = _maybe_tile_concat(ops.conv2d, s, 'conv2d', conv_rnn_h)
+        return _norm_act(s, h, hp)
+    s = vs.sub('%s_h%d' % (hp.conv_rnn, idx))
+    state = conv_rnn_states[len(new_conv_rnn_states)]
+    h, state = _conv_rnn(s, conv_rnn_h, state, filters, hp)
+    new_conv_rnn_states.append(state)
+    return h
 
 
 def savp_cell_zero_state(images, hp, zs=None, vs=None):
@@ -263,6 +286,8 @@ def savp_cell_zero_state(images, hp, zs=None, vs=None):
         h_, w_ = h_ * 2, w_ * 2
         if use_conv_rnn:
             states.append((h_, w_, out_channels))
+    if getattr(hp, 'ablation_rnn', False):
+        states = []                                                              # `and not self.hparams.ablation_rnn` (:272,277,288)
     learn = bool(getattr(hp, 'learn_initial_state', False))
     if learn and vs is None:
         raise ValueError('learn_initial_state needs the scope the initial-state variables live in')
@@ -286,7 +311,7 @@ def savp_cell_zero_state(images, hp, zs=None, vs=None):
             conv_rnn_states.append(initial((sh, sw, sc)))
     st = {'time': 0, 'gen_image': torch.zeros(B, H, W, C, dtype=dt),
           'last_images': [images[0]] * hp.last_frames, 'conv_rnn_states': conv_rnn_states}
-    if zs is not None and hp.use_rnn_z:
+    if zs is not None and hp.use_rnn_z and not getattr(hp, 'ablation_rnn', False):
         if hp.rnn == 'lstm':
             c0 = initial((hp.nz,))
             h0 = initial((hp.nz,))
@@ -315,7 +340,10 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
     state_action_z = None
     rnn_z_state = None
     if 'zs' in inputs:
-        if hp.use_rnn_z:
+        if hp.use_rnn_z and getattr(hp, 'ablation_rnn', False):                  # :426-429: dense + tanh under scope fc_z, no state
+            v = vs.sub('fc_z')
+            state_action_z = torch.tanh(ops.dense(inputs['zs'], v['dense/kernel'], v['dense/bias']))
+        elif hp.use_rnn_z:
             if hp.rnn == 'lstm':
                 v = vs.sub('lstm_z').sub('basic_lstm_cell')
                 c0, h0 = states['rnn_z_state']
@@ -353,11 +381,8 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
         h = _downsample(s, h, hp, kernel_size)
         h = _norm_act(s, h, hp)
         if use_conv_rnn:
-            s = vs.sub('%s_h%d' % (hp.conv_rnn, i))
             conv_rnn_h = add_z(h) if hp.where_add == 'all' else h
-            conv_rnn_state = conv_rnn_states[len(new_conv_rnn_states)]
-            conv_rnn_h, conv_rnn_state = _conv_rnn(s, conv_rnn_h, conv_rnn_state, out_channels, hp)
-            new_conv_rnn_states.append(conv_rnn_state)
+            conv_rnn_h = _conv_rnn_layer(vs, i, conv_rnn_h, conv_rnn_states, new_conv_rnn_states, out_channels, hp)
         layers.append((h, conv_rnn_h) if use_conv_rnn else (h,))
 
     num_encoder_layers = len(layers)
@@ -372,11 +397,8 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
         h = _upsample(s, h, hp)
         h = _norm_act(s, h, hp)
         if use_conv_rnn:
-            s = vs.sub('%s_h%d' % (hp.conv_rnn, len(layers)))
             conv_rnn_h = add_z(h) if hp.where_add == 'all' else h
-            conv_rnn_state = conv_rnn_states[len(new_conv_rnn_states)]
-            conv_rnn_h, conv_rnn_state = _conv_rnn(s, conv_rnn_h, conv_rnn_state, out_channels, hp)
-            new_conv_rnn_states.append(conv_rnn_state)
+            conv_rnn_h = _conv_rnn_layer(vs, len(layers), conv_rnn_h, conv_rnn_states, new_conv_rnn_states, out_channels, hp)
         layers.append((h, conv_rnn_h) if use_conv_rnn else (h,))
     assert len(new_conv_rnn_states) == len(conv_rnn_states)
 

@@ -2,7 +2,7 @@
 (oracle/savp.py, which looks variables up by those names) are written separately; the product's ParamStore is built from the table and its
 parity is judged against the oracle.  For every option combination below: the oracle's generator_fn runs on exactly the table's variables
 (no missing name, no shape it cannot use) and READS every generator variable of the table (none is dead weight the product would carry,
-train, save and all-reduce for nothing).  Covers options the HIP path still refuses (learn_initial_state, conv_rnn_norm_layer='none', rnn='gru')."""
+train, save and all-reduce for nothing).  Covers options the HIP path still refuses (learn_initial_state, conv_rnn_norm_layer='none', rnn='gru', the two rnn ablations)."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +28,10 @@ CASES = {
     'learn_initial_state_gru': dict(nz=4, learn_initial_state=True, conv_rnn='gru'),
     'rnn_gru': dict(nz=4, rnn='gru', use_e_rnn=True, learn_prior=True, nef=8),
     'rnn_gru_learn_initial_state': dict(nz=4, rnn='gru', learn_initial_state=True),
+    'ablation_rnn': dict(nz=4, ablation_rnn=True),
+    'ablation_rnn_untiled_learn_initial_state': dict(nz=4, ablation_rnn=True, use_tile_concat=False, learn_initial_state=True),
+    'ablation_conv_rnn_norm': dict(nz=4, ablation_conv_rnn_norm=True),
+    'ablation_conv_rnn_norm_gru_untiled': dict(nz=4, ablation_conv_rnn_norm=True, conv_rnn='gru', use_tile_concat=False),
     'conv_rnn_norm_none': dict(nz=4, conv_rnn_norm_layer='none'),
     'conv_rnn_norm_none_untiled_gru': dict(nz=4, conv_rnn_norm_layer='none', use_tile_concat=False, conv_rnn='gru'),
 }

@@ -118,7 +118,10 @@ def generator_variable_specs(hp, image_shape):
             encoder_specs('generator/prior/', True)
 
     p = 'generator/rnn/savp_cell/'
-    if nz and hp.use_rnn_z:
+    if nz and hp.use_rnn_z and getattr(hp, 'ablation_rnn', False):
+        specs[p + 'fc_z/dense/kernel'] = ((nz, nz), 'tn0.02')                       # dense + tanh instead of the cell (savp_model.py:426-429)
+        specs[p + 'fc_z/dense/bias'] = ((nz,), 'zeros')
+    elif nz and hp.use_rnn_z:
         rnn_cell_specs(p + '%s_z/' % hp.rnn, nz, nz)                                # scope '%s_z' % rnn (savp_model.py:426)
     tile = hp.use_tile_concat
     zc = nz if tile else 0          # channels added by tile_concat
@@ -129,14 +132,29 @@ def generator_variable_specs(hp, image_shape):
             specs[scope + 'InstanceNorm/beta'] = ((c,), 'zeros')
             specs[scope + 'InstanceNorm/gamma'] = ((c,), 'ones')
 
+    ablation_rnn = bool(getattr(hp, 'ablation_rnn', False))
+    cell_norm = hp.conv_rnn_norm_layer != 'none' and not getattr(hp, 'ablation_conv_rnn_norm', False)
+
     def conv_rnn(scope, cx, f, add_z):
         cin = cx + (zc if add_z else 0)
+        if ablation_rnn:
+            # savp_model.py:474-478 / :510-513: conv2d 5x5 (+ dense(z) without tile_concat) -> norm_layer -> activation, scope conv_h<i>
+            specs[scope + 'conv2d/kernel'] = ((5, 5, cin, f), 'tn0.02')
+            specs[scope + 'conv2d/bias'] = ((f,), 'zeros')
+            if add_z and nz and not tile:
+                specs[scope + 'dense/kernel'] = ((nz, f), 'tn0.02')
+            norm(scope, f)
+            return
+        if getattr(hp, 'ablation_conv_rnn_norm', False) and hp.conv_rnn_norm_layer != 'none':
+            # :380-384: the cell is built without a normalizer; normalizer_fn(h) keeps its variables in its default scope beside the cell's
+            specs[scope + 'InstanceNorm/beta'] = ((f,), 'zeros')
+            specs[scope + 'InstanceNorm/gamma'] = ((f,), 'ones')
         if hp.conv_rnn == 'lstm':
             s = scope + 'basic_conv2dlstm_cell/'
             specs[s + 'kernel'] = ((5, 5, cin + f, 4 * f), 'tn0.02')
             if add_z and nz and not tile:
                 specs[s + 'weights'] = ((nz, 4 * f), 'tn0.02')
-            if hp.conv_rnn_norm_layer == 'none':
+            if not cell_norm:
                 specs[s + 'bias'] = ((4 * f,), 'zeros')
             else:
                 specs[s + 'input_transform_forget_output/gamma'] = ((4 * f,), 'ones')
@@ -150,7 +168,7 @@ def generator_variable_specs(hp, image_shape):
             if add_z and nz and not tile:
                 specs[s + 'gates/weights'] = ((nz, 2 * f), 'tn0.02')
                 specs[s + 'candidate/weights'] = ((nz, f), 'tn0.02')
-            if hp.conv_rnn_norm_layer == 'none':
+            if not cell_norm:
                 specs[s + 'gates/bias'] = ((2 * f,), 'ones')
                 specs[s + 'candidate/bias'] = ((f,), 'zeros')
             else:
@@ -174,7 +192,7 @@ def generator_variable_specs(hp, image_shape):
             specs[s + 'dense/kernel'] = ((nz, f), 'tn0.02')
         norm(s, f)
         if use_rnn:
-            conv_rnn(p + '%s_h%d/' % (hp.conv_rnn, i), f, f, bool(nz) and hp.where_add == 'all')
+            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, i), f, f, bool(nz) and hp.where_add == 'all')
         layer_out.append(f)
         prev = f
     ne = len(enc)
@@ -189,7 +207,7 @@ def generator_variable_specs(hp, image_shape):
             specs[s + 'dense/kernel'] = ((nz, f), 'tn0.02')
         norm(s, f)
         if use_rnn:
-            conv_rnn(p + '%s_h%d/' % (hp.conv_rnn, li), f, f, bool(nz) and hp.where_add == 'all')
+            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, li), f, f, bool(nz) and hp.where_add == 'all')
         layer_out.append(f)
         prev = f
     nl = len(layer_out)
@@ -241,13 +259,13 @@ def generator_variable_specs(hp, image_shape):
         h_, w_ = H, W
         for f, use_rnn in enc:
             h_, w_ = h_ // 2, w_ // 2
-            if use_rnn:
+            if use_rnn and not ablation_rnn:
                 shapes += [(h_, w_, f)] * (2 if hp.conv_rnn == 'lstm' else 1)
         for f, use_rnn in dec:
             h_, w_ = h_ * 2, w_ * 2
-            if use_rnn:
+            if use_rnn and not ablation_rnn:
                 shapes += [(h_, w_, f)] * (2 if hp.conv_rnn == 'lstm' else 1)
-        if nz and hp.use_rnn_z:
+        if nz and hp.use_rnn_z and not ablation_rnn:
             shapes += [(nz,)] * (2 if hp.rnn == 'lstm' else 1)
         for i, shp in enumerate(shapes):
             specs['generator/initial_state_%d/initial_state' % i] = (shp, 'zeros')
