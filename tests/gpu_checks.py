@@ -1003,10 +1003,22 @@ def failures(results):
 
 
 def smoke():
-    """One small hot-path invocation on cuda:0 checked against the oracle (used by __graft_entry__.smoke)."""
+    """One small hot-path invocation on cuda:0 checked against the oracle (used by __graft_entry__.smoke): the gate convolution and the
+    gate block on their own (fp32 and the bf16 bench datapath), then ONE train step of a tiny SAVP model (B = 1, T = 4: forward unroll,
+    BPTT, encoder, losses, Adam) against the oracle's step, and two more steps of the same engine so that the captured step is replayed."""
     res = check_conv(cases=('lstm5x5_32',)) + _check_lstm_case(np.random.default_rng(3), 2, 32, 32, 32, False, '_fused')
     # the bench datapath: bf16 LDS-patch FPROP / DGRAD / WGRAD kernels on the ConvLSTM gate-conv shape
     res += [('bf16/' + n, e, t) for (n, e, t) in check_conv(cases=('lstm5x5_32',), precision=1, tol=1e-2)]
+    from tests import gpu_model_checks as G
+    res += G.check_train_step(B=1, T=4, nz=8, steps=1, tag='smoke_train', video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                              vae_gan_feature_cdist_weight=0.0)
+    hp = G.make_hparams(context_frames=2, sequence_length=4, nz=8, video_sn_vae_gan_weight=0.0, video_sn_gan_weight=0.0,
+                        vae_gan_feature_cdist_weight=0.0)
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    eng = SAVPEngine(hp, (64, 64, 3), 1, mode='train', seed=4, device=DEV)
+    eng.set_images(torch.rand(4, 1, 64, 64, 3, generator=torch.Generator().manual_seed(2)).to(DEV), time_major=True)
+    losses = [float(eng.train_step()['g_loss']) for _ in range(3)]
+    res.append(('smoke_train/replayed_step_is_finite', 0.0 if (eng.graph is not None and all(np.isfinite(losses))) else 1.0, 0.0))
     bad = failures(res)
     if bad:
         raise AssertionError('smoke parity failures: %r' % bad)
