@@ -101,7 +101,10 @@ typedef struct SavpConvArgs {
                                       y (output-gradient) operand holds bf16.
                                       This is the ConvLSTM gate convolution (rnn_ops.py:121): the gate tensor makes its round trip to
                                       the gate kernels in half the bytes */
-    float* stats;                  /* FPROP / DGRAD: [N][C_dst][2] fp32, ATOMICALLY accumulated sum / sum of squares over the pixels
+    double* stats;                 /* FPROP / DGRAD: [N][C_dst][2] FLOAT64, atomically accumulated sum / sum of squares over the pixels
+                                      (per-workgroup fp32 partials folded in a fixed order inside the workgroup, then ONE float64 atomic per
+                                      (sample, channel, workgroup): a float64 sum of fp32 partials is exact, so the result does not depend on
+                                      the workgroups' arrival order -- two runs give the same bits)
                                       of every (sample, channel) of the destination's distance from the bias (y - bias = the fp32 accumulators,
                                       before any rounding: a large bias does not enter the one-pass variance; SavpInormArgs.stats_shift)
                                       = the statistics of the instance norm that follows (rnn_ops.py:148-149, normalization.py:146-170);
@@ -109,7 +112,10 @@ typedef struct SavpConvArgs {
                                       needs whole tiles (savp_conv_stats_ok() tells), no activation, no beta; SAVP_EINVAL otherwise */
     void* ws; int64_t ws_bytes;    /* optional caller-owned scratch (16-byte aligned; written before it is read, so one buffer can serve
                                       every call on a stream).  savp_conv_workspace_bytes() says how much a call can use; without it
-                                      the call takes a kernel that needs none */
+                                      the call takes a kernel that needs none.  FPROP / DGRAD: split-K needs it -- split s stores its share of
+                                      the destination block in slice s and one fold launch adds the slices in split order (deterministic; the
+                                      splits used to meet in the destination through float atomics); without scratch the call runs unsplit,
+                                      with too little it runs with as many splits as fit */
     int32_t dst_gap_at, dst_gap;   /* FPROP / DGRAD, SAVP_PREC_BF16 (ring kernel; SAVP_EINVAL elsewhere): the destination channel count
                                       (Cy for FPROP, Cx for DGRAD) counts LOGICAL channels; logical channel c >= dst_gap_at is physical
                                       channel c + dst_gap of the destination tensor, of the bias and of the packed weights (whose row
@@ -123,12 +129,12 @@ typedef struct SavpConvArgs {
        dy of a fused_instance_norm + activation whose input is nb_x (layers/normalization.py:146-170 differentiated; the ConvLSTM layer's
        conv_pool / upsample convolution in front of the cell input's x slice, savp_model.py:449-464).  The epilogue then also leaves the
        two per-(sample, channel) sums that norm's backward needs -- sum(dy') and sum(dy' * xhat), dy' = dy * act'(gamma * xhat + beta),
-       xhat = (x - mean) * rstd -- in nb_ws [N][nb_nc][2] (fp32, caller zeroes, atomically accumulated), so that
+       xhat = (x - mean) * rstd -- in nb_ws [N][nb_nc][2] (float64, caller zeroes, atomically accumulated: exact, order-independent), so that
        savp_instnorm_act_bwd(stats_ready) runs its apply pass alone. */
     const float* nb_x; int64_t nb_x_sn, nb_x_sp;     /* the norm's input [N][pixels][nb_nc], addressed like a SavpView (pixel = y * W + x) */
     const float *nb_mean, *nb_rstd;                  /* [N][nb_nc] saved by the forward pass */
     const float *nb_gamma, *nb_beta;                 /* [nb_nc] */
-    float* nb_ws;
+    double* nb_ws;                                   /* [N][nb_nc][2] FLOAT64 (see `stats`) */
     int32_t nb_c0, nb_nc, nb_act; float nb_alpha;    /* nb_act: 0 none, 1 relu, 2 leaky relu (nb_alpha) */
 } SavpConvArgs;
 
@@ -155,7 +161,8 @@ int64_t savp_tiled_z_workspace_bytes(int64_t nimg, int32_t C);
 /* 1: savp_conv would honour args->stats (any non-NULL value) for this problem; 0: it would return SAVP_EINVAL -- the caller then
  * leaves stats NULL and lets the instance norm take its own statistics.  No launch, no device access. */
 int savp_conv_stats_ok(const SavpConvArgs* args);
-/* bytes of args->ws this call would use (0: none) -- today the RGB-side weight gradient's per-workgroup partial sums */
+/* bytes of args->ws this call would use (0: none): the RGB-side weight gradient's per-workgroup partial sums; FPROP / DGRAD: the split-K
+ * slices (args->splitk > 1: exactly that many; 0 = automatic: an upper bound of what the library's heuristic can choose) */
 int64_t savp_conv_workspace_bytes(const SavpConvArgs* args);
 /* 1 when, with tile bits 8-9 == 0 (automatic algorithm), a problem-specific kernel takes this call and tile / splitk are not
  * looked at (a tuner can skip its search); 0 otherwise */
@@ -185,7 +192,8 @@ typedef struct SavpInormArgs {
     int32_t ndy; SavpView dy[4];
     SavpView dx; int32_t dx_beta;
     float* dgamma; float* dbeta;
-    float* ws;                     /* optional scratch [N*C*2]: selects the coalesced two-kernel path for planes of >= "inorm_min_hw" (64) pixels */
+    void* ws;                      /* optional scratch [N*C*2] FLOAT64 (8-byte aligned; sums of fp32 partials are exact there, so the statistics do not
+                                      depend on the workgroups' arrival order): selects the coalesced two-kernel path for planes of >= "inorm_min_hw" (64) pixels */
     int32_t ws_clean;              /* 1: the caller guarantees ws is all zero (e.g. a slice of an arena cleared once per step),
                                       0: the library clears it with a memset per call */
     int32_t out_c0[4], out_nc[4];  /* fwd: output k receives channels [out_c0, out_c0 + out_nc) of the normalised tensor, stored from
@@ -229,14 +237,15 @@ typedef struct SavpLstmArgs {
     float* dgates;
     float* dc_prev;
     float *dgamma1, *dbeta1, *dgamma2, *dbeta2;
-    float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(11 + HW) floats (N*F*HW if ws_stats is given): selects the
+    float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(22 + HW) floats (N*F*HW if ws_stats is given; 8-byte aligned): selects the
                                       coalesced three-pass kernels (F a power of two in [16, 256]); NULL = single fused
                                       kernel (HW <= 1024) */
-    float* ws_stats;               /* optional separate reduction workspace, N*F*11 floats */
+    float* ws_stats;               /* optional separate reduction workspace, N*F*22 floats, 8-byte aligned: float64 sums (forward: [N][4F][2] of the
+                                      gate tensor, then [N][F][2] of c_pre, then N*F fp32 shifts; backward: [N][F][2], [N][4F][2]) */
     int32_t ws_stats_clean;        /* 1: the caller guarantees ws_stats is all zero (see SavpInormArgs.ws_clean) */
     int32_t gates_bf16;            /* `gates` holds bf16 (written by savp_conv with out_bf16); coalesced kernels only */
-    int32_t stats1_ready;          /* fwd: the first N*4F*2 floats of ws_stats already hold the per-(sample, gate channel) sum / sum of
-                                      squares of the gate tensor (savp_conv's `stats` epilogue; the remaining N*F*3 floats zero): the
+    int32_t stats1_ready;          /* fwd: the first N*4F*2 float64 of ws_stats already hold the per-(sample, gate channel) sum / sum of
+                                      squares of the gate tensor (savp_conv's `stats` epilogue; the rest zero): the
                                       statistics pass over the gates is skipped -> conv + 2 launches per ConvLSTM cell */
     int32_t h_bf16;                /* fwd: bit k set = destination k of h' is a bf16 tensor (strides in bf16 elements) */
     int32_t dgates_bf16;           /* bwd: `dgates` receives bf16 (its readers are the gate convolution's DGRAD / WGRAD, which round to
@@ -285,7 +294,7 @@ int savp_adam(void* stream, int64_t n, float* p, const float* g, float* m, float
  * CDNA head + mask compositing (cdna_composite.hip): savp_model.py:551-559, 893-923, 634-646.
  * ------------------------------------------------------------------------------------------------------------ */
 int savp_cdna_kernels_fwd(void* stream, const float* raw, float* kern, int32_t N, int32_t kh, int32_t kw, int32_t K);
-int savp_cdna_kernels_bwd(void* stream, const float* raw, const float* dkern, float* draw, int32_t N, int32_t kh, int32_t kw,
+int savp_cdna_kernels_bwd(void* stream, const float* raw, const double* dkern, float* draw, int32_t N, int32_t kh, int32_t kw,
                           int32_t K);
 typedef struct SavpCdnaArgs {
     int32_t N, H, W, C, K, kh, kw;
@@ -294,7 +303,8 @@ typedef struct SavpCdnaArgs {
     SavpView out;                  /* [N,H,W,K*C], channel k*C+c */
     SavpView dout;                 /* bwd: gradient of out */
     SavpView dimg; int32_t dimg_beta;   /* bwd: p may be NULL */
-    float* dkern;                  /* bwd: [N, kh*kw, K], overwritten; may be NULL */
+    double* dkern;                 /* bwd: [N, kh*kw, K] FLOAT64, overwritten; may be NULL.  (The image tiles' partial sums meet here through
+                                      float64 atomics: exact, so the result does not depend on the tiles' arrival order) */
 } SavpCdnaArgs;
 int savp_cdna_apply_fwd(void* stream, const SavpCdnaArgs* a);
 int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a);
@@ -392,7 +402,7 @@ typedef struct {
 int savp_pack_weights_batch(void* stream, int32_t n, const SavpPackItem* items);
 int savp_fold_pool(void* stream, const float* in, float* out, int32_t k, int64_t C, int32_t adjoint);
 int savp_fold_bilinear(void* stream, const float* in, float* out, int32_t k, int32_t Cin, int32_t F, int32_t adjoint);
-/* ws: 8 + 2C + 2K floats; after fwd ws[0]=sigma, ws[1]=1/sigma; u_new receives u_final */
+/* ws: 8 + 2C + 2K + 2 (C + 2) floats, 8-byte aligned (the tail holds float64 accumulators of the forward sums: exact, order-independent); after fwd ws[0]=sigma, ws[1]=1/sigma; u_new receives u_final */
 int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, float* u_new);
 int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, const float* G, float* dW,
                 int32_t beta);

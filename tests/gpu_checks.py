@@ -567,14 +567,14 @@ def check_cdna_composite(seed=5):
         K.cdna_apply_fwd(imgd, kd, ov, kh, kw, Kk)
         out.append((tag + '/apply', rel_err(ov, ref_out), TOL_OP))
         dimg = torch.empty(N, H, W, C, device=DEV)
-        dk = torch.empty(N, kh * kw, Kk, device=DEV)
+        dk = torch.empty(N, kh * kw, Kk, device=DEV, dtype=torch.float64)
         K.cdna_apply_bwd(imgd, kd, dev(dout), dimg, dk, kh, kw, Kk)
         out.append((tag + '/dimg', rel_err(dimg, img.grad), 5e-5))
         # same through a 16-byte aligned channel slice of a wider buffer (the layout the generator uses: fast kernels)
         dwide = torch.zeros(N, H, W, 32 + 4 * ((Kk * C + 3) // 4) + 4, device=DEV)
         dwide[..., 32:32 + Kk * C] = dev(dout)
         dimg2 = torch.empty(N, H, W, C, device=DEV)
-        dk2 = torch.full((N, kh * kw, Kk), float('nan'), device=DEV)
+        dk2 = torch.full((N, kh * kw, Kk), float('nan'), device=DEV, dtype=torch.float64)
         K.cdna_apply_bwd(imgd, kd, dwide[..., 32:32 + Kk * C], dimg2, dk2, kh, kw, Kk)
         out.append((tag + '/dimg_fast', rel_err(dimg2, img.grad), 5e-5))
         draw2 = torch.empty(N, kh * kw * Kk, device=DEV)
@@ -1229,7 +1229,7 @@ def check_conv_stats_fp32(seed=43):
             xv, yv = x32[:, 0].clone(), y32[:, 0].clone()
             dst = yv if fprop else xv
             dst.fill_(float('nan'))
-            stats = torch.zeros(N, cdst, 2, device=DEV)
+            stats = torch.zeros(N, cdst, 2, device=DEV, dtype=torch.float64)
             try:
                 K.conv(mode, geom, xv, yv, wp, bias=bias, tile=tile, precision=1, w16=wp.to(torch.bfloat16), stats=stats)
             except RuntimeError:
@@ -1262,7 +1262,7 @@ def check_conv_stats_fp32(seed=43):
             a = K._fill_conv_args(lib.CONV_FPROP, geom, x32, y32, wp, None, 0, 0, 0.0, None, 0, 0, prec, wp.to(torch.bfloat16), None)
             ok = lib.get().savp_conv_stats_ok(ctypes.byref(a))
         out.append(('convstats_refused_prec%d/probe' % prec, 0.0 if ok == 0 else float('inf'), 1.0))
-        st = torch.zeros(2, 64, 2, device=DEV)
+        st = torch.zeros(2, 64, 2, device=DEV, dtype=torch.float64)
         try:
             K.conv(lib.CONV_FPROP, geom, x32, y32, wp, precision=prec, w16=wp.to(torch.bfloat16), stats=st)
             out.append(('convstats_refused_prec%d/call' % prec, float('inf'), 1.0))
@@ -1415,7 +1415,7 @@ def check_tuning_table(precision='bf16', max_entries=None, seed=41):
                 aux = strided(dst_shape, (y_sw if fprop else x_sw), torch.float32, a32)
                 ref = ref * torch.where(a32 > 0, torch.ones_like(ref), torch.full_like(ref, alpha))
             wp = (pack_wt(w32) if fprop else pack_wd(w32)).contiguous()
-            stats = torch.zeros(N, cdst, 2, device=DEV) if has_stats else None
+            stats = torch.zeros(N, cdst, 2, device=DEV, dtype=torch.float64) if has_stats else None
             K.conv(mode, geom, xv, yv, wp, bias=bias, beta=beta, act=act, alpha=alpha, aux=aux, splitk=sk, tile=tile, precision=prec,
                    w16=wp.to(bf) if has_w16 else None, stats=stats, dst_gap=gap)
             got = dst.float().reshape(dst_shape)
@@ -1523,7 +1523,7 @@ def check_norm_bwd_stats_epilogue(seed=61):
         K.instnorm_act_fwd(x, gamma, beta, [y], mean, rstd, act='relu')
         plain = torch.zeros(N, H, H, Cin, device=DEV)
         K.conv(lib.CONV_DGRAD, geom, plain, dy, wd32, w16=wd16, precision=1, dst_gap=gap, splitk=1)
-        ws = torch.zeros(N, f, 2, device=DEV)
+        ws = torch.zeros(N, f, 2, device=DEV, dtype=torch.float64)
         nb = dict(x=x, mean=mean, rstd=rstd, gamma=gamma, beta=beta, ws=ws, c0=0, act='relu')
         ok = K.conv_stats_ok(lib.CONV_DGRAD, geom, plain, dy, wd32, w16=wd16, dst_gap=gap, norm_bwd=dict(nb, ws=None))
         out.append(('nbstats/%s_offered' % name, 0.0 if ok else 1.0, 0.5))
@@ -1539,7 +1539,7 @@ def check_norm_bwd_stats_epilogue(seed=61):
         ref = torch.stack([d.sum(dim=(1, 2)), (d * xh).sum(dim=(1, 2))], dim=-1)
         out.append(('nbstats/%s_sums' % name, rel_err(ws, ref), 2e-5))
         # split-K: both sums are linear in the accumulators, every split adds its share (the 8x8 gate DGRAD needs the splits to fill the chip)
-        ws2 = torch.zeros(N, f, 2, device=DEV)
+        ws2 = torch.zeros(N, f, 2, device=DEV, dtype=torch.float64)
         got2 = torch.full((N, H, H, Cin), 123.0, device=DEV)
         try:
             K.conv(lib.CONV_DGRAD, geom, got2, dy, wd32, w16=wd16, precision=1, tile=0x311, splitk=2, dst_gap=gap, norm_bwd=dict(nb, ws=ws2))

@@ -471,31 +471,35 @@ GRAD_REL_L2 = 0.22      # bf16 datapath, per-variable gradient vs the oracle (me
 GRAD_REL_L2_BY_CASE = {'c5_step_golden.npz': 0.36}
 
 
-def _golden_step_check(fname, case):
-    """One bf16 train step at a bench shape with the shipped tuning table vs a committed oracle step (tests/golden/<fname>)."""
+def _bench_engine(fname, case, lr=None, graph=None):
+    """The engine of a bench case (tests.gpu_model_checks.BENCH_CASES) on the bf16 datapath with the shipped tuning table, its golden
+    file and noise.  lr: override the recipe's learning rate (0.0: the variables never move, every step repeats step 0)."""
     from tests import gpu_model_checks as G
-    from tests.golden.make_b16_step_golden import sample_index
     from video_prediction_amd import kernels as K
     from video_prediction_amd.models.savp_model import SAVPEngine
     gold = np.load(os.path.join(HERE, 'golden', fname))
     B, T = int(gold['B']), int(gold['T'])
     assert (B, T) == (case['B'], case['T'])
     hp, vals, images, noise = G.recipe_case(**case)
+    if lr is not None:
+        hp.lr = lr
     K.set_conv_precision('bf16')
-    saved = dict(K.AUTOTUNE, cache=dict(K.AUTOTUNE['cache']))
-    try:
-        K.enable_autotune(True)
-        n = K.load_tuning(os.path.join(os.path.dirname(HERE), 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
-        assert n >= 200
-        eng = SAVPEngine(hp, (case['H'], case['W'], case['C']), B, mode='train', values=vals, device='cuda:0')
-        eng.set_images(images.float().cuda(), time_major=True)
-        info = eng.train_step(noise, return_grads=True)
-        torch.cuda.synchronize()
-    finally:
-        K.set_conv_precision('f32')
-        K.AUTOTUNE.update(enabled=saved['enabled'], cache=saved['cache'])
+    K.enable_autotune(True)
+    n = K.load_tuning(os.path.join(os.path.dirname(HERE), 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
+    assert n >= 200
+    eng = SAVPEngine(hp, (case['H'], case['W'], case['C']), B, mode='train', values=vals, device='cuda:0')
+    if graph is not None:
+        eng.use_graph = graph
+    eng.set_images(images.float().cuda(), time_major=True)
+    return eng, gold, noise
+
+
+def _compare_with_golden(fname, case, gold, eng, info, grads, grad_tol):
+    """losses / sampled frames / per-variable gradients of one step against the committed oracle step.  grads: {'d_grads': {name:
+    tensor}, 'g_grads': {...}}.  Returns (checked, projected, worst)."""
+    from tests.golden.make_b16_step_golden import sample_index
+    B = case['B']
     bad = []
-    grad_tol = GRAD_REL_L2_BY_CASE.get(fname, GRAD_REL_L2)
 
     def lrel(got, want):
         return abs(float(got) - float(want)) / max(abs(float(want)), 0.05)
@@ -517,7 +521,7 @@ def _golden_step_check(fname, case):
         names = [k.split('/', 1)[1].rsplit('/', 1)[0] for k in gold.files if k.startswith(key + '/') and k.endswith('/norm')]
         gmax = max(float(gold['%s/%s/max' % (key, nme)]) for nme in names)
         for nme in names:
-            g = info[key][nme].detach()
+            g = grads[key][nme].detach()
             ref = gold['%s/%s/sample' % (key, nme)].astype(np.float64)
             got = g.reshape(-1)[torch.from_numpy(sample_index(nme, g.numel())).to(g.device)].double().cpu().numpy()
             checked += 1
@@ -542,8 +546,22 @@ def _golden_step_check(fname, case):
                     if pe > grad_tol and float(np.abs(proj.cpu().numpy() - want).max()) > 2e-3 * gmax * np.sqrt(g2.numel() / want.size):
                         bad.append((nme, 'projection rel L2 %.3f' % pe))
     assert checked >= 100
-    assert not bad, (bad, 'worst per-variable gradient rel L2 %.3f at %s' % worst)
+    assert not bad, (fname, bad, 'worst per-variable gradient rel L2 %.3f at %s' % worst)
     return checked, projected, worst
+
+
+def _golden_step_check(fname, case):
+    """One bf16 train step at a bench shape with the shipped tuning table vs a committed oracle step (tests/golden/<fname>)."""
+    from video_prediction_amd import kernels as K
+    saved = dict(K.AUTOTUNE, cache=dict(K.AUTOTUNE['cache']))
+    try:
+        eng, gold, noise = _bench_engine(fname, case)
+        info = eng.train_step(noise, return_grads=True)
+        torch.cuda.synchronize()
+    finally:
+        K.set_conv_precision('f32')
+        K.AUTOTUNE.update(enabled=saved['enabled'], cache=saved['cache'])
+    return _compare_with_golden(fname, case, gold, eng, info, info, GRAD_REL_L2_BY_CASE.get(fname, GRAD_REL_L2))
 
 
 def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
@@ -568,6 +586,94 @@ def test_bench_workloads_c4_c5_bf16_step_at_bench_shape_vs_oracle_golden(config)
     from tests import gpu_model_checks as G
     checked, projected, worst = _golden_step_check('%s_step_golden.npz' % config, G.BENCH_CASES[config])
     assert projected >= 40
+
+
+# replayed-vs-eager gates at the bench shapes (the atomically summed statistics are accumulated in float64 -- exact, hence
+# order-independent -- and every other reduction upstream of a bf16 rounding runs in a fixed order: DESIGN.md section 5)
+REPLAY_LOSS_REL = 1e-6          # per-step losses, replayed vs launched one by one (loss scalars themselves are atomically summed block partials)
+REPLAY_FRAMES_ABS = 0.0         # generated frames: bit-identical
+REPLAY_MOMENT_REL_L2 = 1e-5     # Adam m / v of both groups (weight gradients are atomically accumulated tile partials: fp32 summation order)
+
+
+def _bench_steps(fname, case, graph, steps):
+    """`steps` train steps of a bench case at lr = 0 from the golden's variables and noise; returns what the replay test compares."""
+    eng, gold, noise = _bench_engine(fname, case, lr=0.0, graph=graph)
+    aux0 = eng.store.groups['aux'].p.clone()
+    losses = []
+    for _ in range(steps):
+        info = eng.train_step(noise)
+        losses.append(torch.stack([info['d_loss'].reshape(()), info['g_loss'].reshape(())] +
+                                  [l.reshape(()) for l, w in info['g_losses'].values()]).clone())
+    return eng, gold, noise, aux0, torch.stack(losses)
+
+
+@pytest.mark.parametrize('config', ['c2', 'c4', 'c5'])
+def test_the_replayed_bench_step_is_the_eager_step_and_matches_the_golden(config):
+    """What bench.py TIMES is a replayed hipGraph of the bf16 step at the bench shape; the golden tests above run that step launch by
+    launch (return_grads=True keeps it eager).  Here, at the bench shape of c2 / c4 / c5 with the shipped tuning table and lr = 0:
+    (a) 5 steps launched one by one against 1 eager + 1 captured + 3 replayed steps from the same variables and noise: per-step losses,
+    the generated frames and Adam's moments of both groups must agree -- frames bit for bit, the rest to fp32 summation order of the
+    final weight-gradient / loss partials; (b) one more REPLAY from the golden's state (spectral-norm u vectors restored, moments
+    cleared: the replay then executes step 0) against the committed oracle step: losses, sampled frames, and the per-variable gradients
+    recovered from Adam's first moment m = (1 - beta1) g, with the golden test's gates.  A replay that differs from the eager step -- the
+    round-4 memset nodes, a stale staged scalar, a workspace captured at the wrong offset -- fails (a) or (b)."""
+    import gc
+    import json
+    from tests import gpu_model_checks as G
+    from video_prediction_amd import kernels as K
+    case = G.BENCH_CASES[config]
+    fname = '%s_step_golden.npz' % config
+    saved = dict(K.AUTOTUNE, cache=dict(K.AUTOTUNE['cache']))
+    steps = 5
+    try:
+        eng, gold, noise, aux0, le = _bench_steps(fname, case, False, steps)
+        assert eng.graph is None
+        G_ = eng.store.groups
+        me = {g: (G_[g].m.clone(), G_[g].v.clone()) for g in ('g', 'd')}
+        fe = eng.gen.gen.v.clone()
+        del eng, G_
+        gc.collect()
+        torch.cuda.empty_cache()
+        eng, gold, noise, aux0, lr_ = _bench_steps(fname, case, True, steps)
+        assert eng.graph is not None and eng.graph.segments == 1
+        G_ = eng.store.groups
+        errs = {}
+        for g in ('g', 'd'):
+            for which, nm in ((0, 'm'), (1, 'v')):
+                a, b = me[g][which].double(), (G_[g].m if which == 0 else G_[g].v).double()
+                assert torch.isfinite(b).all()
+                errs[g + '.' + nm] = float((a - b).norm() / max(float(a.norm()), 1e-30))
+        loss_rel = float(((lr_ - le).abs() / le.abs().clamp_min(0.05)).max())
+        frames_abs = float((eng.gen.gen.v.float() - fe.float()).abs().max())
+        frames_differ = int((eng.gen.gen.v != fe).sum())
+        # (b) the replay as step 0: golden state, cleared moments
+        G_['aux'].p.copy_(aux0)
+        for g in ('g', 'd'):
+            G_[g].m.zero_()
+            G_[g].v.zero_()
+        info = eng.train_step(noise)
+        torch.cuda.synchronize()
+        b1 = eng.hp.beta1
+        grads = {'d_grads': {}, 'g_grads': {}}
+        for n in eng.store.names():
+            grp = eng.store.group_of[n]
+            if grp in ('g', 'd'):
+                grads[grp + '_grads'][n] = G_[grp].arena.view_of(G_[grp].m, n) / (1.0 - b1)
+        out_dir = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, 'r05_replay_vs_eager_%s.json' % config), 'w') as f:
+                json.dump({'what': 'bench shape, bf16, shipped table, lr = 0: %d eager steps vs 1 eager + capture + replays' % steps,
+                           'moment_rel_l2': errs, 'worst_loss_rel': loss_rel, 'frames_max_abs': frames_abs,
+                           'frame_elements_that_differ': frames_differ}, f, indent=1)
+        assert frames_abs <= REPLAY_FRAMES_ABS, (config, frames_abs, frames_differ)
+        assert loss_rel <= REPLAY_LOSS_REL, (config, loss_rel)
+        for k, e in errs.items():
+            assert e <= REPLAY_MOMENT_REL_L2, (config, k, e, errs)
+        checked, projected, worst = _compare_with_golden(fname, case, gold, eng, info, grads, GRAD_REL_L2)
+        assert projected >= 40
+    finally:
+        K.set_conv_precision('f32')
+        K.AUTOTUNE.update(enabled=saved['enabled'], cache=saved['cache'])
 
 
 def test_bf16_loss_curve_tracks_fp32_over_50_steps():

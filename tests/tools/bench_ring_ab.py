@@ -69,7 +69,7 @@ def main():
                         pass
         if mname == 'fprop' and Cy % 64 == 0:
             y16 = torch.empty(N, H, W, Cy, device=DEV, dtype=torch.bfloat16)
-            st = torch.zeros(N, Cy, 2, device=DEV)
+            st = torch.zeros(N, Cy, 2, device=DEV, dtype=torch.float64)
             x16 = x.to(torch.bfloat16)
             for alg in (0x300, 0x700):
                 for t in (0x11, 0x12, 0x21, 0x22):

@@ -44,7 +44,7 @@ img = in0[..., 0:C]
 tslot = maskin[..., 32:32 + KK * C]
 dslot = dmaskin[..., 32:32 + KK * C]
 dimg = torch.empty(N, H, W, C, device=DEV)
-dkern = torch.empty(N, 25, KK, device=DEV)
+dkern = torch.empty(N, 25, KK, device=DEV, dtype=torch.float64)
 px = N * H * W
 report('cdna_apply_fwd', t(lambda: K.cdna_apply_fwd(img, kern, tslot, 5, 5, KK)), px * (3 + 12) * 4)
 report('cdna_apply_bwd (img+kern)', t(lambda: K.cdna_apply_bwd(img, kern, dslot, dimg, dkern, 5, 5, KK)), px * (3 + 12 + 3) * 4)

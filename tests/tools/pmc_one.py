@@ -27,7 +27,7 @@ def run():
     if mode == lib.CONV_DGRAD:
         y = torch.randn(N, H, W, Cy, device='cuda')
     w = torch.randn(k * k * Cx * Cy, device='cuda') * 0.05
-    st = torch.zeros(N, Cy, 2, device='cuda') if cell else None
+    st = torch.zeros(N, Cy, 2, device='cuda', dtype=torch.float64) if cell else None
     geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
     for _ in range(6):
         K.conv(mode, geom, x, y, w, tile=tile, w16=w.to(torch.bfloat16), splitk=0 if tile == 0 else int(os.environ.get('SK', '1')), stats=st)

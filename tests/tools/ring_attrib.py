@@ -36,7 +36,7 @@ def run(spec, roles, wave, ablate):
     st = None
     if cell:
         y = torch.empty(N, H, W, Cy, device='cuda', dtype=torch.bfloat16)
-        st = torch.zeros(N, Cy, 2, device='cuda')
+        st = torch.zeros(N, Cy, 2, device='cuda', dtype=torch.float64)
     dg = None
     if gap:
         f = (Cx - 8) // 2

@@ -33,7 +33,7 @@ for spec in sys.argv[1:]:
     st = None
     if cell:
         y = torch.empty(N, H, W, Cy, device='cuda', dtype=torch.bfloat16)
-        st = torch.zeros(N, Cy, 2, device='cuda')
+        st = torch.zeros(N, Cy, 2, device='cuda', dtype=torch.float64)
     w16 = w.to(torch.bfloat16)
     try:
         for _ in range(5):

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(CK_NT) void cdna_kernels_fwd_kernel(const float* __
 }
 
 // draw = ((dkern - sum(dkern*kern)) / s) * [raw + ident - shift > 0]
-__global__ __launch_bounds__(CK_NT) void cdna_kernels_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ dkern,
+__global__ __launch_bounds__(CK_NT) void cdna_kernels_bwd_kernel(const float* __restrict__ raw, const double* __restrict__ dkern,
                                                                  float* __restrict__ draw, int kh, int kw, int K) {
     __shared__ float sh[CK_NT];
     const int n = blockIdx.x, e = threadIdx.x, taps = kh * kw;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(CK_NT) void cdna_kernels_bwd_kernel(const float* __
     if (live) {
         const int t = e / K;
         pre = raw[base + e] + ident_at(t / kw, t % kw, kh, kw) - RELU_SHIFT;
-        d = dkern[base + e];
+        d = (float)dkern[base + e];
         v = fmaxf(pre, 0.f) + RELU_SHIFT;
     }
     const float s = cdna_tap_sum(sh, v, e, taps, K, live);
@@ -87,7 +87,7 @@ extern "C" int savp_cdna_kernels_fwd(void* stream, const float* raw, float* kern
     hipLaunchKernelGGL(cdna_kernels_fwd_kernel, dim3(N), dim3(CK_NT), 0, (hipStream_t)stream, raw, kern, kh, kw, K);
     return LAUNCH_OK();
 }
-extern "C" int savp_cdna_kernels_bwd(void* stream, const float* raw, const float* dkern, float* draw, int32_t N, int32_t kh,
+extern "C" int savp_cdna_kernels_bwd(void* stream, const float* raw, const double* dkern, float* draw, int32_t N, int32_t kh,
                                      int32_t kw, int32_t K) {
     if (!raw || !dkern || !draw || N < 1 || kh * kw * K > CK_NT) return SAVP_EINVAL;
     hipLaunchKernelGGL(cdna_kernels_bwd_kernel, dim3(N), dim3(CK_NT), 0, (hipStream_t)stream, raw, dkern, draw, kh, kw, K);
@@ -109,7 +109,7 @@ struct CdnaP {
     // bwd
     const float* dout; long long do_sn, do_sp;
     float* dimg; long long di_sn, di_sp; int dimg_beta;
-    float* dkern;                                // [N, kh*kw, K]  (overwritten)
+    double* dkern;                               // [N, kh*kw, K] float64 (overwritten): the tiles' partial sums meet here through float64 atomics -- exact, order-independent
 };
 
 __global__ __launch_bounds__(NT) void cdna_apply_fwd_kernel(CdnaP p) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NT) void cdna_apply_bwd_kern_kernel(CdnaP p) {
     __syncthreads();
     if (threadIdx.x < taps) {
         const int t = threadIdx.x;
-        p.dkern[((long long)n * taps + t) * p.K + k] = sh[t] + sh[MAXTAPS + t] + sh[2 * MAXTAPS + t] + sh[3 * MAXTAPS + t];
+        p.dkern[((long long)n * taps + t) * p.K + k] = (double)(sh[t] + sh[MAXTAPS + t] + sh[2 * MAXTAPS + t] + sh[3 * MAXTAPS + t]);
     }
 }
 
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NT) void cdna_bwd_kern_fast_kernel(CdnaP p, int chu
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NV; i += NT)
-        unsafeAtomicAdd(p.dkern + (long long)n * NV + i, sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i]);
+        unsafeAtomicAdd(p.dkern + (long long)n * NV + i, (double)(sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i]));
 }
 
 // ---- LDS-tiled 5x5 kernels (compile-time K, C): a workgroup owns a 16x16 pixel tile --------------------------------------------
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(NT) void cdna_bwd_img_tiled_kernel(CdnaP p, int til
     // vec bit 1: clear this sample's kernel-gradient accumulator for the cdna_bwd_kern launch that follows on the stream (it
     // adds with atomics; saves the launcher a 12 KB memset per timestep)
     if ((vec & 2) && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 25 * TK; i += NT) p.dkern[(long long)n * 25 * TK + i] = 0.f;
+        for (int i = threadIdx.x; i < 25 * TK; i += NT) p.dkern[(long long)n * 25 * TK + i] = 0.0;
     vec &= 1;
     stage_dout_halo<TK, TC>(p, n, ty0, tx0, vec, dts);
     __syncthreads();
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NT) void cdna_bwd_kern_tiled_kernel(CdnaP p, int ti
 #pragma unroll
             for (int k = 0; k < TK; ++k) {
                 const float s = wsum(acc[t][k]);
-                if (lane == 0) unsafeAtomicAdd(p.dkern + ((long long)n * 25 + t_lo + t) * TK + k, s);
+                if (lane == 0) unsafeAtomicAdd(p.dkern + ((long long)n * 25 + t_lo + t) * TK + k, (double)s);
             }
         }
     }
@@ -615,7 +615,8 @@ static int fill_cdna(CdnaP& p, const SavpCdnaArgs* a) {
     p.out = (float*)a->out.p; p.o_sn = a->out.sn; p.o_sp = a->out.sp;
     p.dout = (const float*)a->dout.p; p.do_sn = a->dout.sn; p.do_sp = a->dout.sp;
     p.dimg = (float*)a->dimg.p; p.di_sn = a->dimg.sn; p.di_sp = a->dimg.sp; p.dimg_beta = a->dimg_beta;
-    p.dkern = a->dkern;
+    p.dkern = (double*)a->dkern;
+    if (p.dkern && (((uintptr_t)p.dkern) & 7)) return SAVP_EINVAL;
     return SAVP_OK;
 }
 
@@ -663,7 +664,7 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
             else hipLaunchKernelGGL((cdna_bwd_img_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, v2);
         }
         if (p.dkern) {
-            if (!p.dimg) savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            if (!p.dimg) savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(double), st);
             dim3 grid(tiles_x * tiles_y, a->N);
             if (kind == 3) hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 3>), grid, dim3(NT), 0, st, p, tiles_x, vec);
             else hipLaunchKernelGGL((cdna_bwd_kern_tiled_kernel<4, 1>), grid, dim3(NT), 0, st, p, tiles_x, vec);
@@ -680,7 +681,7 @@ extern "C" int savp_cdna_apply_bwd(void* stream, const SavpCdnaArgs* a) {
     if (p.dkern) {
         if (fast) {
             const int chunk = 512;
-            savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(float), st);
+            savp_zero_async(p.dkern, (size_t)a->N * 25 * 4 * sizeof(double), st);
             dim3 gk((a->H * a->W + chunk - 1) / chunk, a->N);
             if (fast == 3) hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 3>), gk, dim3(NT), 0, st, p, chunk);
             else hipLaunchKernelGGL((cdna_bwd_kern_fast_kernel<5, 5, 4, 1>), gk, dim3(NT), 0, st, p, chunk);

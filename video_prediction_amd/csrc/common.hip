@@ -4,6 +4,7 @@
 #include <string.h>
 #include "savp_hip.h"
 #include "opts.h"
+#include "conv_common.h"
 
 extern "C" const char* savp_version(void) { return "savp_hip 0.1 gfx950"; }
 
@@ -75,4 +76,55 @@ extern "C" int savp_allreduce_bucket(void* comm, void* stream, void* buf, int64_
     }
     // in place, fp32 (ncclFloat32 = 7), sum (ncclSum = 0); the 1/K of average=True is folded into savp_adam's gscale
     return fn(buf, buf, (size_t)count, 7, 0, comm, (hipStream_t)stream) == 0 ? SAVP_OK : SAVP_ELAUNCH;
+}
+
+// ---- deterministic split-K (conv_common.h) --------------------------------------------------------------------------------------
+int splitk_fit(const SavpConvArgs* a, int want, long long block_elems) {
+    if (want <= 1) return 1;
+    if (!a->ws || a->ws_bytes <= 0 || block_elems <= 0 || (((uintptr_t)a->ws) & 15)) return 1;
+    const long long fit = a->ws_bytes / (block_elems * (long long)sizeof(float));
+    if (fit < 2) return 1;
+    return want < fit ? want : (int)fit;
+}
+
+__global__ __launch_bounds__(256) void splitk_fold_kernel(float* __restrict__ out, const float* __restrict__ part, int splitk, long long n4, long long n,
+                                                          int beta, int Cd, int gap_at, int gap) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 s = beta ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splitk; ++k) {                       // fixed order: the result does not depend on which split finished first
+            const float4 v = reinterpret_cast<const float4*>(part + (long long)k * n)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (gap) {                                               // the gap's channels were computed by nobody (SavpConvArgs.dst_gap)
+            const int c = (int)((i * 4) % Cd);
+            float* e = &s.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j >= gap_at && c + j < gap_at + gap) e[j] = beta ? reinterpret_cast<const float*>(out)[i * 4 + j] : 0.f;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_fold_scalar_kernel(float* __restrict__ out, const float* __restrict__ part, int splitk, long long n, int beta,
+                                                                 int Cd, int gap_at, int gap) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % Cd);
+        if (gap && c >= gap_at && c < gap_at + gap) { if (!beta) out[i] = 0.f; continue; }
+        float s = beta ? out[i] : 0.f;
+        for (int k = 0; k < splitk; ++k) s += part[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
+void splitk_fold(float* out, const float* part, int splitk, long long n, int beta, int Cd, int gap_at, int gap, hipStream_t st) {
+    const bool vec = (n % 4 == 0) && (Cd % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && ((((uintptr_t)part) & 15) == 0);
+    const long long work = vec ? n / 4 : n;
+    long long blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, part, splitk, n / 4, n, beta, Cd, gap_at, gap);
+    else hipLaunchKernelGGL(splitk_fold_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, part, splitk, n, beta, Cd, gap_at, gap);
 }

@@ -54,6 +54,7 @@ struct ConvP {
     const float* bias;
     const float* aux;
     int splitk;
+    float* part; long long part_sz;   // split-K > 1: split s writes its share of the (dense) destination block to part + s * part_sz; splitk_fold adds them in split order
     int bf16;
     int tm, tn;          // tile counts (1-D XCD-aware launch grids)
     unsigned long long magW, magHW, magDHW;   // WGRAD fast division by Wo, Ho*Wo, Do*Ho*Wo
@@ -65,7 +66,7 @@ struct ConvP {
     // ring kernel (conv_ring.hip)
     int src16;                                // source activations are bf16 (strides in elements)
     int cell;                                 // bf16 destination through LDS + per-(sample, channel) statistics
-    float* stats;                             // [N][Nout][2] sum / sum of squares, atomically accumulated (cell mode; may be null)
+    double* stats;                            // [N][Nout][2] sum / sum of squares, float64, atomically accumulated: exact, hence order-independent (may be null)
     // bf16 source staged by LDS-DMA (src16 && dma_patch): the patch as a sequence of 16-byte slots
     int dma_patch;                            // 1: stage_patch_dma (16-byte aligned bf16 source)
     const void* zero16;                       // 16 zero bytes in global memory (source of halo / padding slots)
@@ -76,7 +77,7 @@ struct ConvP {
     // change made conv_patch_kernel 10-19 % SLOWER in the step (its main loop's register allocation) and was not kept there.
     int pre;
     // conv_ring_kernel: backward statistics of the instance norm whose output gradient this convolution produces (SavpConvArgs.nb_*)
-    const float* nb_x; long long nb_x_sn, nb_x_sp; const float *nb_mean, *nb_rstd, *nb_gamma, *nb_beta; float* nb_ws;
+    const float* nb_x; long long nb_x_sn, nb_x_sp; const float *nb_mean, *nb_rstd, *nb_gamma, *nb_beta; double* nb_ws;
     int nb_c0, nb_nc, nb_act; float nb_alpha;
     int gap_at, gap;                          // conv_ring_kernel: logical output column c >= gap_at is physical weight row / destination channel c + gap (SavpConvArgs.dst_gap)
     int wwarm;                                // conv_ring_kernel: warm the L2 with the column tile's weight block first (option ring_wwarm)
@@ -142,6 +143,15 @@ bool conv_s2dgrad_try(const SavpConvArgs* a, hipStream_t st, int* rc);
 bool conv_s2dgrad_applies(const SavpConvArgs* a);
 
 extern thread_local hipEvent_t g_savp_prof_start, g_savp_prof_stop;      // common.hip: savp_prof_arm
+
+// Deterministic split-K (common.hip).  The K splits of a FPROP / DGRAD launch used to meet in the destination through float atomics, in
+// arrival order: two runs of one step differed in the last bit, and in the bf16 datapath that bit decides roundings downstream.  Now split
+// s stores its share of the (dense) destination block in its own slice of the caller's scratch (SavpConvArgs.ws) and one fold launch adds
+// the slices in split order -- where the old path launched a fill kernel to clear the block, so the launch count is unchanged.
+// splitk_fit: the largest split count <= want whose slices fit the scratch (1 = no scratch: the call runs unsplit).
+int splitk_fit(const SavpConvArgs* a, int want, long long block_elems);
+// out[i] = (beta ? out[i] : 0) + sum_s part[s * n + i]; channels [gap_at, gap_at + gap) of every Cd-wide pixel are cleared instead (beta 0)
+void splitk_fold(float* out, const float* part, int splitk, long long n, int beta, int Cd, int gap_at, int gap, hipStream_t st);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

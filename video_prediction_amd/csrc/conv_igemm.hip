@@ -341,8 +341,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fd_kernel(ConvP p) {
                 if (off < 0) continue;
                 float v = acc[i][j][r] + bias;
                 float* q = dst + off + col;
-                if (p.splitk > 1) {               // partial sums: destination pre-zeroed (or beta) by the launcher
-                    unsafeAtomicAdd(q, v);
+                if (p.splitk > 1) {               // this split's share (conv_common.h: deterministic split-K)
+                    (p.part + (long long)split * p.part_sz + (dst - p.out))[off + col] = v;
                     continue;
                 }
                 if (p.beta) v += *q;
@@ -754,7 +754,25 @@ static bool ring_default() {
 }
 
 extern "C" int64_t savp_conv_workspace_bytes(const SavpConvArgs* a) {
-    if (!a || a->mode != SAVP_CONV_WGRAD) return 0;
+    if (!a) return 0;
+    if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
+        // deterministic split-K (conv_common.h): one slice of the dense destination block per split.  An explicit split count is taken as
+        // it is; for the automatic one (0) the bound of every kernel's heuristic: min(16, 512 / tiles) with the largest tile (256 x 128)
+        if (a->act != SAVP_ACT_NONE || a->out_bf16 || a->stats || a->splitk == 1) return 0;
+        const bool dg = a->mode == SAVP_CONV_DGRAD;
+        const long long dD = dg ? a->D : a->Do, dH = dg ? a->H : a->Ho, dW_ = dg ? a->W : a->Wo;
+        const long long Cd = (dg ? a->Cx : a->Cy) + (a->dst_gap > 0 ? a->dst_gap : 0);
+        const long long block = (long long)a->N * dD * dH * dW_ * Cd;
+        long long S = a->splitk;
+        if (S <= 0) {
+            const long long tiles = ((block / Cd + 255) / 256) * ((Cd + 127) / 128);
+            if (tiles > 192) return 0;
+            S = 512 / tiles;
+            if (S > 16) S = 16;
+        }
+        return S > 1 ? S * block * (long long)sizeof(float) : 0;
+    }
+    if (a->mode != SAVP_CONV_WGRAD) return 0;
     const long long thin = conv_thin_workspace_bytes(a);
     const long long bias = a->bias ? (long long)SAVP_COLSUM_WS_FLOATS * 4 : 0;      // the separate bias-gradient pass (savp_colsum)
     return thin > bias ? thin : bias;
@@ -774,10 +792,10 @@ extern "C" int savp_conv_stats_ok(const SavpConvArgs* a) {
     ConvP p;
     p.bf16 = 1; p.w16 = (const unsigned short*)a->w_bf16; p.src16 = a->src_bf16 ? 1 : 0; p.splitk = 1; p.tm = p.tn = 1;
     p.gap_at = a->dst_gap ? a->dst_gap_at : 0x7fffffff; p.gap = a->dst_gap;
-    p.nb_ws = a->nb_ws; p.nb_c0 = a->nb_c0; p.nb_nc = a->nb_nc;
+    p.nb_ws = (double*)a->nb_ws; p.nb_c0 = a->nb_c0; p.nb_nc = a->nb_nc; p.part = nullptr; p.part_sz = 0;
     if (a->dst_gap && !a->nb_ws) return 0;                      // forward statistics of a gapped destination: not offered
     SavpConvArgs b = *a;
-    if (!b.stats && !b.nb_ws) b.stats = (float*)(uintptr_t)16;   // any non-NULL value: only the plan is made
+    if (!b.stats && !b.nb_ws) b.stats = (double*)(uintptr_t)16;   // any non-NULL value: only the plan is made
     int wm = 0, wn = 0;
     if (b.tile & 0xff) { wm = (b.tile >> 4) & 15; wn = b.tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return 0; }
     int rc = SAVP_OK;
@@ -800,13 +818,13 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     p.w = (const float*)a->w;
     p.w16 = nullptr;
     p.bias = a->bias; p.aux = a->aux;
-    p.splitk = 1; p.tm = p.tn = 1;
+    p.splitk = 1; p.tm = p.tn = 1; p.part = nullptr; p.part_sz = 0;
     p.src16 = a->src_bf16 ? 1 : 0; p.cell = 0; p.stats = nullptr;
     p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
     const bool gapped = a->dst_gap != 0;
     if (gapped && (a->dst_gap < 0 || a->dst_gap_at < 0 || a->mode == SAVP_CONV_WGRAD)) return SAVP_EINVAL;
     p.gap_at = gapped ? a->dst_gap_at : 0x7fffffff; p.gap = gapped ? a->dst_gap : 0;
-    p.nb_ws = a->nb_ws;
+    p.nb_ws = (double*)a->nb_ws;
     if (a->nb_ws) {
         if (a->mode == SAVP_CONV_WGRAD || !a->nb_x || !a->nb_mean || !a->nb_rstd || !a->nb_gamma || !a->nb_beta || a->nb_c0 < 0 || a->nb_nc < 1 ||
             a->nb_act < 0 || a->nb_act > 2)
@@ -879,15 +897,19 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
                 if (splitk > 16) splitk = 16;
             }
         }
-        if (splitk > 1 && !a->beta) {
-            // destination must be one dense block so that it can be cleared with a single memset
+        if (splitk > 1) {
+            // the destination must be one dense block: split s stores its share at the same offsets of its slice of the scratch
             const long long dD = dg ? a->D : a->Do, dH = dg ? a->H : a->Ho, dW_ = dg ? a->W : a->Wo;
             const long long s_n = dg ? a->x_sn : a->y_sn, s_d = dg ? a->x_sd : a->y_sd, s_h = dg ? a->x_sh : a->y_sh,
                             s_w = dg ? a->x_sw : a->y_sw;
             const bool dense = (s_w == Nout) && (s_h == dW_ * Nout) && (dD == 1 || s_d == dH * dW_ * Nout) &&
                                (s_n == dD * dH * dW_ * Nout);
-            if (dense) savp_zero_async(p.out, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
-            else splitk = 1;
+            if (!dense) splitk = 1;
+            else {
+                p.part_sz = (long long)a->N * dD * dH * dW_ * Nout;
+                splitk = splitk_fit(a, splitk, p.part_sz);
+                p.part = (float*)a->ws;
+            }
         }
         p.splitk = splitk;
         p.tm = (int)((Mmax + BM - 1) / BM); p.tn = (int)((Nout + BN - 1) / BN);
@@ -896,6 +918,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         else if (wm == 2 && wn == 1) err = launch_fd<2, 1>(p, vec, grid, st);
         else if (wm == 1 && wn == 2) err = launch_fd<1, 2>(p, vec, grid, st);
         else err = launch_fd<1, 1>(p, vec, grid, st);
+        if (splitk > 1 && err == hipSuccess) {
+            splitk_fold(p.out, p.part, splitk, p.part_sz, a->beta, Nout, 0, 0, st);
+            err = hipGetLastError();
+        }
     } else if (a->mode == SAVP_CONV_WGRAD) {
         p.out = (float*)a->w;
         if (algo != 1) {                                   // LDS patch WGRAD (conv_wgrad_patch.hip)

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(ConvP p) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
                 const int off = (r >> 2) * e_sh + (r & 3) * e_sw + 32 * j;
                 float v = acc[i][j][r] + bias;
-                if (p.splitk > 1) {
-                    unsafeAtomicAdd(dst + off, v);
+                if (p.splitk > 1) {                            // this split's share (conv_common.h: deterministic split-K)
+                    (p.part + (long long)split * p.part_sz + (dst - p.out))[off] = v;
                     continue;
                 }
                 if (p.beta) v += dst[off];
@@ -439,18 +439,26 @@ bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced
         }
     }
     if (splitk > iters) splitk = (int)iters;
-    if (splitk > 1 && !a->beta) {
+    if (splitk > 1) {
         const long long dD = Dm;
         const bool dense = (d_sw == Nout) && (d_sh == dW_ * Nout) && (dD == 1 || d_sd == dH * dW_ * Nout) &&
                            (d_sn == dD * dH * dW_ * Nout);
-        if (dense) savp_zero_async(p.out, (size_t)a->N * dD * dH * dW_ * Nout * sizeof(float), st);
-        else splitk = 1;
+        if (!dense) splitk = 1;
+        else {
+            p.part_sz = (long long)a->N * dD * dH * dW_ * Nout;
+            splitk = splitk_fit(a, splitk, p.part_sz);
+            p.part = (float*)a->ws;
+        }
     }
     p.splitk = splitk;
     dim3 grid((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     hipError_t err;
     ablate_init();
     err = (nw == 8) ? launch_patch_tile<8>(p, wm, wn, nks, grid, lds, st) : launch_patch_tile<4>(p, wm, wn, nks, grid, lds, st);
+    if (splitk > 1 && err == hipSuccess) {
+        splitk_fold(p.out, p.part, splitk, p.part_sz, a->beta, Nout, 0, 0, st);
+        err = hipGetLastError();
+    }
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
     return true;
 }

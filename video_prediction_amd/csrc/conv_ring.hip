@@ -19,7 +19,6 @@
 // Applies to stride-1 and strided 2-D / 3-D FPROP and DGRAD problems in SAVP_PREC_BF16 exactly like conv_patch.hip (same ConvP
 // geometry fields, filled by conv_ring_try); the plain fp32 epilogue (bias / LeakyReLU / sigmoid / beta / split-K) is kept.
 #include "conv_common.h"
-#include "zero_fill.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -537,10 +536,12 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // (launcher guarantees: full tiles, Nout % BN == 0, nimg % ni == 0, split-K 1, no bias / activation / beta)
         constexpr int TP = BN / 2 + 4;                        // dwords per tile row (bf16 pairs; 16-byte aligned rows)
         unsigned* T = reinterpret_cast<unsigned*>(smem);      // [BM][TP]
-        float* stat = reinterpret_cast<float*>(T + BM * TP);  // [ni][BN][2]
+        // statistics: one slot per (32-row block of the tile, column), written by exactly one lane -- no LDS atomics; the blocks of an image
+        // are folded in a fixed order below and leave as ONE float64 atomic per (image, channel, workgroup).  A sum of fp32 partials in
+        // float64 is exact (no rounding unless the partials span more than 2^29 in magnitude), hence independent of the order in which the
+        // workgroups arrive: two runs of the step produce the same bits.
+        float* stat = reinterpret_cast<float*>(T + BM * TP);  // [BM / 32][BN][2]
         __syncthreads();                                      // ring and patch are dead
-        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
-        __syncthreads();
         const bool odd = lane & 1;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -553,8 +554,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
                 s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
                 if (khalf == 0) {
-                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
-                    unsafeAtomicAdd(d, s); unsafeAtomicAdd(d + 1, q);      // ds_add_f32 (plain atomicAdd on LDS floats is a CAS loop)
+                    float* d = stat + ((rowb >> 5) * BN + wn0 + 32 * j + l31) * 2;
+                    d[0] = s; d[1] = q;
                 }
                 const int cp = (wn0 + 32 * j + (l31 & ~1)) >> 1;
 #pragma unroll
@@ -583,11 +584,14 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
             *reinterpret_cast<uint4*>(dst) = v;
         }
         if (p.stats) {
+            const int bpi = 1 << (rsh - 5);                   // 32-row blocks per image of the tile
             for (int i = tid; i < ni * BN * 2; i += NT) {
                 const int im = i / (BN * 2), rem = i - im * (BN * 2);
                 const int gi = img0 + im;
                 const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
+                float t = 0.f;
+                for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
+                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
             }
         }
         RT(6);
@@ -608,13 +612,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // per-(image, channel) sum / sum of squares of conv + bias leave with this kernel and the norm's own statistics pass (one more
         // launch that re-reads the tensor) disappears.  Launcher guarantees: full tiles, every tile row block inside one image,
         // split-K 1, no activation / beta; one global atomic per (image, channel, workgroup) as in the cell epilogue.
-        float* stat = reinterpret_cast<float*>(smem);         // [ni][BN][2]
+        float* stat = reinterpret_cast<float*>(smem);         // [BM / 32][BN][2]: one slot per (32-row block, column), see the cell epilogue
         __syncthreads();                                      // ring and patch are dead
-        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            const int im = (wm0 + i * 32) >> rsh;
+            const int blk = (wm0 + i * 32) >> 5;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int col = col0 + 32 * j;
@@ -627,18 +629,23 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sm += v; q += v * v; acc[i][j][r] = v + bias; }
                 sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
                 if (khalf == 0 && col < Nout) {
-                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
-                    unsafeAtomicAdd(d, sm); unsafeAtomicAdd(d + 1, q);
+                    float* d = stat + (blk * BN + wn0 + 32 * j + l31) * 2;
+                    d[0] = sm; d[1] = q;
                 }
             }
         }
         biased = true;
         __syncthreads();
+        const int bpi = 1 << (rsh - 5);
         for (int i = tid; i < ni * BN * 2; i += NT) {
             const int im = i / (BN * 2), rem = i - im * (BN * 2);
             const int gi = img0 + im;
             const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-            if (n0 + (rem >> 1) < Nout) unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), stat[i]);
+            if (n0 + (rem >> 1) < Nout) {
+                float t = 0.f;
+                for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
+                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
+            }
         }
     }
     if (p.nb_ws) {
@@ -647,10 +654,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
         // backward needs, sum(dy') and sum(dy' * xhat) with dy' = dy * act'(gamma * xhat + beta), leave with the accumulators -- the norm's
         // statistics launch (one more pass over x and dy) disappears.  The mask is the forward apply pass's expression, bit for bit.
         // Launcher guarantees: whole tiles, a row block inside one image, unit destination strides per pixel, split-K 1, no act / beta.
-        float* stat = reinterpret_cast<float*>(smem);         // [ni][BN][2]
+        float* stat = reinterpret_cast<float*>(smem);         // [BM / 32][BN][2]: one slot per (32-row block, column), see the cell epilogue
         __syncthreads();                                      // ring and patch are dead
-        for (int i = tid; i < ni * BN * 2; i += NT) stat[i] = 0.f;
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int rowb = wm0 + i * 32;
@@ -680,18 +685,23 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 }
                 sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
                 if (khalf == 0 && in) {
-                    float* d = stat + (im * BN + wn0 + 32 * j + l31) * 2;
-                    unsafeAtomicAdd(d, sm); unsafeAtomicAdd(d + 1, q);
+                    float* d = stat + ((rowb >> 5) * BN + wn0 + 32 * j + l31) * 2;
+                    d[0] = sm; d[1] = q;
                 }
             }
         }
         __syncthreads();
+        const int bpi = 1 << (rsh - 5);
         for (int i = tid; i < ni * BN * 2; i += NT) {
             const int im = i / (BN * 2), rem = i - im * (BN * 2);
             const int gi = img0 + im;
             const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
             const int cc = n0 + (rem >> 1) - p.nb_c0;
-            if (cc >= 0 && cc < p.nb_nc && n0 + (rem >> 1) < Nout) unsafeAtomicAdd(p.nb_ws + ((long long)n * p.nb_nc + cc) * 2 + (rem & 1), stat[i]);
+            if (cc >= 0 && cc < p.nb_nc && n0 + (rem >> 1) < Nout) {
+                float t = 0.f;
+                for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
+                unsafeAtomicAdd(p.nb_ws + ((long long)n * p.nb_nc + cc) * 2 + (rem & 1), (double)t);
+            }
         }
     }
 #pragma unroll
@@ -726,8 +736,8 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
                 const int off = (r >> 2) * e_sh + (r & 3) * e_sw + pcol[j];
                 float v = acc[i][j][r] + bias;
-                if (p.splitk > 1) {
-                    unsafeAtomicAdd(dst + off, v);
+                if (p.splitk > 1) {                            // this split's share: its own slice of the scratch, folded in split order afterwards
+                    (p.part + (long long)split * p.part_sz + (dst - p.out))[off] = v;
                     continue;
                 }
                 if (p.beta) v += dst[off];
@@ -839,7 +849,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     if (spp < 1) return false;
     const bool cell = a->out_bf16 != 0;
     if (cell) {
-        const size_t epi = (size_t)BM * (BN / 2 + 4) * 4 + (size_t)ni * BN * 2 * 4;
+        const size_t epi = (size_t)BM * (BN / 2 + 4) * 4 + (size_t)(BM / 32) * BN * 2 * 4;
         if (epi > lds) lds = epi;
         if (lds > budget) return false;
         const long long nimg = (long long)a->N * Dm;
@@ -850,13 +860,13 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     if ((long long)a->N * Dm >= (1 << 24)) return false;
     if ((long long)ni * PH * PW * spp * nks * 4 >= (1 << 24)) return false;
     p.cell = cell ? 1 : 0;
-    p.stats = (float*)a->stats;
+    p.stats = (double*)a->stats;
     if (a->stats && !cell) {
         // statistics of an fp32 destination: whole tiles only (every accumulator is a real output), no split-K, nothing after the bias
         const long long nimg = (long long)a->N * Dm;
         const bool even = !dg || (a->H % a->sh == 0 && a->W % a->sw == 0);       // every output phase has the same extent
         if (a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || !even || (a->splitk > 1) ||
-            (size_t)ni * BN * 2 * 4 > lds)
+            (size_t)(BM / 32) * BN * 2 * 4 > lds)
             return false;
     }
     if (a->nb_ws) {
@@ -865,7 +875,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         const long long nimg = (long long)a->N * Dm;
         // (split-K is fine: both sums are linear in the accumulators -- the mask depends on x only -- so every split adds its share)
         if (cell || a->stats || a->act != SAVP_ACT_NONE || a->beta || Hm % tih || Wm % 8 || nimg % ni || phases != 1 || Dm != 1 ||
-            a->sh != 1 || a->sw != 1 || a->nb_c0 + a->nb_nc > Nout || (size_t)ni * BN * 2 * 4 > lds)
+            a->sh != 1 || a->sw != 1 || a->nb_c0 + a->nb_nc > Nout || (size_t)(BM / 32) * BN * 2 * 4 > lds)
             return false;
     }
     p.s1_ph = PH; p.s1_pw = PW; p.s1_th = (Hm + tih - 1) / tih; p.s1_tw = tW; p.s1_tih = tih;
@@ -896,13 +906,19 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         }
     }
     if (splitk > iters) splitk = (int)iters;
-    if (splitk > 1 && !a->beta) {
+    if (splitk > 1) {
         const long long dD = Dm;
-        // one dense block (cleared with a single memset; a column gap's channels are cleared with it: nobody reads them)
+        // the destination must be one dense block: split s stores its share at the same offsets of its slice of the scratch (a column
+        // gap's channels are cleared by the fold: nobody reads them)
         const long long Cd = Nout + p.gap;
         const bool dense = (d_sw == Cd) && (d_sh == dW_ * Cd) && (dD == 1 || d_sd == dH * dW_ * Cd) &&
                            (d_sn == dD * dH * dW_ * Cd);
         if (!dense) splitk = 1;
+        else {
+            p.part_sz = (long long)a->N * dD * dH * dW_ * Cd;
+            splitk = splitk_fit(a, splitk, p.part_sz);
+            p.part = (float*)a->ws;
+        }
     }
     p.splitk = splitk;
     patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
@@ -955,14 +971,13 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
     }
     if (!ok) return false;
     if (dry) return true;                                        // savp_conv_stats_ok: the plan exists, nothing is launched
-    if (p.splitk > 1 && !a->beta) {
-        const int Dm = dg ? a->D : a->Do;
-        const long long dW_ = dg ? a->W : a->Wo;
-        savp_zero_async(p.out, (size_t)a->N * Dm * dH * dW_ * (Nout + p.gap) * sizeof(float), st);
-    }
     ablate_init();
     hipError_t err = (pl.nw == 8) ? launch_ring_tile<8>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st)
                                   : launch_ring_tile<4>(p, pl.wm, pl.wn, pl.nks, pl.grid, pl.lds, st);
+    if (p.splitk > 1 && err == hipSuccess) {
+        splitk_fold(p.out, p.part, p.splitk, p.part_sz, a->beta, Nout + p.gap, p.gap ? p.gap_at : 0, p.gap, st);
+        err = hipGetLastError();
+    }
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
     return true;
 }

@@ -21,6 +21,9 @@ extern "C" int savp_convlstm_cell_fwd(void* stream, const SavpConvLstmCellArgs* 
     // statistics hand-over: the conv's epilogue fills the head of the gate block's workspace, and the gate block is told so
     if ((c.stats != nullptr) != (g.stats1_ready != 0)) return SAVP_EINVAL;
     if (c.stats && (void*)c.stats != g.ws_stats) return SAVP_EINVAL;
+    // the `stats` epilogue sums the accumulators WITHOUT the bias and the gate block reads them as sums around 0 (rnn_ops.py:122-125: the gate
+    // convolution has no bias when a normaliser follows): a biased convolution here would silently shift the mean
+    if (c.stats && c.bias) return SAVP_EINVAL;
     int rc = savp_conv(stream, &c);
     if (rc != SAVP_OK) return rc;
     return savp_convlstm_gates_fwd(stream, &g);

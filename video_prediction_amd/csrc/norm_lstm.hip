@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_kernel(InormP p) {
 // Sums are taken around the first pixel's value (shifted variance) to keep E[x^2]-E[x]^2 well conditioned.
 //   ws layout per call: [N][C][2] floats, zeroed by the launcher.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void inorm_stats_kernel(InormP p, float* ws) {
+__global__ __launch_bounds__(NT) void inorm_stats_kernel(InormP p, double* ws) {
     extern __shared__ float sh[];                 // [rows][2*C]
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
@@ -224,11 +224,12 @@ __global__ __launch_bounds__(NT) void inorm_stats_kernel(InormP p, float* ws) {
         float t = 0.f;
         for (int r = 0; r < rows; ++r) t += sh[r * 2 * C + i];
         const int c = i % C, which = i / C;
-        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, t);
+        // float64 accumulator: a sum of fp32 partials is exact there, so the result does not depend on the workgroups' arrival order
+        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, (double)t);
     }
 }
 
-__global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* ws, int unshifted, const float* shift) {
+__global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const double* ws, int unshifted, const float* shift) {
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
     if (prow >= rows) return;
@@ -241,10 +242,10 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const float* 
     const float kk[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float* w = ws + ((long long)n * C + c4 * 4 + e) * 2;
-        const float ms = w[0] * inv;
-        const float var = fmaxf(w[1] * inv - ms * ms, 0.f);
-        m[e] = kk[e] + ms; r[e] = rsqrtf(var + p.eps);
+        const double* w = ws + ((long long)n * C + c4 * 4 + e) * 2;
+        const double ms = w[0] * (double)inv;
+        const float var = fmaxf((float)(w[1] * (double)inv - ms * ms), 0.f);
+        m[e] = kk[e] + (float)ms; r[e] = rsqrtf(var + p.eps);
     }
     if (blockIdx.x == 0 && prow == 0) {
 #pragma unroll
@@ -281,7 +282,7 @@ __device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c
     return d;
 }
 
-__global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, float* ws) {
+__global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, double* ws) {
     extern __shared__ float sh[];
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, float* ws
         float t = 0.f;
         for (int rr = 0; rr < rows; ++rr) t += sh[rr * 2 * C + i];
         const int c = i % C, which = i / C;
-        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, t);
+        unsafeAtomicAdd(ws + ((long long)n * C + c) * 2 + which, (double)t);
     }
 }
 
-__global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const float* ws) {
+__global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const double* ws) {
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
     const int c4 = threadIdx.x % C4, prow = threadIdx.x / C4, rows = NT / C4;
     if (prow >= rows) return;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         m[e] = p.mean[(long long)n * C + c4 * 4 + e]; r[e] = p.rstd[(long long)n * C + c4 * 4 + e];
-        s1[e] = ws[((long long)n * C + c4 * 4 + e) * 2]; s2[e] = ws[((long long)n * C + c4 * 4 + e) * 2 + 1];
+        s1[e] = (float)ws[((long long)n * C + c4 * 4 + e) * 2]; s2[e] = (float)ws[((long long)n * C + c4 * 4 + e) * 2 + 1];
     }
     // dbeta / dgamma = the per-sample sums added up over samples: one atomic per (sample, channel) here instead of one per
     // (workgroup, channel) in the statistics pass (512 workgroups hammering C addresses made that pass latency-bound)
@@ -381,17 +382,17 @@ extern "C" int savp_instnorm_act_fwd(void* stream, const SavpInormArgs* a) {
         hipStream_t st = (hipStream_t)stream;
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
-        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 1, a->stats_shift);
+        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const double*)a->ws, 1, a->stats_shift);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(double), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
-        hipLaunchKernelGGL(inorm_stats_kernel, grid, dim3(NT), lds, st, p, a->ws);
-        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws, 0, (const float*)nullptr);
+        hipLaunchKernelGGL(inorm_stats_kernel, grid, dim3(NT), lds, st, p, (double*)a->ws);
+        hipLaunchKernelGGL(inorm_apply_kernel, grid, dim3(NT), 0, st, p, (const double*)a->ws, 0, (const float*)nullptr);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     hipLaunchKernelGGL(inorm_fwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
@@ -420,17 +421,17 @@ extern "C" int savp_instnorm_act_bwd(void* stream, const SavpInormArgs* a) {
         hipStream_t st = (hipStream_t)stream;
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
-        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws);
+        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const double*)a->ws);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     if (use_large_plane_path(a)) {
         hipStream_t st = (hipStream_t)stream;
-        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(float), st);
+        if (!a->ws_clean) savp_zero_async(a->ws, (size_t)a->N * a->C * 2 * sizeof(double), st);
         p.chunk = inorm_chunk(a);
         dim3 grid((a->HW + p.chunk - 1) / p.chunk, a->N);
         size_t lds = (size_t)(NT / (a->C / 4)) * 2 * a->C * sizeof(float);
-        hipLaunchKernelGGL(inorm_bwd_stats_kernel, grid, dim3(NT), lds, st, p, a->ws);
-        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const float*)a->ws);
+        hipLaunchKernelGGL(inorm_bwd_stats_kernel, grid, dim3(NT), lds, st, p, (double*)a->ws);
+        hipLaunchKernelGGL(inorm_bwd_apply_kernel, grid, dim3(NT), 0, st, p, (const double*)a->ws);
         return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     }
     hipLaunchKernelGGL(inorm_bwd_kernel, dim3(a->N * (a->C / 4)), dim3(NT), 0, (hipStream_t)stream, p);
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmP p) {
 //   pass 3  lstm_out_kernel: normalise c_pre, h = tanh(c) * sigmoid(o), write c_new and the h destinations
 // Shifted sums (shift = the value at pixel 0) keep E[x^2] - E[x]^2 well conditioned, exactly as the instance-norm path.
 // ------------------------------------------------------------------------------------------------------------
-struct LstmWs { float* s1; float* s2; float* k2; float* so; };
+struct LstmWs { double* s1; double* s2; float* k2; float* so; };     // s1, s2: float64 sums (exact, order-independent: inorm_stats_kernel)
 
 __global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int chunk) {
     extern __shared__ float sh[];                     // [rows][2*F]
@@ -732,10 +733,10 @@ __global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int ch
         const float kk[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float* s = w.s1 + ((long long)n * 4 * F + q * F + c0 + c) * 2;
-            const float ms = s[0] * inv;
-            const float var = fmaxf(s[1] * inv - ms * ms, 0.f);
-            mu[q * 4 + c] = kk[c] + ms; rs[q * 4 + c] = rsqrtf(var + p.eps);
+            const double* s = w.s1 + ((long long)n * 4 * F + q * F + c0 + c) * 2;
+            const double ms = s[0] * (double)inv;
+            const float var = fmaxf((float)(s[1] * (double)inv - ms * ms), 0.f);
+            mu[q * 4 + c] = kk[c] + (float)ms; rs[q * 4 + c] = rsqrtf(var + p.eps);
             ga[q * 4 + c] = p.g1[q * F + c0 + c]; be[q * 4 + c] = p.b1[q * F + c0 + c];
         }
     }
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(NT) void lstm_cell_kernel(LstmP p, LstmWs w, int ch
     for (int i = threadIdx.x; i < 2 * F; i += NT) {
         float t = 0.f;
         for (int r = 0; r < rows; ++r) t += sh[r * 2 * F + i];
-        unsafeAtomicAdd(w.s2 + ((long long)n * F + (i % F)) * 2 + (i / F), t);
+        unsafeAtomicAdd(w.s2 + ((long long)n * F + (i % F)) * 2 + (i / F), (double)t);
     }
 }
 
@@ -799,10 +800,10 @@ __global__ __launch_bounds__(NT) void lstm_out_kernel(LstmP p, LstmWs w, int chu
     float m2[4], r2[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float* s = w.s2 + ((long long)n * F + c0 + c) * 2;
-        const float ms = s[0] * inv;
-        const float var = fmaxf(s[1] * inv - ms * ms, 0.f);
-        m2[c] = kk[c] + ms; r2[c] = rsqrtf(var + p.eps);
+        const double* s = w.s2 + ((long long)n * F + c0 + c) * 2;
+        const double ms = s[0] * (double)inv;
+        const float var = fmaxf((float)(s[1] * (double)inv - ms * ms), 0.f);
+        m2[c] = kk[c] + (float)ms; r2[c] = rsqrtf(var + p.eps);
     }
     if (blockIdx.x == 0 && prow == 0) {
         st4(p.mean2 + (long long)n * F + c0, make_float4(m2[0], m2[1], m2[2], m2[3]));
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(NT) void lstm_out_kernel(LstmP p, LstmWs w, int chu
 //   pass 2  d c_pre through the second norm, d c_prev, raw d(i, j, f) ; r1 = sum dg, sum dg * xh ; dgamma2 / dbeta2
 //   pass 3  dgates through the first norm ; dgamma1 / dbeta1
 // ------------------------------------------------------------------------------------------------------------
-struct LstmBws { float* r2; float* r1; float* dz2; };
+struct LstmBws { double* r2; double* r1; float* dz2; };            // r2, r1: float64 sums (exact, order-independent)
 
 struct LstmLane {            // per-thread constants of the (sample, 4 channels) column this thread owns
     float mu[16], rs[16], ga[16], be[16], mu2[4], rs2[4], g2[4], b2[4];
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd1_kernel(LstmP p, LstmBws w, int c
     for (int i = threadIdx.x; i < 2 * F; i += NT) {
         float t = 0.f;
         for (int r = 0; r < rows; ++r) t += sh[r * 2 * F + i];
-        unsafeAtomicAdd(w.r2 + ((long long)n * F + (i % F)) * 2 + (i / F), t);
+        unsafeAtomicAdd(w.r2 + ((long long)n * F + (i % F)) * 2 + (i / F), (double)t);
     }
 }
 
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd2_kernel(LstmP p, LstmBws w, int c
     float r2a[4], r2b[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        r2a[c] = w.r2[((long long)n * F + c0 + c) * 2]; r2b[c] = w.r2[((long long)n * F + c0 + c) * 2 + 1];
+        r2a[c] = (float)w.r2[((long long)n * F + c0 + c) * 2]; r2b[c] = (float)w.r2[((long long)n * F + c0 + c) * 2 + 1];
     }
     if (blockIdx.x == 0 && prow == 0) {
 #pragma unroll
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd2_kernel(LstmP p, LstmBws w, int c
         float t = 0.f;
         for (int r = 0; r < rows; ++r) t += sh[r * 8 * F + i];
         const int which = i / (4 * F), ch = i % (4 * F);
-        unsafeAtomicAdd(w.r1 + ((long long)n * 4 * F + ch) * 2 + which, t);
+        unsafeAtomicAdd(w.r1 + ((long long)n * 4 * F + ch) * 2 + which, (double)t);
     }
 }
 
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd3_kernel(LstmP p, LstmBws w, int c
         for (int c = 0; c < 4; ++c) {
             const long long o = (long long)n * 4 * F + q * F + c0 + c;
             mu[q * 4 + c] = p.mean1[o]; rs[q * 4 + c] = p.rstd1[o]; ga[q * 4 + c] = p.g1[q * F + c0 + c];
-            s1[q * 4 + c] = w.r1[o * 2]; s2[q * 4 + c] = w.r1[o * 2 + 1];
+            s1[q * 4 + c] = (float)w.r1[o * 2]; s2[q * 4 + c] = (float)w.r1[o * 2 + 1];
         }
     if (blockIdx.x == 0 && prow == 0) {
 #pragma unroll
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void lstm_block_owner(int nslab, int xcd_map, int& n,
 }
 
 template <int Q, int PPT, bool G16>
-__global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float* __restrict__ s1, int nslab, int xcd_map) {
+__global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const double* __restrict__ s1, int nslab, int xcd_map) {
     __shared__ float sh[LSTM_SUM_FLOATS(16, Q)];
     LT(0);
     constexpr int ROWS = NT / Q;
@@ -1153,14 +1154,16 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
 #pragma unroll
         for (int t = 0; t < PPT; ++t) cpq[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 g1q[4], b1q[4], sa[4], sb[4];
+    float4 g1q[4], b1q[4];
+    double2 sd[4][4];                                 // [gate][channel] {sum, sum of squares}: float64 from the conv epilogue (exact sums)
 #pragma unroll
     for (int g = 0; g < 4; ++g) { g1q[g] = ld4(p.g1 + g * F + c0); b1q[g] = ld4(p.b1 + g * F + c0); }
     if (s1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float* s = s1 + ((long long)n * 4 * F + g * F + c0) * 2;
-            sa[g] = ld4(s); sb[g] = ld4(s + 4);
+            const double2* s = reinterpret_cast<const double2*>(s1 + ((long long)n * 4 * F + g * F + c0) * 2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sd[g][c] = s[c];
         }
     }
     const float4 g2q = ld4(p.g2 + c0), b2q = ld4(p.b2 + c0);
@@ -1178,12 +1181,11 @@ __global__ __launch_bounds__(NT) void lstm_fused_fwd_kernel(LstmP p, const float
     if (s1) {          // unshifted sums of the fp32 accumulators (conv epilogue): [sum, sumsq] pairs per channel
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float su[4] = {sa[g].x, sa[g].z, sb[g].x, sb[g].z}, sq[4] = {sa[g].y, sa[g].w, sb[g].y, sb[g].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float m = su[c] * inv;
-                mu[g * 4 + c] = m;
-                rs[g * 4 + c] = rsqrtf(fmaxf(sq[c] * inv - m * m, 0.f) + p.eps);
+                const double m = sd[g][c].x * (double)inv;
+                mu[g * 4 + c] = (float)m;
+                rs[g * 4 + c] = rsqrtf(fmaxf((float)(sd[g][c].y * (double)inv - m * m), 0.f) + p.eps);
             }
         }
     } else {
@@ -1508,7 +1510,9 @@ static int fill_lstm(LstmP& p, const SavpLstmArgs* a) {
 }
 
 // workspace floats of the coalesced forward: ws1 [N][4F][2] + ws2 [N][F][2] + k2 [N][F] + sigmoid(o) [N][HW][F]
-static long long lstm_ws_floats(const SavpLstmArgs* a) { return (long long)a->N * a->F * ((a->ws_stats ? 0 : 11) + (long long)a->HW); }
+// reduction workspace: float64 sums -- forward s1 [N][4F][2] + s2 [N][F][2] (+ k2 [N][F] fp32), backward r2 [N][F][2] + r1 [N][4F][2]: N*F*22 floats
+#define LSTM_RED_FLOATS 22
+static long long lstm_ws_floats(const SavpLstmArgs* a) { return (long long)a->N * a->F * ((a->ws_stats ? 0 : LSTM_RED_FLOATS) + (long long)a->HW); }
 static bool lstm_coalesced_ok(const SavpLstmArgs* a) {
     const int F = a->F;
     return a->ws && a->ws_floats >= lstm_ws_floats(a) && F >= 16 && F <= 256 && (F & (F - 1)) == 0 && a->HW >= 16;
@@ -1522,7 +1526,7 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     {
         int Q, PPT, nslab, xcd_map;
         if (lstm_fused_cfg(a, true, Q, PPT, nslab, xcd_map)) {
-            const float* s1 = a->stats1_ready ? (const float*)a->ws_stats : nullptr;
+            const double* s1 = a->stats1_ready ? (const double*)a->ws_stats : nullptr;
             LSTM_FUSED_DISPATCH(LSTM_FWD_LAUNCH, p, s1, nslab, xcd_map);
             return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
         }
@@ -1530,12 +1534,14 @@ extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     if (lstm_coalesced_ok(a)) {
         const int N = a->N, F = a->F, HW = a->HW;
         LstmWs w;
-        w.s1 = a->ws_stats ? a->ws_stats : a->ws;
-        w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = w.s2 + (size_t)N * F * 2;
-        w.so = a->ws_stats ? a->ws : w.k2 + (size_t)N * F;
+        float* red = a->ws_stats ? a->ws_stats : a->ws;
+        if (((uintptr_t)red) & 7) return SAVP_EINVAL;
+        w.s1 = reinterpret_cast<double*>(red);
+        w.s2 = w.s1 + (size_t)N * 4 * F * 2; w.k2 = reinterpret_cast<float*>(w.s2 + (size_t)N * F * 2);
+        w.so = a->ws_stats ? a->ws : red + (size_t)N * F * LSTM_RED_FLOATS;
         if (a->stats1_ready && !a->ws_stats) return SAVP_EINVAL;
         if (!a->stats1_ready) {
-        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.s1, (size_t)N * F * 10 * sizeof(float), st);
+        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.s1, (size_t)N * F * 20 * sizeof(float), st);
         if (a->gates_bf16) return SAVP_EINVAL;             // bf16 gates come with their statistics from the conv epilogue
         // pass 1: shifted sums of the gate tensor, the instance-norm statistics kernel with C = 4F
         InormP q;
@@ -1580,10 +1586,12 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
         hipStream_t st = (hipStream_t)stream;
         const int N = a->N, F = a->F, HW = a->HW;
         LstmBws w;
-        w.r2 = a->ws_stats ? a->ws_stats : a->ws;
+        float* red = a->ws_stats ? a->ws_stats : a->ws;
+        if (((uintptr_t)red) & 7) return SAVP_EINVAL;
+        w.r2 = reinterpret_cast<double*>(red);
         w.r1 = w.r2 + (size_t)N * F * 2;
-        w.dz2 = a->ws_stats ? a->ws : w.r1 + (size_t)N * 4 * F * 2;
-        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.r2, (size_t)N * F * 10 * sizeof(float), st);
+        w.dz2 = a->ws_stats ? a->ws : red + (size_t)N * F * LSTM_RED_FLOATS;
+        if (!(a->ws_stats && a->ws_stats_clean)) savp_zero_async(w.r2, (size_t)N * F * 20 * sizeof(float), st);
         const int rows = NT / (F / 4);
         long long c = ((long long)HW * N + 511) / 512;
         if (c < rows) c = rows;

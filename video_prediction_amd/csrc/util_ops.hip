@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NT) void dense_partial_kernel(const float* __restri
 // the kernel's time is a single memory round trip plus 16 NTL MFMAs; with the loads interleaved between dependent MFMAs, as hipcc
 // schedules them by default, a group paid 6-7 serial round trips (52 us for the 3.3 MB CDNA head).
 // MFMA i of a group contracts k = base + 16*half + i: any bijection of the group's 32 k onto (instruction, half) is a valid order.
-// The waves' accumulators meet in LDS (ds_add_f32), one plain store per output of the slice.
+// The waves' accumulators meet in LDS in wave order (deterministic), one plain store per output of the slice.
 typedef float dm_f32x16 __attribute__((ext_vector_type(16)));
 template <int NTL, bool VEC>   // 32-column tiles: NTL * 32 >= C; VEC: W rows allow aligned NTL-wide vector loads (C % NTL == 0)
 __global__ __launch_bounds__(256) void dense_mfma_partial_kernel(const float* __restrict__ x, long long xs, int M, long long Kd, int C,
@@ -685,16 +685,22 @@ __global__ __launch_bounds__(256) void dense_mfma_partial_kernel(const float* __
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][t], acc[t], 0, 0, 0);
         }
-        for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 256) red[i] = 0.f;
-        __syncthreads();
+        // the four waves' accumulators meet in LDS in wave order, one wave per round (a wave covers every element of the block exactly
+        // once): a fixed summation order -- ds_add_f32 from four racing waves made the sum depend on their arrival order, and this
+        // layer's output feeds bf16 roundings downstream
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+                for (int t = 0; t < NTL; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;                            // C/D layout of the 32x32 MFMAs
-                unsafeAtomicAdd(&red[row * (32 * NTL) + NTL * l31 + t], acc[t][r]);          // ds_add_f32
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;                    // C/D layout of the 32x32 MFMAs
+                        float* d = &red[row * (32 * NTL) + NTL * l31 + t];
+                        *d = (w == 0 ? 0.f : *d) + acc[t][r];
+                    }
             }
-        __syncthreads();
+            __syncthreads();
+        }
         for (int i = threadIdx.x; i < 32 * 32 * NTL; i += 256) {
             const int row = i / (32 * NTL), c = i - row * (32 * NTL);
             if (row < mb && c < C) part[((long long)blockIdx.x * M + m0 + row) * C + c] = red[i];

@@ -227,14 +227,19 @@ extern "C" int savp_fold_bilinear(void* stream, const float* in, float* out, int
 // ---------------------------------------------------------------------------------------------------------------
 // spectral norm.  W [K, C] (K = prod(kernel dims, Cin), C = Cout), u [C].
 //   a = W u ; v = a/(|a|+eps) ; b = W^T v ; u' = b/(|b|+eps) ; sigma = v^T W u' = |b|^2/(|b|+eps)
-// workspace ws (floats): [0]=sigma [1]=1/sigma [2]=|a| [3]=|b| [4]=kappa [5]=<G,W> [6]=a.gv [7]=|a|^2 acc
-//                        [8 .. 8+C) = b ; [8+C .. 8+2C) = u' ; [8+2C .. 8+2C+K) = a ; [.. +K) = gv/ga
+// workspace ws (floats): [0]=sigma [1]=1/sigma [2]=|a| [3]=|b| [4]=kappa [5]=<G,W> [6]=a.gv [7]=(unused)
+//                        [8 .. 8+C) = b ; [8+C .. 8+2C) = u' ; [8+2C .. 8+2C+K) = a ; [.. +K) = gv/ga ;
+//                        then, 8-byte aligned, FLOAT64 accumulators: [0] = |a|^2, [1 .. 1+C) = W^T a -- the forward sums that many
+//                        workgroups add to atomically.  float64 because a sum of fp32 partials is exact there: sigma (and with it every
+//                        weight of the discriminator) does not depend on the workgroups' arrival order.
+//                        Total: 8 + 2C + 2K + 2 (C + 2) floats; ws 8-byte aligned.
 // ---------------------------------------------------------------------------------------------------------------
 #define SN_EPS 1e-12f
+__host__ __device__ __forceinline__ double* sn_acc64(float* ws, long long K, int C) { return reinterpret_cast<double*>(ws + 8 + 2 * C + 2 * K); }
 
 // y[k] = sum_c W[k,c] x[c]; one wave per row; optionally accumulates sum_k y[k]^2 into *sq and sum_k y[k]*z[k] into *dotz
 __device__ __forceinline__ void sn_rows_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                             float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx) {
+                                             float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sqacc = 0.f, dzacc = 0.f;
     for (long long k = bx * 4LL + wave; k < K; k += (long long)gx * 4) {
@@ -248,13 +253,13 @@ __device__ __forceinline__ void sn_rows_body(const float* __restrict__ W, long l
         }
     }
     if (lane == 0) {
-        if (sq) unsafeAtomicAdd(sq, sqacc);
+        if (sq) unsafeAtomicAdd(sq, (double)sqacc);
         if (dotz) unsafeAtomicAdd(dotz, dzacc);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                          float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                          float xscale, float* __restrict__ y, double* sq, const float* z,
                                                           float* dotz) {
     sn_rows_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
 }
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restric
 // channels): LPR lanes x float4 cover one row, a wave covers 64/LPR consecutive rows per pass = 1 KB of contiguous memory,
 // two passes in flight.  (The one-element-per-lane kernel above spends its time in shuffles and exposed load latency.)
 __device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                 float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx) {
+                                                 float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpr = C >> 2, rpw = 64 / lpr;
     const int c4 = lane & (lpr - 1), sub = lane / lpr;
@@ -286,13 +291,13 @@ __device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, lo
     }
     sqacc = wsum(sqacc); dzacc = wsum(dzacc);
     if (lane == 0) {
-        if (sq) unsafeAtomicAdd(sq, sqacc);
+        if (sq) unsafeAtomicAdd(sq, (double)sqacc);
         if (dotz) unsafeAtomicAdd(dotz, dzacc);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                              float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                              float xscale, float* __restrict__ y, double* sq, const float* z,
                                                               float* dotz) {
     sn_rows_vec_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
 }
@@ -304,7 +309,7 @@ static bool sn_vec_ok(const float* W, const float* x, int C) {
 
 // narrow matrices (C <= 16, e.g. the discriminators' final linear [65536, 1]): one THREAD per row
 __device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                    float xscale, float* __restrict__ y, float* sq, const float* z, float* dotz, int bx, int gx,
+                                                    float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx,
                                                     float* sh) {
     float sqacc = 0.f, dzacc = 0.f;
     for (long long k = bx * (long long)NT + threadIdx.x; k < K; k += (long long)gx * NT) {
@@ -316,7 +321,7 @@ __device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W,
         if (z) dzacc += s * z[k];
     }
     float t = block_sum1(sqacc, sh);
-    if (threadIdx.x == 0 && sq) unsafeAtomicAdd(sq, t);
+    if (threadIdx.x == 0 && sq) unsafeAtomicAdd(sq, (double)t);
     if (dotz) {
         float t2 = block_sum1(dzacc, sh);
         if (threadIdx.x == 0) unsafeAtomicAdd(dotz, t2);
@@ -324,7 +329,7 @@ __device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W,
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                                 float xscale, float* __restrict__ y, float* sq, const float* z,
+                                                                 float xscale, float* __restrict__ y, double* sq, const float* z,
                                                                  float* dotz) {
     __shared__ float sh[4];
     sn_rows_narrow_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x, sh);
@@ -332,25 +337,25 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __
 
 // y[c] += sum_k W[k,c] x[k]   (atomic; y zeroed by the caller)
 __device__ __forceinline__ void sn_cols_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                             float* __restrict__ y, int rows_per_block, int bx) {
+                                             double* __restrict__ y, int rows_per_block, int bx) {
     const long long k0 = (long long)bx * rows_per_block;
     const long long k1 = min(K, k0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += NT) {
         float s = 0.f;
         for (long long k = k0; k < k1; ++k) s += W[k * C + c] * x[k];
-        unsafeAtomicAdd(y + c, s);
+        unsafeAtomicAdd(y + c, (double)s);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                          float* __restrict__ y, int rows_per_block) {
+                                                          double* __restrict__ y, int rows_per_block) {
     sn_cols_body(W, K, C, x, y, rows_per_block, blockIdx.x);
 }
 
 // vectorised variant (C = 4 * LPR, LPR a power of two <= 64): thread = (column quad, row slot), float4 loads of full rows,
 // LDS reduction over the row slots, one atomic per column and block
 __device__ __forceinline__ void sn_cols_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                 float* __restrict__ y, int rows_per_block, int bx, float4* sh) {
+                                                 double* __restrict__ y, int rows_per_block, int bx, float4* sh) {
     const int lpr = C >> 2, slots = NT / lpr;
     const int c4 = threadIdx.x & (lpr - 1), sub = threadIdx.x / lpr;
     const long long k0 = (long long)bx * rows_per_block;
@@ -366,25 +371,26 @@ __device__ __forceinline__ void sn_cols_vec_body(const float* __restrict__ W, lo
     if (threadIdx.x < lpr) {
         float4 t = sh[threadIdx.x];
         for (int r = 1; r < slots; ++r) { const float4 v = sh[r * lpr + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        unsafeAtomicAdd(y + c4 * 4, t.x); unsafeAtomicAdd(y + c4 * 4 + 1, t.y);
-        unsafeAtomicAdd(y + c4 * 4 + 2, t.z); unsafeAtomicAdd(y + c4 * 4 + 3, t.w);
+        unsafeAtomicAdd(y + c4 * 4, (double)t.x); unsafeAtomicAdd(y + c4 * 4 + 1, (double)t.y);
+        unsafeAtomicAdd(y + c4 * 4 + 2, (double)t.z); unsafeAtomicAdd(y + c4 * 4 + 3, (double)t.w);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_cols_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                              float* __restrict__ y, int rows_per_block) {
+                                                              double* __restrict__ y, int rows_per_block) {
     __shared__ float4 sh[NT];
     sn_cols_vec_body(W, K, C, x, y, rows_per_block, blockIdx.x, sh);
 }
 
 // single workgroup: finish the forward scalars. bt = W^T a (unnormalised)
-__device__ __forceinline__ void sn_finalize_body(float* ws, int C, float* u_new, float* sh) {
-    const float na = sqrtf(ws[7]);
+__device__ __forceinline__ void sn_finalize_body(float* ws, long long K, int C, float* u_new, float* sh) {
+    const double* acc64 = sn_acc64(ws, K, C);             // [0] = |a|^2, [1 .. 1 + C) = W^T a (exact float64 sums)
+    const float na = sqrtf((float)acc64[0]);
     const float s = na + SN_EPS;
     float* b = ws + 8;
     float* up = ws + 8 + C;
     float acc = 0.f;
-    for (int c = threadIdx.x; c < C; c += NT) { float v = b[c] / s; b[c] = v; acc += v * v; }
+    for (int c = threadIdx.x; c < C; c += NT) { float v = (float)acc64[1 + c] / s; b[c] = v; acc += v * v; }
     const float nb2 = block_sum1(acc, sh);
     const float nb = sqrtf(nb2);
     for (int c = threadIdx.x; c < C; c += NT) { float v = b[c] / (nb + SN_EPS); up[c] = v; if (u_new) u_new[c] = v; }
@@ -395,31 +401,32 @@ __device__ __forceinline__ void sn_finalize_body(float* ws, int C, float* u_new,
     }
 }
 
-__global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, int C, float* u_new) {
+__global__ __launch_bounds__(NT) void sn_finalize_kernel(float* ws, long long K, int C, float* u_new) {
     __shared__ float sh[4];
-    sn_finalize_body(ws, C, u_new, sh);
+    sn_finalize_body(ws, K, C, u_new, sh);
 }
 
 extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, const float* u, float* ws, float* u_new) {
-    // ws must hold 8 + 2C + 2K floats.  On return ws[1] = 1/sigma (device scalar for pack_weights), u_new = u_final.
-    if (!W || !u || !ws || K < 1 || C < 1) return SAVP_EINVAL;
+    // ws must hold 8 + 2C + 2K + 2 (C + 2) floats, 8-byte aligned.  On return ws[1] = 1/sigma (device scalar for pack_weights), u_new = u_final.
+    if (!W || !u || !ws || K < 1 || C < 1 || (((uintptr_t)ws) & 7)) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    savp_zero_async(ws, (size_t)(8 + C) * sizeof(float), st);
+    double* acc64 = sn_acc64(ws, K, C);
+    savp_zero_async(acc64, (size_t)(C + 1) * sizeof(double), st);
     float* a = ws + 8 + 2 * C;
     unsigned nb = (unsigned)((K + 3) / 4);
     if (nb > 2048) nb = 2048;
     if (C <= 16) {
         unsigned nbn = (unsigned)((K + NT - 1) / NT);
         if (nbn > 1024) nbn = 1024;
-        hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7,
+        hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64,
                            (const float*)nullptr, (float*)nullptr);
     } else if (sn_vec_ok(W, u, C)) {
         const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);     // rows per block pass pair
         unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
-        hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7,
+        hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64,
                            (const float*)nullptr, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, ws + 7, (const float*)nullptr,
+        hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64, (const float*)nullptr,
                            (float*)nullptr);
     }
     if (sn_vec_ok(W, W, C)) {
@@ -427,13 +434,13 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
         const int slots = NT / (C >> 2);
         if (rpb < 4 * slots) rpb = 4 * slots;
         hipLaunchKernelGGL(sn_gemv_cols_vec_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
-                           (const float*)a, ws + 8, rpb);
+                           (const float*)a, acc64 + 1, rpb);
     } else {
         int rpb = 64;
         hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3((unsigned)((K + rpb - 1) / rpb)), dim3(NT), 0, st, W, (long long)K, C,
-                           (const float*)a, ws + 8, rpb);
+                           (const float*)a, acc64 + 1, rpb);
     }
-    hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(NT), 0, st, ws, C, u_new);
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(NT), 0, st, ws, (long long)K, C, u_new);
     return LAUNCH_OK();
 }
 
@@ -487,15 +494,15 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
         unsigned nbn = (unsigned)((K + NT - 1) / NT);
         if (nbn > 1024) nbn = 1024;
         hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f,
-                           a + K, (float*)nullptr, (const float*)a, ws + 6);
+                           a + K, (double*)nullptr, (const float*)a, ws + 6);
     } else if (sn_vec_ok(W, ws + 8, C)) {
         const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);
         unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
         hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
-                           (float*)nullptr, (const float*)a, ws + 6);
+                           (double*)nullptr, (const float*)a, ws + 6);
     } else {
         hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
-                           (float*)nullptr, (const float*)a, ws + 6);
+                           (double*)nullptr, (const float*)a, ws + 6);
     }
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nb), dim3(NT), 0, st, G, (long long)K, C, u, (const float*)ws, dW, beta);
     return LAUNCH_OK();
@@ -516,6 +523,10 @@ __global__ __launch_bounds__(NT) void snb_zero_kernel(SnBatch b, int off, int co
     const SnB& t = b.it[blockIdx.y];
     const int n = count_plus_c < 0 ? -count_plus_c : count_plus_c + t.C;          // negative: fixed count; else count + C floats
     for (int i = threadIdx.x; i < n; i += NT) t.ws[off + i] = 0.f;
+    if (count_plus_c >= 0) {                                                       // forward: the float64 accumulators as well
+        double* acc64 = sn_acc64(t.ws, t.K, t.C);
+        for (int i = threadIdx.x; i < t.C + 1; i += NT) acc64[i] = 0.0;
+    }
 }
 
 // phase 0: a = W u (+ |a|^2 -> ws[7]);  phase 1 (backward): wb = W b (+ a . wb -> ws[6])
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(NT) void snb_rows_kernel(SnBatch b, int phase) {
     float* a = t.ws + 8 + 2 * t.C;
     const float* x = phase == 0 ? t.u : (const float*)(t.ws + 8);
     float* y = phase == 0 ? a : a + t.K;
-    float* sq = phase == 0 ? t.ws + 7 : nullptr;
+    double* sq = phase == 0 ? sn_acc64(t.ws, t.K, t.C) : nullptr;
     const float* z = phase == 0 ? nullptr : (const float*)a;
     float* dotz = phase == 0 ? nullptr : t.ws + 6;
     if (t.C <= 16) {
@@ -554,18 +565,18 @@ __global__ __launch_bounds__(NT) void snb_cols_kernel(SnBatch b) {
         const int slots = NT / (t.C >> 2);
         if (rpb < 4 * slots) rpb = 4 * slots;
         if ((long long)blockIdx.x * rpb >= t.K) return;
-        sn_cols_vec_body(t.W, t.K, t.C, a, t.ws + 8, rpb, blockIdx.x, sh);
+        sn_cols_vec_body(t.W, t.K, t.C, a, sn_acc64(t.ws, t.K, t.C) + 1, rpb, blockIdx.x, sh);
     } else {
         const int rpb = (int)max(64ll, (t.K + 511) / 512);
         if ((long long)blockIdx.x * rpb >= t.K) return;
-        sn_cols_body(t.W, t.K, t.C, a, t.ws + 8, rpb, blockIdx.x);
+        sn_cols_body(t.W, t.K, t.C, a, sn_acc64(t.ws, t.K, t.C) + 1, rpb, blockIdx.x);
     }
 }
 
 __global__ __launch_bounds__(NT) void snb_finalize_kernel(SnBatch b) {
     __shared__ float sh[4];
     const SnB& t = b.it[blockIdx.y];
-    sn_finalize_body(t.ws, t.C, t.u_new, sh);
+    sn_finalize_body(t.ws, t.K, t.C, t.u_new, sh);
 }
 
 __global__ __launch_bounds__(NT) void snb_dot_kernel(SnBatch b) {
@@ -609,7 +620,7 @@ static int snb_fill(SnBatch& b, int32_t n, const SavpSnItem* items, bool bwd) {
     b.n = n;
     for (int i = 0; i < n; ++i) {
         const SavpSnItem& s = items[i];
-        if (!s.W || !s.u || !s.ws || s.K < 1 || s.C < 1 || (bwd && (!s.G || !s.dW))) return SAVP_EINVAL;
+        if (!s.W || !s.u || !s.ws || s.K < 1 || s.C < 1 || (bwd && (!s.G || !s.dW)) || (((uintptr_t)s.ws) & 7)) return SAVP_EINVAL;
         SnB& t = b.it[i];
         t.W = s.W; t.K = s.K; t.C = s.C; t.u = s.u; t.ws = s.ws; t.u_new = s.u_new; t.G = s.G; t.dW = s.dW; t.beta = s.beta;
         t.vec = (s.C > 16 && sn_vec_ok(s.W, s.u, s.C) && sn_vec_ok(s.W, s.ws + 8, s.C)) ? 1 : 0;

@@ -185,11 +185,11 @@ def _tune(a, mode, dst, w, return_all=False):
         scratch = None
         real_stats = a.stats
         if a.stats:                      # tuning runs must not accumulate into the real statistics
-            stats_scratch = torch.zeros(a.N * (a.Cx if mode == lib.CONV_DGRAD else a.Cy) * 2, device=dst.device)
+            stats_scratch = torch.zeros(a.N * (a.Cx if mode == lib.CONV_DGRAD else a.Cy) * 2, device=dst.device, dtype=torch.float64)
             a.stats = stats_scratch.data_ptr()
         real_nb = a.nb_ws
         if a.nb_ws:                      # ... nor into the real norm-backward sums
-            nb_scratch = torch.zeros(a.N * a.nb_nc * 2, device=dst.device)
+            nb_scratch = torch.zeros(a.N * a.nb_nc * 2, device=dst.device, dtype=torch.float64)
             a.nb_ws = nb_scratch.data_ptr()
         if a.beta:                       # never accumulate tuning runs into the real destination
             scratch = torch.empty_like(dst)
@@ -205,6 +205,10 @@ def _tune(a, mode, dst, w, return_all=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for tile, sk in cands:
         a.tile, a.splitk = tile, sk
+        if mode != lib.CONV_WGRAD:
+            a.ws, a.ws_bytes = None, 0
+            if sk != 1:
+                _conv_scratch(a, dst.device)      # the split-K slices (without scratch the candidate would silently run unsplit)
         if fn(st, ctypes.byref(a)) != 0:
             continue
         t = 1e30
@@ -233,20 +237,26 @@ def _tune(a, mode, dst, w, return_all=False):
     return best or (0, 0)
 
 
+def _conv_scratch(a, device):
+    """Hand savp_conv the caller-owned scratch this call can use (savp_conv_workspace_bytes: split-K slices, weight-gradient partials)."""
+    need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
+    if need:
+        ws = scratch(device, (need + 3) // 4)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+
+
 def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
          dst_gap=None, norm_bwd=None, defer=False):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
-    destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] fp32 (zeroed by the caller)
+    destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] float64 (stats_ws: zeroed by the caller)
     receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only); dst_gap = (first, count):
     `count` destination channels from `first` on are left out (neither computed nor written)."""
-    lib.require_device(w, bias, aux, stats)
+    lib.require_device(w, bias, aux)
+    lib.require_stats(stats, (norm_bwd or {}).get('ws'))
     lib.require_device_any(x, y)
     a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd)
-    if mode == lib.CONV_WGRAD:           # caller-owned scratch (today: the RGB-side weight gradient's partial sums)
-        need = lib.get().savp_conv_workspace_bytes(ctypes.byref(a))
-        if need:
-            ws = scratch(w.device, (need + 3) // 4)
-            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if mode == lib.CONV_WGRAD:           # caller-owned scratch: the RGB-side weight gradient's partial sums
+        _conv_scratch(a, w.device)
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
@@ -277,6 +287,8 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
                 e1.record()
                 INSITU['events'].append((key, e0, e1))
                 return
+    if mode != lib.CONV_WGRAD and a.splitk != 1:
+        _conv_scratch(a, w.device)     # split-K slices (deterministic split-K: include/savp_hip.h SavpConvArgs.ws)
     if CONV_CALL_LOG is not None:      # profiling aid (tests/conv_shape_profile.py): launch order -> problem shape
         CONV_CALL_LOG.append((mode, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, tuple(geom.k), tuple(geom.s), a.tile, a.splitk))
     if defer:                          # the filled argument block (tile / split-K chosen) for a fused-operator entry point; nothing is launched
@@ -415,8 +427,15 @@ def zero_arena(device):
     return a
 
 
+def stats_ws(device, N, C):
+    """An all-zero FLOAT64 [N, C, 2] reduction workspace from the step's zero arena: what conv(stats=...), the norm_bwd['ws'] epilogue and the
+    coalesced instance-norm kernels accumulate their per-(sample, channel) sums in.  float64 because a sum of fp32 partials is exact there:
+    the statistics do not depend on the order in which the workgroups' atomics arrive, so two runs of a step give the same bits."""
+    return zero_arena(device).take(N * C * 4).view(torch.float64).view(N, C, 2)
+
+
 def _inorm_ws(x):
-    return zero_arena(x.device).take(x.shape[0] * x.shape[-1] * 2)
+    return stats_ws(x.device, x.shape[0], x.shape[-1])
 
 
 def _set_ranges(c0_arr, nc_arr, ranges):
@@ -433,7 +452,8 @@ def instnorm_act_fwd(x, gamma, beta, outs, mean, rstd, act='relu', alpha=0.0, ep
     statistics pass is skipped.  stats_shift: that convolution's bias [C] (its sums are taken around the bias); None: no bias."""
     a = lib.SavpInormArgs()
     if stats is not None:
-        lib.require_device(stats, stats_shift)
+        lib.require_device(stats_shift)
+        lib.require_stats(stats)
         a.ws, a.ws_clean, a.stats_ready = stats.data_ptr(), 1, 1
         a.stats_shift = stats_shift.data_ptr() if stats_shift is not None else None
     else:
@@ -459,7 +479,7 @@ def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, d
     convolution that produced dy (conv(..., norm_bwd=...)): the statistics pass is skipped."""
     a = lib.SavpInormArgs()
     if stats is not None:
-        lib.require_device(stats)
+        lib.require_stats(stats)
         a.ws, a.ws_clean, a.stats_ready = stats.data_ptr(), 1, 1
     else:
         a.ws, a.ws_clean = _inorm_ws(x).data_ptr(), 1
@@ -498,6 +518,9 @@ def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
     return a
 
 
+LSTM_RED_FLOATS = 22       # include/savp_hip.h: SavpLstmArgs.ws_stats
+
+
 def lstm_ws_floats(N, HW, F):
     """Scratch size (floats) that selects the coalesced three-pass ConvLSTM kernels (include/savp_hip.h); the small
     reduction workspace comes from the zero arena."""
@@ -509,15 +532,15 @@ def _lstm_ws(a, gates, ws, ws_stats=None):
         lib.require_device(ws)
         a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     if ws_stats is None:
-        ws_stats = zero_arena(gates.device).take(a.N * a.F * 11)
+        ws_stats = zero_arena(gates.device).take(a.N * a.F * LSTM_RED_FLOATS)
     a.ws_stats, a.ws_stats_clean = ws_stats.data_ptr(), 1
 
 
 def lstm_stats_ws(device, N, F):
-    """An all-zero reduction workspace [N*F*11] of the coalesced ConvLSTM gate kernels from the step's zero arena; its first
-    N*4F*2 floats, viewed [N, 4F, 2], are what savp_conv's `stats` epilogue fills for convlstm_gates_fwd(stats1=...)."""
-    ws = zero_arena(device).take(N * F * 11)
-    return ws, ws[:N * 4 * F * 2].view(N, 4 * F, 2)
+    """An all-zero reduction workspace [N*F*22 floats] of the ConvLSTM gate kernels from the step's zero arena (float64 sums, see stats_ws);
+    its head, viewed as float64 [N, 4F, 2], is what savp_conv's `stats` epilogue fills for convlstm_gates_fwd(stats1=...)."""
+    ws = zero_arena(device).take(N * F * LSTM_RED_FLOATS)
+    return ws, ws[:N * 4 * F * 4].view(torch.float64).view(N, 4 * F, 2)
 
 
 def convlstm_gates_fwd(gates, c_prev, g1, b1, g2, b2, c_new, hs, stats, eps=1e-6, forget_bias=1.0, ws=None, stats1=None, defer=False):
@@ -907,7 +930,7 @@ def fold_bilinear(inp, out, k, Cin, F, adjoint=False):
 
 
 def sn_ws_size(K, C):
-    return 8 + 2 * C + 2 * K
+    return 8 + 2 * C + 2 * K + 2 * (C + 2)       # + the float64 forward accumulators (csrc/weight_prep.hip)
 
 
 def sn_fwd(W, u, ws, u_new=None):

@@ -166,6 +166,17 @@ def require_device(*tensors):
             raise RuntimeError('expected float32, got %s' % t.dtype)
 
 
+def require_stats(*tensors):
+    """float64 [N, C, 2] reduction workspaces (kernels.stats_ws)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('video_prediction_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
+        if t.dtype != torch.float64 or (t.data_ptr() & 7):
+            raise RuntimeError('statistics workspaces are float64 (kernels.stats_ws), got %s' % t.dtype)
+
+
 def require_device_any(*tensors):
     """Activations that may be fp32 or bf16 (ring conv kernel)."""
     for t in tensors:

@@ -235,7 +235,10 @@ class SAVPGenerator(object):
             self.cdna_dense = ConvLayer(store, prefix + 'cdna_kernels/dense/kernel', prefix + 'cdna_kernels/dense/bias', 'conv',
                                         (1, 1), (1, 1), (0, 0))
             self.cdna_raw = Act((T1, N, kh * kw * nk), dev, grad=g)
-            self.cdna_kern = Act((T1, N, kh * kw, nk), dev, grad=g)
+            self.cdna_kern = Act((T1, N, kh * kw, nk), dev, grad=False)
+            # gradient of the normalised CDNA kernels of ONE timestep, float64: the image tiles' partial sums meet in it through float64
+            # atomics (exact, order-independent: include/savp_hip.h SavpCdnaArgs.dkern); consumed by cdna_kernels_bwd right away
+            self.cdna_dkern = torch.zeros(N, kh * kw, nk, device=dev, dtype=torch.float64) if g else None
             tf_convs = [self.cdna_dense]
         else:
             # flow: h_flow = relu(IN(conv3x3)); flows = conv3x3 -> 2*nk   (savp_model.py:522-530)
@@ -437,7 +440,7 @@ class SAVPGenerator(object):
                 ck = ('cstats', K.PRECISION['value'])          # the answer depends on the datapath in use: decided once per precision
                 if ck not in L:
                     L[ck] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
-                st = K.zero_arena(self.dev).take(N * f * 2) if L[ck] else None
+                st = K.stats_ws(self.dev, N, f) if L[ck] else None
                 nrm = L['norm']
                 if L['rnn'] and self.gru:
                     L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
@@ -535,7 +538,7 @@ class SAVPGenerator(object):
         if ok is None:
             c = pre.shape[-1]
             ok = self._cstats[(name, K.PRECISION['value'])] = bool(CONV_STATS and c <= 256 and (c & (c - 1)) == 0 and conv.stats_ok(x, pre))
-        st = K.zero_arena(self.dev).take(self.N * pre.shape[-1] * 2) if ok else None
+        st = K.stats_ws(self.dev, self.N, pre.shape[-1]) if ok else None
         self._conv_in_act(conv, x, pre, st, nrm, outs, t, **kw)
 
     def _conv_in_act(self, conv, x, pre, st, nrm, outs, t, **kw):
@@ -559,11 +562,14 @@ class SAVPGenerator(object):
         key = (key, K.PRECISION['value'])
         ok = holder.get(key)
         if ok is None:
-            ok = holder[key] = bool(NORM_BWD_STATS and dx.dtype == torch.float32 and x.shape[-1] <= 256 and
+            # savp_instnorm_act_bwd(stats_ready) runs the coalesced apply pass alone: C % 4 == 0, C <= 256 and a whole number of pixel rows
+            # per 256-thread workgroup (256 % (C / 4) == 0) -- the forward twin's guard (non-power-of-two ngf would otherwise raise in every backward)
+            c = x.shape[-1]
+            ok = holder[key] = bool(NORM_BWD_STATS and dx.dtype == torch.float32 and c <= 256 and c % 4 == 0 and 256 % (c // 4) == 0 and
                                     conv.norm_bwd_ok(dy, dx, t_, skip))
         if not ok:
             return None
-        t_['ws'] = K.zero_arena(self.dev).take(self.N * x.shape[-1] * 2)
+        t_['ws'] = K.stats_ws(self.dev, self.N, x.shape[-1])
         return t_
 
     def _in_act_conv_bwd(self, L, t, y0, dys, st):
@@ -605,9 +611,9 @@ class SAVPGenerator(object):
             # pixel transformation head (everything behind its 3x3 feature conv)
             dslot = maskin.g[t][..., self.o_cdna:self.o_cdna + self.nk * C]
             if self.tf == 'cdna':
-                K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], dslot, self.dimg_cdna, self.cdna_kern.g[t], self.kh,
+                K.cdna_apply_bwd(in0.v[t][..., 0:C], self.cdna_kern.v[t], dslot, self.dimg_cdna, self.cdna_dkern, self.kh,
                                  self.kw, self.nk)
-                K.cdna_kernels_bwd(self.cdna_raw.v[t], self.cdna_kern.g[t], self.cdna_raw.g[t], self.kh, self.kw, self.nk)
+                K.cdna_kernels_bwd(self.cdna_raw.v[t], self.cdna_dkern, self.cdna_raw.g[t], self.kh, self.kw, self.nk)
                 self.cdna_dense.backward_data(self.cdna_raw.g[t], self.hsmall.g[t].reshape(N, -1), beta=0)
             else:
                 if self.tf == 'flow':
