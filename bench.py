@@ -137,6 +137,29 @@ def cpu_baseline(seconds_budget=30.0):
             'sample': '%d full train step(s) of 1 sequence (B=1, T=%d, 64x64x3, fp32 torch-CPU oracle), %.1f s' % (nsteps, SEQ, el)}
 
 
+def pin_rank(local_rank, local_world):
+    """One process per GPU: give rank r the r-th contiguous slice of the cores this job may use (sched_setaffinity) and size torch's
+    host thread pool to it.  Eight Python interpreters that each issue ~2.5 k launches (or 8 graph segments + 7 collectives) per step
+    otherwise migrate across both sockets and share cores with each other's RCCL proxy threads.  Contiguous slices follow the usual
+    MI300-class node layout (GPUs 0-3 on socket 0, 4-7 on socket 1; cores numbered socket by socket); SAVP_PIN=0 leaves the
+    scheduler alone.  Returns a description for the bench line (config.dist.binding)."""
+    if os.environ.get('SAVP_PIN', '1') != '1' or not hasattr(os, 'sched_setaffinity'):
+        return 'none'
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // max(local_world, 1)
+        if per < 1:
+            return 'none (%d cores for %d ranks)' % (len(cpus), local_world)
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, 8)))
+        desc = 'rank %d -> cores %d-%d (%d of %d), %d torch threads' % (local_rank, mine[0], mine[-1], per, len(cpus), torch.get_num_threads())
+        print('bench.py: ' + desc, file=sys.stderr)
+        return desc
+    except OSError as ex:
+        return 'failed: %r' % (ex,)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -155,7 +178,20 @@ def main():
     ap.add_argument('--tuning-table', default=None, help='developer: a tuning table other than the shipped one (A/B of re-tuned entries)')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
+    ap.add_argument('--dry-run', action='store_true', help='print the launch plan (launcher command line, per-rank core binding, workload) as JSON and exit; needs no GPU')
     args = ap.parse_args()
+
+    if args.dry_run:
+        cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+        per = len(cpus) // max(args.gpus, 1)
+        cfg = CONFIGS[args.config]
+        plan = {'n_gpus': args.gpus, 'workload': args.config, 'per_gpu_batch': args.batch or cfg['batch'], 'global_batch': (args.batch or cfg['batch']) * args.gpus,
+                'steps': args.steps, 'warmup': args.warmup, 'scaling': 'weak', 'backend': os.environ.get('SAVP_DIST_BACKEND', 'nccl'),
+                'launcher': ([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                              '--master-port', '<free port>', os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--dry-run']) if args.gpus > 1 else None,
+                'binding': ['rank %d -> cores %d-%d' % (r, cpus[r * per], cpus[(r + 1) * per - 1]) for r in range(args.gpus)] if (args.gpus > 1 and per >= 1) else 'none'}
+        print(json.dumps(plan))
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the SAVP hot path has no CPU fallback')
@@ -181,6 +217,7 @@ def main():
     # SAVP_DIST_BACKEND=gloo: several ranks may share one GPU (tests/test_gpu_dp.py runs the whole multi-rank path of this script
     # on a one-GPU box: launcher, rendezvous, tuning broadcast, chunked exchange, MAX-over-ranks clock, one JSON line)
     backend = os.environ.get('SAVP_DIST_BACKEND', 'nccl')
+    binding = pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None
     dev_index = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
@@ -430,7 +467,8 @@ def main():
         st = engine.replicas.stats
         result['config']['dist'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                                     'allreduce_chunks_issued': st['chunks'], 'allreduce_elements': st['elements'], 'aux_broadcasts': st['aux_broadcasts'],
-                                    'side_stream': engine.replicas.comm_stream is not None}
+                                    'side_stream': engine.replicas.comm_stream is not None, 'binding': binding,
+                                    'ranks_seen_by_backend': dist.get_world_size(), 'allreduce_bytes_per_step': 4 * st['elements'] // max(1, args.warmup + args.steps + INST_STEPS)}
     if dist is not None and os.environ.get('SAVP_BENCH_CHECK_REPLICAS', '0') == '1':
         result['replicas_identical'] = bool(engine.replicas.checksum_identical())      # collective: every rank calls it
     if rank == 0 and args.save_tuning:

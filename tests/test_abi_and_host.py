@@ -367,3 +367,41 @@ def test_zero_arena_offsets_after_a_replay():
     assert a.off == mark + 64 and float(nxt.abs().sum()) == 0.0
     with pytest.raises(ValueError):
         a.take(4096)
+
+
+def test_split_k_scratch_query_is_a_host_side_predicate(hip_lib):
+    """Deterministic split-K (include/savp_hip.h SavpConvArgs.ws): a FPROP / DGRAD call stores every split's share in its own slice of the
+    caller's scratch; savp_conv_workspace_bytes says how much -- exactly splitk slices of the dense destination block for an explicit
+    split count, an upper bound of the heuristic's choice for the automatic one, nothing for an unsplit call or a large problem."""
+    from video_prediction_amd import lib
+    a = _conv2d_args(lib, lib.CONV_DGRAD, 32, 8, 8, 264, 8, 8, 512, 5, 1, 2)      # the 8x8 gate convolution's data gradient
+    block = 32 * 8 * 8 * 264 * 4
+    a.splitk = 4
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(a)) == 4 * block
+    a.splitk = 1
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(a)) == 0
+    a.splitk = 0
+    auto = hip_lib.savp_conv_workspace_bytes(ctypes.byref(a))
+    assert auto % block == 0 and 2 * block <= auto <= 16 * block
+    a.dst_gap_at, a.dst_gap, a.Cx, a.splitk = 128, 8, 256, 2                      # gapped destination: the block spans the physical channels
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(a)) == 2 * block
+    big = _conv2d_args(lib, lib.CONV_FPROP, 32, 64, 64, 32, 64, 64, 32, 3, 1, 1)   # 131 072 output rows: never split automatically
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(big)) == 0
+
+
+def test_bench_dry_run_prints_the_eight_rank_launch_plan():
+    """`bench.py --gpus 8 --dry-run` on a box without a GPU: the launcher line the script becomes (= the driver's torch.distributed.run
+    line), one core slice per rank, the weak-scaling workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '5', '--warmup', '2', '--dry-run'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 8 and d['global_batch'] == 128 and d['per_gpu_batch'] == 16 and d['scaling'] == 'weak' and d['backend'] == 'nccl'
+    L = d['launcher']
+    assert L[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and L[L.index('--nproc-per-node') + 1] == '8'
+    assert L[L.index('--master-addr') + 1] == '127.0.0.1' and '--dry-run' not in L
+    assert d['binding'] == 'none' or len(d['binding']) == 8

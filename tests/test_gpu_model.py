@@ -195,29 +195,30 @@ def _run_steps(monkeypatch, graph, steps, conv_algo=None, precision='f32'):
 
 
 def test_hipgraph_replay_matches_eager_steps(monkeypatch):
-    """The captured launch sequence (hipGraph) is the eager step.  The steps are not bit-reproducible (atomically accumulated
-    reductions) and Adam's sign-like first updates amplify that noise, so: (a) losses of 4 steps agree loosely with the eager
-    run -- a stale KL weight or noise tensor in the replays would be far outside; (b) the step-dependent scalars the graph reads
-    from device memory (Adam's lr_t of both groups, the annealed KL weight) are checked exactly after every step."""
+    """The captured launch sequence (hipGraph) is the eager step.  Since round 5 every reduction upstream of a rounding is
+    order-independent (float64 statistic sums, fixed-order folds, split-K slices), what differs between two runs is the fp32 summation
+    order of the final weight-gradient tiles and loss partials: (a) losses of 4 steps at lr = 1e-3 agree to 1e-5 / 1e-4 (measured
+    7e-7 ... 3e-6; round 4 needed 3e-3 / 1e-2) -- a stale KL weight or noise tensor in the replays would be far outside; (b) the
+    step-dependent scalars the graph reads from device memory (Adam's lr_t of both groups, the annealed KL weight) are checked
+    exactly after every step."""
     import math
     from video_prediction_amd.models.base_model import kl_weight, learning_rate
     le, _, ge = _run_steps(monkeypatch, False, 4)
     lg, _, gg = _run_steps(monkeypatch, True, 4)
     assert gg and not ge
-    # gate (round 4): the FIRST step sees identical variables and noise, so replay and eager differ by fp32 summation order only
-    # (atomically accumulated statistics): 3e-3 of max(1, |loss|); the later steps carry that noise through Adam's sign-like first
-    # updates at lr = 1e-3 and the GAN terms: 1e-2 (round 3: 5e-2 for all four).  The measured spread is written next to the other evidence so that the
-    # gate can follow the measurement (profiles/r04_graph_vs_eager_spread.json).
+    # the FIRST step sees identical variables and noise: loss partials in another order only; the later steps carry the last-bit
+    # differences of the weight gradients through Adam's sign-like first updates at lr = 1e-3.  The measured spread is written next to
+    # the other evidence (profiles/r05_graph_vs_eager_spread.json).
     spread = [max(abs(d0 - d1) / max(1.0, abs(d0)), abs(g0 - g1) / max(1.0, abs(g0))) for (d0, g0), (d1, g1) in zip(le, lg)]
     out_dir = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(out_dir):
         import json
-        with open(os.path.join(out_dir, 'r04_graph_vs_eager_spread.json'), 'w') as f:
+        with open(os.path.join(out_dir, 'r05_graph_vs_eager_spread.json'), 'w') as f:
             json.dump({'what': 'max over (d_loss, g_loss) of |replay - eager| / max(1, |eager|) per step, fp32 datapath, B=2, T=12, lr=1e-3',
                        'per_step': spread, 'eager': le, 'replay': lg}, f, indent=1)
-    assert spread[0] <= 3e-3, (spread, le, lg)           # measured on MI355X (profiles/r04_graph_vs_eager_spread.json): 8.2e-4
+    assert spread[0] <= 1e-5, (spread, le, lg)           # measured on MI355X (profiles/r05_graph_vs_eager_spread.json): 6.8e-7 (round 4, float atomics: 8.2e-4)
     for sp in spread[1:]:
-        assert sp <= 1e-2, (spread, le, lg)              # measured: 4.3e-4 ... 7.6e-4 (round 3 gated all four steps at 5e-2)
+        assert sp <= 1e-4, (spread, le, lg)              # measured: 1.1e-6 ... 2.9e-6 (round 4: 4.3e-4 ... 7.6e-4)
     # scalars: rebuild the engine in graph mode and watch d_scal
     from tests.gpu_model_checks import make_hparams
     from video_prediction_amd.models.savp_model import SAVPEngine
@@ -262,12 +263,13 @@ def _adam_moments_after(monkeypatch, graph, precision, steps):
         K.set_conv_precision('f32')
 
 
-@pytest.mark.parametrize('precision,tol', [('f32', 5e-3), ('bf16', 0.5)])
+@pytest.mark.parametrize('precision,tol', [('f32', 5e-6), ('bf16', 5e-6)])
 def test_replayed_steps_accumulate_the_same_adam_moments_as_eager_steps(monkeypatch, precision, tol):
     """Gradient-level statement of "the replay IS the step", over more replays than any other test makes: 16 steps at lr = 0, replayed
     against launched one by one, from identical seeds; Adam's m (beta1 = 0.5: the last few gradients) and v (beta2 = 0.999: all of them)
-    of the generator / encoder and discriminator groups must agree -- fp32 datapath to summation-order noise (tight), bf16 datapath to its
-    run-to-run spread (atomically summed statistics feed bf16 roundings, DESIGN.md section 5: loose).  Before csrc/zero_fill.h the replayed run
+    of the generator / encoder and discriminator groups must agree -- on BOTH datapaths to the fp32 summation order of the final
+    weight-gradient tiles (5e-6 of the group's norm; measured 2e-9 ... 2.5e-7).  Round 4 needed 0.5 for the bf16 generator moment:
+    atomically summed statistics fed bf16 roundings; they are float64 sums now.  Before csrc/zero_fill.h the replayed run
     of such a model went non-finite after ~8 steps (memset nodes of a replayed hipGraph)."""
     steps = 16
     me, le, ge = _adam_moments_after(monkeypatch, False, precision, steps)
@@ -284,18 +286,12 @@ def test_replayed_steps_accumulate_the_same_adam_moments_as_eager_steps(monkeypa
     out_dir = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(out_dir):                                # the measurement the gates follow (copied to profiles/ with the round's evidence)
         import json
-        with open(os.path.join(out_dir, 'r04_replay_vs_eager_moments_%s.json' % precision), 'w') as f:
+        with open(os.path.join(out_dir, 'r05_replay_vs_eager_moments_%s.json' % precision), 'w') as f:
             json.dump({'what': 'replayed vs eager, 16 steps at lr = 0: relative L2 of Adam m / v per group; worst relative loss difference',
                        'precision': precision, 'moment_rel_l2': errs, 'worst_loss_rel': rel, 'gate_moments': tol}, f, indent=1)
-    # fp32: summation order only.  bf16: the step is not run-to-run reproducible (atomically summed statistics feed bf16 roundings) and at
-    # B = 2 the generator's first moment carries the last steps' spread -- a 5e-2 gate on everything passed in one lease and failed in the
-    # next.  What this case must catch -- a replay that goes non-finite or accumulates something else entirely -- is far outside the gates.
-    # measured on MI355X (profiles/r04_replay_vs_eager_moments_*.json): f32 6.3e-4 everywhere; bf16 g.m 0.135 (beta1 = 0.5: half of it is the
-    # LAST step's gradient, whose bf16 run-to-run spread at B = 2 is ~0.2), g.v 0.019, d.m 0.011, d.v 4e-4, losses 4.5e-5
     for k, e in errs.items():
-        gate = tol if precision == 'f32' else (0.5 if k == 'g.m' else 0.1)
-        assert e <= gate, (precision, k, e, errs)
-    assert rel <= (1e-3 if precision == 'f32' else 2e-2), (precision, rel)      # measured 6.7e-7 / 4.5e-5
+        assert e <= tol, (precision, k, e, errs)
+    assert rel <= 1e-5, (precision, rel)                 # measured 4.7e-7 / 4.5e-7
 
 
 def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_train_replay(monkeypatch):
@@ -332,7 +328,9 @@ def test_generate_replays_as_one_hipgraph_and_shares_the_zero_arena_with_the_tra
             assert arena.off == mark
             if i == 0:
                 torch.cuda.synchronize()
-                assert float(arena.buf[:mark].abs().sum()) > 0.0 and float(arena.buf[mark:].abs().sum()) == 0.0
+                # (the arena holds float64 sums since round 5: look at the raw words, not at float32 values of double halves)
+                raw = arena.buf.view(torch.int32)
+                assert int((raw[:mark] != 0).sum()) > 0 and int((raw[mark:] != 0).sum()) == 0
             got = eng.generate(noise)                           # eager takes: behind the replay's mark
             assert float((got - ref).abs().max()) <= 1e-4, i
         # (a) replayed unroll
@@ -461,15 +459,7 @@ def test_train_and_generate_scripts(tmp_path):
     assert len(pngs) == 2 * 2 * 10 and 'gen_image_00001_01_09.png' in pngs          # 2 sequences x 2 samples x 10 future frames
 
 
-GRAD_REL_L2 = 0.22      # bf16 datapath, per-variable gradient vs the oracle (measured worst on MI355X: 0.19; run-to-run spread 0.02)
-# c5 (128x128): the worst variables are 32-element instance-norm parameters of the 64x64 layers (h0 beta 0.274, h4 gamma 0.224 on
-# MI355X) -- sums over 8 x 29 planes of 4096 pixels of terms that cancel to ~2 % of their magnitude (abs error 1.9e-2 of the group's
-# largest gradient); the exact-fp32 datapath passes the per-op-tolerance gate at this plane size (gpu_model_checks.check_config_c5), so this is bf16 rounding.
-# The bf16 step is not run-to-run reproducible (atomically summed statistics feed bf16 roundings: ~2e-2 relative L2 between two runs of one
-# build) and this variable moves with it: h0 beta 0.274 and 0.303 in two leases of round 4 (profiles/r04_full_gputest.log
-# is the second).  Gate = the larger measurement + 2.5 x that spread.
-GRAD_REL_L2_BY_CASE = {'c5_step_golden.npz': 0.36}
-
+GRAD_REL_L2 = 0.22      # bf16 datapath, per-variable gradient vs the oracle (measured worst on MI355X: 0.19 at c2; the step is reproducible since round 5)
 
 def _bench_engine(fname, case, lr=None, graph=None):
     """The engine of a bench case (tests.gpu_model_checks.BENCH_CASES) on the bf16 datapath with the shipped tuning table, its golden
@@ -494,9 +484,43 @@ def _bench_engine(fname, case, lr=None, graph=None):
     return eng, gold, noise
 
 
+_F32_GRADS = {}
+
+
+def _f32_datapath_grads(fname, case):
+    """Per-variable gradients of the same bench step on the EXACT-fp32 datapath of the same build (cached per case)."""
+    from video_prediction_amd import kernels as K
+    if fname not in _F32_GRADS:
+        from tests import gpu_model_checks as G
+        from video_prediction_amd.models.savp_model import SAVPEngine
+        hp, vals, images, noise = G.recipe_case(**case)
+        prev = K.PRECISION['value']
+        K.set_conv_precision('f32')
+        try:
+            K.load_tuning(os.path.join(os.path.dirname(HERE), 'video_prediction_amd', 'tuning_gfx950_f32.json'))
+            e32 = SAVPEngine(hp, (case['H'], case['W'], case['C']), case['B'], mode='train', values=vals, device='cuda:0')
+            e32.set_images(images.float().cuda(), time_major=True)
+            i32 = e32.train_step(noise, return_grads=True)
+            torch.cuda.synchronize()
+            _F32_GRADS[fname] = {k: v.detach().clone() for key in ('d_grads', 'g_grads') for k, v in i32[key].items()}
+            del e32, i32
+            torch.cuda.empty_cache()
+        finally:
+            K.PRECISION['value'] = prev
+    return _F32_GRADS[fname]
+
+
 def _compare_with_golden(fname, case, gold, eng, info, grads, grad_tol):
     """losses / sampled frames / per-variable gradients of one step against the committed oracle step.  grads: {'d_grads': {name:
-    tensor}, 'g_grads': {...}}.  Returns (checked, projected, worst)."""
+    tensor}, 'g_grads': {...}}.  Returns (checked, projected, worst).
+
+    ONE gradient gate for every case (round 4 carried a fitted per-case exception for c5).  A variable may miss it only as an EXPLAINED
+    cancellation case, checked here rather than waved through: a norm parameter of <= 64 elements whose gradient on the exact-fp32
+    datapath of the SAME build (same kernels, same launch sequence, operands not rounded) matches the oracle to 3e-2 relative L2, and
+    whose bf16 error stays below 3e-2 of the group's largest gradient.  That is c5's h0 InstanceNorm/beta (0.29 relative L2, deterministic
+    since round 5): d beta = sum over 8 x 29 planes of 64 x 64 pixels of dy * relu', where dy = W^T dpre and sum(dpre) = 0 over every
+    plane (an instance norm's input gradient sums to zero), so the value is only the correlation of 576 weight-weighted terms with the
+    ReLU mask; the bf16 rounding of W is the SAME relative perturbation at every pixel and does not average out over the plane."""
     from tests.golden.make_b16_step_golden import sample_index
     B = case['B']
     bad = []
@@ -546,7 +570,28 @@ def _compare_with_golden(fname, case, gold, eng, info, grads, grad_tol):
                     if pe > grad_tol and float(np.abs(proj.cpu().numpy() - want).max()) > 2e-3 * gmax * np.sqrt(g2.numel() / want.size):
                         bad.append((nme, 'projection rel L2 %.3f' % pe))
     assert checked >= 100
-    assert not bad, (fname, bad, 'worst per-variable gradient rel L2 %.3f at %s' % worst)
+    explained = []
+    grad_fail = [b for b in bad if len(b) == 3 and isinstance(b[1], str) and b[1].startswith('rel L2')]
+    if grad_fail and len(grad_fail) <= 4:
+        g32 = _f32_datapath_grads(fname, case)
+        for b in grad_fail:
+            nme = b[0]
+            key = 'd_grads' if nme in grads['d_grads'] else 'g_grads'
+            g = grads[key][nme].detach()
+            if g.numel() > 64 or not (nme.endswith('beta') or nme.endswith('gamma')):
+                continue
+            idx = torch.from_numpy(sample_index(nme, g.numel())).to(g.device)
+            ref = gold['%s/%s/sample' % (key, nme)].astype(np.float64)
+            got32 = g32[nme].reshape(-1)[idx].double().cpu().numpy()
+            got16 = g.reshape(-1)[idx].double().cpu().numpy()
+            names = [k.split('/', 1)[1].rsplit('/', 1)[0] for k in gold.files if k.startswith(key + '/') and k.endswith('/norm')]
+            gmax = max(float(gold['%s/%s/max' % (key, n_)]) for n_ in names)
+            e32 = float(np.linalg.norm(got32 - ref) / max(np.linalg.norm(ref), 1e-30))
+            a16 = float(np.abs(got16 - ref).max()) / gmax
+            if e32 <= 3e-2 and a16 <= 3e-2:
+                explained.append((nme, b[1], 'fp32 datapath rel L2 %.1e' % e32, 'bf16 abs/gmax %.1e' % a16))
+                bad.remove(b)
+    assert not bad, (fname, bad, 'worst per-variable gradient rel L2 %.3f at %s' % worst, explained)
     return checked, projected, worst
 
 
@@ -561,7 +606,7 @@ def _golden_step_check(fname, case):
     finally:
         K.set_conv_precision('f32')
         K.AUTOTUNE.update(enabled=saved['enabled'], cache=saved['cache'])
-    return _compare_with_golden(fname, case, gold, eng, info, info, GRAD_REL_L2_BY_CASE.get(fname, GRAD_REL_L2))
+    return _compare_with_golden(fname, case, gold, eng, info, info, GRAD_REL_L2)
 
 
 def test_bench_problem_b16_t30_bf16_step_vs_oracle_golden():
@@ -590,9 +635,9 @@ def test_bench_workloads_c4_c5_bf16_step_at_bench_shape_vs_oracle_golden(config)
 
 # replayed-vs-eager gates at the bench shapes (the atomically summed statistics are accumulated in float64 -- exact, hence
 # order-independent -- and every other reduction upstream of a bf16 rounding runs in a fixed order: DESIGN.md section 5)
-REPLAY_LOSS_REL = 1e-6          # per-step losses, replayed vs launched one by one (loss scalars themselves are atomically summed block partials)
+REPLAY_LOSS_REL = 1e-5          # per-step losses, replayed vs launched one by one (the loss SCALARS are atomically summed fp32 block partials; measured 1.9e-6 ... 2.8e-6)
 REPLAY_FRAMES_ABS = 0.0         # generated frames: bit-identical
-REPLAY_MOMENT_REL_L2 = 1e-5     # Adam m / v of both groups (weight gradients are atomically accumulated tile partials: fp32 summation order)
+REPLAY_MOMENT_REL_L2 = 5e-6     # Adam m / v of both groups (weight gradients are atomically accumulated tile partials: fp32 summation order; measured 4e-8 ... 6.4e-7)
 
 
 def _bench_steps(fname, case, graph, steps):
@@ -614,7 +659,7 @@ def test_the_replayed_bench_step_is_the_eager_step_and_matches_the_golden(config
     (a) 5 steps launched one by one against 1 eager + 1 captured + 3 replayed steps from the same variables and noise: per-step losses,
     the generated frames and Adam's moments of both groups must agree -- frames bit for bit, the rest to fp32 summation order of the
     final weight-gradient / loss partials; (b) one more REPLAY from the golden's state (spectral-norm u vectors restored, moments
-    cleared: the replay then executes step 0) against the committed oracle step: losses, sampled frames, and the per-variable gradients
+    cleared, the recipe's learning rate staged: the replay then executes step 0) against the committed oracle step: losses, sampled frames, and the per-variable gradients
     recovered from Adam's first moment m = (1 - beta1) g, with the golden test's gates.  A replay that differs from the eager step -- the
     round-4 memset nodes, a stale staged scalar, a workspace captured at the wrong offset -- fails (a) or (b)."""
     import gc
@@ -646,11 +691,16 @@ def test_the_replayed_bench_step_is_the_eager_step_and_matches_the_golden(config
         loss_rel = float(((lr_ - le).abs() / le.abs().clamp_min(0.05)).max())
         frames_abs = float((eng.gen.gen.v.float() - fe.float()).abs().max())
         frames_differ = int((eng.gen.gen.v != fe).sum())
-        # (b) the replay as step 0: golden state, cleared moments
+        # (b) the replay as step 0: golden state (lr = 0 left the variables where they started; the spectral-norm u vectors are restored),
+        # cleared moments and step counters, and the RECIPE's learning rate -- the generator's GAN terms are taken against the discriminator
+        # AFTER its Adam update (base_model.py:498-505), so the replay has to make that update like the golden step did
         G_['aux'].p.copy_(aux0)
         for g in ('g', 'd'):
             G_[g].m.zero_()
             G_[g].v.zero_()
+            G_[g].t = 0
+        eng.step = 0
+        eng.hp.lr = G.recipe_case(**case)[0].lr
         info = eng.train_step(noise)
         torch.cuda.synchronize()
         b1 = eng.hp.beta1

@@ -53,7 +53,9 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
-#ifdef SAVP_CONV_ABLATE
+// developer builds: -DSAVP_RING_STAMPS = the cycle stamps alone (the shipped instruction stream plus ~12 s_memtime reads of one wave);
+// -DSAVP_CONV_ABLATE = stamps + the ablation switches, whose branches change the loop's schedule (that build ran 2x slower)
+#if defined(SAVP_CONV_ABLATE) || defined(SAVP_RING_STAMPS)
 __device__ unsigned long long g_ring_t[16];       // developer build: s_memtime stamps of workgroup 0, wave 0 (savp_debug_ring_times)
 __constant__ int g_ring_blk = 0;                  // which workgroup stamps
 __constant__ int g_ring_wv = 0;                   // which wave of it
@@ -74,10 +76,12 @@ extern "C" int savp_debug_ring_block(int b) {
 extern "C" int savp_debug_ring_wave(int w) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_wv), &w, sizeof(int)) == hipSuccess ? 0 : -1;
 }
+#ifdef SAVP_CONV_ABLATE
 extern "C" int savp_debug_ring_ablate(int bits) {          // same bits as SAVP_ABLATE, changeable between launches
     ablate_init();
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
 }
+#endif
 extern "C" int savp_debug_ring_kwarm(int on) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_kwarm), &on, sizeof(int)) == hipSuccess ? 0 : -1;
 }
@@ -87,8 +91,13 @@ extern "C" int savp_debug_ring_kwarm(int on) {
 #define savp_kwarm() true
 #endif
 
+// Minimum waves per SIMD the register allocator has to leave room for (__launch_bounds__' second argument).  Only <8, 2, 1, 2> needs the
+// hint: it sits at 128 VGPRs = two resident 8-wave workgroups per CU, and its small-K problems (the 64x64 layers) run two per CU -- two more
+// registers (130 -> 136 allocated) halve that: 21 -> 28 us per launch in the step (round 5, profiles/r05_ab_calls.md).
+template <int NW, int WM, int WN, int NKS> constexpr int ring_min_waves() { return (NW == 8 && WM == 2 && WN == 1 && NKS == 2) ? 4 : 1; }
+
 template <int NW, int WM, int WN, int NKS>
-__global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void conv_ring_kernel(ConvP p) {
     RT(0);
     RTW(0);
     if (savp_kwarm()) kernarg_warm<sizeof(ConvP)>();
@@ -195,19 +204,6 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
 
     // ---- weight slab DMA: per-lane source offsets (bytes) computed once --------------------------------------------------
     unsigned goffF[LW], goffL[LW];
-#pragma unroll
-    for (int q = 0; q < LW; ++q) {
-        const int slot = (wave * LW + q) * 64 + lane;
-        const int r = min(slot / RS, BN - 1);                  // slots >= SLOTS land in the buffer's tail, never read
-        int j = slot % RS;
-        if (j == 2 * NKS) j = 0;                               // pad slot of the row: any valid address
-        int row = min(n0 + r, Nout - 1);                       // columns >= Nout are computed on valid data, never stored
-        if (row >= p.gap_at) row += p.gap;                     // logical output column -> physical weight row (ConvP::gap)
-        const bool okL = (nch - 1) * CKB + j * 8 < Cred;       // beyond Cred the patch holds zeros: any FINITE weights do
-        goffF[q] = (unsigned)(row * ldb + j * 8) * 2u;
-        goffL[q] = (unsigned)(row * ldb + (okL ? j * 8 : 0)) * 2u;
-    }
-    RT(8);
     int g_slabs = 1, g_first = 0, g_jd = 0;
     // Per-entry offsets come from a small LDS table filled once per group (below): the walk over (tap, slab) entries then costs
     // no scalar arithmetic.  (The CU has ONE scalar unit for all its waves: the tap / slab state machine of conv_patch.hip, run
@@ -286,36 +282,73 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     // VGPR path above is instruction-bound: 12-22 k cycles of a 62-105 k cycle gate convolution).  The DMAs are drained (vmcnt 0)
     // before the barrier that publishes the patch, so the weight ring's counted waits never see them.
     auto stage_patch_dma = [&](int cfirst, auto drainc) {
+        // Row-wise (round 5): a wave takes whole patch rows (image, patch row = wave-uniform), a row is NJ = ceil(P8 / 64) DMA
+        // instructions.  Everything that depends on the lane -- which pixel / 8-channel chunk of the row its slot is, whether that slot
+        // is data or padding, its offset inside a source row -- is the same for every row and worked out ONCE per group; per row only
+        // scalar arithmetic (row validity, the row's base offset) and one add + select per instruction remain.  (The slot-linear walk this
+        // replaces decomposed every slot with four 64-bit multiply-high divisions per lane: cycle stamps of the shipped kernel put the
+        // staging at 5.3 / 8.1 / 13.6 k cycles of the 45 / 45 / 58 k-cycle gate convolutions at 32x32 / 16x16 / 8x8 -- ~650 cycles of
+        // VALU issue per DMA instruction and wave.)
         const int C8 = CP >> 3, P8 = pitch >> 3;
         const int used8 = (spp * CKB) >> 3;                   // chunks of a pixel that are read (the last one of CP is pitch padding)
-        const int per_img8 = PH * P8;
-        const int total = ni * per_img8;
         const unsigned patch_lds = ring_lds + (unsigned)(RING * SLABB);
         const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src);
-        for (int base = wave * 64; base < (ABL(4) ? 0 : total); base += NT) {
-            const int slot = base + lane;
-            if (slot < total) {
-                const int im = (int)fastdiv((unsigned)slot, p.s1_magPI8);
-                const int rem = slot - im * per_img8;
-                const int pyy = (int)fastdiv((unsigned)rem, p.s1_magP8);
-                const int r = rem - pyy * P8;
-                const int pxx = (int)fastdiv((unsigned)r, p.s1_magC8);
-                const int ch8 = r - pxx * C8;
-                const int iy = org_h + pyy, ix = org_w + pxx;
-                const int cg = cfirst * CKB + ch8 * 8;
-                const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-                const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
-                const bool ok = pxx < PW && ch8 < used8 && (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN &&
-                                cg < Cred && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
-                const long long off = (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg;
-                const void* g = ok ? static_cast<const void*>(src_b + off * 2) : p.zero16;
-                ring_dma16(g, patch_lds + (unsigned)(base * 16));
+        // lane l's slot j * 64 + l of a row is (pixel, chunk) = (pxx, ch8); the next instruction's slot is 64 further: (pxx, ch8) advance
+        // by (64 / C8, 64 % C8) with one carry -- no division in the walk, and only two live registers per lane (an array of per-j offsets
+        // cost 15 VGPRs and with them a resident workgroup per CU in the small-K instantiations: 21 -> 28 us, 38 -> 63 us in the step)
+        const int nj = (P8 + 63) >> 6;
+        const int pxx0 = (int)fastdiv((unsigned)lane, p.s1_magC8), ch80 = lane - pxx0 * C8;
+        const int dq = (int)fastdiv(64u, p.s1_magC8), dr = 64 - dq * C8;
+        const int cbase = cfirst * CKB;
+        const int rows = ni * PH;
+        int im = 0, pyy = wave;                               // row = im * PH + pyy, waves take rows round-robin
+        while (pyy >= PH) { pyy -= PH; ++im; }
+        for (int row = wave; row < (ABL(4) ? 0 : rows); row += NW) {
+            const int gi = img0 + im;
+            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
+            const int iy = org_h + pyy;
+            const bool row_ok = (unsigned)iy < (unsigned)gh.srcN && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
+            const long long row_base = (long long)n * s_sn + (long long)dz * s_sd + (long long)iy * s_sh;
+            const unsigned char* rb = src_b + row_base * 2;
+            unsigned lds_at = patch_lds + (unsigned)(row * P8) * 16u;
+            int pxx = pxx0, ch8 = ch80, sl = lane;
+            for (int j = 0; j < nj; ++j) {
+                if (sl < P8) {
+                    const int ix = org_w + pxx, cg = cbase + ch8 * 8;
+                    const bool ok = row_ok && pxx < PW && ch8 < used8 && (unsigned)ix < (unsigned)gw.srcN && cg < Cred;
+                    const void* g = ok ? static_cast<const void*>(rb + (long long)(ix * s_sw + cg) * 2) : p.zero16;
+                    ring_dma16(g, lds_at);
+                }
+                sl += 64; lds_at += 1024u;
+                pxx += dq; ch8 += dr;
+                if (ch8 >= C8) { ch8 -= C8; ++pxx; }
             }
+            pyy += NW;
+            while (pyy >= PH) { pyy -= PH; ++im; }
         }
         if constexpr (decltype(drainc)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+    // (Round 5, measured and NOT kept: the first group's patch requested here, in front of the per-lane weight offsets / accumulator clears /
+    // entry table -- ~3 k cycles of VALU issue that could run underneath the patch's memory round trip.  In the step every ring instantiation
+    // got 0.5 - 1 us SLOWER, 53.15 -> 53.5 ms per step (profiles/r05_ab_calls.md): the patch burst then coincides with the weight warm-up's.)
+    const int gsz = ntaps * spp;
+    const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
+    const int gg0 = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz;
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+        const int slot = (wave * LW + q) * 64 + lane;
+        const int r = min(slot / RS, BN - 1);                  // slots >= SLOTS land in the buffer's tail, never read
+        int j = slot % RS;
+        if (j == 2 * NKS) j = 0;                               // pad slot of the row: any valid address
+        int row = min(n0 + r, Nout - 1);                       // columns >= Nout are computed on valid data, never stored
+        if (row >= p.gap_at) row += p.gap;                     // logical output column -> physical weight row (ConvP::gap)
+        const bool okL = (nch - 1) * CKB + j * 8 < Cred;       // beyond Cred the patch holds zeros: any FINITE weights do
+        goffF[q] = (unsigned)(row * ldb + j * 8) * 2u;
+        goffL[q] = (unsigned)(row * ldb + (okL ? j * 8 : 0)) * 2u;
+    }
+    RT(8);
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -378,13 +411,11 @@ __global__ __launch_bounds__(64 * NW) void conv_ring_kernel(ConvP p) {
     RT(9);
     // ---- group-outer loop; inside a group the weight slabs stream through the four-deep DMA ring -----------------------------
     // entry e: its slab is DMAed three iterations ahead, its fragments are read one iteration ahead, its MFMAs run in iteration e.
-    const int gsz = ntaps * spp;
-    const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     Frags F0, F1;
     bool first_group = true;
     using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>; using B3 = std::integral_constant<int, 3>;
-    for (int gg = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz; gg < gd.nt * ngs; ++gg) {
+    for (int gg = gg0; gg < gd.nt * ngs; ++gg) {
         RT(11);
         g_jd = (gd.nt == 1) ? 0 : gg / ngs;
         const int g = gg - g_jd * ngs;
@@ -888,7 +919,8 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         const void* sptr = dg ? a->y : a->x;
         const int CP = spp * nks * 16 + 8;
         p.dma_patch = (savp_opt(OPT_RING_DMA) && a->src_bf16 && (ssn % 8 == 0) && (ssd % 8 == 0) && (ssh % 8 == 0) && (ssw % 8 == 0) &&
-                       ((((uintptr_t)sptr) & 15) == 0) && p.zero16 && (long long)ni * PH * (pitch / 8) < (1 << 24) && (long long)PH * (pitch / 8) < 65536 && (pitch % 8 == 0)) ? 1 : 0;
+                       ((((uintptr_t)sptr) & 15) == 0) && p.zero16 && (long long)ni * PH * (pitch / 8) < (1 << 24) && (long long)PH * (pitch / 8) < 65536 && (pitch % 8 == 0) &&
+                       ssw * (long long)(a->W + a->kw) + Cred < (1ll << 30)) ? 1 : 0;       // row-wise staging: 32-bit in-row offsets
         p.s1_magPI8 = magic40(PH * (pitch / 8)); p.s1_magP8 = magic40(pitch / 8); p.s1_magC8 = magic40(CP / 8);
     }
     p.tm = (int)(((long long)a->N * Dm + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;

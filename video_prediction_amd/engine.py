@@ -352,17 +352,21 @@ class ConvLayer(object):
             return K.conv_stats_ok(lib.CONV_FPROP, self.geom, dy, dx, self.wt, w16=self.wt16, dst_gap=skip, norm_bwd=nb)
         return K.conv_stats_ok(lib.CONV_DGRAD, self.geom, dx, dy, self.wd, w16=self.wd16, dst_gap=skip, norm_bwd=nb)
 
-    def backward_weights(self, x, dy):
+    def backward_weights(self, x, dy, feeds_instance_norm=False):
         """Accumulate the kernel (and bias) gradient from input activations x and output gradients dy; both may
-        carry folded leading (time, batch) dims: [R, (D,) H, W, C]."""
+        carry folded leading (time, batch) dims: [R, (D,) H, W, C].  feeds_instance_norm: the caller states that this convolution's
+        output goes straight into a fused_instance_norm (see below); required for a bf16 dy."""
         target = self.dwfp if self.padded else (self.dwf if self.dwf is not None else self.dW)
+        if dy.dtype == torch.bfloat16 and self.dbias is not None and not feeds_instance_norm:
+            raise NotImplementedError('bias gradient from a bf16 output gradient: only for a convolution in front of an instance norm '
+                                      '(feeds_instance_norm=True), whose bias gradient is identically zero')
         # A bf16 dy is the gradient an instance norm's backward wrote (SAVPGenerator.act16).  The convolution in front of a
         # fused_instance_norm (every conv_pool2d / upsample_conv2d / 3x3 head of the cell, savp_model.py:449-500,522-567,625-631) has an
         # identically zero bias gradient: the norm's input gradient gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) sums to zero
         # over each (sample, channel) plane because sum(xhat) = 0.  The reference's value is that zero plus fp32 rounding noise; column
         # sums of the bf16-ROUNDED gradient would be noise 2^-9 / 2^-24 times larger (measured 2e-3 of the group's largest gradient at
         # T = 40), so with a bf16 dy the bias gradient is left at its exact value, zero.
-        db = self.dbias if dy.dtype != torch.bfloat16 else None
+        db = None if (feeds_instance_norm and dy.dtype == torch.bfloat16) else self.dbias
         if self.kind == 'up':
             K.conv(lib.CONV_WGRAD, self.geom, dy, x, target)
             if db is not None:
@@ -474,8 +478,8 @@ class ConcatConv(object):
     def norm_bwd_ok(self, dy, dx, norm_bwd, skip=None):
         return self.inner.norm_bwd_ok(dy, dx, norm_bwd, skip)
 
-    def backward_weights(self, x, dy):
-        self.inner.backward_weights(x, dy)
+    def backward_weights(self, x, dy, feeds_instance_norm=False):
+        self.inner.backward_weights(x, dy, feeds_instance_norm=feeds_instance_norm)
 
     def finish_weight_grad(self):
         self.inner.finish_weight_grad()

@@ -712,7 +712,7 @@ class SAVPGenerator(object):
         # ---- weight gradients: one split-K GEMM per layer over all (t, n) ----------------------------------------
         for L in self.layers:
             b, pre = L['in'], L['pre']
-            L['conv'].backward_weights(b.flat(b.v), pre.flat(pre.g))
+            L['conv'].backward_weights(b.flat(b.v), pre.flat(pre.g), feeds_instance_norm=True)
             if L['rnn'] and self.gru:
                 a, gt, cd = L['a'], L['gates'], L['cand']
                 L['rconv'].backward_weights(a.flat(a.v)[..., 0:L['cin1']], gt.flat(gt.g))
@@ -726,15 +726,15 @@ class SAVPGenerator(object):
             self.cdna_dense.backward_weights(hs.v.reshape(T1 * N, -1), self.cdna_raw.g.reshape(T1 * N, -1))
         else:
             if not self.merge_heads:
-                self.tf_conv.backward_weights(hl.flat(hl.v), hl.flat(self.tf_pre.g))
+                self.tf_conv.backward_weights(hl.flat(hl.v), hl.flat(self.tf_pre.g), feeds_instance_norm=True)
             self.tf_out.backward_weights(hl.flat(self.tf_h.v), hl.flat(self.tf_raw.g))
         if self.merge_heads:
-            self.heads_conv.backward_weights(hl.flat(hl.v), hl.flat(self.heads_pre.g))
+            self.heads_conv.backward_weights(hl.flat(hl.v), hl.flat(self.heads_pre.g), feeds_instance_norm=True)
             self.heads_norm.finish()
         else:
             if self.scratch:
-                self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g))
-            self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g))
+                self.scratch_conv.backward_weights(hl.flat(hl.v), hl.flat(self.scratch_pre.g), feeds_instance_norm=True)
+            self.masks_conv.backward_weights(hl.flat(hl.v), hl.flat(self.masks_pre.g), feeds_instance_norm=True)
         if self.scratch:
             self.scratch_out.backward_weights(hl.flat(self.scratch_h.v), self.dscratch_pre.reshape(T1 * N, self.H, self.W, self.Cs))
         self.masks_out.backward_weights(hl.flat(maskin.v)[..., 0:self.mask_cin], hl.flat(self.logits.g))

@@ -77,18 +77,23 @@ class _StepProgram(object):
         arena.hi = 0
         try:
             with torch.cuda.stream(self.stream):
-                self._begin()
-                engine._rec = self
-                out = body()
-                self._end()
-        except Exception:
-            if self.cur is not None:
                 try:
-                    self.cur.capture_end()
+                    self._begin()
+                    engine._rec = self
+                    out = body()
+                    self._end()
                 except Exception:
-                    pass
-                self.cur = None
-            raise
+                    # end the open capture ON THE CAPTURE STREAM (capture_end checks the stream it began on; outside this `with` it
+                    # would raise, the exception would be swallowed and the stream would stay in capture mode: the caller's eager
+                    # fallback then fails in its first synchronize)
+                    if self.cur is not None:
+                        try:
+                            self.cur.capture_end()
+                        except Exception:
+                            pass
+                        self.cur = None
+                    self.items = []
+                    raise
         finally:
             engine._rec = None
         main.wait_stream(self.stream)
