@@ -91,10 +91,12 @@ extern "C" int savp_debug_ring_kwarm(int on) {
 #define savp_kwarm() true
 #endif
 
-// Minimum waves per SIMD the register allocator has to leave room for (__launch_bounds__' second argument).  Only <8, 2, 1, 2> needs the
-// hint: it sits at 128 VGPRs = two resident 8-wave workgroups per CU, and its small-K problems (the 64x64 layers) run two per CU -- two more
+// Minimum waves per SIMD the register allocator has to leave room for (__launch_bounds__' second argument).  The 8-wave instantiations whose
+// LDS footprint lets two workgroups share a CU get the hint (128 VGPRs): <8, 1, 1, <= 3> and <8, 2, 1, 2> (<8, 1, 1, 4> would spill).  E.g. <8, 2, 1, 2> sits at 128 VGPRs = two resident 8-wave workgroups per CU, and its small-K problems (the 64x64 layers) run two per CU -- two more
 // registers (130 -> 136 allocated) halve that: 21 -> 28 us per launch in the step (round 5, profiles/r05_ab_calls.md).
-template <int NW, int WM, int WN, int NKS> constexpr int ring_min_waves() { return (NW == 8 && WM == 2 && WN == 1 && NKS == 2) ? 4 : 1; }
+template <int NW, int WM, int WN, int NKS> constexpr int ring_min_waves() {
+    return (NW == 8 && ((WM == 2 && WN == 1 && NKS == 2) || (WM == 1 && WN == 1 && NKS <= 3))) ? 4 : 1;
+}
 
 template <int NW, int WM, int WN, int NKS>
 __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void conv_ring_kernel(ConvP p) {
@@ -215,8 +217,13 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         if (ABL(1)) return;
         const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.w16) + (te.x & 0x7fffffffu);
         const bool last = (te.x >> 31) != 0;
+#ifdef SAVP_RING_DMA_ABLATE          // developer timing builds only (wrong results): issue at most this many of the LW slab DMAs per wave and entry
+        constexpr int NQ = SAVP_RING_DMA_ABLATE < LW ? SAVP_RING_DMA_ABLATE : LW;
+#else
+        constexpr int NQ = LW;
+#endif
 #pragma unroll
-        for (int q = 0; q < LW; ++q) ring_dma16(wp + (last ? goffL[q] : goffF[q]), dma_lds + (unsigned)(BUF * SLABB + q * 1024));
+        for (int q = 0; q < NQ; ++q) ring_dma16(wp + (last ? goffL[q] : goffF[q]), dma_lds + (unsigned)(BUF * SLABB + q * 1024));
     };
 
     // ---- input patch of one slab group (fp32 or bf16 source; zero outside the image, beyond Cred and for images >= N) ----
@@ -282,50 +289,86 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     // VGPR path above is instruction-bound: 12-22 k cycles of a 62-105 k cycle gate convolution).  The DMAs are drained (vmcnt 0)
     // before the barrier that publishes the patch, so the weight ring's counted waits never see them.
     auto stage_patch_dma = [&](int cfirst, auto drainc) {
-        // Row-wise (round 5): a wave takes whole patch rows (image, patch row = wave-uniform), a row is NJ = ceil(P8 / 64) DMA
-        // instructions.  Everything that depends on the lane -- which pixel / 8-channel chunk of the row its slot is, whether that slot
-        // is data or padding, its offset inside a source row -- is the same for every row and worked out ONCE per group; per row only
-        // scalar arithmetic (row validity, the row's base offset) and one add + select per instruction remain.  (The slot-linear walk this
-        // replaces decomposed every slot with four 64-bit multiply-high divisions per lane: cycle stamps of the shipped kernel put the
-        // staging at 5.3 / 8.1 / 13.6 k cycles of the 45 / 45 / 58 k-cycle gate convolutions at 32x32 / 16x16 / 8x8 -- ~650 cycles of
-        // VALU issue per DMA instruction and wave.)
-        const int C8 = CP >> 3, P8 = pitch >> 3;
-        const int used8 = (spp * CKB) >> 3;                   // chunks of a pixel that are read (the last one of CP is pitch padding)
-        const unsigned patch_lds = ring_lds + (unsigned)(RING * SLABB);
-        const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src);
-        // lane l's slot j * 64 + l of a row is (pixel, chunk) = (pxx, ch8); the next instruction's slot is 64 further: (pxx, ch8) advance
-        // by (64 / C8, 64 % C8) with one carry -- no division in the walk, and only two live registers per lane (an array of per-j offsets
-        // cost 15 VGPRs and with them a resident workgroup per CU in the small-K instantiations: 21 -> 28 us, 38 -> 63 us in the step)
-        const int nj = (P8 + 63) >> 6;
-        const int pxx0 = (int)fastdiv((unsigned)lane, p.s1_magC8), ch80 = lane - pxx0 * C8;
-        const int dq = (int)fastdiv(64u, p.s1_magC8), dr = 64 - dq * C8;
-        const int cbase = cfirst * CKB;
-        const int rows = ni * PH;
-        int im = 0, pyy = wave;                               // row = im * PH + pyy, waves take rows round-robin
-        while (pyy >= PH) { pyy -= PH; ++im; }
-        for (int row = wave; row < (ABL(4) ? 0 : rows); row += NW) {
-            const int gi = img0 + im;
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-            const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
-            const int iy = org_h + pyy;
-            const bool row_ok = (unsigned)iy < (unsigned)gh.srcN && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
-            const long long row_base = (long long)n * s_sn + (long long)dz * s_sd + (long long)iy * s_sh;
-            const unsigned char* rb = src_b + row_base * 2;
-            unsigned lds_at = patch_lds + (unsigned)(row * P8) * 16u;
-            int pxx = pxx0, ch8 = ch80, sl = lane;
-            for (int j = 0; j < nj; ++j) {
-                if (sl < P8) {
-                    const int ix = org_w + pxx, cg = cbase + ch8 * 8;
-                    const bool ok = row_ok && pxx < PW && ch8 < used8 && (unsigned)ix < (unsigned)gw.srcN && cg < Cred;
-                    const void* g = ok ? static_cast<const void*>(rb + (long long)(ix * s_sw + cg) * 2) : p.zero16;
-                    ring_dma16(g, lds_at);
-                }
-                sl += 64; lds_at += 1024u;
-                pxx += dq; ch8 += dr;
-                if (ch8 >= C8) { ch8 -= C8; ++pxx; }
+        if constexpr (NKS >= 3) {
+            // Row-wise (round 5; the instantiations with >= 3 k-steps per slab -- the ConvLSTM gate convolutions and the other wide-channel
+            // layers): a wave takes whole patch rows (image, patch row = wave-uniform), a row is ceil(P8 / 64) DMA instructions.  Everything
+            // that depends on the lane -- which pixel / 8-channel chunk of the row its slot is, whether that slot is data or padding, its
+            // offset inside a source row -- is the same for every row and worked out ONCE per group; per row only scalar arithmetic (row
+            // validity, the row's base offset) and one add + select per instruction remain.  The slot-linear walk below decomposes every
+            // slot with four 64-bit multiply-high divisions per lane: cycle stamps put its staging at 8.1 / 13.6 k cycles of the 45 / 58
+            // k-cycle gate convolutions at 16x16 / 8x8 (now 4.7 / 4.7 k: the memory round trip of the burst; 32x32 was there already).
+            // In the step (rocprofv3, profiles/r05_ab_calls.md): <8,1,1,3> 24.1 -> 22.0 us, <8,2,1,4> 42.4 -> 36.8, <4,1,1,6> 31.9 ->
+            // 28.7, <8,2,1,5> 37.9 -> 35.3, <4,1,1,8> 36.2 -> 34.1.  NOT for NKS <= 2: the per-lane offset array costs ~15 VGPRs, and the
+            // small-K instantiations live on two to five resident workgroups per CU (<8,2,1,2> 21 -> 28 us, <4,2,1,1> 38 -> 63 us with it;
+            // a register-lean incremental walk instead of the array lost as much on <8,1,1,4>: per-row scalar work behind spilled SGPRs).
+            const int C8 = CP >> 3, P8 = pitch >> 3;
+            const int used8 = (spp * CKB) >> 3;               // chunks of a pixel that are read (the last one of CP is pitch padding)
+            const unsigned patch_lds = ring_lds + (unsigned)(RING * SLABB);
+            const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src);
+            constexpr int NJMAX = 8;                          // launcher: P8 <= 512 slots per patch row (ring_plan), else slot-linear
+            const int nj = (P8 + 63) >> 6;
+            int rel[NJMAX];                                   // element offset inside a source row, or -1: a zero slot in every row
+#pragma unroll
+            for (int j = 0; j < NJMAX; ++j) {
+                const int sl = j * 64 + lane;
+                const int pxx = (int)fastdiv((unsigned)sl, p.s1_magC8);
+                const int ch8 = sl - pxx * C8;
+                const int ix = org_w + pxx;
+                const int cg = cfirst * CKB + ch8 * 8;
+                const bool ok = sl < P8 && pxx < PW && ch8 < used8 && (unsigned)ix < (unsigned)gw.srcN && cg < Cred;
+                rel[j] = ok ? ix * s_sw + cg : -1;
             }
-            pyy += NW;
+            const int rows = ni * PH;
+            int im = 0, pyy = wave;                           // row = im * PH + pyy, waves take rows round-robin
             while (pyy >= PH) { pyy -= PH; ++im; }
+            for (int row = wave; row < (ABL(4) ? 0 : rows); row += NW) {
+                const int gi = img0 + im;
+                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
+                const int iy = org_h + pyy;
+                const bool row_ok = (unsigned)iy < (unsigned)gh.srcN && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
+                const long long row_base = (long long)n * s_sn + (long long)dz * s_sd + (long long)iy * s_sh;
+                const unsigned char* rb = src_b + row_base * 2;
+                const unsigned lds_row = patch_lds + (unsigned)(row * P8) * 16u;
+#pragma unroll
+                for (int j = 0; j < NJMAX; ++j) {
+                    if (j < nj && j * 64 + lane < P8) {
+                        const void* g = (row_ok && rel[j] >= 0) ? static_cast<const void*>(rb + (long long)rel[j] * 2) : p.zero16;
+                        ring_dma16(g, lds_row + (unsigned)(j * 1024));
+                    }
+                }
+                pyy += NW;
+                while (pyy >= PH) { pyy -= PH; ++im; }
+            }
+        } else {
+            const int C8 = CP >> 3, P8 = pitch >> 3;
+            const int used8 = (spp * CKB) >> 3;                   // chunks of a pixel that are read (the last one of CP is pitch padding)
+            const int per_img8 = PH * P8;
+            const int total = ni * per_img8;
+            const unsigned patch_lds = ring_lds + (unsigned)(RING * SLABB);
+            const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src);
+            for (int base = wave * 64; base < (ABL(4) ? 0 : total); base += NT) {
+                const int slot = base + lane;
+                if (slot < total) {
+                    const int im = (int)fastdiv((unsigned)slot, p.s1_magPI8);
+                    const int rem = slot - im * per_img8;
+                    const int pyy = (int)fastdiv((unsigned)rem, p.s1_magP8);
+                    const int r = rem - pyy * P8;
+                    const int pxx = (int)fastdiv((unsigned)r, p.s1_magC8);
+                    const int ch8 = r - pxx * C8;
+                    const int iy = org_h + pyy, ix = org_w + pxx;
+                    const int cg = cfirst * CKB + ch8 * 8;
+                    const int gi = img0 + im;
+                    const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                    const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
+                    const bool ok = pxx < PW && ch8 < used8 && (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN &&
+                                    cg < Cred && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
+                    const long long off = (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg;
+                    const void* g = ok ? static_cast<const void*>(src_b + off * 2) : p.zero16;
+                    ring_dma16(g, patch_lds + (unsigned)(base * 16));
+                }
+            }
+
         }
         if constexpr (decltype(drainc)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -920,7 +963,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
         const int CP = spp * nks * 16 + 8;
         p.dma_patch = (savp_opt(OPT_RING_DMA) && a->src_bf16 && (ssn % 8 == 0) && (ssd % 8 == 0) && (ssh % 8 == 0) && (ssw % 8 == 0) &&
                        ((((uintptr_t)sptr) & 15) == 0) && p.zero16 && (long long)ni * PH * (pitch / 8) < (1 << 24) && (long long)PH * (pitch / 8) < 65536 && (pitch % 8 == 0) &&
-                       ssw * (long long)(a->W + a->kw) + Cred < (1ll << 30)) ? 1 : 0;       // row-wise staging: 32-bit in-row offsets
+                       (nks <= 2 || (pitch / 8 <= 512 && ssw * (long long)(a->W + a->kw) + Cred < (1ll << 30)))) ? 1 : 0;       // row-wise staging (nks >= 3): <= 8 DMA instructions per patch row, 32-bit in-row offsets
         p.s1_magPI8 = magic40(PH * (pitch / 8)); p.s1_magP8 = magic40(pitch / 8); p.s1_magC8 = magic40(CP / 8);
     }
     p.tm = (int)(((long long)a->N * Dm + ni - 1) / ni) * p.s1_th * tW; p.tn = (Nout + BN - 1) / BN;
