@@ -532,6 +532,11 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #else
         constexpr bool LATE = false;
 #endif
+        // What bounds this loop (round 5, stamps-only builds, profiles/r05_ring_loop_findings.md): the LDS ARRAY.  With the slab DMAs ablated
+        // the 16x16 gate convolution's loop takes 19.9 k cycles, with them 29.9 k (32x32: 18.5 -> 22.9 k, 8x8: 19.5 -> 30.0 k): every
+        // 1 KB LDS-DMA piece lands through the LDS write path (~64 B/clk) and takes ~16 array cycles from the fragment reads, which already
+        // need 2 KB per MFMA with the 32 x 32 wave tile (1.5 KB with 32 x 64).  It is NOT the DMA latency: an eight-deep ring (seven slabs of
+        // look-ahead, built and measured) made the same loop 5 % slower, and wide slabs give the same 45 % of the matrix pipe per tile.
         // (the table entries are wave-uniform: kept in scalar registers)
         auto sld = [&](int i) { const uint2 t = etab[i]; return make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)t.x), (unsigned)__builtin_amdgcn_readfirstlane((int)t.y)); };
         {
