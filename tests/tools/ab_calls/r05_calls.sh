@@ -1,0 +1,116 @@
+#!/bin/bash
+# The GPU leases of round 5 as they were run: `gpurun -- bash tests/tools/ab_calls/r05_calls.sh <n>`.  Each case is one lease (smoke guard,
+# parity, in-call A/B through tests/tools/ab_run.sh, stamps / per-kernel profiles); results: profiles/r05_ab_calls.md.  Variant libraries
+# (video_prediction_amd/ab/libsavp_hip_<tag>.so) come from tests/tools/build_variant.sh and are not kept in the tree.
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+t0=$(date +%s)
+smoke() { python bench.py --steps 2 --warmup 2 --no-f32 --no-cpu-baseline --inst-steps 1 > $O/smoke.json 2> $O/smoke.err || { echo "SMOKE FAILED"; tail -25 $O/smoke.err; exit 1; }; }
+case "$1" in
+1)
+  # Round 5, first lease: (i) the new replayed-vs-eager test at the bench shapes (records the distances of the CURRENT kernels: float
+  # atomics), (ii) parity of the two patches staged by round 4 (ring lane table, generic-conv fragment pre-read) on every shipped tuning-table
+  # instantiation, (iii) their in-call A/B.
+  O=gpurun_out/r05a; mkdir -p $O
+  smoke
+  timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -k "replayed_bench_step" > $O/replay_test.log 2>&1; echo "replay test rc=$? $(( $(date +%s)-t0 ))s"; tail -15 $O/replay_test.log | cut -c1-600
+  SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_both.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "table or conv" > $O/both_ops.log 2>&1; echo "both ops rc=$? $(( $(date +%s)-t0 ))s"; tail -4 $O/both_ops.log | cut -c1-400
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh base "" lanetab "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_lanetab.so" preread "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_preread.so" both "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_both.so"
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+2)
+  # Round 5, second lease: the deterministic-reduction build -- whole GPU suite (incl. the replayed-vs-eager test at the bench shapes), the
+  # round-4 library against it in one call, and cycle stamps of the shipped gate-convolution instantiations (stamps-only developer build).
+  O=gpurun_out/r05b; mkdir -p $O
+  smoke
+  timeout 1200 python -m pytest tests -q -m gpu -x --deselect tests/test_gpu_model.py::test_the_replayed_bench_step_is_the_eager_step_and_matches_the_golden > $O/gputest.log 2>&1; echo "gputest rc=$? $(( $(date +%s)-t0 ))s"; tail -12 $O/gputest.log | cut -c1-400
+  timeout 600 python -m pytest tests/test_gpu_model.py -q -m gpu -k "replayed_bench_step" > $O/replay_test.log 2>&1; echo "replay test rc=$? $(( $(date +%s)-t0 ))s"; grep -E "^E  |passed|failed" $O/replay_test.log | cut -c1-300 | head -20
+  for c in c2 c4 c5; do cat gpurun_out/r05_replay_vs_eager_$c.json | tr -d '\n'; echo; done
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh r04 "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_r04.so" det ""
+  for spec in lstm_h0:fprop:712:cell16 lstm_h1:fprop:711:cell16 lstm_h2:fprop:311:cell16 lstm_h0:dgrad:711:src16 lstm_h2:dgrad:311:src16; do
+    for blk in 0 100 200; do
+      RING_BLOCK=$blk SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_stamps.so python tests/tools/ring_times.py $spec 2>&1 | grep -v amdgpu.ids | sed "s/^/blk$blk /"
+    done
+  done | tee $O/ring_stamps.log
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+3)
+  # Round 5, third lease: row-wise LDS-DMA patch staging in the ring kernel -- parity (every shipped tuning-table instantiation, the bench-shape
+  # goldens now under ONE gradient gate, the replayed-vs-eager tests with their measured gates), in-call A/B against the build before it, stamps.
+  O=gpurun_out/r05c; mkdir -p $O
+  smoke
+  timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu > $O/ops.log 2>&1; echo "ops rc=$? $(( $(date +%s)-t0 ))s"; tail -5 $O/ops.log | cut -c1-300
+  timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -k "replay or golden or hipgraph or recipe_shapes" > $O/model.log 2>&1; echo "model rc=$? $(( $(date +%s)-t0 ))s"; grep -E "^E  .*(Assert|assert)|passed|failed" $O/model.log | cut -c1-600 | head -20
+  for c in c2 c4 c5; do cat gpurun_out/r05_replay_vs_eager_$c.json | tr -d '\n'; echo; done
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh det "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_det.so" rowdma ""
+  OUT=$O/c5 REPS=1 CONFIG=c5 BENCH_ARGS="--steps 20 --warmup 4 --no-f32 --no-cpu-baseline --inst-steps 4" bash tests/tools/ab_run.sh det "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_det.so" rowdma ""
+  for spec in lstm_h0:fprop:712:cell16 lstm_h1:fprop:711:cell16 lstm_h2:fprop:311:cell16 lstm_h0:dgrad:711:src16; do
+    SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_stamps.so python tests/tools/ring_times.py $spec 2>&1 | grep -v amdgpu.ids
+  done | tee $O/ring_stamps.log
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+4)
+  # Round 5, fourth lease: per-kernel view (rocprofv3 kernel stats of 6 eager steps) of the ring kernel's patch-staging variants -- slot-linear
+  # (before), row-wise (default now), row-wise + first group requested before the rest of the prologue -- and the repaired golden / replay tests.
+  O=gpurun_out/r05d; mkdir -p $O
+  smoke
+  timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -k "replayed_bench or golden" > $O/model.log 2>&1; echo "model rc=$? $(( $(date +%s)-t0 ))s"; grep -E "^E  .*(Assert|assert)|passed|failed" $O/model.log | cut -c1-700 | head -20
+  for v in det rowdma earlypatch; do
+    lib=$PWD/video_prediction_amd/ab/libsavp_hip_$v.so; [ $v = rowdma ] && lib=$PWD/video_prediction_amd/libsavp_hip.so
+    SAVP_LIB=$lib bash tests/tools/prof_step.sh r05d/$v 2>&1 | tail -2
+  done
+  python tests/tools/compare_stats.py $O/det_kernel_stats.csv $O/rowdma_kernel_stats.csv 6 | tee $O/cmp_det_rowdma.txt
+  python tests/tools/compare_stats.py $O/rowdma_kernel_stats.csv $O/earlypatch_kernel_stats.csv 6 | tee $O/cmp_rowdma_early.txt
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh det "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_det.so" rowdma "" early "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_earlypatch.so"
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+5)
+  # Round 5, fifth lease: row-wise patch staging, second version (incremental walk, no per-j array) -- conv parity, per-kernel view and step A/B
+  # against the slot-linear build.
+  O=gpurun_out/r05f; mkdir -p $O
+  smoke
+  timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "conv or table or cell" > $O/ops.log 2>&1; echo "ops rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/ops.log | cut -c1-300
+  for v in det rowdma3; do
+    lib=$PWD/video_prediction_amd/ab/libsavp_hip_$v.so; [ $v = rowdma3 ] && lib=$PWD/video_prediction_amd/libsavp_hip.so
+    SAVP_LIB=$lib bash tests/tools/prof_step.sh r05f/$v 2>&1 | tail -1
+  done
+  python tests/tools/compare_stats.py $O/det_kernel_stats.csv $O/rowdma3_kernel_stats.csv 6 | tee $O/cmp_det_rowdma3.txt
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh det "SAVP_LIB=video_prediction_amd/ab/libsavp_hip_det.so" rowdma3 ""
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+7)
+  # Round 5, seventh lease: what the slab DMAs cost the ring kernel's main loop -- stamps-only builds with all / one / none of the LW slab DMA
+  # instructions per wave and entry (timing builds, results wrong by construction).
+  O=gpurun_out/r05g; mkdir -p $O
+  for v in stamps stampsd1 stampsd0; do
+    for spec in lstm_h0:fprop:712:cell16 lstm_h1:fprop:711:cell16 lstm_h2:fprop:311:cell16 lstm_h0:dgrad:711:src16; do
+      SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_$v.so python tests/tools/ring_times.py $spec 2>&1 | grep -v "amdgpu.ids\|per wave" | sed "s/^/$v /"
+    done
+  done | tee $O/ring_dma_ablate.log
+  ;;
+8)
+  # Round 5, eighth lease: wide weight slabs (8 / 9 k-steps per entry: the look-ahead of three entries then covers the LDS-DMA latency) against the
+  # shipped instantiations of the 16x16 / 8x8 gate convolutions, stamps-only build, isolated launches.
+  O=gpurun_out/r05h; mkdir -p $O
+  for spec in lstm_h1:fprop:711:cell16 lstm_h1:fprop:1711:cell16 lstm_h1:fprop:1311:cell16 lstm_h1:fprop:312:cell16 lstm_h2:fprop:311:cell16 lstm_h2:fprop:1311:cell16 lstm_h2:fprop:1711:cell16 lstm_h1:dgrad:711:src16 lstm_h1:dgrad:1711:src16 lstm_h2:dgrad:311:src16 lstm_h2:dgrad:1311:src16; do
+    SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_stamps.so python tests/tools/ring_times.py $spec 2>&1 | grep -v "amdgpu.ids\|per wave"
+  done | tee $O/ring_wide.log
+  ;;
+9)
+  # Round 5, ninth lease: eight-deep weight ring for the small-tile ring instantiations (option ring_deep) -- conv parity (every shipped table
+  # instantiation runs with it), stamps of the 16x16 gate convolutions with / without, in-call A/B of the step, per-kernel view.
+  O=gpurun_out/r05j; mkdir -p $O
+  smoke
+  timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "conv or table or cell" > $O/ops.log 2>&1; echo "ops rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/ops.log | cut -c1-300
+  for d in 0 1; do for spec in lstm_h1:fprop:711:cell16 lstm_h1:dgrad:711:src16 lstm_h0:dgrad:711:src16; do
+    SAVP_RING_DEEP=$d SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_stamps.so python tests/tools/ring_times.py $spec 2>&1 | grep -v "amdgpu.ids\|per wave" | sed "s/^/deep$d /"
+  done; done | tee $O/ring_deep_stamps.log
+  for v in deep0 deep1; do
+    SAVP_RING_DEEP=${v#deep} bash tests/tools/prof_step.sh r05j/$v 2>&1 | tail -1
+  done
+  python tests/tools/compare_stats.py $O/deep0_kernel_stats.csv $O/deep1_kernel_stats.csv 6 | tee $O/cmp_deep.txt
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh deep0 "SAVP_RING_DEEP=0" deep1 "SAVP_RING_DEEP=1"
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9>"; exit 2 ;;
+esac
