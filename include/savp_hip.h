@@ -251,6 +251,10 @@ typedef struct SavpLstmArgs {
     int32_t dgates_bf16;           /* bwd: `dgates` receives bf16 (its readers are the gate convolution's DGRAD / WGRAD, which round to
                                       bf16 anyway); the raw gate gradients between the passes then live in dgates_raw.  Coalesced kernels only */
     float* dgates_raw;             /* bwd, with dgates_bf16: fp32 scratch [N,HW,4F] (three-pass kernels only) */
+    int32_t no_norm;               /* 1: the cell WITHOUT a normaliser (conv_rnn_norm_layer = 'none' / ablation_conv_rnn_norm, rnn_ops.py:122-125,
+                                      148-165 with normalizer_fn = None): `gates` holds conv + bias (fp32), i, j, f, o = split(gates);
+                                      c' = c*sigmoid(f+fb) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o) -- pointwise, no statistics, the
+                                      norm parameters / mean / rstd arguments are not read */
 } SavpLstmArgs;
 int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a);
 int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a);
@@ -359,6 +363,13 @@ int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* 
                     int32_t T, int32_t B, int32_t nz, float forget_bias);
 int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
                     const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias);
+/* The same with a learned initial state (learn_initial_state, savp_model.py:295-307,344-352): c0 / h0 [nz] are tiled over the batch (NULL =
+ * zero); bwd ADDS their gradients (what step 0 hands back, summed over the batch) to dc0 / dh0 [nz] (NULL = not wanted). */
+int savp_lstm_z_fwd_init(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates, float* cs,
+                         int32_t T, int32_t B, int32_t nz, float forget_bias, const float* c0, const float* h0);
+int savp_lstm_z_bwd_init(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
+                         const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias,
+                         const float* c0, const float* h0, float* dc0, float* dh0);
 /* BasicLSTMCell over all timesteps (recurrent encoder of posterior_fn / prior_fn, savp_model.py:31-43,66-76).
  * A [T,B,I+U]: x_t in columns [0,I) (caller), h_{t-1} in [I,I+U) (written by fwd); W [I+U,4U], gate order i,j,f,o.
  * bwd produces dG [T,B,4U] and dA [T,B,I+U] (first I columns = dL/dx); dW = A^T dG and db = colsum(dG) are the caller's GEMM. */
@@ -366,6 +377,15 @@ int savp_lstm_seq_fwd(void* stream, float* A, const float* W, const float* bias,
                       int32_t T, int32_t B, int32_t I, int32_t U, float forget_bias);
 int savp_lstm_seq_bwd(void* stream, const float* A, const float* W, const float* gates, const float* cs, const float* dh_out,
                       float* dG, float* dA, int32_t T, int32_t B, int32_t I, int32_t U, float forget_bias);
+/* tf.contrib.rnn.GRUCell over all timesteps (rnn = 'gru': the latent's cell, savp_model.py:358-359, and the encoders' recurrent tail, :38-41):
+ * [r, u] = sigmoid([x, h] Wg + bg), c = tanh([x, r*h] Wc + bc), h' = u*h + (1-u)*c, zero initial state.  A [T,B,I+U]: x_t in columns [0,I)
+ * (caller), h_{t-1} in [I,I+U) (written by fwd); Wg [I+U,2U] (r first), Wc [I+U,U].  fwd also fills A2 = [x | r*h_{t-1}] (the candidate GEMM's
+ * input), ru [T,B,2U], cand [T,B,U], hout [T,B,U].  bwd produces dGg [T,B,2U], dGc [T,B,U] (gradients of the two pre-activations) and
+ * dA [T,B,I+U] (first I columns = dL/dx); dWg = A^T dGg, dWc = A2^T dGc and the bias column sums are the caller's GEMMs.  U <= 512. */
+int savp_gru_seq_fwd(void* stream, float* A, float* A2, const float* Wg, const float* bg, const float* Wc, const float* bc, float* hout,
+                     float* ru, float* cand, int32_t T, int32_t B, int32_t I, int32_t U);
+int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, const float* Wc, const float* ru, const float* cand, const float* dh_out,
+                     float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U);
 /* KL between two diagonal Gaussians (losses.py:61-67; learn_prior): value into *kl_out (optional), klw-weighted gradient ADDED
  * to dmu1 / dls1 / dmu2 / dls2 (all four or none); ls*_raw are the unclipped log-variances. */
 int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,

@@ -70,6 +70,8 @@ def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, *
             vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('beta') or k.endswith('bias'):
             vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('initial_state'):        # learn_initial_state: zero-initialised in the reference; perturbed so that they matter
+            vals[k] = (0.3 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('kernel'):
             vals[k] = (vals[k] * 3).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
@@ -139,6 +141,8 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
             vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('beta') or k.endswith('bias'):
             vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('initial_state'):        # learn_initial_state: zero-initialised in the reference; perturbed so that they matter
+            vals[k] = (0.3 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('kernel') and k.startswith('generator'):
             vals[k] = (vals[k] * 3).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
@@ -225,6 +229,8 @@ def recipe_case(B, T=30, H=64, W=64, C=3, seed=0, context=2, nz=8, kl_weight=1.0
             vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('beta') or k.endswith('bias'):
             vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('initial_state'):        # learn_initial_state: zero-initialised in the reference; perturbed so that they matter
+            vals[k] = (0.3 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('kernel') and k.startswith('generator'):
             vals[k] = (vals[k] * 3).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
@@ -462,4 +468,22 @@ def check_eval_best_of_n(B=2, T=6, H=32, W=32, C=3, num_samples=4):
     r = OM.metrics_fn(images, gens[0], hp.context_frames)
     for k in r:
         res.append(('metrics_fn/' + k, rel(m[k], r[k]), 2e-3))
+    return res
+
+
+def check_cell_options():
+    """The options of SAVPCell that no shipped recipe sets, each forward (fp32 datapath vs the fp64 oracle) and through one train step:
+    learn_initial_state (savp_model.py:295-307,344-352), ablation_rnn (:272-291,426-429,466-474,502-509), ablation_conv_rnn_norm
+    (:380-384), conv_rnn_norm_layer = 'none' (rnn_ops.py:122-125), rnn = 'gru' for the latent's cell and the encoders' recurrent tail
+    (:38-41,358-359)."""
+    res = []
+    cases = [('learn_init', dict(learn_initial_state=True)),
+             ('learn_init_gru', dict(learn_initial_state=True, conv_rnn='gru')),
+             ('abl_rnn', dict(ablation_rnn=True)),
+             ('abl_cell_norm', dict(ablation_conv_rnn_norm=True)),
+             ('cell_norm_none', dict(conv_rnn_norm_layer='none')),
+             ('rnn_gru', dict(rnn='gru', use_e_rnn=True, nef=16))]
+    for tag, over in cases:
+        res += check_generator_forward(nz=8, B=2, T=5, tag='gen_fwd_' + tag, **over)
+        res += check_train_step(B=2, T=5, nz=8, steps=1, tag='train_' + tag, **over)
     return res

@@ -69,6 +69,13 @@ def test_learned_prior_and_recurrent_encoder_vs_oracle():
     _assert_ok(res)
 
 
+def test_cell_options_no_shipped_recipe_sets_vs_oracle():
+    """learn_initial_state, ablation_rnn, ablation_conv_rnn_norm, conv_rnn_norm_layer='none', rnn='gru': forward and train-step parity
+    (round 4 restated them in the oracle and the variable table; the HIP path raised)."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_cell_options())
+
+
 def test_config_c1_deterministic_b4_t12_forward_and_train_vs_oracle():
     """BASELINE configs[0] at its own shape (not scaled): deterministic generator, nz=0, B=4, T=12, 64x64x3, the
     ours_deterministic_l1 recipe."""

@@ -1518,10 +1518,88 @@ static bool lstm_coalesced_ok(const SavpLstmArgs* a) {
     return a->ws && a->ws_floats >= lstm_ws_floats(a) && F >= 16 && F <= 256 && (F & (F - 1)) == 0 && a->HW >= 16;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The cell without a normaliser (SavpLstmArgs.no_norm): pointwise.  A thread owns 4 channels of one pixel; float4 accesses.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void lstm_plain_fwd_kernel(LstmP p) {
+    const int F4 = p.F >> 2;
+    const long long total = (long long)p.N * p.HW * F4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int c0 = (int)(i % F4) * 4;
+        const long long px = i / F4;                       // n * HW + pixel
+        const int n = (int)(px / p.HW), q = (int)(px - (long long)n * p.HW);
+        const float* g = p.gates + px * 4 * p.F + c0;
+        const float4 gi = ld4(g), gj = ld4(g + p.F), gf = ld4(g + 2 * p.F), go = ld4(g + 3 * p.F);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)q * p.cp_sp + c0);
+        const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, jv[4] = {gj.x, gj.y, gj.z, gj.w}, fv[4] = {gf.x, gf.y, gf.z, gf.w},
+                    ov[4] = {go.x, go.y, go.z, go.w}, cv[4] = {cp.x, cp.y, cp.z, cp.w};
+        float cn[4], h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cn[c] = cv[c] * sigmoidf_(fv[c] + p.forget_bias) + sigmoidf_(iv[c]) * tanhf_(jv[c]);
+            h[c] = tanhf_(cn[c]) * sigmoidf_(ov[c]);
+        }
+        st4(p.c_new + px * p.F + c0, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        for (int k = 0; k < p.nh; ++k)
+            st4x(p.h[k], (long long)n * p.h_sn[k] + (long long)q * p.h_sp[k] + c0, make_float4(h[0], h[1], h[2], h[3]), p.h16[k]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void lstm_plain_bwd_kernel(LstmP p) {
+    const int F4 = p.F >> 2;
+    const long long total = (long long)p.N * p.HW * F4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int c0 = (int)(i % F4) * 4;
+        const long long px = i / F4;
+        const int n = (int)(px / p.HW), q = (int)(px - (long long)n * p.HW);
+        const float* g = p.gates + px * 4 * p.F + c0;
+        const float4 gi = ld4(g), gj = ld4(g + p.F), gf = ld4(g + 2 * p.F), go = ld4(g + 3 * p.F);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f), dcn = cp, dh4 = cp;
+        if (p.c_prev) cp = ld4(p.c_prev + (long long)n * p.cp_sn + (long long)q * p.cp_sp + c0);
+        if (p.dc_new) dcn = ld4(p.dc_new + px * p.F + c0);
+        for (int k = 0; k < p.ndh; ++k) {
+            const float4 t = ld4(p.dh[k] + (long long)n * p.dh_sn[k] + (long long)q * p.dh_sp[k] + c0);
+            dh4.x += t.x; dh4.y += t.y; dh4.z += t.z; dh4.w += t.w;
+        }
+        const float iv[4] = {gi.x, gi.y, gi.z, gi.w}, jv[4] = {gj.x, gj.y, gj.z, gj.w}, fv[4] = {gf.x, gf.y, gf.z, gf.w},
+                    ov[4] = {go.x, go.y, go.z, go.w}, cv[4] = {cp.x, cp.y, cp.z, cp.w}, dhv[4] = {dh4.x, dh4.y, dh4.z, dh4.w},
+                    dcv[4] = {dcn.x, dcn.y, dcn.z, dcn.w};
+        float di[4], dj[4], df[4], dO[4], dcp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float si = sigmoidf_(iv[c]), tj = tanhf_(jv[c]), sf = sigmoidf_(fv[c] + p.forget_bias), so = sigmoidf_(ov[c]);
+            const float tc = tanhf_(cv[c] * sf + si * tj);
+            const float dc = dhv[c] * so * (1.f - tc * tc) + dcv[c];
+            di[c] = dc * tj * si * (1.f - si);
+            dj[c] = dc * si * (1.f - tj * tj);
+            df[c] = dc * cv[c] * sf * (1.f - sf);
+            dO[c] = dhv[c] * tc * so * (1.f - so);
+            dcp[c] = dc * sf;
+        }
+        float* d = p.dgates + px * 4 * p.F + c0;
+        st4(d, make_float4(di[0], di[1], di[2], di[3])); st4(d + p.F, make_float4(dj[0], dj[1], dj[2], dj[3]));
+        st4(d + 2 * p.F, make_float4(df[0], df[1], df[2], df[3])); st4(d + 3 * p.F, make_float4(dO[0], dO[1], dO[2], dO[3]));
+        if (p.dc_prev) st4(p.dc_prev + px * p.F + c0, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+    }
+}
+
+static int lstm_plain(void* stream, const SavpLstmArgs* a, const LstmP& p, bool fwd) {
+    if (a->gates_bf16 || a->dgates_bf16 || a->stats1_ready || !a->gates || (((uintptr_t)a->gates) & 15)) return SAVP_EINVAL;
+    if (fwd ? !a->c_new : !a->dgates) return SAVP_EINVAL;
+    const long long total = (long long)a->N * a->HW * (a->F / 4);
+    long long blocks = (total + NT - 1) / NT;
+    if (blocks > 4096) blocks = 4096;
+    if (fwd) hipLaunchKernelGGL(lstm_plain_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(lstm_plain_bwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+}
+
 extern "C" int savp_convlstm_gates_fwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
+    if (a->no_norm) return lstm_plain(stream, a, p, true);
     hipStream_t st = (hipStream_t)stream;
     {
         int Q, PPT, nslab, xcd_map;
@@ -1573,6 +1651,7 @@ extern "C" int savp_convlstm_gates_bwd(void* stream, const SavpLstmArgs* a) {
     LstmP p;
     int rc = fill_lstm(p, a);
     if (rc) return rc;
+    if (a->no_norm) return lstm_plain(stream, a, p, false);
     {
         int Q, PPT, nslab, xcd_map;
         if (lstm_fused_cfg(a, false, Q, PPT, nslab, xcd_map)) {

@@ -41,11 +41,12 @@ __device__ __forceinline__ float block_sum1(float v, float* sh) {
 #define MAXNZ 64
 __global__ void lstm_z_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ W, const float* __restrict__ bias,
                                   float* __restrict__ hout, float* __restrict__ gates, float* __restrict__ cs, int T, int B,
-                                  int nz, float forget_bias) {
+                                  int nz, float forget_bias, const float* __restrict__ c0, const float* __restrict__ h0) {
     __shared__ float sh_h[MAXNZ], sh_z[MAXNZ], sh_g[4 * MAXNZ];
     const int b = blockIdx.x, j = threadIdx.x;
-    float c = 0.f;
-    if (j < nz) sh_h[j] = 0.f;
+    // initial state: zero, or the learned per-unit vectors c0 / h0 [nz] tiled over the batch (learn_initial_state, savp_model.py:295-307,344-352)
+    float c = (c0 && j < nz) ? c0[j] : 0.f;
+    if (j < nz) sh_h[j] = h0 ? h0[j] : 0.f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         if (j < nz) sh_z[j] = zs[((long long)t * B + b) * nz + j];
@@ -70,7 +71,8 @@ __global__ void lstm_z_fwd_kernel(const float* __restrict__ zs, const float* __r
 __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __restrict__ W, const float* __restrict__ hout,
                                   const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dh_out,
                                   float* __restrict__ dzs, float* __restrict__ dW, float* __restrict__ db, int T, int B, int nz,
-                                  float forget_bias) {
+                                  float forget_bias, const float* __restrict__ c0, const float* __restrict__ h0, float* __restrict__ dc0,
+                                  float* __restrict__ dh0) {
     __shared__ float sh_dg[4 * MAXNZ], sh_x[2 * MAXNZ], sh_dh[MAXNZ];
     const int b = blockIdx.x, j = threadIdx.x;
     float dWcol[2 * MAXNZ];
@@ -86,7 +88,7 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
             float gi = gates[o * 4 * nz + j], gj = gates[o * 4 * nz + nz + j], gf = gates[o * 4 * nz + 2 * nz + j],
                   go = gates[o * 4 * nz + 3 * nz + j];
             float c = cs[o * nz + j];
-            float cprev = t > 0 ? cs[(o - B) * nz + j] : 0.f;
+            float cprev = t > 0 ? cs[(o - B) * nz + j] : (c0 ? c0[j] : 0.f);
             float dh = dh_out[o * nz + j] + sh_dh[j];
             float so = sigm(go), tc = tanh_(c);
             float dc = dh * so * (1.f - tc * tc) + dc_next;
@@ -97,7 +99,7 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
             sh_dg[3 * nz + j] = dh * tc * so * (1.f - so);
             dc_next = dc * sf;
             sh_x[j] = zs[o * nz + j];
-            sh_x[nz + j] = t > 0 ? hout[(o - B) * nz + j] : 0.f;
+            sh_x[nz + j] = t > 0 ? hout[(o - B) * nz + j] : (h0 ? h0[j] : 0.f);
         }
         __syncthreads();
         const float dgj = sh_dg[j];
@@ -119,13 +121,26 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
     for (int i = 0; i < 2 * MAXNZ; ++i)
         if (i < 2 * nz) unsafeAtomicAdd(dW + i * 4 * nz + j, dWcol[i]);
     unsafeAtomicAdd(db + j, dbj);
+    // gradients of the learned initial state: what step 0 hands back, summed over the batch (the variables are tiled over it)
+    if (j < nz) {
+        if (dc0) unsafeAtomicAdd(dc0 + j, dc_next);
+        if (dh0) unsafeAtomicAdd(dh0 + j, sh_dh[j]);
+    }
 }
 
 extern "C" int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates,
                                float* cs, int32_t T, int32_t B, int32_t nz, float forget_bias) {
     if (!zs || !W || !bias || !hout || !gates || !cs || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_z_fwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, bias, hout, gates, cs, T, B, nz,
-                       forget_bias);
+                       forget_bias, (const float*)nullptr, (const float*)nullptr);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_lstm_z_fwd_init(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates,
+                                    float* cs, int32_t T, int32_t B, int32_t nz, float forget_bias, const float* c0, const float* h0) {
+    if (!zs || !W || !bias || !hout || !gates || !cs || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_z_fwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, bias, hout, gates, cs, T, B, nz,
+                       forget_bias, c0, h0);
     return LAUNCH_OK();
 }
 
@@ -134,7 +149,16 @@ extern "C" int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, co
                                int32_t nz, float forget_bias) {
     if (!zs || !W || !hout || !gates || !cs || !dh_out || !dzs || !dW || !db || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_z_bwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, hout, gates, cs, dh_out, dzs, dW,
-                       db, T, B, nz, forget_bias);
+                       db, T, B, nz, forget_bias, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_lstm_z_bwd_init(void* stream, const float* zs, const float* W, const float* hout, const float* gates,
+                                    const float* cs, const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B,
+                                    int32_t nz, float forget_bias, const float* c0, const float* h0, float* dc0, float* dh0) {
+    if (!zs || !W || !hout || !gates || !cs || !dh_out || !dzs || !dW || !db || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
+    hipLaunchKernelGGL(lstm_z_bwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, hout, gates, cs, dh_out, dzs, dW,
+                       db, T, B, nz, forget_bias, c0, h0, dc0, dh0);
     return LAUNCH_OK();
 }
 
@@ -247,6 +271,133 @@ extern "C" int savp_lstm_seq_bwd(void* stream, const float* A, const float* W, c
     if (!A || !W || !gates || !cs || !dh_out || !dG || !dA || U < 16 || U > MAXU || (U & 15) || I < 1 || I + U > 4096) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B), dim3(4 * U), (size_t)(5 * U) * sizeof(float), (hipStream_t)stream, A, W, gates,
                        cs, dh_out, dG, dA, T, B, I, U, forget_bias);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tf.contrib.rnn.GRUCell over all timesteps (rnn = 'gru': the latent's cell savp_model.py:358-359 and the encoders' recurrent tail :38-41):
+//   [r, u] = sigmoid([x, h] Wg + bg) (r first);  c = tanh([x, r*h] Wc + bc);  h' = u*h + (1 - u)*c;  zero initial state.
+// A [T,B,I+U]: x_t in columns [0,I) (caller), h_{t-1} in [I,I+U) (written by fwd).  fwd also leaves A2 = [x | r*h_{t-1}] (the candidate
+// GEMM's input, needed for its weight gradient), ru [T,B,2U] (gate values), cand [T,B,U], hout [T,B,U].  One workgroup per batch row,
+// 2U threads.  bwd produces dGg [T,B,2U] / dGc [T,B,U] (gradients of the two pre-activations) and dA [T,B,I+U] (first I columns =
+// dL/dx); dWg = A^T dGg, dWc = A2^T dGc and the bias column sums are the caller's GEMMs (like savp_lstm_seq_*).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void gru_seq_fwd_kernel(float* __restrict__ A, float* __restrict__ A2, const float* __restrict__ Wg, const float* __restrict__ bg,
+                                   const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ hout,
+                                   float* __restrict__ ru, float* __restrict__ cand, int T, int B, int I, int U) {
+    extern __shared__ float sh_gru[];
+    const int K = I + U;
+    float* sh_a = sh_gru;               // [K]  [x_t | h_{t-1}]
+    float* sh_ru = sh_gru + K;          // [2U]
+    float* sh_rh = sh_ru + 2 * U;       // [U]
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < U) sh_a[I + j] = 0.f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const long long o = (long long)t * B + b;
+        for (int i = j; i < I; i += 2 * U) sh_a[i] = A[o * K + i];
+        __syncthreads();
+        {
+            float g = bg[j];
+            for (int i = 0; i < K; ++i) g += sh_a[i] * Wg[(long long)i * 2 * U + j];
+            const float v = sigm(g);
+            sh_ru[j] = v;
+            ru[o * 2 * U + j] = v;
+        }
+        __syncthreads();
+        if (j < U) sh_rh[j] = sh_ru[j] * sh_a[I + j];
+        for (int i = j; i < I; i += 2 * U) A2[o * K + i] = sh_a[i];
+        __syncthreads();
+        if (j < U) {
+            float g = bc[j];
+            for (int i = 0; i < I; ++i) g += sh_a[i] * Wc[(long long)i * U + j];
+            for (int i = 0; i < U; ++i) g += sh_rh[i] * Wc[(long long)(I + i) * U + j];
+            const float c = tanh_(g), u = sh_ru[U + j], hp = sh_a[I + j];
+            const float h = u * hp + (1.f - u) * c;
+            cand[o * U + j] = c;
+            hout[o * U + j] = h;
+            A[o * K + I + j] = hp;
+            A2[o * K + I + j] = sh_rh[j];
+        }
+        __syncthreads();
+        if (j < U) sh_a[I + j] = hout[o * U + j];
+        __syncthreads();
+    }
+}
+
+__global__ void gru_seq_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Wg, const float* __restrict__ Wc,
+                                   const float* __restrict__ ru, const float* __restrict__ cand, const float* __restrict__ dh_out,
+                                   float* __restrict__ dGg, float* __restrict__ dGc, float* __restrict__ dA, int T, int B, int I, int U) {
+    extern __shared__ float sh_gru[];
+    const int K = I + U;
+    float* sh_dgc = sh_gru;             // [U]
+    float* sh_dgg = sh_dgc + U;         // [2U]
+    float* sh_dxc = sh_dgg + 2 * U;     // [I]  dL/dx through the candidate
+    float* sh_drh = sh_dxc + I;         // [U]  dL/d(r * h_prev)
+    float* sh_dh = sh_drh + U;          // [U]  dL/dh_t carried from step t+1
+    float* sh_dhp = sh_dh + U;          // [U]  direct part of dL/dh_{t-1}
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int lane = j & 63, wave = j >> 6, nwaves = (2 * U + 63) >> 6;
+    if (j < U) sh_dh[j] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const long long o = (long long)t * B + b;
+        float hp = 0.f, r = 0.f, u = 0.f, du = 0.f, dhp = 0.f;
+        if (j < U) {
+            hp = A[o * K + I + j]; r = ru[o * 2 * U + j]; u = ru[o * 2 * U + U + j];
+            const float c = cand[o * U + j];
+            const float dh = dh_out[o * U + j] + sh_dh[j];
+            du = dh * (hp - c);
+            dhp = dh * u;
+            const float dgc = dh * (1.f - u) * (1.f - c * c);
+            sh_dgc[j] = dgc;
+            dGc[o * U + j] = dgc;
+        }
+        __syncthreads();
+        for (int i = wave; i < K; i += nwaves) {                    // [dx_c | d(r h)] = Wc dgc: one wave per row
+            float s = 0.f;
+            for (int q = lane; q < U; q += 64) s += Wc[(long long)i * U + q] * sh_dgc[q];
+            s = wsum(s);
+            if (lane == 0) { if (i < I) sh_dxc[i] = s; else sh_drh[i - I] = s; }
+        }
+        __syncthreads();
+        if (j < U) {
+            const float drh = sh_drh[j];
+            const float dgr = drh * hp * r * (1.f - r), dgu = du * u * (1.f - u);
+            sh_dgg[j] = dgr; sh_dgg[U + j] = dgu;
+            dGg[o * 2 * U + j] = dgr; dGg[o * 2 * U + U + j] = dgu;
+            sh_dhp[j] = dhp + drh * r;
+        }
+        __syncthreads();
+        for (int i = wave; i < K; i += nwaves) {                    // [dx_g | dh_g] = Wg dgg
+            float s = 0.f;
+            for (int q = lane; q < 2 * U; q += 64) s += Wg[(long long)i * 2 * U + q] * sh_dgg[q];
+            s = wsum(s);
+            if (lane == 0) {
+                if (i < I) dA[o * K + i] = s + sh_dxc[i];
+                else { const float v = s + sh_dhp[i - I]; dA[o * K + i] = v; sh_dh[i - I] = v; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int savp_gru_seq_fwd(void* stream, float* A, float* A2, const float* Wg, const float* bg, const float* Wc, const float* bc,
+                                float* hout, float* ru, float* cand, int32_t T, int32_t B, int32_t I, int32_t U) {
+    if (!A || !A2 || !Wg || !bg || !Wc || !bc || !hout || !ru || !cand || U < 1 || U > 512 || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    const int nt = ((2 * U + 63) / 64) * 64;
+    if (nt > 1024) return SAVP_EINVAL;
+    // (threads beyond 2U would index past the gate arrays: the launch uses exactly 2U threads -- any count is legal, waves are padded)
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(B), dim3(2 * U), (size_t)(I + U + 3 * U) * sizeof(float), (hipStream_t)stream, A, A2, Wg, bg,
+                       Wc, bc, hout, ru, cand, T, B, I, U);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, const float* Wc, const float* ru, const float* cand,
+                                const float* dh_out, float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U) {
+    if (!A || !Wg || !Wc || !ru || !cand || !dh_out || !dGg || !dGc || !dA || U < 1 || U > 512 || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(B), dim3(2 * U), (size_t)(6 * U + I) * sizeof(float), (hipStream_t)stream, A, Wg, Wc, ru,
+                       cand, dh_out, dGg, dGc, dA, T, B, I, U);
     return LAUNCH_OK();
 }
 

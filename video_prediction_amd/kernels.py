@@ -513,6 +513,9 @@ def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
     a.gates_bf16 = int(gates.dtype == torch.bfloat16)
     if c_prev is not None:
         a.c_prev = view(c_prev)
+    if g1 is None:                      # the cell without a normaliser (SavpLstmArgs.no_norm): pointwise gate math, no parameters / statistics
+        a.no_norm = 1
+        return a
     a.gamma1, a.beta1, a.gamma2, a.beta2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
     a.mean1, a.rstd1, a.mean2, a.rstd2 = [s.data_ptr() for s in stats]
     return a
@@ -576,7 +579,8 @@ def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates
     a.dc_new = dc_new.data_ptr() if dc_new is not None else None
     a.dgates = dgates.data_ptr()
     a.dc_prev = dc_prev.data_ptr() if dc_prev is not None else None
-    a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = [d.data_ptr() for d in dparams]
+    if not a.no_norm:
+        a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = [d.data_ptr() for d in dparams]
     if defer:
         return a
     lib.check(lib.get().savp_convlstm_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_bwd')
@@ -817,16 +821,40 @@ def composite_bwd(logits, timgs, dgen, dlogits, drow, timgs_offset, M=None):
 # ---------------------------------------------------------------------------------------------------------------
 # small ops
 # ---------------------------------------------------------------------------------------------------------------
-def lstm_z_fwd(zs, W, b, hout, gates, cs, forget_bias=1.0):
+def lstm_z_fwd(zs, W, b, hout, gates, cs, forget_bias=1.0, init=None):
+    """init: (c0, h0) [nz] each -- the learned initial state, tiled over the batch (learn_initial_state); None = zero state."""
     T, B, nz = zs.shape
-    lib.check(_L().savp_lstm_z_fwd(lib.stream(), _p(zs), _p(W), _p(b), _p(hout), _p(gates), _p(cs), T, B, nz, float(forget_bias)),
-              'savp_lstm_z_fwd')
+    c0, h0 = init if init is not None else (None, None)
+    lib.require_device(zs, W, b, hout, gates, cs, c0, h0)
+    lib.check(_L().savp_lstm_z_fwd_init(lib.stream(), _p(zs), _p(W), _p(b), _p(hout), _p(gates), _p(cs), T, B, nz, float(forget_bias),
+                                        _p(c0), _p(h0)), 'savp_lstm_z_fwd')
 
 
-def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0):
+def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0, init=None, dinit=None):
+    """init = (c0, h0) as in lstm_z_fwd; dinit = (dc0, dh0) [nz]: their gradients are ADDED there."""
     T, B, nz = zs.shape
-    lib.check(_L().savp_lstm_z_bwd(lib.stream(), _p(zs), _p(W), _p(hout), _p(gates), _p(cs), _p(dh_out), _p(dzs), _p(dW), _p(db),
-                                   T, B, nz, float(forget_bias)), 'savp_lstm_z_bwd')
+    c0, h0 = init if init is not None else (None, None)
+    dc0, dh0 = dinit if dinit is not None else (None, None)
+    lib.require_device(c0, h0, dc0, dh0)
+    lib.check(_L().savp_lstm_z_bwd_init(lib.stream(), _p(zs), _p(W), _p(hout), _p(gates), _p(cs), _p(dh_out), _p(dzs), _p(dW), _p(db),
+                                        T, B, nz, float(forget_bias), _p(c0), _p(h0), _p(dc0), _p(dh0)), 'savp_lstm_z_bwd')
+
+
+def gru_seq_fwd(A, A2, Wg, bg, Wc, bc, hout, ru, cand, n_in):
+    """GRUCell over time (include/savp_hip.h): A [T,B,I+U] with x in [..., :I]; fills A[..., I:], A2, hout, ru, cand."""
+    T, B, Kd = A.shape
+    U = Kd - n_in
+    lib.require_device(A, A2, Wg, bg, Wc, bc, hout, ru, cand)
+    lib.check(_L().savp_gru_seq_fwd(lib.stream(), _p(A), _p(A2), _p(Wg), _p(bg), _p(Wc), _p(bc), _p(hout), _p(ru), _p(cand), T, B, n_in, U),
+              'savp_gru_seq_fwd')
+
+
+def gru_seq_bwd(A, Wg, Wc, ru, cand, dh_out, dGg, dGc, dA, n_in):
+    T, B, Kd = A.shape
+    U = Kd - n_in
+    lib.require_device(A, Wg, Wc, ru, cand, dh_out, dGg, dGc, dA)
+    lib.check(_L().savp_gru_seq_bwd(lib.stream(), _p(A), _p(Wg), _p(Wc), _p(ru), _p(cand), _p(dh_out), _p(dGg), _p(dGc), _p(dA), T, B, n_in, U),
+              'savp_gru_seq_bwd')
 
 
 def lstm_seq_fwd(A, W, b, hout, gates, cs, n_in, forget_bias=1.0):

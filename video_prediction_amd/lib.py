@@ -214,7 +214,7 @@ class SavpLstmArgs(ctypes.Structure):
         ('ndh', c_i32), ('dh', SavpView * 4), ('dc_new', c_vp), ('dgates', c_vp), ('dc_prev', c_vp),
         ('dgamma1', c_vp), ('dbeta1', c_vp), ('dgamma2', c_vp), ('dbeta2', c_vp),
         ('ws', c_vp), ('ws_floats', ctypes.c_int64), ('ws_stats', c_vp), ('ws_stats_clean', c_i32),
-        ('gates_bf16', c_i32), ('stats1_ready', c_i32), ('h_bf16', c_i32), ('dgates_bf16', c_i32), ('dgates_raw', c_vp),
+        ('gates_bf16', c_i32), ('stats1_ready', c_i32), ('h_bf16', c_i32), ('dgates_bf16', c_i32), ('dgates_raw', c_vp), ('no_norm', c_i32),
     ]
 
 
@@ -285,6 +285,10 @@ register('savp_prof_armed', [])
 register('savp_prof_elapsed_us', [c_vp, c_vp, ctypes.POINTER(c_f32)])
 register('savp_kl_gauss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
+register('savp_gru_seq_fwd', [c_vp] * 10 + [c_i32] * 4)
+register('savp_gru_seq_bwd', [c_vp] * 10 + [c_i32] * 4)
+register('savp_lstm_z_fwd_init', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp])
+register('savp_lstm_z_bwd_init', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
 register('savp_reparam_bwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp])
 register('savp_lp_loss', [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp])

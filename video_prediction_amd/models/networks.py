@@ -35,8 +35,9 @@ class PosteriorEncoder(object):
         if hp.norm_layer != 'instance':
             raise NotImplementedError('HIP encoder covers norm_layer=instance')
         self.recurrent = bool(prior or hp.use_e_rnn)
-        if self.recurrent and hp.rnn != 'lstm':
-            raise NotImplementedError('rnn=%r: only the BasicLSTMCell tail is on the HIP path' % (hp.rnn,))
+        if self.recurrent and hp.rnn not in ('lstm', 'gru'):
+            raise NotImplementedError(hp.rnn)                                  # savp_model.py:40-41
+        self.gru = bool(self.recurrent and hp.rnn == 'gru')
         self.pairs = torch.zeros(max(M, 1), H, W, 2 * C, device=dev)
         self.C = C
         self.layers = []
@@ -70,18 +71,34 @@ class PosteriorEncoder(object):
             U = self.U = hp.nef * 4
             s = prefix + 'layer_%d/' % (hp.n_layers + 1)
             self.fc = ConvLayer(store, s + 'dense/kernel', s + 'dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
-            s = prefix + '%s/rnn/basic_lstm_cell/' % hp.rnn
-            # the cell's [2U,4U] kernel as a 1x1 layer object: only its WGRAD entry is used (dW = A^T dG over all (t,b) rows)
-            self.cell = ConvLayer(store, s + 'kernel', s + 'bias', 'conv', (1, 1), (1, 1), (0, 0))
-            self.cell.need_wt = self.cell.need_wd = False
             self.A = torch.zeros(T1, B, 2 * U, device=dev)                  # [dense(feat)_t | h_{t-1}]
             self.hout = torch.empty(T1, B, U, device=dev)
-            self.gates = torch.empty(T1, B, 4 * U, device=dev)
-            self.cs = torch.empty(T1, B, U, device=dev)
             if train:
                 self.dh = torch.empty(T1, B, U, device=dev)
-                self.dG = torch.empty(T1, B, 4 * U, device=dev)
                 self.dA = torch.empty(T1, B, 2 * U, device=dev)
+            if self.gru:
+                # tf.contrib.rnn.GRUCell (savp_model.py:38-39): gates/{kernel [2U,2U], bias}, candidate/{kernel [2U,U], bias}; as with the
+                # LSTM cell the kernels are 1x1 layer objects of which only the WGRAD entry is used
+                s = prefix + 'gru/rnn/gru_cell/'
+                self.cell_g = ConvLayer(store, s + 'gates/kernel', s + 'gates/bias', 'conv', (1, 1), (1, 1), (0, 0))
+                self.cell_c = ConvLayer(store, s + 'candidate/kernel', s + 'candidate/bias', 'conv', (1, 1), (1, 1), (0, 0))
+                for c_ in (self.cell_g, self.cell_c):
+                    c_.need_wt = c_.need_wd = False
+                self.A2 = torch.zeros(T1, B, 2 * U, device=dev)             # [dense(feat)_t | r_t * h_{t-1}]
+                self.ru = torch.empty(T1, B, 2 * U, device=dev)
+                self.cand = torch.empty(T1, B, U, device=dev)
+                if train:
+                    self.dGg = torch.empty(T1, B, 2 * U, device=dev)
+                    self.dGc = torch.empty(T1, B, U, device=dev)
+            else:
+                s = prefix + '%s/rnn/basic_lstm_cell/' % hp.rnn
+                # the cell's [2U,4U] kernel as a 1x1 layer object: only its WGRAD entry is used (dW = A^T dG over all (t,b) rows)
+                self.cell = ConvLayer(store, s + 'kernel', s + 'bias', 'conv', (1, 1), (1, 1), (0, 0))
+                self.cell.need_wt = self.cell.need_wd = False
+                self.gates = torch.empty(T1, B, 4 * U, device=dev)
+                self.cs = torch.empty(T1, B, U, device=dev)
+                if train:
+                    self.dG = torch.empty(T1, B, 4 * U, device=dev)
             hin = U
         self.mu_fc = ConvLayer(store, prefix + 'z_mu/dense/kernel', prefix + 'z_mu/dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
         self.ls_fc = ConvLayer(store, prefix + 'z_log_sigma_sq/dense/kernel', prefix + 'z_log_sigma_sq/dense/bias', 'conv',
@@ -124,7 +141,11 @@ class PosteriorEncoder(object):
         if self.recurrent:
             U = self.U
             self.fc.forward(self.feat, self.A.reshape(R, 2 * U)[:, :U])                        # savp_model.py:32-33 / 66-67
-            K.lstm_seq_fwd(self.A, self.cell.W, self.cell.bias, self.hout, self.gates, self.cs, U)     # :35-43 / 69-76
+            if self.gru:
+                K.gru_seq_fwd(self.A, self.A2, self.cell_g.W, self.cell_g.bias, self.cell_c.W, self.cell_c.bias, self.hout, self.ru,
+                              self.cand, U)                                                    # :38-43 with rnn = 'gru'
+            else:
+                K.lstm_seq_fwd(self.A, self.cell.W, self.cell.bias, self.hout, self.gates, self.cs, U)     # :35-43 / 69-76
         hin = self._head_input()
         self.mu_fc.forward(hin, self.mu.reshape(R, -1))
         self.ls_fc.forward(hin, self.ls_raw.reshape(R, -1))
@@ -155,8 +176,13 @@ class PosteriorEncoder(object):
         self.ls_fc.backward_weights(hin, dls2)
         if self.recurrent:
             U = self.U
-            K.lstm_seq_bwd(self.A, self.cell.W, self.gates, self.cs, self.dh, self.dG, self.dA, U)
-            self.cell.backward_weights(self.A.reshape(R, 2 * U), self.dG.reshape(R, 4 * U))         # dW = A^T dG, db = colsum(dG)
+            if self.gru:
+                K.gru_seq_bwd(self.A, self.cell_g.W, self.cell_c.W, self.ru, self.cand, self.dh, self.dGg, self.dGc, self.dA, U)
+                self.cell_g.backward_weights(self.A.reshape(R, 2 * U), self.dGg.reshape(R, 2 * U))
+                self.cell_c.backward_weights(self.A2.reshape(R, 2 * U), self.dGc.reshape(R, U))
+            else:
+                K.lstm_seq_bwd(self.A, self.cell.W, self.gates, self.cs, self.dh, self.dG, self.dA, U)
+                self.cell.backward_weights(self.A.reshape(R, 2 * U), self.dG.reshape(R, 4 * U))     # dW = A^T dG, db = colsum(dG)
             dx = self.dA.reshape(R, 2 * U)[:, :U]
             self.fc.backward_data(dx, self.dfeat, beta=0)
             self.fc.backward_weights(self.feat, dx)

@@ -96,20 +96,34 @@ class SAVPGenerator(object):
         dev = store.device
         self.dev = dev
         self._cstats = {}                # head name -> the conv's epilogue supplies the instance norm's statistics (decided at first use)
-        if hp.conv_rnn not in ('lstm', 'gru') or hp.conv_rnn_norm_layer != 'instance' or hp.norm_layer != 'instance':
-            raise NotImplementedError('HIP path covers conv_rnn in (lstm, gru) with instance norm')
+        if hp.conv_rnn not in ('lstm', 'gru') or hp.conv_rnn_norm_layer not in ('instance', 'none') or hp.norm_layer != 'instance':
+            raise NotImplementedError('HIP path covers conv_rnn in (lstm, gru) with instance norm (or no normaliser inside the LSTM cell)')
+        # The ConvLSTM cell WITHOUT a normaliser (rnn_ops.py:122-125: the gate convolution then has a bias; :148-165 with normalizer_fn None):
+        # conv_rnn_norm_layer = 'none', or ablation_conv_rnn_norm (savp_model.py:380-384: the cell is built without one and the layer's OUTPUT
+        # h -- not the state handed to the next step -- goes through normalizer_fn, variables under <cell scope>/InstanceNorm/).
+        self.cell_plain = bool(hp.conv_rnn_norm_layer == 'none' or hp.ablation_conv_rnn_norm)
+        self.out_norm = bool(hp.ablation_conv_rnn_norm)
+        if self.out_norm and hp.conv_rnn_norm_layer == 'none':
+            raise TypeError("ablation_conv_rnn_norm with conv_rnn_norm_layer='none': the reference calls normalizer_fn = None (savp_model.py:384)")
+        if self.cell_plain and hp.conv_rnn != 'lstm' and not hp.ablation_rnn:
+            raise NotImplementedError('the normaliser-free cell is on the HIP path for conv_rnn = lstm only')
         if hp.downsample_layer != 'conv_pool2d' or hp.upsample_layer != 'upsample_conv2d' or hp.activation_layer != 'relu':
             raise NotImplementedError('HIP path covers conv_pool2d / upsample_conv2d / relu')
         if hp.transformation not in ('cdna', 'flow', 'dna') or hp.last_frames != 1 or not hp.num_transformed_images:
             raise NotImplementedError('HIP path covers transformation in (cdna, flow, dna) with last_frames=1')
         if tuple(hp.dilation_rate) != (1, 1):
             raise NotImplementedError('dilation_rate != (1, 1)')
-        if hp.nz and hp.use_rnn_z and hp.rnn != 'lstm':
-            raise NotImplementedError("rnn=%r: the latent's recurrent cell is built as an LSTMCell only (savp_model.py:354-362)" % (hp.rnn,))
+        if hp.nz and hp.use_rnn_z and hp.rnn not in ('lstm', 'gru') and not hp.ablation_rnn:
+            raise NotImplementedError(hp.rnn)                                  # savp_model.py:360-361
+        if hp.nz and hp.use_rnn_z and hp.rnn == 'gru' and hp.learn_initial_state:
+            raise NotImplementedError('learn_initial_state with the GRU latent cell')
         if hp.where_add not in ('input', 'all', 'middle'):
             raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
-        if hp.ablation_rnn or hp.ablation_conv_rnn_norm or hp.learn_initial_state:
-            raise NotImplementedError('HIP path does not cover the rnn ablations / learn_initial_state')
+        # ablation_rnn (savp_model.py:272-291,426-429,466-474,502-509): no recurrent state anywhere -- every conv-RNN becomes conv2d 5x5
+        # (+ tiled z) -> norm -> ReLU under scope conv_h<i>, the latent's cell becomes dense + tanh under scope fc_z
+        self.abl_rnn = bool(hp.ablation_rnn)
+        if self.abl_rnn and hp.learn_initial_state:
+            raise ValueError('learn_initial_state has no state to learn under ablation_rnn')
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
@@ -168,7 +182,13 @@ class SAVPGenerator(object):
             L['hw'] = (h_, w_)
             L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g, grad_dtype=a16 if f % 8 == 0 else torch.float32)
             L['norm'] = Norm(store, s + 'InstanceNorm/', T1, N, f, dev)
-            if use_rnn and hp.conv_rnn == 'gru':
+            if use_rnn and self.abl_rnn:
+                r = prefix + 'conv_h%d/' % i
+                L['a'] = Act((T1, N, h_, w_, ceil4(f + zr)), dev, grad=g, dtype=a16 if ceil4(f + zr) % 8 == 0 else torch.float32)
+                L['pre2'] = Act((T1, N, h_, w_, f), dev, grad=g, grad_dtype=a16 if f % 8 == 0 else torch.float32)
+                L['rconv'] = ConvLayer(store, r + 'conv2d/kernel', r + 'conv2d/bias', 'conv', (5, 5), (1, 1), (2, 2), cx_pad=ceil4(f + zr))
+                L['n2'] = Norm(store, r + 'InstanceNorm/', T1, N, f, dev)
+            elif use_rnn and hp.conv_rnn == 'gru':
                 # Conv2DGRUCell (rnn_ops.py:174-267): a = [x | z | h_prev | r*h_prev]; the gates conv reads the first
                 # f+zc+f channels of the same buffer (a channel-slice view), the candidate conv reads all of it
                 r = prefix + 'gru_h%d/conv2dgru_cell/' % i
@@ -187,7 +207,7 @@ class SAVPGenerator(object):
                 r = prefix + 'lstm_h%d/basic_conv2dlstm_cell/' % i
                 # fused ConvLSTM cell of the bf16 datapath: the gate convolution's epilogue produces the statistics of the first
                 # instance norm and stores the gate pre-activations as bf16 (csrc/conv_ring.hip) -> conv + 2 launches per cell
-                L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and
+                L['fused'] = (K.PRECISION['value'] == 1 and os.environ.get('SAVP_FUSED_CELL', '1') == '1' and not self.cell_plain and
                               h_ % 8 == 0 and w_ % 8 == 0 and 16 <= f <= 256 and (f & (f - 1)) == 0 and (f + zr + f) % 8 == 0)
                 # The cell's input buffer [x | z | h] and the gate gradient are held in bf16 (round 3: validated on MI355X, identical
                 # numbers -- their only readers are the gate convolution's FPROP / DGRAD / WGRAD, which round to bf16 when they stage
@@ -202,9 +222,13 @@ class SAVPGenerator(object):
                 L['dg_raw'] = torch.empty(N, h_, w_, 4 * f, device=dev) if dg_dt == torch.bfloat16 else None
                 L['c'] = Act((T1, N, h_, w_, f), dev, grad=False)
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
-                L['rconv'] = ConvLayer(store, r + 'kernel', None, 'conv', (5, 5), (1, 1), (2, 2))
-                L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
-                L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
+                L['rconv'] = ConvLayer(store, r + 'kernel', (r + 'bias') if self.cell_plain else None, 'conv', (5, 5), (1, 1), (2, 2))
+                if not self.cell_plain:
+                    L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
+                    L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
+                if self.out_norm:
+                    L['h_raw'] = Act((T1, N, h_, w_, f), dev, grad=g)
+                    L['onorm'] = Norm(store, prefix + 'lstm_h%d/InstanceNorm/' % i, T1, N, f, dev)
                 # The data gradient of the gate convolution leaves the tiled-z channels of [x | z | h] out (their gradient is a per-sample
                 # sum, taken once over all timesteps from region sums of the gate gradient: csrc/tiled_z.hip), which keeps its column count
                 # on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256).  bf16 datapath (the ring kernel owns the column gap).
@@ -311,13 +335,55 @@ class SAVPGenerator(object):
         if nz:
             self.zs = Act((T1, N, nz), dev, grad=g)
             self.rnn_z = Act((T1, N, nz), dev, grad=g, zero_grad=True)
-            if self.use_rnn_z:
+            if self.use_rnn_z and self.abl_rnn:
+                self.fc_z = ConvLayer(store, prefix + 'fc_z/dense/kernel', prefix + 'fc_z/dense/bias', 'conv', (1, 1), (1, 1), (0, 0))
+                self.fcz_pre = Act((T1 * N, 1, 1, nz), dev, grad=g)
+            elif self.use_rnn_z and hp.rnn == 'gru':            # tf.contrib.rnn.GRUCell under scope gru_z (savp_model.py:358-359,426)
+                z = prefix + 'gru_z/gru_cell/'
+                self.zg = ConvLayer(store, z + 'gates/kernel', z + 'gates/bias', 'conv', (1, 1), (1, 1), (0, 0))
+                self.zc = ConvLayer(store, z + 'candidate/kernel', z + 'candidate/bias', 'conv', (1, 1), (1, 1), (0, 0))
+                for c_ in (self.zg, self.zc):
+                    c_.need_wt = c_.need_wd = False
+                self.zA = torch.zeros(T1, N, 2 * nz, device=dev)
+                self.zA2 = torch.zeros(T1, N, 2 * nz, device=dev)
+                self.z_ru = torch.empty(T1, N, 2 * nz, device=dev)
+                self.z_cand = torch.empty(T1, N, nz, device=dev)
+                if g:
+                    self.z_dGg = torch.empty(T1, N, 2 * nz, device=dev)
+                    self.z_dGc = torch.empty(T1, N, nz, device=dev)
+                    self.z_dA = torch.empty(T1, N, 2 * nz, device=dev)
+            elif self.use_rnn_z:
                 z = prefix + 'lstm_z/basic_lstm_cell/'
                 self.zW, self.zb = store[z + 'kernel'], store[z + 'bias']
                 self.dzW, self.dzb = store.grad(z + 'kernel'), store.grad(z + 'bias')
                 self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
                 self.z_cs = torch.empty(T1, N, nz, device=dev)
         self.gru = hp.conv_rnn == 'gru'
+        # ---- learn_initial_state (savp_model.py:295-307,344-352): the conv-RNN states and the rnn_z state start from variables
+        # `generator/initial_state_<i>/initial_state` (i = position in nest.flatten of {'conv_rnn_states': [...], 'rnn_z_state': ...}: layer
+        # order, LSTM tuples as (c, h), the latent cell last), tiled over the batch; both unrolls (N = 2B) share them.  Forward: a broadcast
+        # copy into step 0's state slots; backward: what step 0 hands back, summed over the batch.
+        self.learn_init = bool(hp.learn_initial_state)
+        if self.learn_init:
+            k = 0
+
+            def var(shape):
+                nonlocal k
+                name = 'generator/initial_state_%d/initial_state' % k
+                k += 1
+                assert tuple(store[name].shape) == tuple(shape), (name, tuple(store[name].shape), shape)
+                return store[name], (store.grad(name) if g else None)
+            for L in self.layers:
+                if not L['rnn']:
+                    continue
+                hw_f = L['hw'] + (L['f'],)
+                if not self.gru:
+                    L['c0v'], L['c0g'] = var(hw_f)
+                    L['c0'] = torch.empty((N,) + hw_f, device=dev)
+                L['h0v'], L['h0g'] = var(hw_f)
+            if self.use_rnn_z:
+                self.z_c0, self.z_dc0 = var((nz,))
+                self.z_h0, self.z_dh0 = var((nz,))
         # ---- merged 3x3 heads on the last decoder layer (SAVP_MERGE_HEADS=0: one launch per head, the reference's structure) ----
         # h6_scratch, h6_masks (and h6_flow / h6_dna_kernel) all read h_last through a 3x3 conv + instance norm + relu: ONE conv with
         # concatenated output channels, ONE instance norm over them, outputs routed by channel range; backward likewise.
@@ -336,7 +402,8 @@ class SAVPGenerator(object):
             self.heads_pre = Act((T1, N, H, W, self.nheads * ngf), dev, grad=g, grad_dtype=a16 if (self.nheads * ngf) % 8 == 0 else torch.float32)
             head_convs = [self.heads_conv]
         self.convs = [L['conv'] for L in self.layers] + [L['rconv'] for L in self.layers if L['rnn']] + \
-                     [L['cconv'] for L in self.layers if L['rnn'] and self.gru] + \
+                     [L['cconv'] for L in self.layers if L['rnn'] and self.gru and not self.abl_rnn] + \
+                     ([self.fc_z] if (self.use_rnn_z and self.abl_rnn) else []) + \
                      tf_convs + head_convs + ([self.scratch_out] if self.scratch else []) + [self.masks_out]
         # only FPROP packs needed at inference
         self._routes()
@@ -387,8 +454,15 @@ class SAVPGenerator(object):
         self.gt_mask = gt_mask
         if nz:
             self.zs.v.copy_(zs)
-            if self.use_rnn_z:
-                K.lstm_z_fwd(self.zs.v, self.zW, self.zb, self.rnn_z.v, self.z_gates, self.z_cs)
+            if self.use_rnn_z and self.abl_rnn:           # tanh(dense(z)) (savp_model.py:426-429)
+                self.fc_z.forward(self.zs.v.reshape(T1 * N, 1, 1, nz), self.fcz_pre.v)
+                torch.tanh(self.fcz_pre.v.reshape(T1, N, nz), out=self.rnn_z.v)
+            elif self.use_rnn_z and self.hp.rnn == 'gru':
+                self.zA[..., :nz].copy_(self.zs.v)
+                K.gru_seq_fwd(self.zA, self.zA2, self.zg.W, self.zg.bias, self.zc.W, self.zc.bias, self.rnn_z.v, self.z_ru, self.z_cand, nz)
+            elif self.use_rnn_z:
+                K.lstm_z_fwd(self.zs.v, self.zW, self.zb, self.rnn_z.v, self.z_gates, self.z_cs,
+                             init=(self.z_c0, self.z_h0) if self.learn_init else None)
             else:
                 self.rnn_z.v.copy_(self.zs.v)
             zflat = self.rnn_z.v.reshape(T1 * N, nz)
@@ -399,6 +473,13 @@ class SAVPGenerator(object):
                 if L['rnn'] and L['zr']:
                     a = L['a']
                     K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + nz])
+        if self.learn_init:                # step 0's state slots <- the learned initial states, tiled over the batch
+            for L in self.layers:
+                if L['rnn']:
+                    f, hoff = L['f'], L['f'] + L['zr']
+                    L['a'].v[0][..., hoff:hoff + f].copy_(L['h0v'])
+                    if not self.gru:
+                        L['c0'].copy_(L['c0v'])
         in0, maskin = self.layers[0]['in'], self.maskin
         # the first frame feeds every step (savp_model.py:399-400): ONE launch writes it into all T1 steps' buffers -- time is the
         # kernel's sample index (source stride 0), the N*H*W pixels of a step its pixel index
@@ -442,7 +523,11 @@ class SAVPGenerator(object):
                     L[ck] = (CONV_STATS and f <= 256 and (f & (f - 1)) == 0 and L['conv'].stats_ok(L['in'].v[t], L['pre'].v[t]))
                 st = K.stats_ws(self.dev, N, f) if L[ck] else None
                 nrm = L['norm']
-                if L['rnn'] and self.gru:
+                if L['rnn'] and self.abl_rnn:
+                    a = L['a']
+                    self._conv_in_act(L['conv'], L['in'].v[t], L['pre'].v[t], st, nrm, [a.v[t][..., 0:f]], t)
+                    self._conv_norm(('abl', L['idx']), L['rconv'], a.v[t], L['pre2'].v[t], L['n2'], self._out_views(L, t), t)
+                elif L['rnn'] and self.gru:
                     L['conv'].forward(L['in'].v[t], L['pre'].v[t], stats=st)
                     a = L['a']
                     hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
@@ -458,6 +543,16 @@ class SAVPGenerator(object):
                     if t + 1 < T1:
                         outs.append(a.v[t + 1][..., hs:hs + f])
                     K.convgru_out_fwd(L['cand'].v[t], hprev, n2.gamma, n2.beta, n2.mean[t], n2.rstd[t], L['u'][t], outs, eps=EPS_IN)
+                elif L['rnn'] and self.cell_plain:
+                    a = L['a']
+                    self._conv_in_act(L['conv'], L['in'].v[t], L['pre'].v[t], st, nrm, [a.v[t][..., 0:f]], t)
+                    L['rconv'].forward(a.v[t], L['gates'].v[t])                       # conv + bias
+                    nxt_h = [a.v[t + 1][..., f + L['zr']:f + L['zr'] + f]] if t + 1 < T1 else []
+                    hdst = ([L['h_raw'].v[t]] if self.out_norm else self._out_views(L, t)) + nxt_h
+                    K.convlstm_gates_fwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else L.get('c0'), None, None, None, None, L['c'].v[t], hdst, None)
+                    if self.out_norm:
+                        on = L['onorm']
+                        K.instnorm_act_fwd(L['h_raw'].v[t], on.gamma, on.beta, self._out_views(L, t), on.mean[t], on.rstd[t], act='none', eps=EPS_IN)
                 elif L['rnn']:
                     a = L['a']
                     self._conv_in_act(L['conv'], L['in'].v[t], L['pre'].v[t], st, nrm, [a.v[t][..., 0:f]], t)
@@ -473,7 +568,7 @@ class SAVPGenerator(object):
                         outs.append(a.v[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
                     gk = L.get('gate_ktimer')                # bench.py: the gate-block launch's own begin / end stamps
-                    gargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma, n2.beta, L['c'].v[t], outs,
+                    gargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else L.get('c0'), n1.gamma, n1.beta, n2.gamma, n2.beta, L['c'].v[t], outs,
                              [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]])
                     # the whole cell as ONE host call (savp_convlstm_cell_fwd) unless a measurement wants the two launches apart
                     ca = (L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1, defer=True)
@@ -660,6 +755,13 @@ class SAVPGenerator(object):
                 f = L['f']
                 dys = self._out_grads(L, t)
                 nrm = L['norm']
+                if L['rnn'] and self.abl_rnn:
+                    a, n2 = L['a'], L['n2']
+                    K.instnorm_act_bwd(L['pre2'].v[t], n2.gamma, n2.beta, self._out_views(L, t)[0], n2.mean[t], n2.rstd[t], dys, L['pre2'].g[t],
+                                       n2.dgamma, n2.dbeta, act='relu', eps=EPS_IN)
+                    L['rconv'].backward_data(L['pre2'].g[t], a.g[t], beta=0)
+                    self._in_act_conv_bwd(L, t, a.v[t][..., 0:f], [a.g[t][..., 0:f]], None)
+                    continue
                 if L['rnn'] and self.gru:
                     a = L['a']
                     hs, rs_, cin1 = f + L['zr'], f + L['zr'] + f, L['cin1']
@@ -677,14 +779,30 @@ class SAVPGenerator(object):
                     L['rconv'].backward_data(L['gates'].g[t], a.g[t][..., 0:cin1], beta=1)
                     K.instnorm_act_bwd(L['pre'].v[t], nrm.gamma, nrm.beta, a.v[t][..., 0:f], nrm.mean[t], nrm.rstd[t],
                                        [a.g[t][..., 0:f]], L['pre'].g[t], nrm.dgamma, nrm.dbeta, act='relu', eps=EPS_IN)
+                elif L['rnn'] and self.cell_plain:
+                    a = L['a']
+                    if self.out_norm:
+                        on = L['onorm']
+                        K.instnorm_act_bwd(L['h_raw'].v[t], on.gamma, on.beta, self._out_views(L, t)[0], on.mean[t], on.rstd[t], dys,
+                                           L['h_raw'].g[t], on.dgamma, on.dbeta, act='none', eps=EPS_IN)
+                        dys = [L['h_raw'].g[t]]
+                    if t + 1 < T1:
+                        dys.append(a.g[t + 1][..., f + L['zr']:f + L['zr'] + f])
+                    dc_new = L['dc'][(t + 1) & 1] if t + 1 < T1 else None
+                    dc_prev = L['dc'][t & 1] if (t > 0 or self.learn_init) else None
+                    K.convlstm_gates_bwd(L['gates'].v[t], L['c'].v[t - 1] if t > 0 else L.get('c0'), None, None, None, None, None, dys, dc_new,
+                                         L['gates'].g[t], dc_prev, None)
+                    L['rconv'].backward_data(L['gates'].g[t], a.g[t], beta=0)
+                    self._in_act_conv_bwd(L, t, a.v[t][..., 0:f], [a.g[t][..., 0:f]], None)
+                    continue
                 elif L['rnn']:
                     a = L['a']
                     if t + 1 < T1:
                         dys.append(a.g[t + 1][..., f + L['zr']:f + L['zr'] + f])
                     n1, n2 = L['n1'], L['n2']
                     dc_new = L['dc'][(t + 1) & 1] if t + 1 < T1 else None
-                    dc_prev = L['dc'][t & 1] if t > 0 else None
-                    bargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else None, n1.gamma, n1.beta, n2.gamma, n2.beta,
+                    dc_prev = L['dc'][t & 1] if (t > 0 or self.learn_init) else None
+                    bargs = (L['gates'].v[t], L['c'].v[t - 1] if t > 0 else L.get('c0'), n1.gamma, n1.beta, n2.gamma, n2.beta,
                              [n1.mean[t], n1.rstd[t], n2.mean[t], n2.rstd[t]], dys, dc_new, L['gates'].g[t], dc_prev,
                              [n1.dgamma, n1.dbeta, n2.dgamma, n2.dbeta])
                     skip = (f, L['zr']) if L['zless'] else None
@@ -709,11 +827,21 @@ class SAVPGenerator(object):
             if t > 0:
                 K.select_bwd(self.gt_mask[t], [in0.g[t][..., 0:C], self.dimg_cdna] +
                              ([maskin.g[t][..., self.o_prev:self.o_prev + C]] if self.o_prev is not None else []), self.gen.g[t - 1])
+        if self.learn_init:                # gradients of the learned initial states: step 0's state gradients summed over the batch
+            for L in self.layers:
+                if L['rnn']:
+                    f, hoff = L['f'], L['f'] + L['zr']
+                    L['h0g'].add_(L['a'].g[0][..., hoff:hoff + f].float().sum(0))
+                    if not self.gru:
+                        L['c0g'].add_(L['dc'][0].sum(0))
         # ---- weight gradients: one split-K GEMM per layer over all (t, n) ----------------------------------------
         for L in self.layers:
             b, pre = L['in'], L['pre']
             L['conv'].backward_weights(b.flat(b.v), pre.flat(pre.g), feeds_instance_norm=True)
-            if L['rnn'] and self.gru:
+            if L['rnn'] and self.abl_rnn:
+                a, p2 = L['a'], L['pre2']
+                L['rconv'].backward_weights(a.flat(a.v), p2.flat(p2.g), feeds_instance_norm=True)
+            elif L['rnn'] and self.gru:
                 a, gt, cd = L['a'], L['gates'], L['cand']
                 L['rconv'].backward_weights(a.flat(a.v)[..., 0:L['cin1']], gt.flat(gt.g))
                 L['cconv'].backward_weights(a.flat(a.v), cd.flat(cd.g))
@@ -757,7 +885,25 @@ class SAVPGenerator(object):
             elif L['rnn'] and L['zr']:
                 a = L['a']
                 K.colsum(a.flat(a.g)[..., L['f']:L['f'] + nz], drz, per_row=True)
+        if self.use_rnn_z and self.abl_rnn:               # tanh(dense(z)) backward: d pre = d rnn_z * (1 - rnn_z^2)
+            dpre = self.fcz_pre.g.reshape(T1, N, nz)
+            torch.mul(self.rnn_z.v, self.rnn_z.v, out=dpre)
+            dpre.neg_().add_(1.0).mul_(drz)
+            zs4 = self.zs.v.reshape(T1 * N, 1, 1, nz)
+            self.fc_z.backward_data(self.fcz_pre.g, self.zs.g.reshape(T1 * N, 1, 1, nz), beta=0)
+            self.fc_z.backward_weights(zs4, self.fcz_pre.g)
+            self.fc_z.finish_weight_grad()
+            return self.zs.g
+        if self.use_rnn_z and self.hp.rnn == 'gru':
+            R = T1 * N
+            K.gru_seq_bwd(self.zA, self.zg.W, self.zc.W, self.z_ru, self.z_cand, drz, self.z_dGg, self.z_dGc, self.z_dA, nz)
+            self.zg.backward_weights(self.zA.reshape(R, 1, 1, 2 * nz), self.z_dGg.reshape(R, 1, 1, 2 * nz))
+            self.zc.backward_weights(self.zA2.reshape(R, 1, 1, 2 * nz), self.z_dGc.reshape(R, 1, 1, nz))
+            self.zs.g.copy_(self.z_dA[..., :nz])
+            return self.zs.g
         if self.use_rnn_z:
-            K.lstm_z_bwd(self.zs.v, self.zW, self.rnn_z.v, self.z_gates, self.z_cs, drz, self.zs.g, self.dzW, self.dzb)
+            K.lstm_z_bwd(self.zs.v, self.zW, self.rnn_z.v, self.z_gates, self.z_cs, drz, self.zs.g, self.dzW, self.dzb,
+                         init=(self.z_c0, self.z_h0) if self.learn_init else None,
+                         dinit=(self.z_dc0, self.z_dh0) if self.learn_init else None)
             return self.zs.g
         return drz
