@@ -112,5 +112,21 @@ case "$1" in
   OUT=$O REPS=2 bash tests/tools/ab_run.sh deep0 "SAVP_RING_DEEP=0" deep1 "SAVP_RING_DEEP=1"
   echo "total $(( $(date +%s)-t0 ))s"
   ;;
-*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9>"; exit 2 ;;
+12)
+  # twelfth lease: in-step re-tune of the most expensive conv problems on this round's kernels (row-wise staging changed the NKS >= 3
+  # instantiations only), c2 / c4 / c5, then the tuned table against the shipped one
+  O=gpurun_out/r05l; mkdir -p $O
+  smoke
+  T=video_prediction_amd/tuning_gfx950_bf16.json
+  cp $T $O/table_before.json
+  python tests/tools/insitu_tune.py $O/table_c2.json 40 5 > $O/insitu_c2.log 2>&1; tail -3 $O/insitu_c2.log
+  [ -s $O/table_c2.json ] && cp $O/table_c2.json $T
+  CONFIG=c4 python tests/tools/insitu_tune.py $O/table_c4.json 16 4 > $O/insitu_c4.log 2>&1; tail -3 $O/insitu_c4.log
+  [ -s $O/table_c4.json ] && cp $O/table_c4.json $T
+  CONFIG=c5 python tests/tools/insitu_tune.py $O/table_c5.json 16 4 > $O/insitu_c5.log 2>&1; tail -3 $O/insitu_c5.log
+  [ -s $O/table_c5.json ] && cp $O/table_c5.json $T
+  cp $T $O/tuning_gfx950_bf16.json
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh shipped "ARGS=--tuning-table,$O/table_before.json" tuned ""
+  ;;
+*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9|12>"; exit 2 ;;
 esac

@@ -3,6 +3,7 @@
 # applied to the same bench.py command, arms are interleaved `REPS` times inside ONE gpurun call (boxes differ by several percent; only
 # arms of one call are comparable), and one summary line per run is printed and written to $OUT/summary.txt.
 #   usage: OUT=gpurun_out/r05a REPS=2 [CONFIG=c2] [BENCH_ARGS="--steps 30 --warmup 6"] ab_run.sh name1 "ENV1=a ENV2=b" name2 "" ...
+#   an arm may carry extra bench.py arguments as ARGS=--flag,value (commas become spaces)
 #   an arm's environment may name another build of the library: SAVP_LIB=video_prediction_amd/ab/libsavp_hip_<tag>.so (build_variant.sh)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -15,7 +16,9 @@ for rep in $(seq 1 $REPS); do
   for i in "${!names[@]}"; do
     n=${names[$i]}; e=${envs[$i]}
     e=${e//SAVP_LIB=video_prediction_amd/SAVP_LIB=$PWD/video_prediction_amd}
-    env $e python bench.py $B > $OUT/bench_${n}_$rep.json 2> $OUT/bench_${n}_$rep.err
+    x=""; ee=""
+    for tok in $e; do case "$tok" in ARGS=*) x="$x ${tok#ARGS=}";; *) ee="$ee $tok";; esac; done      # ARGS=--flag,value: extra bench.py arguments of this arm
+    env $ee python bench.py $B ${x//,/ } > $OUT/bench_${n}_$rep.json 2> $OUT/bench_${n}_$rep.err
   done
 done
 python - "$OUT" <<'P' | tee $OUT/summary.txt
