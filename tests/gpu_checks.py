@@ -1314,6 +1314,64 @@ def check_ring_weight_warmup_invisible(seed=47, option='ring_wwarm'):
     return out
 
 
+def check_wgrad_dma_staging(seed=53):
+    """LDS-patch weight gradient of two bf16 operands (csrc/conv_wgrad_patch.hip): the LDS-DMA staged kernel (option wgp_dma, default) against
+    the register-staged one on the same bf16 tensors and against the kernel fed the same values in fp32 -- every workgroup shape, ragged
+    planes (border tiles, halo rows / columns from the zero slot), a 16-channel group cut by Cx, channel-slice views of wider buffers,
+    stride 2 and a 3-D layer."""
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+    bf = torch.bfloat16
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32).to(bf)
+
+    def sliced(t, off, width):
+        big = torch.zeros(*t.shape[:-1], width, device=DEV, dtype=t.dtype)
+        v = big[..., off:off + t.shape[-1]]
+        v.copy_(t)
+        return v
+
+    cases = [  # name, N, D, H, W, Cx, Cy, k, s, p, (x slice offset, width), (y slice offset, width)
+        ('lstm16', 6, 1, 16, 16, 136, 256, (1, 5, 5), (1, 1, 1), (0, 2, 2), None, None),
+        ('lstm32', 3, 1, 32, 32, 72, 128, (1, 5, 5), (1, 1, 1), (0, 2, 2), (8, 96), None),
+        ('lstm8', 5, 1, 8, 8, 264, 512, (1, 5, 5), (1, 1, 1), (0, 2, 2), None, (64, 640)),
+        ('ragged', 3, 1, 20, 12, 40, 24, (1, 3, 3), (1, 1, 1), (0, 1, 1), (16, 64), (8, 40)),
+        ('head3', 2, 1, 64, 64, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), None, None),
+        ('stride2', 3, 1, 32, 32, 64, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1), None, None),
+        ('video3d', 2, 5, 16, 16, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), None, None),
+    ]
+    old = lib.get_option('wgp_dma')
+    try:
+        for name, N, D, H, W, Cx, Cy, k, st, pd, xs, ys in cases:
+            Do = (D + 2 * pd[0] - k[0]) // st[0] + 1
+            Ho = (H + 2 * pd[1] - k[1]) // st[1] + 1
+            Wo = (W + 2 * pd[2] - k[2]) // st[2] + 1
+            x, y = rn(N, D, H, W, Cx), rn(N, Do, Ho, Wo, Cy)
+            xv = sliced(x, *xs) if xs else x
+            yv = sliced(y, *ys) if ys else y
+            if D == 1:
+                xv, yv, x32, y32 = xv[:, 0], yv[:, 0], x[:, 0].float().contiguous(), y[:, 0].float().contiguous()
+            else:
+                x32, y32 = x.float().contiguous(), y.float().contiguous()
+            geom = K.ConvGeom(k, st, pd)
+            wshape = (k if D > 1 else k[1:]) + (Cx, Cy)
+            ref = torch.zeros(*wshape, device=DEV)
+            K.conv(lib.CONV_WGRAD, geom, x32, y32, ref, precision=1)
+            res = []
+            for on in (1, 0):
+                lib.set_option('wgp_dma', on)
+                dw = torch.full(wshape, 0.25, device=DEV)               # `+=` contract: accumulates into what is there
+                K.conv(lib.CONV_WGRAD, geom, xv, yv, dw, precision=1)
+                res.append(dw - 0.25)
+            out.append(('wgp_dma_%s/vs_register_staging' % name, rel_err(res[0], res[1].double().cpu()), 1e-5))
+            out.append(('wgp_dma_%s/vs_fp32_operands' % name, rel_err(res[0], ref.double().cpu()), 1e-5))
+    finally:
+        lib.set_option('wgp_dma', old)
+    torch.cuda.synchronize()
+    return out
+
+
 def check_tuning_table(precision='bf16', max_entries=None, seed=41):
     """Runs every entry of video_prediction_amd/tuning_gfx950_<precision>.json as that exact savp_conv call (mode, shapes, view
     strides, bias / w16 / act / beta / bf16 source / bf16 destination / statistics epilogue, the table's tile code and split-K)."""

@@ -88,6 +88,11 @@ def test_ring_kernel_weight_warmup_does_not_change_results():
     _run(gpu_checks.check_ring_weight_warmup_invisible)
 
 
+def test_weight_gradient_lds_dma_staging_equals_register_staging():
+    from tests import gpu_checks
+    _run(gpu_checks.check_wgrad_dma_staging)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

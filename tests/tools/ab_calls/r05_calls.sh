@@ -128,5 +128,23 @@ case "$1" in
   cp $T $O/tuning_gfx950_bf16.json
   OUT=$O REPS=2 bash tests/tools/ab_run.sh shipped "ARGS=--tuning-table,$O/table_before.json" tuned ""
   ;;
-*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9|12>"; exit 2 ;;
+13)
+  # thirteenth lease: the LDS-patch weight gradient at the step's operands (both tensors bf16, 928 images): per-phase cycle stamps of
+  # workgroup 0 / wave 0 (stamps build of conv_wgrad_patch.hip) and the launch times of the shipped build
+  O=gpurun_out/r05m; mkdir -p $O
+  smoke
+  SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py 2>&1 | grep -v amdgpu.ids | tee $O/wgp_stamps.log
+  BF16=1 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_bench.log
+  ;;
+14)
+  # fourteenth lease: LDS-DMA staging of the weight gradient's bf16 operands (option wgp_dma): parity, launch times with / without at the
+  # step's operands, stamps, in-call A/B of the step
+  O=gpurun_out/${OUTDIR:-r05n}; mkdir -p $O
+  smoke
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "weight_gradient or bf16_activation or table" > $O/ops.log 2>&1; echo "ops rc=$?"; tail -5 $O/ops.log | cut -c1-300
+  for d in 1 0; do SAVP_WGP_DMA=$d BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | sed "s/^/dma$d /"; done | tee $O/wgrad_bench.log
+  for d in 1 0; do SAVP_WGP_DMA=$d SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py 2>&1 | grep -v amdgpu.ids | sed "s/^/dma$d /"; done | tee $O/wgp_stamps.log
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh dma0 "SAVP_WGP_DMA=0" dma1 "SAVP_WGP_DMA=1"
+  ;;
+*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9|12|13|14>"; exit 2 ;;
 esac

@@ -21,9 +21,13 @@ def main():
             continue
         x = torch.randn(N, H, W, Cx, device='cuda')
         y = torch.randn(N, H, W, Cy, device='cuda')
+        if os.environ.get('BF16', '0') == '1':              # the step's operands: both tensors stored in bf16
+            x = x.bfloat16(); y = y.bfloat16()
         w = torch.zeros(k, k, Cx, Cy, device='cuda')
         b = torch.zeros(Cy, device='cuda')
         geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
+        if os.environ.get('NOBIAS', '0') == '1':            # the ConvLSTM gate convolutions carry no bias (the instance norm follows)
+            b = None
         fn = lambda: K.conv(lib.CONV_WGRAD, geom, x, y, w, bias=b)
         for _ in range(2):
             fn()

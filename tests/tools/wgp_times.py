@@ -10,6 +10,8 @@ for name, H, W, Cx, Cy, k in SHAPES:
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     x = torch.randn(N, H, W, Cx, device='cuda'); y = torch.randn(N, H, W, Cy, device='cuda')
+    if os.environ.get('BF16', '1') == '1':              # the step's operands: both tensors stored in bf16
+        x = x.bfloat16(); y = y.bfloat16()
     w = torch.zeros(k, k, Cx, Cy, device='cuda')
     geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
     for _ in range(3):

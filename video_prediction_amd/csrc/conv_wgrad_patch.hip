@@ -34,6 +34,15 @@ extern "C" int savp_debug_wgp_times(unsigned long long* out) {
 #endif
 #define LDS_AS __attribute__((address_space(3)))
 
+// LDS-DMA staging (round 5, both operands bf16): lane l of a wave instruction copies 16 bytes from its own global address to LDS byte
+// address lds_dst + 16 l (M0 written in the statement that reads it, as conv_ring.hip's ring_dma16); halo / padding slots read 16 zero bytes
+__device__ __attribute__((aligned(16))) unsigned g_wgp_zero[4] = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void wgp_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 struct WgP {
     const float* x; const float* y; float* dw; float* db;
     long long x_sn, y_sn;
@@ -59,13 +68,20 @@ __device__ __forceinline__ void wgp_sched() {
 
 // NW waves x MTW row tiles (32 rows of dW each) per workgroup.  NPF = float4 prefetch registers per thread for the patch.
 // X16 / Y16: the x / dy tensor holds bf16 (strides in bf16 elements): 8-byte loads, no conversion when parked in LDS.
-template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false>
+// DMA (both bf16, no bias gradient, channel counts and strides multiples of 8): the patch and the dy tile of the NEXT pixel tile are
+// filled by LDS-DMA (NPF = wave instructions per wave for the patch) while the current one multiplies -- no prefetch registers, no
+// conversion, no ds_write, ~6 VALU instructions per 1 KB.  Cycle stamps of the register path at the step's operands (928 images, every
+// ConvLSTM layer alike, profiles/r05_wgrad_stamps.log): per pixel tile 940 cycles waiting for the loads + ds_write, 1 340 at the barrier,
+// 1 890 ISSUING the next tile's 9 loads (~35 VALU instructions each, two waves per SIMD), 1 590 in the 32 MFMAs -- 5 760 for 2 048
+// cycles of matrix work.
+template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false, bool DMA = false>
 __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
+    static_assert(!DMA || (X16 && Y16), "LDS-DMA staging copies bf16 operands as they are");
     constexpr int NT = 64 * NW;
     constexpr int XES = X16 ? 2 : 4;                           // bytes per x element
     constexpr int NPD = (64 * 8 + NT - 1) / NT;                // float4 prefetch registers for the dy tile (64 px x 32 ch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, XCD-aware order: the NB column blocks (and MC channel chunks) of one pixel split are consecutive LOGICAL ids, i.e.
     // they run at the same time on CUs of ONE XCD and read the same x patches / dy tiles through one L2.  With the split index
     // fastest (the first version) the four column blocks of a tile ran hundreds of workgroups apart: every x patch came from HBM
@@ -77,7 +93,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int ngroups = cgc * q.taps;                          // (cx16, tap) row groups of this workgroup
     const int cy0 = nb * 32;
     const int pplane = q.PH * q.pitch;                         // one depth plane of the patch
-    const int patch_elems = q.kd * pplane;                     // the kd input planes under one output plane
+    // the kd input planes under one output plane (DMA: rounded up to whole 1 KB wave instructions, the tail slots receive zeros)
+    const int patch_elems = DMA ? ((q.kd * pplane + 511) & ~511) : q.kd * pplane;
     __bf16* patch = reinterpret_cast<__bf16*>(smem);           // [2][kd][PH * pitch]
     __bf16* dyt = patch + 2 * patch_elems;                     // [2][64 * 32]
 
@@ -91,7 +108,39 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     // then costs one mask test and one add (the first version re-derived channel / row / column / plane bounds and the address
     // from the packed coordinates for every slot of every tile: ~35 VALU instructions per load, more than the MFMA work of a tile).
     unsigned pinfo[NPF], pcoord[NPF], poff[NPF];
-    {
+    // DMA: wave instruction i of this wave fills the 64 consecutive 16-byte slots (i * NW + wave) * 64 ... of the patch [plane][row][pixel]
+    // [CP / 8 slots]; q.magC4 / q.magPP divide by CP / 8 and PH * PW * CP / 8 here (launcher).  A slot is 8 channels of one pixel; the
+    // pad slots of a pixel, channels beyond Cx and the tail of the last instruction read the 16 zero bytes.  Per slot the lane keeps the
+    // 64-bit address of the slot under a patch whose origin is element 0 of the tensor, and the slot's (row | plane, column) as ONE bit
+    // each of a 64-bit word: per tile a slot then costs a mask test (and, and, compare), a 64-bit add of the tile's delta and a select.
+    const int dma_instr = DMA ? (patch_elems >> 9) : 0;        // wave instructions per patch
+    unsigned long long laddr[DMA ? NPF : 1], lbits[DMA ? NPF : 1];
+    unsigned long long yaddr = 0ull; unsigned ybits = 0u;      // dy tile: this lane's slot (waves NW-4 ..)
+    if constexpr (DMA) {
+        const int c8n = q.CP >> 3;
+        const int per_plane = q.PH * q.PW * c8n;
+        const int ptotal = q.kd * per_plane;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = (i * NW + wave) * 64 + lane;
+            const int plane = (int)fastdiv((unsigned)idx, q.magPP);
+            const int rem = idx - plane * per_plane;
+            const int pix = (int)fastdiv((unsigned)rem, q.magC4);
+            const int c8 = rem - pix * c8n;
+            const int pyy = (int)fastdiv((unsigned)pix, q.magPW);
+            const int pxx = pix - pyy * q.PW;
+            const bool ok = idx < ptotal && c8 < 2 * q.CG && ca * 16 + c8 * 8 < q.Cx;
+            laddr[i] = (unsigned long long)(uintptr_t)q.x +
+                       (unsigned long long)(((long long)plane * q.x_sd + (long long)pyy * q.x_sh + (long long)pxx * q.x_sw + ca * 16 + c8 * 8) * 2);
+            // low word: row bit (0 .. 21) | plane bit (22 .. 29) | bit 31 = never valid; high word: column bit
+            lbits[i] = ok ? ((1ull << pyy) | (1ull << (22 + plane)) | (1ull << (32 + pxx))) : (1ull << 31);
+        }
+        const int sl = (wave - (NW - 4)) * 64 + lane;          // (garbage for the waves that do not stage dy: never used there)
+        const int px = (sl >> 2) & 63, c = (sl & 3) << 3;
+        yaddr = (unsigned long long)(uintptr_t)q.y + (unsigned long long)(((long long)(px >> 3) * q.y_sh + (long long)(px & 7) * q.y_sw + cy0 + c) * 2);
+        ybits = (cy0 + c < q.Cy) ? ((1u << (px >> 3)) | (1u << (8 + (px & 7)))) : (1u << 31);
+        for (int i = 0; i < NPF; ++i) { pinfo[i] = 0u; pcoord[i] = 0u; poff[i] = 0u; }
+    } else {
         const int c4n = q.CG * 4;
         const int per_plane = q.PH * q.PW * c4n;
         const int ptotal = q.kd * per_plane;
@@ -177,6 +226,65 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             dmask |= (ok ? 1u : 0u) << i;
         }
     };
+    // DMA: the whole of fetch + stage.  The per-tile scalars (address deltas, validity masks) come from a table in LDS that the
+    // workgroup's threads fill for TCH tiles at a time, one tile per thread: decoding a tile index costs ~150 scalar instructions, and
+    // with every wave doing that for every tile the scalar stream was the fetch phase (stamps, first DMA version: 1 430 cycles per tile
+    // for 4 - 5 DMA instructions per wave).
+    constexpr int TCH = 256;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)smem);
+    uint4* dtab = reinterpret_cast<uint4*>(reinterpret_cast<char*>(smem) + (size_t)(2 * patch_elems + 2 * 64 * 32) * 2);     // [TCH][2]
+    auto range_mask = [](int lo, int hi) -> unsigned {               // bits lo .. hi-1, clamped to [0, 32)
+        lo = max(lo, 0); hi = min(hi, 32);
+        if (hi <= lo) return 0u;
+        return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+    };
+    auto fill_desc = [&](int t0) {
+        const int t = t0 + tid;
+        if (tid < TCH && t < t_end) {
+            const int gi = (int)fastdiv((unsigned)t, q.magTHW);          // (sample, output plane)
+            const int r = t - gi * q.tHW;
+            const int img = (int)fastdiv((unsigned)gi, q.magDo);
+            const int dout = gi - img * q.Do;
+            const int ty = (int)fastdiv((unsigned)r, q.magTW);
+            const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
+            const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw, dz0 = dout - q.pd;
+            const long long xd = ((long long)img * q.x_sn + (long long)dz0 * q.x_sd + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw) * 2;
+            const long long yd = ((long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw) * 2;
+            const unsigned m_lo = (range_mask(-iy0, q.H - iy0) & 0x3fffffu) | ((range_mask(-dz0, q.D - dz0) & 0xffu) << 22);
+            const unsigned m_hi = range_mask(-ix0, q.W - ix0);
+            const unsigned ym = (range_mask(0, q.Ho - oy0) & 0xffu) | ((range_mask(0, q.Wo - ox0) & 0xffu) << 8);
+            dtab[2 * tid] = make_uint4((unsigned)xd, (unsigned)(xd >> 32), (unsigned)yd, (unsigned)(yd >> 32));
+            dtab[2 * tid + 1] = make_uint4(m_lo, m_hi, ym, 0u);
+        }
+    };
+    struct TileD { unsigned long long xd, yd, m; unsigned ym; };
+    auto read_desc = [&](int k) -> TileD {                     // wave-uniform address: one broadcast read, then to scalar registers
+        const uint4 a = dtab[2 * k], b = dtab[2 * k + 1];
+        TileD d;
+        d.xd = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.x) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.y) << 32);
+        d.yd = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.z) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.w) << 32);
+        d.m = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)b.x) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)b.y) << 32);
+        d.ym = (unsigned)__builtin_amdgcn_readfirstlane((int)b.z);
+        return d;
+    };
+    auto fetch_dma = [&](const TileD& d, int buf) {
+        const unsigned long long zero = (unsigned long long)(uintptr_t)g_wgp_zero;
+        const unsigned pbuf = lds0 + (unsigned)(buf * patch_elems * 2);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            if (i * NW + wave < dma_instr) {                    // wave-uniform
+                const bool ok = (d.m & lbits[i]) == lbits[i];
+                const unsigned long long g = ok ? laddr[i] + d.xd : zero;
+                wgp_dma16(reinterpret_cast<const void*>((uintptr_t)g), pbuf + (unsigned)((i * NW + wave) * 1024));
+            }
+        }
+        // dy tile: 64 pixels x 4 slots = 4 wave instructions, taken by the LAST four waves (the first ones carry the patch's remainder)
+        if (wave >= NW - 4) {
+            const bool ok = (d.ym & ybits) == ybits;
+            const unsigned long long g = ok ? yaddr + d.yd : zero;
+            wgp_dma16(reinterpret_cast<const void*>((uintptr_t)g), lds0 + (unsigned)((2 * patch_elems + buf * 64 * 32) * 2 + (wave - (NW - 4)) * 1024));
+        }
+    };
     auto stage = [&](int buf) {
         __bf16* pa = patch + buf * patch_elems;
 #pragma unroll
@@ -244,11 +352,21 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     WT_DECL
-    fetch(t_begin);
+    int tc0 = t_begin;                                         // DMA: first tile of the descriptor table's current chunk
+    if constexpr (DMA) {
+        fill_desc(tc0);
+        __syncthreads();
+        fetch_dma(read_desc(0), 0);
+    } else fetch(t_begin);
     WT(0);
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        stage(buf);
+        TileD nd = {0ull, 0ull, 0ull, 0u};
+        const bool more = t + 1 < t_end, refill = more && (t + 1 - tc0 == TCH);
+        if constexpr (DMA) {
+            if (more && !refill) nd = read_desc(t + 1 - tc0);  // lands while this wave waits for its DMAs and at the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else stage(buf);
         WT(1);
         __syncthreads();
         WT(2);
@@ -293,7 +411,15 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
                 wgp_sched<MTW, PD, 0>();
             }
         };
-        if (t + 1 < t_end) fetch(t + 1);
+        if constexpr (DMA) {
+            if (refill) {                                      // every wave read its last descriptor of the old chunk before the barrier above
+                tc0 = t + 1;
+                fill_desc(tc0);
+                __syncthreads();
+                nd = read_desc(0);
+            }
+            if (more) fetch_dma(nd, buf ^ 1);
+        } else if (more) fetch(t + 1);
         WT(3);
         mma_block();
         WT(4);
@@ -338,14 +464,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     }
 }
 
-template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false>
+template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false, bool DMA = false>
 static hipError_t launch_wgp(const WgP& q, dim3 grid, size_t lds, hipStream_t st) {
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hipFuncSetAttribute((const void*)wgrad_patch_kernel<NW, MTW, NPF, X16, Y16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)wgrad_patch_kernel<NW, MTW, NPF, X16, Y16, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((wgrad_patch_kernel<NW, MTW, NPF, X16, Y16>), grid, dim3(64 * NW), lds, st, q);
+    hipLaunchKernelGGL((wgrad_patch_kernel<NW, MTW, NPF, X16, Y16, DMA>), grid, dim3(64 * NW), lds, st, q);
     return hipGetLastError();
 }
 
@@ -426,8 +552,18 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.magTHW = magic40(q.tHW); q.magTW = magic40(q.tW);
     q.magPP = magic40(q.PH * q.PW * cg * 4); q.magDo = magic40(a->Do); q.magKHW = magic40(q.khw);
     if ((double)q.PT * q.tHW >= 1099511627776.0) return false;
-    const size_t lds = (size_t)2 * a->kd * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
+    size_t lds = (size_t)2 * a->kd * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
     if (lds > 160 * 1024) return false;
+    // LDS-DMA staging: both operands bf16, no bias gradient, every slot of 8 channels whole and 16-byte aligned in both tensors
+    const long long dma_slots = (((long long)a->kd * q.PH * q.pitch + 511) & ~511LL) / 8;
+    const size_t lds_dma = (size_t)dma_slots * 8 * 2 * 2 + (size_t)2 * 64 * 32 * 2 + (size_t)256 * 32;     // + the tile descriptor table
+    const bool s8 = a->x_sn % 8 == 0 && a->x_sd % 8 == 0 && a->x_sh % 8 == 0 && a->x_sw % 8 == 0 && a->y_sn % 8 == 0 && a->y_sd % 8 == 0 &&
+                    a->y_sh % 8 == 0 && a->y_sw % 8 == 0 && a->Cx % 8 == 0 && a->Cy % 8 == 0;
+    const bool dma = savp_opt(OPT_WGP_DMA) && a->src_bf16 && a->out_bf16 && !a->bias && s8 && dma_slots <= 8LL * 64 * nw && lds_dma <= 160 * 1024 && q.PH <= 22 && q.PW <= 32 && a->kd <= 8;
+    if (dma) {
+        lds = lds_dma;
+        q.magC4 = magic40(q.CP / 8); q.magPP = magic40(q.PH * q.PW * (q.CP / 8));
+    }
     const int npf = (a->kd * q.PH * q.PW * cg * 4 + nthreads - 1) / nthreads;
     q.NB = NB; q.MC = MC;
     dim3 grid((unsigned)(q.S * NB * MC), 1u, 1u);
@@ -437,6 +573,15 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     // gradient is stored in bf16): both operands bf16, or dy alone (layer 0: the input image stays fp32), for every workgroup shape;
     // x alone only for the 8 x 8 shape.  A combination that is not instantiated is refused, never read as fp32.
     if (x16 && !y16 && !(nw == 8 && mtw == 8)) { *rc = SAVP_EINVAL; return true; }
+    if (dma) {
+        if (nw == 8 && mtw == 8) err = launch_wgp<8, 8, 8, true, true, true>(q, grid, lds, st);
+        else if (nw == 8 && mtw == 4) err = launch_wgp<8, 4, 8, true, true, true>(q, grid, lds, st);
+        else if (nw == 8) err = launch_wgp<8, 2, 8, true, true, true>(q, grid, lds, st);
+        else if (mtw == 8) err = launch_wgp<4, 8, 8, true, true, true>(q, grid, lds, st);
+        else err = launch_wgp<4, 4, 8, true, true, true>(q, grid, lds, st);
+        *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
+        return true;
+    }
     if (nw == 8 && mtw == 4) err = (npf <= 4) ? launch_wgp_dt<8, 4, 4>(q, grid, lds, st, x16, y16) : launch_wgp_dt<8, 4, 8>(q, grid, lds, st, x16, y16);
     else if (nw == 8 && mtw == 2) err = (npf <= 4) ? launch_wgp_dt<8, 2, 4>(q, grid, lds, st, x16, y16) : launch_wgp_dt<8, 2, 8>(q, grid, lds, st, x16, y16);
     else if (nw == 8) {

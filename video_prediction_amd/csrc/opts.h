@@ -17,6 +17,7 @@ enum SavpOptId {
     OPT_RING_DMA,          // bf16 sources of the ring kernel are staged into the LDS patch by LDS-DMA (1)
     OPT_LSTM_Q,            // developer: force the threads per pixel (channel quads per slab) of the one-launch gate kernels (0 = auto)
     OPT_RING_WWARM,        // ring kernel: workgroups of a column tile pull its weight block into their XCD's L2 first (1)
+    OPT_WGP_DMA,           // LDS-patch weight gradient with both operands bf16: patch and dy tile staged by LDS-DMA (1)
     OPT_COUNT
 };
 
