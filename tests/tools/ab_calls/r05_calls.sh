@@ -146,5 +146,69 @@ case "$1" in
   for d in 1 0; do SAVP_WGP_DMA=$d SAVP_LIB=$PWD/video_prediction_amd/ab/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py 2>&1 | grep -v amdgpu.ids | sed "s/^/dma$d /"; done | tee $O/wgp_stamps.log
   OUT=$O REPS=2 bash tests/tools/ab_run.sh dma0 "SAVP_WGP_DMA=0" dma1 "SAVP_WGP_DMA=1"
   ;;
-*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9|12|13|14>"; exit 2 ;;
+16)
+  O=gpurun_out/r05p; mkdir -p $O
+  for cfg in 0 48 84 44; do SAVP_WGP_CFG=$cfg BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py lstm_h0 lstm_h1 lstm_h2 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg$cfg /"; done | tee $O/wgrad_cfg_sweep.log
+  for sp in 256 512 768; do SAVP_WGP_SPLIT=$sp BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py lstm_h0 lstm_h1 lstm_h2 2>&1 | grep -v amdgpu.ids | sed "s/^/split$sp /"; done | tee -a $O/wgrad_cfg_sweep.log
+  for sp in 512 768 1024; do SAVP_WGP_CFG=48 SAVP_WGP_SPLIT=$sp BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py lstm_h0 lstm_h1 lstm_h2 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg48_split$sp /"; done | tee -a $O/wgrad_cfg_sweep.log
+  ;;
+18)
+  # eighteenth lease: row-group order [tap][channel group] of the LDS-patch weight gradient (bank conflicts of the transpose reads), and the
+  # DMA pieces spread between the MFMAs (variant build -DSAVP_WGP_INTERLEAVE): parity, isolated launches, stamps, counters, step A/B
+  O=gpurun_out/r05r; mkdir -p $O
+  AB=$PWD/video_prediction_amd/ab
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "weight_gradient or bf16_activation or table" > $O/ops.log 2>&1; echo "ops rc=$?"; tail -3 $O/ops.log | cut -c1-300
+  SAVP_LIB=$AB/libsavp_hip_wgil.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "weight_gradient or bf16_activation" > $O/ops_il.log 2>&1; echo "ops interleave rc=$?"; tail -3 $O/ops_il.log | cut -c1-300
+  for v in old new il; do
+    case $v in old) L=$AB/libsavp_hip_wgold.so;; new) L=;; il) L=$AB/libsavp_hip_wgil.so;; esac
+    SAVP_LIB=$L BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | sed "s/^/$v /"
+  done | tee $O/wgrad_bench.log
+  for v in new il; do
+    case $v in new) L=$AB/libsavp_hip_wgstamps.so;; il) L=$AB/libsavp_hip_wgilstamps.so;; esac
+    SAVP_LIB=$L python tests/tools/wgp_times.py lstm_h0 lstm_h1 lstm_h2 head3x3 2>&1 | grep -v amdgpu.ids | sed "s/^/$v /"
+  done | tee $O/wgp_stamps.log
+  bash tests/tools/pmc_wgrad.sh r05r lstm_h1 > /dev/null 2>&1; grep -A4 "pass 1" $O/wgrad_counters.log
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh old "SAVP_LIB=$AB/libsavp_hip_wgold.so" new "" il "SAVP_LIB=$AB/libsavp_hip_wgil.so"
+  ;;
+19)
+  # nineteenth lease: weight gradient, DMA requests two tiles ahead into three buffers, issued by the two halves of the workgroup at opposite
+  # ends of an iteration: parity, isolated launches, stamps, step A/B against the previous build
+  O=gpurun_out/${OUTDIR:-r05s}; mkdir -p $O
+  AB=$PWD/video_prediction_amd/ab
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "weight_gradient or bf16_activation or table" > $O/ops.log 2>&1; echo "ops rc=$?"; tail -3 $O/ops.log | cut -c1-300
+  for v in prev new; do
+    case $v in prev) L=$AB/libsavp_hip_wgprev.so;; new) L=;; esac
+    SAVP_LIB=$L BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | sed "s/^/$v /"
+  done | tee $O/wgrad_bench.log
+  SAVP_LIB=$AB/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py lstm_h0 lstm_h1 lstm_h2 head3x3 2>&1 | grep -v amdgpu.ids | tee $O/wgp_stamps.log
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh prev "SAVP_LIB=$AB/libsavp_hip_wgprev.so" new ""
+  ;;
+20)
+  # twentieth lease: de-phased weight gradient with a deeper fragment read-ahead (6 / 4 MFMAs) against the lock-step build (prev)
+  O=gpurun_out/${OUTDIR:-r05t}; mkdir -p $O
+  AB=$PWD/video_prediction_amd/ab
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "weight_gradient or bf16_activation" > $O/ops.log 2>&1; echo "ops rc=$?"; tail -3 $O/ops.log | cut -c1-300
+  for v in prev pd6 pd4; do
+    case $v in prev) L=$AB/libsavp_hip_wgprev.so;; pd6) L=;; pd4) L=$AB/libsavp_hip_wgpd4.so;; esac
+    SAVP_LIB=$L BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py lstm_h0 lstm_h1 lstm_h2 2>&1 | grep -v amdgpu.ids | sed "s/^/$v /"
+  done | tee $O/wgrad_bench.log
+  SAVP_LIB=$AB/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py lstm_h0 lstm_h1 lstm_h2 2>&1 | grep -v amdgpu.ids | tee $O/wgp_stamps.log
+  ;;
+21)
+  # lease 21: the tile descriptor table on the register-staged weight gradient too (fp32 operands): the whole op suite, isolated launches with
+  # fp32 / bf16 operands, stamps, step A/B against the previous build (DMA + table for bf16 operands only)
+  O=gpurun_out/${OUTDIR:-r05u}; mkdir -p $O
+  AB=$PWD/video_prediction_amd/ab
+  t0=$(date +%s)
+  timeout 1500 python -m pytest tests/test_gpu_ops.py -q -m gpu -x > $O/ops.log 2>&1; echo "ops rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/ops.log | cut -c1-300
+  for v in prev new; do
+    case $v in prev) L=$AB/libsavp_hip_wgprev.so;; new) L=;; esac
+    SAVP_LIB=$L BF16=0 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | sed "s/^/$v f32 /"
+    SAVP_LIB=$L BF16=1 NOBIAS=1 python tests/tools/bench_wgrad.py 2>&1 | grep -v amdgpu.ids | sed "s/^/$v bf16 /"
+  done | tee $O/wgrad_bench.log
+  BF16=0 SAVP_LIB=$AB/libsavp_hip_wgstamps.so python tests/tools/wgp_times.py 2>&1 | grep -v amdgpu.ids | sed "s/^/f32 /" | tee $O/wgp_stamps.log
+  OUT=$O REPS=2 bash tests/tools/ab_run.sh prev "SAVP_LIB=$AB/libsavp_hip_wgprev.so" new ""
+  echo "total $(( $(date +%s)-t0 ))s"
+  ;;
+*) echo "usage: r05_calls.sh <1|2|3|4|5|7|8|9|12|13|14|16|18|19|20|21>  (variant libraries under video_prediction_amd/ab/ are built first: tests/tools/build_variant.sh)"; exit 2 ;;
 esac

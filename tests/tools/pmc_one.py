@@ -40,7 +40,7 @@ def report(d):
         for f in fs:
             if f.endswith('counter_collection.csv'):
                 for row in csv.DictReader(open(os.path.join(r, f))):
-                    if 'conv_' in row['Kernel_Name']:
+                    if os.environ.get('KFILTER', 'conv_') in row['Kernel_Name']:
                         agg[row['Kernel_Name'].split('(')[0][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
     for kn, cs in agg.items():
         print(kn)

@@ -54,6 +54,7 @@ struct WgP {
     int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
     int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
     unsigned long long magC4, magPW, magTaps, magTHW, magTW, magPP, magDo, magKHW;
+    unsigned long long magCG, magCGl;  // divide by the channel groups of a full chunk / of the last chunk (row-group order [tap][group])
 };
 
 // issue order of the MFMA block: in front of MFMA J go the two transpose reads of MFMA J + PD (four when it opens a k-step: + B)
@@ -75,7 +76,7 @@ __device__ __forceinline__ void wgp_sched() {
 // 1 890 ISSUING the next tile's 9 loads (~35 VALU instructions each, two waves per SIMD), 1 590 in the 32 MFMAs -- 5 760 for 2 048
 // cycles of matrix work.
 template <int NW, int MTW, int NPF, bool X16 = false, bool Y16 = false, bool DMA = false>
-__global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MTW == 4) ? 2 : 1) void wgrad_patch_kernel(WgP q) {      // 4 x 4: two workgroups per SIMD set (256 registers)
     static_assert(!DMA || (X16 && Y16), "LDS-DMA staging copies bf16 operands as they are");
     constexpr int NT = 64 * NW;
     constexpr int XES = X16 ? 2 : 4;                           // bytes per x element
@@ -90,13 +91,21 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     const int nb = logical % q.NB, mc = (logical / q.NB) % q.MC, sp = logical / (q.NB * q.MC);
     const int ca = mc * q.CG;                                  // first 16-channel group of this chunk
     const int cgc = min(q.CG, q.G16 - ca);                     // groups in this chunk
-    const int ngroups = cgc * q.taps;                          // (cx16, tap) row groups of this workgroup
+    const int ngroups = cgc * q.taps;                          // (tap, cx16) row groups of this workgroup
+    // Row groups are ordered [tap][channel group]: the two 16-row groups of an MFMA row tile (lanes 0-15 / 16-31 of a transpose read) are
+    // then two channel groups of ONE tap, 32 bytes apart in the patch, and with the pixel stride a multiple of 64 bytes the eight 32-byte
+    // segments of a 32-lane read cover all 64 banks once.  In the first order ([group][tap]) the two halves were consecutive TAPS, one
+    // pixel stride apart: three of their four pixels coincide (broadcast) and the fourth shares its banks with the other half's first --
+    // SQ_LDS_BANK_CONFLICT was 42 % of SQ_LDS_IDX_ACTIVE on the ConvLSTM layers (profiles/r05_wgrad_counters.log).  With an odd number of
+    // groups per chunk one tile in `cgc` still pairs two taps.
+    const unsigned long long mag_cgc = (cgc == q.CG) ? q.magCG : q.magCGl;
     const int cy0 = nb * 32;
     const int pplane = q.PH * q.pitch;                         // one depth plane of the patch
     // the kd input planes under one output plane (DMA: rounded up to whole 1 KB wave instructions, the tail slots receive zeros)
     const int patch_elems = DMA ? ((q.kd * pplane + 511) & ~511) : q.kd * pplane;
     __bf16* patch = reinterpret_cast<__bf16*>(smem);           // [2][kd][PH * pitch]
-    __bf16* dyt = patch + 2 * patch_elems;                     // [2][64 * 32]
+    constexpr int NBUF = 2;
+    __bf16* dyt = patch + NBUF * patch_elems;                  // [NBUF][64 * 32]
 
     // pixel tiles of this split
     const int per = (q.PT + q.S - 1) / q.S;
@@ -161,6 +170,52 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             poff[i] = (unsigned)(((long long)plane * q.x_sd + pyy * q.x_sh + pxx * q.x_sw + c4 * 4) * XES);
         }
     }
+    // ---- DMA: per-tile scalars from a table in LDS ----------------------------------------------------------------------------------
+    // Address deltas and validity masks of a pixel tile come from a table that the workgroup's threads fill for TCH tiles at a time, one
+    // tile per thread: decoding a tile index costs ~150 scalar instructions, and with every wave doing that for every tile the scalar
+    // stream WAS the fetch phase (stamps: 1 430 cycles per tile to issue 4 - 5 DMA instructions per wave; a wave now reads 32 bytes).
+    constexpr int TCH = 256;
+    constexpr int YES = Y16 ? 2 : 4;                           // bytes per dy element
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)smem);
+    uint4* dtab = reinterpret_cast<uint4*>(reinterpret_cast<char*>(smem) + (size_t)(NBUF * patch_elems + NBUF * 64 * 32) * 2);     // [TCH][2]
+    auto range_mask = [](int lo, int hi) -> unsigned {               // bits lo .. hi-1, clamped to [0, 32)
+        lo = max(lo, 0); hi = min(hi, 32);
+        if (hi <= lo) return 0u;
+        return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+    };
+    // a0 / a1: byte deltas of the tile's patch origin / dy tile origin; m0: patch rows | planes << 22, m1: patch columns, m2: dy rows | dy
+    // columns << 8.  (The register-staged path keeps its scalar decode: with the table it was SLOWER -- fp32 operands, 700 -> 770 us on the
+    // 16x16 ConvLSTM layer: its fetch phase is bound by the 9 x 16-byte loads per lane, and the table read sits in front of them.)
+    struct TileD { unsigned long long a0, a1; unsigned m0, m1, m2, m3; };
+    auto fill_desc = [&](int t0) {
+        const int t = t0 + tid;
+        if (tid < TCH && t < t_end) {
+            const int gi = (int)fastdiv((unsigned)t, q.magTHW);          // (sample, output plane)
+            const int r = t - gi * q.tHW;
+            const int img = (int)fastdiv((unsigned)gi, q.magDo);
+            const int dout = gi - img * q.Do;
+            const int ty = (int)fastdiv((unsigned)r, q.magTW);
+            const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
+            const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw, dz0 = dout - q.pd;     // patch origin in the input
+            const unsigned rowmask = range_mask(-iy0, q.H - iy0), colmask = range_mask(-ix0, q.W - ix0), plmask = range_mask(-dz0, q.D - dz0);
+            const unsigned ym = (range_mask(0, q.Ho - oy0) & 0xffu) | ((range_mask(0, q.Wo - ox0) & 0xffu) << 8);
+            const long long yo = (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw;
+            const unsigned long long a0 = (unsigned long long)(((long long)img * q.x_sn + (long long)dz0 * q.x_sd + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw) * 2);
+            const unsigned long long a1 = (unsigned long long)(yo * 2);
+            const unsigned m0 = (rowmask & 0x3fffffu) | ((plmask & 0xffu) << 22), m1 = colmask, m2 = ym, m3 = 0u;
+            dtab[2 * tid] = make_uint4((unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32));
+            dtab[2 * tid + 1] = make_uint4(m0, m1, m2, m3);
+        }
+    };
+    auto read_desc = [&](int k) -> TileD {                     // wave-uniform address: one broadcast read, then to scalar registers
+        const uint4 a = dtab[2 * k], b = dtab[2 * k + 1];
+        auto sc = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        TileD d;
+        d.a0 = (unsigned long long)sc(a.x) | ((unsigned long long)sc(a.y) << 32);
+        d.a1 = (unsigned long long)sc(a.z) | ((unsigned long long)sc(a.w) << 32);
+        d.m0 = sc(b.x); d.m1 = sc(b.y); d.m2 = sc(b.z); d.m3 = sc(b.w);
+        return d;
+    };
     float4 pf[NPF], pd[NPD];
     // bias gradient = column sums of dy, taken from the tiles as they stream by (fp32, before the bf16 rounding); one M chunk only
     const bool do_db = (q.db != nullptr) && (mc == 0);
@@ -226,63 +281,23 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
             dmask |= (ok ? 1u : 0u) << i;
         }
     };
-    // DMA: the whole of fetch + stage.  The per-tile scalars (address deltas, validity masks) come from a table in LDS that the
-    // workgroup's threads fill for TCH tiles at a time, one tile per thread: decoding a tile index costs ~150 scalar instructions, and
-    // with every wave doing that for every tile the scalar stream was the fetch phase (stamps, first DMA version: 1 430 cycles per tile
-    // for 4 - 5 DMA instructions per wave).
-    constexpr int TCH = 256;
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)smem);
-    uint4* dtab = reinterpret_cast<uint4*>(reinterpret_cast<char*>(smem) + (size_t)(2 * patch_elems + 2 * 64 * 32) * 2);     // [TCH][2]
-    auto range_mask = [](int lo, int hi) -> unsigned {               // bits lo .. hi-1, clamped to [0, 32)
-        lo = max(lo, 0); hi = min(hi, 32);
-        if (hi <= lo) return 0u;
-        return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-    };
-    auto fill_desc = [&](int t0) {
-        const int t = t0 + tid;
-        if (tid < TCH && t < t_end) {
-            const int gi = (int)fastdiv((unsigned)t, q.magTHW);          // (sample, output plane)
-            const int r = t - gi * q.tHW;
-            const int img = (int)fastdiv((unsigned)gi, q.magDo);
-            const int dout = gi - img * q.Do;
-            const int ty = (int)fastdiv((unsigned)r, q.magTW);
-            const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
-            const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw, dz0 = dout - q.pd;
-            const long long xd = ((long long)img * q.x_sn + (long long)dz0 * q.x_sd + (long long)iy0 * q.x_sh + (long long)ix0 * q.x_sw) * 2;
-            const long long yd = ((long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw) * 2;
-            const unsigned m_lo = (range_mask(-iy0, q.H - iy0) & 0x3fffffu) | ((range_mask(-dz0, q.D - dz0) & 0xffu) << 22);
-            const unsigned m_hi = range_mask(-ix0, q.W - ix0);
-            const unsigned ym = (range_mask(0, q.Ho - oy0) & 0xffu) | ((range_mask(0, q.Wo - ox0) & 0xffu) << 8);
-            dtab[2 * tid] = make_uint4((unsigned)xd, (unsigned)(xd >> 32), (unsigned)yd, (unsigned)(yd >> 32));
-            dtab[2 * tid + 1] = make_uint4(m_lo, m_hi, ym, 0u);
-        }
-    };
-    struct TileD { unsigned long long xd, yd, m; unsigned ym; };
-    auto read_desc = [&](int k) -> TileD {                     // wave-uniform address: one broadcast read, then to scalar registers
-        const uint4 a = dtab[2 * k], b = dtab[2 * k + 1];
-        TileD d;
-        d.xd = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.x) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.y) << 32);
-        d.yd = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.z) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.w) << 32);
-        d.m = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)b.x) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)b.y) << 32);
-        d.ym = (unsigned)__builtin_amdgcn_readfirstlane((int)b.z);
-        return d;
-    };
     auto fetch_dma = [&](const TileD& d, int buf) {
         const unsigned long long zero = (unsigned long long)(uintptr_t)g_wgp_zero;
         const unsigned pbuf = lds0 + (unsigned)(buf * patch_elems * 2);
+        const unsigned long long dm = (unsigned long long)d.m0 | ((unsigned long long)d.m1 << 32);
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             if (i * NW + wave < dma_instr) {                    // wave-uniform
-                const bool ok = (d.m & lbits[i]) == lbits[i];
-                const unsigned long long g = ok ? laddr[i] + d.xd : zero;
+                const bool ok = (dm & lbits[i]) == lbits[i];
+                const unsigned long long g = ok ? laddr[i] + d.a0 : zero;
                 wgp_dma16(reinterpret_cast<const void*>((uintptr_t)g), pbuf + (unsigned)((i * NW + wave) * 1024));
             }
         }
         // dy tile: 64 pixels x 4 slots = 4 wave instructions, taken by the LAST four waves (the first ones carry the patch's remainder)
         if (wave >= NW - 4) {
-            const bool ok = (d.ym & ybits) == ybits;
-            const unsigned long long g = ok ? yaddr + d.yd : zero;
-            wgp_dma16(reinterpret_cast<const void*>((uintptr_t)g), lds0 + (unsigned)((2 * patch_elems + buf * 64 * 32) * 2 + (wave - (NW - 4)) * 1024));
+            const bool ok = (d.m2 & ybits) == ybits;
+            const unsigned long long g = ok ? yaddr + d.a1 : zero;
+            wgp_dma16(reinterpret_cast<const void*>((uintptr_t)g), lds0 + (unsigned)((NBUF * patch_elems + buf * 64 * 32) * 2 + (wave - (NW - 4)) * 1024));
         }
     };
     auto stage = [&](int buf) {
@@ -337,8 +352,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     for (int i = 0; i < MTW; ++i) {
         const int lg = 2 * (wave * MTW + i) + g;               // local row group
         const int lgc = min(lg, ngroups - 1);
-        const int cl = (int)fastdiv((unsigned)lgc, q.magTaps);
-        const int tap = lgc - cl * q.taps;
+        const int tap = (int)fastdiv((unsigned)lgc, mag_cgc);
+        const int cl = lgc - tap * cgc;
         const int jd = (int)fastdiv((unsigned)tap, q.magKHW);
         const int t2 = tap - jd * q.khw;
         const int u = t2 / q.kw, v = t2 - u * q.kw;
@@ -353,6 +368,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
 
     WT_DECL
     int tc0 = t_begin;                                         // DMA: first tile of the descriptor table's current chunk
+    // (Round 5, measured and NOT kept, profiles/r05_ab_calls.md: the DMA pieces spread between the MFMAs -- the MFMA block then takes 3 000
+    // instead of 1 900 + 650 cycles; requests two tiles ahead into three buffers with the two waves of a SIMD requesting at opposite ends of
+    // an iteration, with 3 / 4 / 6 MFMAs of fragment read-ahead -- a wave's 32 MFMAs take ~1 950 cycles whether or not its SIMD partner
+    // multiplies at the same time, so de-phasing buys nothing and the third buffer costs 3 - 7 %.)
     if constexpr (DMA) {
         fill_desc(tc0);
         __syncthreads();
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
     WT(0);
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        TileD nd = {0ull, 0ull, 0ull, 0u};
+        TileD nd = {0ull, 0ull, 0u, 0u, 0u, 0u};
         const bool more = t + 1 < t_end, refill = more && (t + 1 - tc0 == TCH);
         if constexpr (DMA) {
             if (more && !refill) nd = read_desc(t + 1 - tc0);  // lands while this wave waits for its DMAs and at the barrier
@@ -452,8 +471,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_patch_kernel(WgP q) {
         for (int hh = 0; hh < 2; ++hh) {                       // the two 16-row groups of the tile
             const int lg = 2 * (wave * MTW + i) + hh;
             if (lg >= ngroups) continue;
-            const int cl = (int)fastdiv((unsigned)lg, q.magTaps);
-            const int tap = lg - cl * q.taps;
+            const int tap = (int)fastdiv((unsigned)lg, mag_cgc);
+            const int cl = lg - tap * cgc;
             float* __restrict__ base = dW + ((long long)tap * q.Cx + (ca + cl) * 16) * q.Cy + cy;
 #pragma unroll
             for (int r = 8 * hh; r < 8 * hh + 8; ++r) {
@@ -549,6 +568,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     if (s > q.PT) s = q.PT;
     q.S = (int)s;
     q.magC4 = magic40(cg * 4); q.magPW = magic40(q.PW); q.magTaps = magic40(q.taps);
+    q.magCG = magic40(cg); q.magCGl = magic40(q.G16 - (MC - 1) * cg);
     q.magTHW = magic40(q.tHW); q.magTW = magic40(q.tW);
     q.magPP = magic40(q.PH * q.PW * cg * 4); q.magDo = magic40(a->Do); q.magKHW = magic40(q.khw);
     if ((double)q.PT * q.tHW >= 1099511627776.0) return false;
@@ -556,7 +576,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     if (lds > 160 * 1024) return false;
     // LDS-DMA staging: both operands bf16, no bias gradient, every slot of 8 channels whole and 16-byte aligned in both tensors
     const long long dma_slots = (((long long)a->kd * q.PH * q.pitch + 511) & ~511LL) / 8;
-    const size_t lds_dma = (size_t)dma_slots * 8 * 2 * 2 + (size_t)2 * 64 * 32 * 2 + (size_t)256 * 32;     // + the tile descriptor table
+    const size_t lds_dma = (size_t)dma_slots * 8 * 2 * 2 + (size_t)2 * 64 * 32 * 2 + (size_t)256 * 32;     // two buffers + the tile descriptor table
     const bool s8 = a->x_sn % 8 == 0 && a->x_sd % 8 == 0 && a->x_sh % 8 == 0 && a->x_sw % 8 == 0 && a->y_sn % 8 == 0 && a->y_sd % 8 == 0 &&
                     a->y_sh % 8 == 0 && a->y_sw % 8 == 0 && a->Cx % 8 == 0 && a->Cy % 8 == 0;
     const bool dma = savp_opt(OPT_WGP_DMA) && a->src_bf16 && a->out_bf16 && !a->bias && s8 && dma_slots <= 8LL * 64 * nw && lds_dma <= 160 * 1024 && q.PH <= 22 && q.PW <= 32 && a->kd <= 8;
