@@ -1316,7 +1316,7 @@ def check_ring_weight_warmup_invisible(seed=47, option='ring_wwarm'):
 
 def check_wgrad_dma_staging(seed=53):
     """LDS-patch weight gradient of two bf16 operands (csrc/conv_wgrad_patch.hip): the LDS-DMA staged kernel (option wgp_dma, default) against
-    the register-staged one on the same bf16 tensors and against the kernel fed the same values in fp32 -- every workgroup shape, ragged
+    the register-staged one on the same bf16 tensors and against the exact-fp32 generic kernel on the same values -- every workgroup shape, ragged
     planes (border tiles, halo rows / columns from the zero slot), a 16-channel group cut by Cx, channel-slice views of wider buffers,
     stride 2 and a 3-D layer."""
     out = []
@@ -1357,7 +1357,7 @@ def check_wgrad_dma_staging(seed=53):
             geom = K.ConvGeom(k, st, pd)
             wshape = (k if D > 1 else k[1:]) + (Cx, Cy)
             ref = torch.zeros(*wshape, device=DEV)
-            K.conv(lib.CONV_WGRAD, geom, x32, y32, ref, precision=1)
+            K.conv(lib.CONV_WGRAD, geom, x32, y32, ref, precision=0)        # exact fp32 on the generic kernel: an independent reference
             res = []
             for on in (1, 0):
                 lib.set_option('wgp_dma', on)
@@ -1365,9 +1365,69 @@ def check_wgrad_dma_staging(seed=53):
                 K.conv(lib.CONV_WGRAD, geom, xv, yv, dw, precision=1)
                 res.append(dw - 0.25)
             out.append(('wgp_dma_%s/vs_register_staging' % name, rel_err(res[0], res[1].double().cpu()), 1e-5))
-            out.append(('wgp_dma_%s/vs_fp32_operands' % name, rel_err(res[0], ref.double().cpu()), 1e-5))
+            out.append(('wgp_dma_%s/vs_exact_fp32_kernel' % name, rel_err(res[0], ref.double().cpu()), 5e-5))
     finally:
         lib.set_option('wgp_dma', old)
+    torch.cuda.synchronize()
+    return out
+
+
+def check_wide_thin_fprop(seed=59):
+    """3x3 SAME convolutions from a feature tensor to a few channels (csrc/conv_thin.hip: wthin_fprop_kernel, taken under tile 0 in bf16 precision):
+    against an fp64 tap loop on the bf16-rounded operands (the datapath's contract) and against the general kernels (option thin = 0) --
+    the scratch-image head (32 -> 4, sigmoid, into a channel slice of a wider buffer), the mask convolution (56 -> 8), ragged planes,
+    16 / 64 input channels, 1 / 3 output channels, LeakyReLU, no bias."""
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+    bf = torch.bfloat16
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32)
+
+    cases = [  # name, N, H, W, Cx, Cy, act, has bias, (y slice offset, width), x width
+        ('scratch_head', 4, 64, 64, 32, 4, lib.ACT_SIGMOID, True, (44, 56), 32),
+        ('masks', 3, 64, 64, 56, 8, 0, True, None, 56),
+        ('ragged', 2, 20, 37, 16, 3, lib.ACT_LRELU, True, (1, 8), 24),
+        ('wide64', 2, 33, 64, 64, 8, 0, False, None, 64),
+        ('one_out', 5, 8, 8, 40, 1, 0, True, None, 40),
+    ]
+    old = lib.get_option('thin')
+    try:
+        for name, N, H, W, Cx, Cy, act, hb, ys, xw in cases:
+            x = rn(N, H, W, Cx)
+            xv = torch.zeros(N, H, W, xw, device=DEV)[..., :Cx]
+            xv.copy_(x)
+            w = rn(3, 3, Cx, Cy) * 0.2
+            bias = rn(Cy) if hb else None
+            wt = pack_wt(w)
+            ref = _taps_ref(lib.CONV_FPROP, x.to(bf).double()[:, None], w.to(bf).double()[None], torch.empty(N, 1, H, W, Cy, device=DEV),
+                            (1, 3, 3), (1, 1, 1), (0, 1, 1))[:, 0]
+            if hb:
+                ref = ref + bias.double()
+            if act == lib.ACT_SIGMOID:
+                ref = torch.sigmoid(ref)
+            elif act == lib.ACT_LRELU:
+                ref = torch.where(ref > 0, ref, 0.2 * ref)
+            geom = K.ConvGeom((3, 3), (1, 1), (1, 1))
+            res = []
+            for on in (1, 0):
+                lib.set_option('thin', on)
+                if ys:
+                    big = torch.full((N, H, W, ys[1]), 7.0, device=DEV)
+                    yv = big[..., ys[0]:ys[0] + Cy]
+                else:
+                    big = None
+                    yv = torch.full((N, H, W, Cy), float('nan'), device=DEV)
+                K.conv(lib.CONV_FPROP, geom, xv, yv, wt, bias=bias, act=act, alpha=0.2, precision=1, w16=wt.to(bf))
+                res.append(yv.clone())
+                if big is not None and on == 1:                      # the rest of the wider buffer is untouched
+                    mask = torch.ones(ys[1], dtype=torch.bool, device=DEV)
+                    mask[ys[0]:ys[0] + Cy] = False
+                    out.append(('wthin_%s/neighbours_untouched' % name, float((big[..., mask] - 7.0).abs().max()), 0.5))
+            out.append(('wthin_%s/vs_fp64_taps' % name, rel_err(res[0], ref), 2e-5))
+            out.append(('wthin_%s/vs_general_kernels' % name, rel_err(res[0], res[1].double().cpu()), 2e-5))
+    finally:
+        lib.set_option('thin', old)
     torch.cuda.synchronize()
     return out
 

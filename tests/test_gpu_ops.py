@@ -93,6 +93,11 @@ def test_weight_gradient_lds_dma_staging_equals_register_staging():
     _run(gpu_checks.check_wgrad_dma_staging)
 
 
+def test_wide_to_thin_3x3_convolution_vs_fp64_taps_and_general_kernels():
+    from tests import gpu_checks
+    _run(gpu_checks.check_wide_thin_fprop)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

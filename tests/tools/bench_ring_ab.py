@@ -24,6 +24,7 @@ SHAPES = [  # name, mode, N, H, W, Cx, Cy, k
     ('head3x3', 'dgrad', 32, 64, 64, 32, 32, 3),
     ('masks_out', 'fprop', 32, 64, 64, 56, 8, 3),
     ('masks_out', 'dgrad', 32, 64, 64, 56, 8, 3),
+    ('dec64', 'fprop', 32, 64, 64, 32, 64, 3), ('dec64', 'dgrad', 32, 64, 64, 32, 64, 3),        # the merged 3x3 heads on the last decoder layer
     # the ConvLSTM gate convolutions of bench.py's other workloads (tests/tools/pmc_cell_report.py PMC_SET=c4 / c5)
     ('c4_h0', 'fprop', 32, 32, 32, 96, 128, 5), ('c4_h1', 'fprop', 32, 16, 16, 160, 256, 5), ('c4_h2', 'fprop', 32, 8, 8, 288, 512, 5),
     ('c5_h4', 'fprop', 16, 16, 16, 520, 1024, 5), ('c5_h5', 'fprop', 16, 32, 32, 264, 512, 5),

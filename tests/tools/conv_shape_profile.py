@@ -30,9 +30,13 @@ def run():
 def report(d):
     calls = json.load(open('/tmp/conv_calls.json'))
     path = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith('kernel_trace.csv')][0]
-    rows = [r for r in csv.DictReader(open(path)) if re.search(r'conv_fd_kernel|conv_patch_kernel|conv_wgrad|wgrad_patch', r['Kernel_Name'])]
+    # one kernel per logged call: the main kernel of every conv algorithm (fold / reduce / clear launches are companions, not calls)
+    rows = [r for r in csv.DictReader(open(path))
+            if re.search(r'conv_fd_kernel|conv_patch_kernel|conv_ring_kernel|conv_wgrad|wgrad_patch_kernel|thin_fprop_kernel|thin_wgrad_kernel|s2dgrad_kernel|thin_dgrad',
+                         r['Kernel_Name'])]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     rows = rows[-len(calls):]
+    print('logged calls %d, conv kernels in the trace tail %d' % (len(calls), len(rows)))
     agg = collections.defaultdict(lambda: [0, 0.0, ''])
     for c, r in zip(calls, rows):
         k = tuple(tuple(x) if isinstance(x, list) else x for x in c[:12])

@@ -37,6 +37,7 @@ struct ThinP {
     int tilesX, tilesY, items, per_wg;
     int flip;                                          // FPROP kernel used as DGRAD: weight tap TAPS - 1 - s (the transposed conv's mirror)
     const float* zero;                                 // 16 bytes of zeros in global memory (the source of out-of-range pixels)
+    const unsigned short* w16; int Cy;                 // wide -> thin FPROP: packed bf16 weights [Cy][9 * Cx], output channels
 };
 
 // one input pixel (CX <= 4 channels, zero outside the tensor) as raw floats: converted when it is parked in LDS, so that the loads
@@ -177,6 +178,117 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(ThinP p) {
         __builtin_amdgcn_sched_barrier(0);                     // ... and keep the pins themselves below the MFMAs / stores
 #pragma unroll
         for (int i = 0; i < NSL; ++i) THIN_PIN4(pv[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Wide -> thin FPROP (round 5): a 3x3 stride-1 SAME convolution from a feature tensor (Cx a multiple of 8, <= 64) to a FEW channels
+// (Cy <= 32 computed, only the first Cy stored) -- the generator's scratch-image head (32 -> 3 or 4, sigmoid, written into a channel
+// slice of the mask convolution's input) and the mask convolution itself (56 -> 8).  0.3 - 0.6 GFLOP over 17 - 29 MB: HBM-bound
+// (~6 us), but the general kernels spend 23 - 26 us on it per time step (per-workgroup prologue + patch staging for 9 - 18 (tap,
+// slab) entries of work, a 64-column tile for 4 - 8 real columns).  Same organisation as thin_fprop_kernel: a work item is 4 x 32 output
+// pixels (a row per wave), the next item's pixels are in flight while this one multiplies, the WHOLE weight matrix sits in registers (9 taps x NKT
+// k-steps of 16 channels, one 16-byte load each from the packed bf16 copy), A fragments are tap-shifted ds_read_b128 of the bf16 patch
+// (pixel stride an odd multiple of 16 bytes: conflict-free).
+// ------------------------------------------------------------------------------------------------------------
+#define WF_R 4                                                 // output rows per work item: one per wave
+#define WF_PR (WF_R + 2)
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void wthin_fprop_kernel(ThinP p) {
+    constexpr int SPP = 4 * NKT;                               // float4 slots per patch pixel (16 NKT channels, zero beyond Cx)
+    constexpr int PSTR = 32 * NKT + 16;                        // LDS bytes per pixel: 80 / 144 = 5 / 9 x 16
+    constexpr int PPL = WF_PR * TF_PC;                         // patch pixels (SAME padding is staged as zeros)
+    constexpr int NSL = (PPL * SPP + 255) / 256;
+    constexpr int NE = 9 * NKT;                                // (tap, k-step) entries
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    // weights: lane = output channel l31 (zero beyond Cy), k = 8 half + j  <->  channel 16 ks + 8 half + j of tap t.  In registers for the
+    // lifetime of the kernel up to 32 input channels (72 VGPRs); beyond (144) they are parked in LDS as ready-made B fragments
+    // [entry][lane] -- with them in registers the kernel needs > 256 VGPRs, i.e. ONE 4-wave workgroup per CU and nothing to hide its latencies
+    constexpr bool WLDS = NKT > 2;
+    char* wl = wsm + PPL * PSTR;                               // [NE][64] x 16 bytes
+    bf16x8 bw[WLDS ? 1 : NE];
+    auto w_of = [&](int e, int l31_, int half_) -> uint4 {
+        const int t = e / NKT, c0 = 16 * (e % NKT) + 8 * half_;
+        const bool live = l31_ < p.Cy && c0 < p.Cx;            // unconditional (clamped) load + select: all of them in flight at once
+        const uint4 v = *reinterpret_cast<const uint4*>(p.w16 + (live ? (long long)l31_ * 9 * p.Cx + t * p.Cx + c0 : 0ll));
+        return live ? v : make_uint4(0u, 0u, 0u, 0u);
+    };
+    if constexpr (WLDS) {
+        constexpr int NWL = (NE * 64 + 255) / 256;
+        uint4 wv[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) { const int idx = min(tid + 256 * i, NE * 64 - 1); wv[i] = w_of(idx >> 6, idx & 31, (idx >> 5) & 1); }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) { const int idx = tid + 256 * i; if (idx < NE * 64) *reinterpret_cast<uint4*>(wl + idx * 16) = wv[i]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) bw[e] = __builtin_bit_cast(bf16x8, w_of(e, l31, half));
+    }
+    float bias = 0.f;
+    if (p.bias && l31 < p.Cy) bias = p.bias[l31];
+    float4 pv[NSL];
+    auto fetch = [&](const ThinItem& q) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int s = tid + 256 * i;
+            const int px = s / SPP, c4 = s - px * SPP;
+            const int r = px / TF_PC, c = px - r * TF_PC;
+            const int iy = q.y0 + r - 1, ix = q.x0 + c - 1;
+            const bool ok = px < PPL && c4 * 4 < p.Cx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* __restrict__ src = ok ? p.x + ((long long)q.n * p.x_sn + (long long)iy * p.x_sh + (long long)ix * p.x_sw + c4 * 4) : p.zero;
+            pv[i] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    const int it_begin = blockIdx.x * p.per_wg, it_end = min(p.items, (int)(blockIdx.x + 1) * p.per_wg);
+    if (it_begin >= it_end) return;
+    fetch(thin_item(p, it_begin, WF_R, TF_C));
+    for (int it = it_begin; it < it_end; ++it) {
+        const ThinItem q = thin_item(p, it, WF_R, TF_C);
+        __syncthreads();                                       // the previous item's reads are done
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int s = tid + 256 * i;
+            const int px = s / SPP, c4 = s - px * SPP;
+            if (px < PPL)
+                *reinterpret_cast<bf16x4v*>(wsm + px * PSTR + c4 * 8) = bf16x4v{(__bf16)pv[i].x, (__bf16)pv[i].y, (__bf16)pv[i].z, (__bf16)pv[i].w};
+        }
+        __syncthreads();
+        if (it + 1 < it_end) fetch(thin_item(p, it + 1, WF_R, TF_C));
+        const LDS_AS char* pl = (const LDS_AS char*)wsm + (wave * TF_PC + l31) * PSTR + half * 16;
+        const int oy = q.y0 + wave;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // fragment reads run three entries ahead of their MFMA (left alone, hipcc reads all 9 NKT fragments first: 72 - 144 more registers)
+        auto a_of = [&](int e) -> bf16x8 { const int t = e / NKT; return *(const LDS_AS bf16x8*)(pl + ((t / 3) * TF_PC + t % 3) * PSTR + (e % NKT) * 32); };
+        constexpr int AD = 3;
+        bf16x8 af[AD + 1], bf[WLDS ? AD + 1 : 1];
+        const LDS_AS char* wll = (const LDS_AS char*)wl + lane * 16;
+        auto b_of = [&](int e) -> bf16x8 { return *(const LDS_AS bf16x8*)(wll + e * 1024); };
+#pragma unroll
+        for (int e = 0; e < AD; ++e) { af[e] = a_of(e); if constexpr (WLDS) bf[e] = b_of(e); }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e + AD < NE) { af[(e + AD) % (AD + 1)] = a_of(e + AD); if constexpr (WLDS) bf[(e + AD) % (AD + 1)] = b_of(e + AD); }
+            if constexpr (WLDS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[e % (AD + 1)], bf[e % (AD + 1)], acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[e % (AD + 1)], bw[e], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, WLDS ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if (oy < p.H && l31 < p.Cy) {
+            float* __restrict__ dst = p.y + (long long)q.n * p.y_sn + (long long)oy * p.y_sh + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ox = q.x0 + (i & 3) + 8 * (i >> 2) + 4 * half;    // accumulator row = output pixel of the 32-wide row tile
+                if (ox < p.W) {
+                    float v = acc[i] + bias;
+                    if (p.act == SAVP_ACT_LRELU) v = v > 0.f ? v : v * p.alpha;
+                    else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                    dst[(long long)ox * p.y_sw] = v;
+                }
+            }
+        }
     }
 }
 
@@ -364,6 +476,19 @@ static long long thin_wgrad_ws_floats(const SavpConvArgs* a) {
     return (long long)nwg * (9 * a->kd * a->Cx * 32 + 32);
 }
 
+// wide -> thin FPROP (wthin_fprop_kernel): 2-D 3x3 stride-1 SAME, fp32 tensors, Cx % 8 == 0 <= 64, Cy <= 8, packed bf16 weights at hand
+static bool wthin_applies(const SavpConvArgs* a) {
+    if (!thin_enabled() || a->mode != SAVP_CONV_FPROP || a->precision != SAVP_PREC_BF16) return false;
+    if (!(a->kd == 1 && a->kh == 3 && a->kw == 3 && a->pd == 0 && a->ph == 1 && a->pw == 1 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->D == 1 &&
+          a->Do == 1 && a->Ho == a->H && a->Wo == a->W && a->N >= 1 && a->H >= 1 && a->W >= 1))
+        return false;
+    if (a->Cx % 8 || a->Cx < 16 || a->Cx > 64 || a->Cy < 1 || a->Cy > 8) return false;
+    if (a->src_bf16 || a->out_bf16 || a->stats || a->beta || a->aux || !a->w_bf16 || !aligned16(a->w_bf16)) return false;
+    if (a->act != SAVP_ACT_NONE && a->act != SAVP_ACT_LRELU && a->act != SAVP_ACT_SIGMOID) return false;
+    if ((a->x_sn % 4) || (a->x_sh % 4) || (a->x_sw % 4) || !aligned16(a->x)) return false;
+    return (long long)a->N * a->H * a->W < (1ll << 31) / 64;
+}
+
 // Is this call the kernel's problem (everything except the workspace)?
 static bool thin_applies_geom(const SavpConvArgs* a) {
     if (!thin_enabled() || !thin_geometry_ok(a)) return false;
@@ -381,6 +506,7 @@ long long conv_thin_workspace_bytes(const SavpConvArgs* a) {
 }
 
 bool conv_thin_applies(const SavpConvArgs* a) {
+    if (wthin_applies(a)) return true;
     if (!thin_applies_geom(a)) return false;
     // the weight gradient leaves one partial dW per workgroup in caller-owned scratch; without it the general kernel runs
     return a->mode != SAVP_CONV_WGRAD || (a->ws && aligned16(a->ws) && a->ws_bytes >= conv_thin_workspace_bytes(a));
@@ -395,6 +521,21 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     if (!zero_of[dev_ord] && hipGetSymbolAddress((void**)&zero_of[dev_ord], HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     ThinP p;
     p.zero = zero_of[dev_ord];
+    if (wthin_applies(a)) {
+        thin_fill(p, a, WF_R, TF_C, 1024);                    // four rows x 32 pixels per item; two to four resident workgroups per CU
+        p.w16 = (const unsigned short*)a->w_bf16; p.Cy = a->Cy; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;
+        const dim3 grid((unsigned)((p.items + p.per_wg - 1) / p.per_wg));
+        const int nkt = a->Cx <= 32 ? 2 : 4;
+        const size_t lds = (size_t)(WF_PR * TF_PC) * (32 * nkt + 16) + (nkt > 2 ? (size_t)9 * nkt * 64 * 16 : 0);
+        if (nkt == 2) hipLaunchKernelGGL((wthin_fprop_kernel<2>), grid, dim3(256), lds, st, p);
+        else {
+            static bool attr = false;
+            if (!attr) { hipFuncSetAttribute((const void*)wthin_fprop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+            hipLaunchKernelGGL((wthin_fprop_kernel<4>), grid, dim3(256), lds, st, p);
+        }
+        *rc = hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+        return true;
+    }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         thin_fill(p, a, TF_R, TF_C, 1024);                    // four resident workgroups per CU: one full wave of them
         p.w = (const float*)a->w; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;

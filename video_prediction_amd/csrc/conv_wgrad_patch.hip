@@ -1,4 +1,4 @@
-// conv_wgrad_patch.hip -- weight gradient of stride-1 2-D convolutions on the bf16 MFMA pipe, LDS-patch formulation.
+// conv_wgrad_patch.hip -- weight gradient of 2-D / 3-D convolutions (strides 1 - 2, depth stride 1) on the bf16 MFMA pipe, LDS-patch formulation.
 //
 //   dW[u, v, cx, cy] = sum over (n, oy, ox) of x[n, oy + u - ph, ox + v - pw, cx] * dy[n, oy, ox, cy]
 //
@@ -48,7 +48,9 @@ struct WgP {
     long long x_sn, y_sn;
     int x_sh, x_sw, y_sh, y_sw;
     int H, W, Ho, Wo, Cx, Cy, ph, pw, kw, sh, sw;
-    int D, Do, kd, pd, khw;            // depth (3-D convs, depth stride 1): input / output planes, depth taps, pad, kh*kw
+    int D, Do, kd, pd, khw, sd;        // depth (3-D convs): input / output planes, depth taps, pad, kh*kw, depth stride (the launcher admits 1: the
+                                       // 4x4x4 stride-2 layers of the video discriminator need more patch than the prefetch registers / 8 DMA
+                                       // instructions per wave hold, so nothing exercises 2)
     long long x_sd, y_sd;
     int taps, G16, CG, S, NB, MC;      // taps, 16-channel groups of Cx, groups per chunk, pixel splits, column blocks, channel chunks
     int PH, PW, CP, pitch;             // patch geometry (bf16 elements)
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MTW == 4) ? 2 : 1) void wgrad_
             const int dout = gi - img * q.Do;
             const int ty = (int)fastdiv((unsigned)r, q.magTW);
             const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
-            const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw, dz0 = dout - q.pd;     // patch origin in the input
+            const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw, dz0 = dout * q.sd - q.pd;     // patch origin in the input
             const unsigned rowmask = range_mask(-iy0, q.H - iy0), colmask = range_mask(-ix0, q.W - ix0), plmask = range_mask(-dz0, q.D - dz0);
             const unsigned ym = (range_mask(0, q.Ho - oy0) & 0xffu) | ((range_mask(0, q.Wo - ox0) & 0xffu) << 8);
             const long long yo = (long long)img * q.y_sn + (long long)dout * q.y_sd + (long long)oy0 * q.y_sh + (long long)ox0 * q.y_sw;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MTW == 4) ? 2 : 1) void wgrad_
         const int ty = (int)fastdiv((unsigned)r, q.magTW);
         const int oy0 = ty * 8, ox0 = (r - ty * q.tW) * 8;
         const int iy0 = oy0 * q.sh - q.ph, ix0 = ox0 * q.sw - q.pw;       // patch origin in the input plane
-        const int dz0 = dout - q.pd;                                       // input plane under patch plane 0 (depth stride 1)
+        const int dz0 = dout * q.sd - q.pd;                                // input plane under patch plane 0
         // wave-uniform validity masks of the patch rows / columns / planes of this tile (PH, PW <= 22, kd <= 8)
         auto range_mask = [](int lo, int hi) -> unsigned {               // bits lo .. hi-1, clamped to [0, 32)
             lo = max(lo, 0); hi = min(hi, 32);
@@ -502,7 +504,8 @@ static hipError_t launch_wgp_dt(const WgP& q, dim3 grid, size_t lds, hipStream_t
     return launch_wgp<NW, MTW, NPF, false, false>(q, grid, lds, st);
 }
 
-// Returns true when the call was handled (2-D, stride 1, bf16 precision, channel counts % 4, <= 8 taps per side).
+// Returns true when the call was handled (2-D / 3-D, strides <= 2 in the plane and 1 in depth, bf16 precision, channel counts % 4, <= 8 taps per side,
+// >= 64 output pixels per plane, a patch that fits the prefetch registers).
 bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
@@ -517,7 +520,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     q.x_sn = a->x_sn; q.y_sn = a->y_sn;
     q.x_sh = (int)a->x_sh; q.x_sw = (int)a->x_sw; q.y_sh = (int)a->y_sh; q.y_sw = (int)a->y_sw;
     q.H = a->H; q.W = a->W; q.Ho = a->Ho; q.Wo = a->Wo; q.Cx = a->Cx; q.Cy = a->Cy; q.ph = a->ph; q.pw = a->pw; q.kw = a->kw; q.sh = a->sh; q.sw = a->sw;
-    q.D = a->D; q.Do = a->Do; q.kd = a->kd; q.pd = a->pd; q.khw = a->kh * a->kw; q.x_sd = a->x_sd; q.y_sd = a->y_sd;
+    q.D = a->D; q.Do = a->Do; q.kd = a->kd; q.pd = a->pd; q.sd = a->sd; q.khw = a->kh * a->kw; q.x_sd = a->x_sd; q.y_sd = a->y_sd;
     q.taps = a->kd * a->kh * a->kw;
     q.G16 = (a->Cx + 15) / 16;
     q.PH = 7 * a->sh + a->kh; q.PW = 7 * a->sw + a->kw;           // input rows / columns under an 8x8 output tile
