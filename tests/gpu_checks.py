@@ -1432,6 +1432,48 @@ def check_wide_thin_fprop(seed=59):
     return out
 
 
+def check_thin8_wide_dgrad(seed=61):
+    """Data gradient of a 3x3 SAME convolution with 8 output channels (csrc/conv_thin.hip: thin8_wide_kernel, taken under tile 0 in bf16 precision;
+    the mask convolution's): against an fp64 tap loop on the bf16-rounded operands and the general kernels (option thin = 0); beta 0 / 1
+    (accumulating into the gradient already there), 56 / 44 / 64 / 13 input channels, ragged planes, a channel-slice destination."""
+    out = []
+    rng = torch.Generator(device=DEV).manual_seed(seed)
+    bf = torch.bfloat16
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=rng, device=DEV, dtype=torch.float32)
+
+    cases = [('masks', 3, 64, 64, 56, 1, 56), ('kth', 2, 64, 64, 44, 1, 44), ('full', 2, 16, 33, 64, 0, 64), ('odd', 4, 21, 9, 13, 1, 20), ('beta0', 2, 40, 40, 56, 0, 72)]
+    old = lib.get_option('thin')
+    try:
+        for name, N, H, W, Cx, beta, xw in cases:
+            dy = rn(N, H, W, 8)
+            w = rn(3, 3, Cx, 8) * 0.2
+            wd = pack_wd(w)
+            x0 = rn(N, H, W, Cx)
+            ref = _taps_ref(lib.CONV_DGRAD, torch.zeros(N, 1, H, W, Cx, dtype=torch.float64, device=DEV), w.to(bf).double()[None], dy.to(bf).double()[:, None],
+                            (1, 3, 3), (1, 1, 1), (0, 1, 1))[:, 0]
+            if beta:
+                ref = ref + x0.double()
+            geom = K.ConvGeom((3, 3), (1, 1), (1, 1))
+            res = []
+            for on in (1, 0):
+                lib.set_option('thin', on)
+                big = torch.full((N, H, W, xw), 7.0, device=DEV)
+                xv = big[..., xw - Cx:]
+                xv.copy_(x0)
+                K.conv(lib.CONV_DGRAD, geom, xv, dy, wd, beta=beta, precision=1, w16=wd.to(bf))
+                res.append(xv.clone())
+                if on == 1 and xw > Cx:
+                    out.append(('thin8_%s/neighbours_untouched' % name, float((big[..., :xw - Cx] - 7.0).abs().max()), 0.5))
+            out.append(('thin8_%s/vs_fp64_taps' % name, rel_err(res[0], ref), 2e-5))
+            out.append(('thin8_%s/vs_general_kernels' % name, rel_err(res[0], res[1].double().cpu()), 2e-5))
+    finally:
+        lib.set_option('thin', old)
+    torch.cuda.synchronize()
+    return out
+
+
 def check_tuning_table(precision='bf16', max_entries=None, seed=41):
     """Runs every entry of video_prediction_amd/tuning_gfx950_<precision>.json as that exact savp_conv call (mode, shapes, view
     strides, bias / w16 / act / beta / bf16 source / bf16 destination / statistics epilogue, the table's tile code and split-K)."""

@@ -98,6 +98,11 @@ def test_wide_to_thin_3x3_convolution_vs_fp64_taps_and_general_kernels():
     _run(gpu_checks.check_wide_thin_fprop)
 
 
+def test_thin_to_wide_data_gradient_of_the_mask_convolution_vs_fp64_taps_and_general_kernels():
+    from tests import gpu_checks
+    _run(gpu_checks.check_thin8_wide_dgrad)
+
+
 def test_flow_warp_and_dna():
     from tests import gpu_checks
     _run(gpu_checks.check_warp_dna)

@@ -35,3 +35,21 @@ for name, H, W, Cx, Cy, act, ywidth, old_tile in CASES:
         ts.sort()
         print('%-12s %-8s median %6.1f us  min %6.1f us' % (name, label, ts[4], ts[0]))
     lib.set_option('thin', 1)
+# the mask convolution's data gradient (56 <- 8, accumulating)
+dy = torch.randn(N, 64, 64, 8, device='cuda'); dx = torch.zeros(N, 64, 64, 56, device='cuda')
+w = torch.randn(3, 3, 56, 8, device='cuda') * 0.1
+wd = w.reshape(-1, 56, 8).permute(1, 0, 2).reshape(56, -1).contiguous(); wd16 = wd.to(torch.bfloat16)
+geom = K.ConvGeom((3, 3), (1, 1), (1, 1))
+for label, thin, tile in (('thin8', 1, 0), ('general', 0, 0x321)):
+    lib.set_option('thin', thin)
+    fn = lambda: K.conv(lib.CONV_DGRAD, geom, dx, dy, wd, beta=1, precision=1, w16=wd16, tile=tile, splitk=1 if tile else 0)
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(9):
+        flush.add_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print('%-12s %-8s median %6.1f us  min %6.1f us' % ('masks_dgrad', label, ts[4], ts[0]))
+lib.set_option('thin', 1)

@@ -182,6 +182,104 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(ThinP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Thin -> wide with 8 thin channels (round 5): the data gradient of the mask convolution (56 <- 8, accumulated into the gradient of its
+// input: beta = 1) -- K = 72, 29 MB written (+ 29 MB read back for the accumulation) per launch, 36 us on the ring kernel.  As
+// thin_fprop_kernel with a pixel = ONE 16-byte LDS word of 8 bf16 channels: a k-step of 16 is two taps (lane half h supplies tap 2 ks + h),
+// up to 64 wide channels as two 32-column blocks, weights (5 k-steps x 2 blocks) in registers from the packed bf16 copy, every store
+// instruction writes two 128-byte runs.  flip = the transposed convolution's mirrored taps (DGRAD).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void thin8_wide_kernel(ThinP p) {
+    constexpr int NS = 5;                                       // k-steps: taps 0 .. 9 (tap 9 = zeros)
+    constexpr int PPL = TF_PR * TF_PC, ZP = PPL;                // patch pixels; index of the all-zero pixel
+    __shared__ __attribute__((aligned(16))) uint4 patch8[PPL + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    bf16x8 bw[NS][2];
+    int aoff[NS];                                               // byte offset of the lane's tap per k-step (-1: zero pixel)
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        const int s = 2 * ks + half;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = 32 * b + l31;
+            const bool live = s < 9 && col < p.Cy;              // p.Cy = wide channels here
+            const uint4 v = *reinterpret_cast<const uint4*>(p.w16 + (live ? (long long)col * 72 + (p.flip ? 8 - s : s) * 8 : 0ll));
+            bw[ks][b] = __builtin_bit_cast(bf16x8, live ? v : make_uint4(0u, 0u, 0u, 0u));
+        }
+        aoff[ks] = s < 9 ? ((s / 3) * TF_PC + s % 3) * 16 : -1;
+    }
+    if (tid == 0) patch8[ZP] = make_uint4(0u, 0u, 0u, 0u);
+    constexpr int NSL = (PPL * 2 + 255) / 256;                  // float4 slots: two per pixel
+    float4 pv[NSL];
+    auto fetch = [&](const ThinItem& q) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int s = tid + 256 * i;
+            const int px = s >> 1, c4 = s & 1;
+            const int r = px / TF_PC, c = px - r * TF_PC;
+            const int iy = q.y0 + r - 1, ix = q.x0 + c - 1;
+            const bool ok = px < PPL && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* __restrict__ src = ok ? p.x + ((long long)q.n * p.x_sn + (long long)iy * p.x_sh + (long long)ix * p.x_sw + c4 * 4) : p.zero;
+            pv[i] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    const int it_begin = blockIdx.x * p.per_wg, it_end = min(p.items, (int)(blockIdx.x + 1) * p.per_wg);
+    if (it_begin >= it_end) return;
+    fetch(thin_item(p, it_begin, TF_R, TF_C));
+    for (int it = it_begin; it < it_end; ++it) {
+        const ThinItem q = thin_item(p, it, TF_R, TF_C);
+        __syncthreads();                                       // the previous item's reads are done
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int s = tid + 256 * i;
+            if ((s >> 1) < PPL)
+                reinterpret_cast<bf16x4v*>(patch8)[s] = bf16x4v{(__bf16)pv[i].x, (__bf16)pv[i].y, (__bf16)pv[i].z, (__bf16)pv[i].w};
+        }
+        __syncthreads();
+        if (it + 1 < it_end) fetch(thin_item(p, it + 1, TF_R, TF_C));
+        const LDS_AS char* pl = (const LDS_AS char*)patch8;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr, oy = q.y0 + r;
+            if (oy >= p.H) continue;                           // wave-uniform
+            float* __restrict__ dst = p.y + (long long)q.n * p.y_sn + (long long)oy * p.y_sh + l31;
+            // the accumulation's old values: requested before the MFMAs, consumed behind them
+            float old[2][16];
+            if (p.flip > 1) {                                  // (flip bit 1 = beta)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ox = min(q.x0 + (i & 3) + 8 * (i >> 2) + 4 * half, p.W - 1), col = min(32 * b + l31, p.Cy - 1);
+                        old[b][i] = dst[(long long)ox * p.y_sw + (col - l31)];
+                    }
+            }
+            const int base = (r * TF_PC + l31) * 16;
+            f32x16 acc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                const bf16x8 af = *(const LDS_AS bf16x8*)(pl + (aoff[ks] < 0 ? ZP * 16 : base + aoff[ks]));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[ks][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[ks][1], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = 32 * b + l31;
+                if (col >= p.Cy) continue;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ox = q.x0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    if (ox < p.W) dst[(long long)ox * p.y_sw + 32 * b] = acc[b][i] + (p.flip > 1 ? old[b][i] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Wide -> thin FPROP (round 5): a 3x3 stride-1 SAME convolution from a feature tensor (Cx a multiple of 8, <= 64) to a FEW channels
 // (Cy <= 32 computed, only the first Cy stored) -- the generator's scratch-image head (32 -> 3 or 4, sigmoid, written into a channel
 // slice of the mask convolution's input) and the mask convolution itself (56 -> 8).  0.3 - 0.6 GFLOP over 17 - 29 MB: HBM-bound
@@ -489,6 +587,18 @@ static bool wthin_applies(const SavpConvArgs* a) {
     return (long long)a->N * a->H * a->W < (1ll << 31) / 64;
 }
 
+// thin -> wide DGRAD with 8 thin channels (thin8_wide_kernel): 2-D 3x3 stride-1 SAME, fp32 tensors, Cy == 8, Cx <= 64, beta 0 / 1, packed bf16 weights
+static bool thin8_applies(const SavpConvArgs* a) {
+    if (!thin_enabled() || a->mode != SAVP_CONV_DGRAD || a->precision != SAVP_PREC_BF16) return false;
+    if (!(a->kd == 1 && a->kh == 3 && a->kw == 3 && a->pd == 0 && a->ph == 1 && a->pw == 1 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->D == 1 &&
+          a->Do == 1 && a->Ho == a->H && a->Wo == a->W && a->N >= 1 && a->H >= 1 && a->W >= 1))
+        return false;
+    if (a->Cy != 8 || a->Cx < 1 || a->Cx > 64) return false;
+    if (a->src_bf16 || a->out_bf16 || a->stats || a->aux || a->bias || a->act != SAVP_ACT_NONE || !a->w_bf16 || !aligned16(a->w_bf16)) return false;
+    if ((a->y_sn % 4) || (a->y_sh % 4) || (a->y_sw % 4) || !aligned16(a->y)) return false;
+    return (long long)a->N * a->H * a->W < (1ll << 31) / 64;
+}
+
 // Is this call the kernel's problem (everything except the workspace)?
 static bool thin_applies_geom(const SavpConvArgs* a) {
     if (!thin_enabled() || !thin_geometry_ok(a)) return false;
@@ -506,7 +616,7 @@ long long conv_thin_workspace_bytes(const SavpConvArgs* a) {
 }
 
 bool conv_thin_applies(const SavpConvArgs* a) {
-    if (wthin_applies(a)) return true;
+    if (wthin_applies(a) || thin8_applies(a)) return true;
     if (!thin_applies_geom(a)) return false;
     // the weight gradient leaves one partial dW per workgroup in caller-owned scratch; without it the general kernel runs
     return a->mode != SAVP_CONV_WGRAD || (a->ws && aligned16(a->ws) && a->ws_bytes >= conv_thin_workspace_bytes(a));
@@ -521,6 +631,14 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     if (!zero_of[dev_ord] && hipGetSymbolAddress((void**)&zero_of[dev_ord], HIP_SYMBOL(g_thin_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     ThinP p;
     p.zero = zero_of[dev_ord];
+    if (thin8_applies(a)) {
+        thin_fill(p, a, TF_R, TF_C, 512);                     // ThinP.x = dy (8 channels), ThinP.y = dx (wide); two resident workgroups per CU
+        p.w16 = (const unsigned short*)a->w_bf16; p.Cy = a->Cx; p.flip = 1 | (a->beta ? 2 : 0);
+        const dim3 grid((unsigned)((p.items + p.per_wg - 1) / p.per_wg));
+        hipLaunchKernelGGL(thin8_wide_kernel, grid, dim3(256), 0, st, p);
+        *rc = hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
+        return true;
+    }
     if (wthin_applies(a)) {
         thin_fill(p, a, WF_R, TF_C, 1024);                    // four rows x 32 pixels per item; two to four resident workgroups per CU
         p.w16 = (const unsigned short*)a->w_bf16; p.Cy = a->Cy; p.bias = a->bias; p.act = a->act; p.alpha = a->alpha;
