@@ -17,7 +17,7 @@ hipGraph SEGMENTS with the collectives issued by the host between them (models/s
   roofline_cell-- the fused cell (gate conv + ONE gate-block launch) against both roofs, same instrumented steps.
   roofline_step-- the whole train step: SURVEY.md 8(d)'s algorithmic TFLOP per sequence x sequences / measured time, against the same peak.
   roofline_cell-- also `kernel_only`: the same cells on the two launches' own begin / end stamps (gate conv + gate block).
-  kernel_families_ms -- kernel time per step by family, quoted from profiles/r04_kernel_families.json (like `roofline.traffic` from the
+  kernel_families_ms -- kernel time per step by family, quoted from profiles/r05_kernel_families.json (like `roofline.traffic` from the
                   PMC file) ONLY when that file's source id equals this checkout's (video_prediction_amd.lib.source_id).
   config       -- besides the workload: `submission` (hipGraph replay / ... in N segments with replicas / eager launches), `eager_ms_per_step`
                   (the same step launch by launch), `host_issue_ms_per_step` (host time to ISSUE one eager step with an idle GPU) and, with a
@@ -391,7 +391,7 @@ def main():
     traffic, traffic_src, traffic_alg, traffic_note = None, None, None, None
     from video_prediction_amd import lib as _lib
     src_id = _lib.source_id()
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         pmc_path = os.path.join(ROOT, 'profiles', '%s_convlstm_cell_pmc_%s.json' % (rnd, args.precision))
         if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
             try:
@@ -447,15 +447,17 @@ def main():
     # kernel time by family: not measurable from inside the run; quoted from the committed rocprofv3 kernel stats of the SAME kernel
     # sources + tuning tables (tests/tools/kernel_families.py stamps the source id), else left out
     if args.config == 'c2' and args.batch == 16:
-        fam_path = os.path.join(ROOT, 'profiles', 'r04_kernel_families.json')
-        try:
-            fam = json.load(open(fam_path))
-            if fam.get('source_id') == src_id:
-                result['kernel_families_ms'] = {'source': 'profiles/r04_kernel_families.json (rocprofv3 --kernel-trace --stats, 6 eager steps, same source id)',
-                                                'launches_per_step': fam['launches_per_step'], 'kernel_ms_per_step': fam['kernel_ms_per_step'],
-                                                'families': {k: v['ms_per_step'] for k, v in fam['families'].items()}}
-        except Exception:
-            pass
+        for rnd in ('r05', 'r04'):
+            fam_path = os.path.join(ROOT, 'profiles', '%s_kernel_families.json' % rnd)
+            try:
+                fam = json.load(open(fam_path))
+                if fam.get('source_id') == src_id:
+                    result['kernel_families_ms'] = {'source': 'profiles/%s_kernel_families.json (rocprofv3 --kernel-trace --stats, 6 eager steps, same source id)' % rnd,
+                                                    'launches_per_step': fam['launches_per_step'], 'kernel_ms_per_step': fam['kernel_ms_per_step'],
+                                                    'families': {k: v['ms_per_step'] for k, v in fam['families'].items()}}
+                    break
+            except Exception:
+                pass
     # whole step against the conv roofline (algorithmic FLOPs per sequence and train step, fwd + data-grad + weight-grad)
     step_tflop = {'c2': 0.684, 'c4': 1.004, 'c5': 4.81}.get(args.config)
     if step_tflop:

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round 4 evidence in ONE lease (gpurun -- 'bash tests/tools/r04_final.sh'); everything lands in gpurun_out/r04/, what is judged is copied
-# to profiles/r04_*:
-#   collect_profiles.sh r04   default bench line (f32 object, cpu_baseline), rocprofv3 kernel stats + last-step trace, gate-conv PMC (c2)
+# A round's evidence in ONE lease (gpurun -- 'bash tests/tools/final_evidence.sh r05'); everything lands in gpurun_out/<tag>/, what is judged is
+# copied to profiles/<tag>_*:
+#   collect_profiles.sh <tag> default bench line (f32 object, cpu_baseline), rocprofv3 kernel stats + last-step trace, gate-conv PMC (c2)
 #   the whole GPU suite
 #   bench lines of c4 / c5 / c1, the forced-RCCL world-1 line under torch.distributed.run, the two-rank line over gloo
 #   gate-conv PMC of c4 / c5; inference throughput (bench_generate.py); the hipGraph memset-node probe
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
-TAG=r04
+TAG=${1:-r05}
 O=gpurun_out/$TAG; mkdir -p $O
 t0=$(date +%s)
 python bench.py --steps 2 --warmup 2 --no-f32 --no-cpu-baseline --inst-steps 1 > $O/smoke.json 2> $O/smoke.err || { echo "SMOKE FAILED"; tail -25 $O/smoke.err; exit 1; }

@@ -6,10 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from video_prediction_amd import lib
 
-FAMILIES = (('ring conv (FPROP / DGRAD, LDS patch + DMA weight ring)', ('conv_ring',)), ('weight gradients', ('wgrad',)),
+FAMILIES = (('ring conv (FPROP / DGRAD, LDS patch + DMA weight ring)', ('conv_ring',)), ('RGB-side / thin / stride-2 DGRAD convs', ('thin_fprop', 'wthin_', 'thin8', 's2dgrad')),
+            ('weight gradients', ('wgrad',)),
             ('ConvLSTM gate block', ('lstm_fused', 'lstm_fwd', 'lstm_bwd', 'lstm_gates')), ('instance norm', ('inorm',)),
             ('generic conv (implicit GEMM)', ('conv_fd',)), ('patch conv', ('conv_patch',)), ('CDNA + composite', ('cdna', 'composite')),
-            ('RGB-side / stride-2 DGRAD convs', ('thin_', 's2dgrad')), ('tiled-z gradient', ('tiled_z',)), ('dense', ('dense',)),
+            ('tiled-z gradient', ('tiled_z',)), ('dense', ('dense',)),
             ('weight prep (spectral norm, packs, folds)', ('snb_', 'pack_', 'fold_', 'sn_')), ('fills / copies / selects', ('fill', 'copy', 'select', 'Fill', 'tile_channels')))
 
 
