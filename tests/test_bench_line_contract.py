@@ -1,4 +1,4 @@
-"""The bench.py contract, checked on the committed lines of the round (profiles/r04_bench*.json; bench.py itself needs the GPU): the keys the
+"""The bench.py contract, checked on the committed lines of the round (profiles/r05_bench*.json; bench.py itself needs the GPU): the keys the
 driver reads, the roofline / cpu_baseline objects of the tier, internal consistency of the numbers, and that what the line quotes from
 profiles/ (counter traffic, kernel families) belongs to the checkout's kernel sources."""
 import glob
@@ -18,8 +18,8 @@ def _line(path):
     return json.loads(rows[-1])
 
 
-@pytest.mark.parametrize('name', ['r04_bench.json', 'r04_bench_final.json', 'r04_bench_c4_kth.json', 'r04_bench_c5_128.json',
-                                  'r04_bench_c1_det.json', 'r04_bench_rccl_world1_forced.json', 'r04_bench_2ranks_one_gpu_gloo.json'])
+@pytest.mark.parametrize('name', ['r05_bench.json', 'r05_bench_final.json', 'r05_bench_c4_kth.json', 'r05_bench_c5_128.json',
+                                  'r05_bench_c1_det.json', 'r05_bench_rccl_world1_forced.json', 'r05_bench_2ranks_one_gpu_gloo.json'])
 def test_committed_bench_lines_follow_the_contract(name):
     d = _line(os.path.join(ROOT, 'profiles', name))
     for k in REQUIRED:
@@ -36,7 +36,7 @@ def test_committed_bench_lines_follow_the_contract(name):
 
 def test_default_line_carries_the_tier_objects_and_same_source_evidence():
     from video_prediction_amd import lib
-    d = _line(os.path.join(ROOT, 'profiles', 'r04_bench_final.json'))
+    d = _line(os.path.join(ROOT, 'profiles', 'r05_bench_final.json'))
     assert d['n_gpus'] == 1 and d['config']['workload'].startswith('c2') and d['config']['global_batch'] == 16 and d['config']['seq_len'] == 30
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'frames/s' and c['sample']
@@ -44,8 +44,8 @@ def test_default_line_carries_the_tier_objects_and_same_source_evidence():
     assert r['bound'] == 'mfma' and r['peak'] == 2500.0                      # dense bf16 MFMA peak (MI355X_MICROARCH.md), not the sparse figure
     # counter traffic and kernel families are quoted only from files of the same kernel sources + tuning tables
     # (the id recorded in the committed files, not the working tree's: a later kernel change makes bench.py stop quoting them by itself)
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_convlstm_cell_pmc_bf16.json')))
-    fam = json.load(open(os.path.join(ROOT, 'profiles', 'r04_kernel_families.json')))
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_convlstm_cell_pmc_bf16.json')))
+    fam = json.load(open(os.path.join(ROOT, 'profiles', 'r05_kernel_families.json')))
     sid = pmc['source_id']
     assert fam['source_id'] == sid and sid in r['traffic_unit'] and len(sid) == len(lib.source_id())
     assert r['traffic'] == pmc['avg_hbm_bytes_per_launch_five_layers'] and r['traffic'] >= r['algorithmic_bytes'] > 0
