@@ -226,6 +226,11 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         for (int q = 0; q < NQ; ++q) ring_dma16(wp + (last ? goffL[q] : goffF[q]), dma_lds + (unsigned)(BUF * SLABB + q * 1024));
     };
 
+    // Per-GROUP arguments (index-arithmetic constants of the entry table and of the patch staging, the staging switches) are read from the
+    // kernel-argument segment at the head of every slab group through a pointer laundered there (round 5, as the epilogue's): ~25 scalar
+    // registers that otherwise stay live across the main loop.
+    typedef const ConvP __attribute__((address_space(4))) ConvPK;
+    ConvPK* pgk = (ConvPK*)__builtin_amdgcn_kernarg_segment_ptr();
     // ---- input patch of one slab group (fp32 or bf16 source; zero outside the image, beyond Cred and for images >= N) ----
     auto stage_patch = [&](int cfirst, auto s16c) {
         constexpr bool S16 = decltype(s16c)::value;        // compile-time: a runtime branch inside the loop serialises the loads
@@ -242,16 +247,16 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = min(base + u * NT, total - 1);
-                const int im = (int)fastdiv((unsigned)idx, p.s1_magPI);
+                const int im = (int)fastdiv((unsigned)idx, (*pgk).s1_magPI);
                 const int rem = idx - im * per_img;
-                const int pix = (int)fastdiv((unsigned)rem, p.s1_magC4);
+                const int pix = (int)fastdiv((unsigned)rem, (*pgk).s1_magC4);
                 const int c = (rem - pix * c4n) << 2;
-                const int pyy = (int)fastdiv((unsigned)pix, p.s1_magPW);
+                const int pyy = (int)fastdiv((unsigned)pix, (*pgk).s1_magPW);
                 const int pxx = pix - pyy * PW;
                 const int iy = org_h + pyy, ix = org_w + pxx;
                 const int cg = cfirst * CKB + c;
                 const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
                 const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                 const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
                                 (unsigned)dz < (unsigned)gd.srcN;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int j = 0; j < NJMAX; ++j) {
                 const int sl = j * 64 + lane;
-                const int pxx = (int)fastdiv((unsigned)sl, p.s1_magC8);
+                const int pxx = (int)fastdiv((unsigned)sl, (*pgk).s1_magC8);
                 const int ch8 = sl - pxx * C8;
                 const int ix = org_w + pxx;
                 const int cg = cfirst * CKB + ch8 * 8;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             while (pyy >= PH) { pyy -= PH; ++im; }
             for (int row = wave; row < (ABL(4) ? 0 : rows); row += NW) {
                 const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
                 const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                 const int iy = org_h + pyy;
                 const bool row_ok = (unsigned)iy < (unsigned)gh.srcN && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
                 for (int j = 0; j < NJMAX; ++j) {
                     if (j < nj && j * 64 + lane < P8) {
-                        const void* g = (row_ok && rel[j] >= 0) ? static_cast<const void*>(rb + (long long)rel[j] * 2) : p.zero16;
+                        const void* g = (row_ok && rel[j] >= 0) ? static_cast<const void*>(rb + (long long)rel[j] * 2) : (*pgk).zero16;
                         ring_dma16(g, lds_row + (unsigned)(j * 1024));
                     }
                 }
@@ -350,21 +355,21 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             for (int base = wave * 64; base < (ABL(4) ? 0 : total); base += NT) {
                 const int slot = base + lane;
                 if (slot < total) {
-                    const int im = (int)fastdiv((unsigned)slot, p.s1_magPI8);
+                    const int im = (int)fastdiv((unsigned)slot, (*pgk).s1_magPI8);
                     const int rem = slot - im * per_img8;
-                    const int pyy = (int)fastdiv((unsigned)rem, p.s1_magP8);
+                    const int pyy = (int)fastdiv((unsigned)rem, (*pgk).s1_magP8);
                     const int r = rem - pyy * P8;
-                    const int pxx = (int)fastdiv((unsigned)r, p.s1_magC8);
+                    const int pxx = (int)fastdiv((unsigned)r, (*pgk).s1_magC8);
                     const int ch8 = r - pxx * C8;
                     const int iy = org_h + pyy, ix = org_w + pxx;
                     const int cg = cfirst * CKB + ch8 * 8;
                     const int gi = img0 + im;
-                    const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                    const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
                     const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                     const bool ok = pxx < PW && ch8 < used8 && (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN &&
                                     cg < Cred && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
                     const long long off = (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg;
-                    const void* g = ok ? static_cast<const void*>(src_b + off * 2) : p.zero16;
+                    const void* g = ok ? static_cast<const void*>(src_b + off * 2) : (*pgk).zero16;
                     ring_dma16(g, patch_lds + (unsigned)(base * 16));
                 }
             }
@@ -478,10 +483,12 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         if (!first_group) __syncthreads();
         first_group = false;
         RT(10);
+        asm volatile("" : "+s"(pgk));
+        ConvPK& pg = *pgk;
         auto entry_of = [&](int ent) {                     // (tap, slab) entry -> {weight byte offset | last-slab flag, patch byte offset}
-            const int tap = divq(ent, g_slabs, g_slabs == spp ? p.s1_magSpp : p.s1_magTail), sl = ent - tap * g_slabs;
-            const int jh = divq(tap, kw, p.s1_magKw), jw = tap - jh * kw;
-            const int f_tap = ((gd.t0 + g_jd * gd.tstep) * p.kh + (gh.t0 + jh * gh.tstep)) * p.kw + (gw.t0 + jw * gw.tstep);
+            const int tap = divq(ent, g_slabs, g_slabs == spp ? pg.s1_magSpp : pg.s1_magTail), sl = ent - tap * g_slabs;
+            const int jh = divq(tap, kw, pg.s1_magKw), jw = tap - jh * kw;
+            const int f_tap = ((gd.t0 + g_jd * gd.tstep) * pg.kh + (gh.t0 + jh * gh.tstep)) * pg.kw + (gw.t0 + jw * gw.tstep);
             const int f_cc = g_first + sl;
             const int pu = gh.jstep > 0 ? jh * gh.jstep : (kh - 1 - jh) * -gh.jstep;
             const int pv = gw.jstep > 0 ? jw * gw.jstep : (kw - 1 - jw) * -gw.jstep;
@@ -495,8 +502,8 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         // same source in one call.  The slab requests queue behind ~40 patch requests per workgroup either way; issued early they only
         // delay the patch, which everything waits for.  Removed.)
         {
-            if (p.dma_patch) stage_patch_dma(g_first, std::true_type{});
-            else if (p.src16) stage_patch(g_first, std::true_type{});
+            if (pg.dma_patch) stage_patch_dma(g_first, std::true_type{});
+            else if (pg.src16) stage_patch(g_first, std::true_type{});
             else stage_patch(g_first, std::false_type{});
             __syncthreads();                                   // table + patch visible
             RT(2);
@@ -605,12 +612,21 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         RT(4);
     }
 
-    const long long d_sn = dgrad ? p.x_sn : p.y_sn, d_sd = dgrad ? p.x_sd : p.y_sd;
-    const int d_sh = (int)(dgrad ? p.x_sh : p.y_sh), d_sw = (int)(dgrad ? p.x_sw : p.y_sw);
+    // ---- the epilogue reads its arguments from the kernel-argument segment AGAIN, behind the main loop (round 5): the destination's strides
+    // and pointers, bias / activation / statistics / norm-backward arguments are ~55 scalar registers that nothing in front of this point
+    // needs; loaded with the prologue's s_loads they stayed live through the whole kernel and the prologue spilled and restored ~400 SGPRs
+    // through VGPR lanes (v_writelane / v_readlane: a quarter of its ~1 700 instructions).  The pointer is laundered through an empty asm
+    // so that the loads cannot be merged with / hoisted to the prologue's; the segment's lines are hot (every workgroup of the launch reads
+    // the same 550 bytes).
+    ConvPK* pek = (ConvPK*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pek));
+    ConvPK& pe = *pek;
+    const long long d_sn = dgrad ? pe.x_sn : pe.y_sn, d_sd = dgrad ? pe.x_sd : pe.y_sd;
+    const int d_sh = (int)(dgrad ? pe.x_sh : pe.y_sh), d_sw = (int)(dgrad ? pe.x_sw : pe.y_sw);
 
     RT(5);
     if (ABL(8) && acc[0][0][0] != 123.f) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    if (p.cell) {
+    if (pe.cell) {
         // ---- "cell" epilogue: per-(image, channel) sum / sum of squares + bf16 rows through LDS ---------------------------------
         // (launcher guarantees: full tiles, Nout % BN == 0, nimg % ni == 0, split-K 1, no bias / activation / beta)
         constexpr int TP = BN / 2 + 4;                        // dwords per tile row (bf16 pairs; 16-byte aligned rows)
@@ -649,28 +665,28 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             }
         }
         __syncthreads();
-        unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
+        unsigned short* out16 = reinterpret_cast<unsigned short*>(pe.out);
         constexpr int CH = BN / 8;                            // 16-byte pieces per tile row
         for (int idx = tid; idx < BM * CH; idx += NT) {
             const int row = idx / CH, c8 = idx - row * CH;
             const int im = row >> rsh, rr = row - (im << rsh);
             const int gi = img0 + im;
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
             const int py = oy0 + (rr >> 3), px = ox0 + (rr & 7);
             const uint4 v = *reinterpret_cast<const uint4*>(T + row * TP + c8 * 4);
             unsigned short* dst = out16 + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
                                   (long long)(gh.ob + py * gh.os) * d_sh + (long long)(gw.ob + px * gw.os) * d_sw + n0 + c8 * 8;
             *reinterpret_cast<uint4*>(dst) = v;
         }
-        if (p.stats) {
+        if (pe.stats) {
             const int bpi = 1 << (rsh - 5);                   // 32-row blocks per image of the tile
             for (int i = tid; i < ni * BN * 2; i += NT) {
                 const int im = i / (BN * 2), rem = i - im * (BN * 2);
                 const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+                const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
                 float t = 0.f;
                 for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
-                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
+                unsafeAtomicAdd(pe.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
             }
         }
         RT(6);
@@ -682,11 +698,11 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     const int col0 = n0 + wn0 + l31;
     int pcol[WN];                                             // physical destination channel of this lane's column j (ConvP::gap)
 #pragma unroll
-    for (int j = 0; j < WN; ++j) pcol[j] = col0 + 32 * j + ((col0 + 32 * j) >= p.gap_at ? p.gap : 0);
+    for (int j = 0; j < WN; ++j) pcol[j] = col0 + 32 * j + ((col0 + 32 * j) >= pe.gap_at ? pe.gap : 0);
     const int px0 = ox0 + 4 * khalf;
-    const bool plain = (p.splitk == 1) && !p.beta && (p.act == SAVP_ACT_NONE);
+    const bool plain = (pe.splitk == 1) && !pe.beta && (pe.act == SAVP_ACT_NONE);
     bool biased = false;                                      // the bias is already in the accumulators
-    if (p.stats) {
+    if (pe.stats) {
         // ---- statistics of an fp32 destination (the instance norm behind a generator convolution, normalization.py:146-170): the
         // per-(image, channel) sum / sum of squares of conv + bias leave with this kernel and the norm's own statistics pass (one more
         // launch that re-reads the tensor) disappears.  Launcher guarantees: full tiles, every tile row block inside one image,
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int col = col0 + 32 * j;
-                const float bias = (p.bias && col < Nout) ? p.bias[col] : 0.f;
+                const float bias = (pe.bias && col < Nout) ? pe.bias[col] : 0.f;
                 // the sums are taken AROUND THE BIAS (of the accumulators alone): sum(y - b), sum((y - b)^2).  One-pass variance
                 // E[v^2] - E[v]^2 cancels when |mean| >> std; a large bias -- the usual reason for a large mean -- no longer enters it
                 // (savp_instnorm_act_fwd(stats_ready, stats_shift = this bias) adds it back to the mean)
@@ -719,15 +735,15 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         for (int i = tid; i < ni * BN * 2; i += NT) {
             const int im = i / (BN * 2), rem = i - im * (BN * 2);
             const int gi = img0 + im;
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
             if (n0 + (rem >> 1) < Nout) {
                 float t = 0.f;
                 for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
-                unsafeAtomicAdd(p.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
+                unsafeAtomicAdd(pe.stats + ((long long)n * Nout + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
             }
         }
     }
-    if (p.nb_ws) {
+    if (pe.nb_ws) {
         // ---- backward statistics of the instance norm whose OUTPUT gradient this kernel produces (SavpConvArgs.nb_*): the destination's
         // logical channels [nb_c0, nb_c0 + nb_nc) are dy of y = act(gamma * xhat + beta), xhat = (x - mean) * rstd; the two sums that norm's
         // backward needs, sum(dy') and sum(dy' * xhat) with dy' = dy * act'(gamma * xhat + beta), leave with the accumulators -- the norm's
@@ -740,25 +756,25 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             const int rowb = wm0 + i * 32;
             const int im = rowb >> rsh;
             const int gi = img0 + im;
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
+            const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
             const int py0 = oy0 + ((rowb - (im << rsh)) >> 3);
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int cc = col0 + 32 * j - p.nb_c0;         // channel of the norm
-                const bool in = cc >= 0 && cc < p.nb_nc && col0 + 32 * j < Nout;
+                const int cc = col0 + 32 * j - pe.nb_c0;         // channel of the norm
+                const bool in = cc >= 0 && cc < pe.nb_nc && col0 + 32 * j < Nout;
                 const int cq = in ? cc : 0;
-                const float mu = p.nb_mean[(long long)n * p.nb_nc + cq], rs = p.nb_rstd[(long long)n * p.nb_nc + cq];
-                const float ga = p.nb_gamma[cq], be = p.nb_beta[cq];
-                const float* xp = p.nb_x + (long long)n * p.nb_x_sn + ((long long)py0 * Wm + px0) * p.nb_x_sp + cq;
+                const float mu = pe.nb_mean[(long long)n * pe.nb_nc + cq], rs = pe.nb_rstd[(long long)n * pe.nb_nc + cq];
+                const float ga = pe.nb_gamma[cq], be = pe.nb_beta[cq];
+                const float* xp = pe.nb_x + (long long)n * pe.nb_x_sn + ((long long)py0 * Wm + px0) * pe.nb_x_sp + cq;
                 float xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xp[((r >> 2) * Wm + (r & 3)) * p.nb_x_sp];      // all 16 loads in flight
+                for (int r = 0; r < 16; ++r) xv[r] = xp[((r >> 2) * Wm + (r & 3)) * pe.nb_x_sp];      // all 16 loads in flight
                 float sm = 0.f, q = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float xh = (xv[r] - mu) * rs;
                     const float y = xh * ga + be;
-                    const float gr = p.nb_act == 1 ? (y > 0.f ? 1.f : 0.f) : (p.nb_act == 2 ? (y > 0.f ? 1.f : p.nb_alpha) : 1.f);
+                    const float gr = pe.nb_act == 1 ? (y > 0.f ? 1.f : 0.f) : (pe.nb_act == 2 ? (y > 0.f ? 1.f : pe.nb_alpha) : 1.f);
                     const float d = acc[i][j][r] * gr;
                     sm += d; q += d * xh;
                 }
@@ -774,12 +790,12 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         for (int i = tid; i < ni * BN * 2; i += NT) {
             const int im = i / (BN * 2), rem = i - im * (BN * 2);
             const int gi = img0 + im;
-            const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-            const int cc = n0 + (rem >> 1) - p.nb_c0;
-            if (cc >= 0 && cc < p.nb_nc && n0 + (rem >> 1) < Nout) {
+            const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
+            const int cc = n0 + (rem >> 1) - pe.nb_c0;
+            if (cc >= 0 && cc < pe.nb_nc && n0 + (rem >> 1) < Nout) {
                 float t = 0.f;
                 for (int b = 0; b < bpi; ++b) t += stat[(im * bpi + b) * (BN * 2) + rem];
-                unsafeAtomicAdd(p.nb_ws + ((long long)n * p.nb_nc + cc) * 2 + (rem & 1), (double)t);
+                unsafeAtomicAdd(pe.nb_ws + ((long long)n * pe.nb_nc + cc) * 2 + (rem & 1), (double)t);
             }
         }
     }
@@ -790,8 +806,8 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         const int py0 = oy0 + ((rowb - (im << rsh)) >> 3);
         const int gi = img0 + im;
         if (gi >= nimg) continue;
-        const int n = (int)fastdiv((unsigned)gi, p.s1_magDm);
-        float* __restrict__ dst = p.out + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
+        const int n = (int)fastdiv((unsigned)gi, pe.s1_magDm);
+        float* __restrict__ dst = pe.out + (long long)n * d_sn + (long long)(gd.ob + (gi - n * Dm) * gd.os) * d_sd +
                                   (long long)(gh.ob + py0 * gh.os) * d_sh +
                                   (long long)(gw.ob + px0 * gw.os) * d_sw;
         const bool full = (py0 + 4 <= Hm) && (ox0 + TW <= Wm);
@@ -799,30 +815,30 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 if (col0 + 32 * j >= Nout) continue;
-                const float bias = (p.bias && !biased) ? p.bias[pcol[j]] : 0.f;
+                const float bias = (pe.bias && !biased) ? pe.bias[pcol[j]] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(r >> 2) * e_sh + (r & 3) * e_sw + pcol[j]] = acc[i][j][r] + bias;
             }
             continue;
         }
-        const float* __restrict__ aux = p.aux ? p.aux + (dst - p.out) : nullptr;
+        const float* __restrict__ aux = pe.aux ? pe.aux + (dst - pe.out) : nullptr;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (col0 + 32 * j >= Nout) continue;
-            const float bias = (p.bias && split == 0 && !biased) ? p.bias[pcol[j]] : 0.f;
+            const float bias = (pe.bias && split == 0 && !biased) ? pe.bias[pcol[j]] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!full && (py0 + (r >> 2) >= Hm || px0 + (r & 3) >= Wm)) continue;
                 const int off = (r >> 2) * e_sh + (r & 3) * e_sw + pcol[j];
                 float v = acc[i][j][r] + bias;
-                if (p.splitk > 1) {                            // this split's share: its own slice of the scratch, folded in split order afterwards
-                    (p.part + (long long)split * p.part_sz + (dst - p.out))[off] = v;
+                if (pe.splitk > 1) {                            // this split's share: its own slice of the scratch, folded in split order afterwards
+                    (pe.part + (long long)split * pe.part_sz + (dst - pe.out))[off] = v;
                     continue;
                 }
-                if (p.beta) v += dst[off];
-                if (p.act == SAVP_ACT_LRELU) v = fmaxf(v, p.alpha * v);
-                else if (p.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                else if (p.act == SAVP_ACT_DLRELU_FROM_OUT) v *= (aux[off] > 0.f ? 1.f : p.alpha);
+                if (pe.beta) v += dst[off];
+                if (pe.act == SAVP_ACT_LRELU) v = fmaxf(v, pe.alpha * v);
+                else if (pe.act == SAVP_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                else if (pe.act == SAVP_ACT_DLRELU_FROM_OUT) v *= (aux[off] > 0.f ? 1.f : pe.alpha);
                 dst[off] = v;
             }
         }
