@@ -29,7 +29,7 @@ const char* savp_version(void);
 /* Kernel-selection switches (process-wide; SAVP_EINVAL for an unknown name).  Names and defaults: "conv_ring" 0 (auto algorithm
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1, "ring_dma" 1 (problem-specific kernels / LDS-DMA patch staging of bf16 sources on), "ring_wwarm" 1 (the ring kernel's
  * workgroups pull their column tile's weight block into the XCD's L2 first), "wgp_dma" 1 (weight gradient of two bf16 operands: LDS-DMA
- * staging), "colsum_2stage" 1,
+ * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "colsum_2stage" 1,
  * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);

@@ -81,6 +81,7 @@ struct ConvP {
     int nb_c0, nb_nc, nb_act; float nb_alpha;
     int gap_at, gap;                          // conv_ring_kernel: logical output column c >= gap_at is physical weight row / destination channel c + gap (SavpConvArgs.dst_gap)
     int wwarm;                                // conv_ring_kernel: warm the L2 with the column tile's weight block first (option ring_wwarm)
+    int early;                                // conv_ring_kernel: request the first group's DMA-staged patch at the top of the prologue (option ring_early)
     DimGeom gD, gH, gW;
     int s1_tih_sh;                            // log2(s1_tih): tile rows per image are a power of two
     int s1_ngs, s1_itper;                     // slab groups per depth tap, (tap, slab) entries per K split

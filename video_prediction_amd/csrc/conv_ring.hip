@@ -169,35 +169,6 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- L2 warm-up of this column tile's weight block ------------------------------------------------------------------
-    // The block (BN rows x ldb bf16, contiguous in the packed layout) is streamed by every workgroup of the tile through a
-    // four-deep DMA ring: three slabs (~1.5 k cycles) of look-ahead.  Inside the train step the weights are cold (each layer's
-    // are touched once per time step, tens of MB of other traffic in between) and an L2 miss costs more than the look-ahead:
-    // the in-step gate convolutions ran 5-15 us above their back-to-back time (tests/tools/insitu_tune.py).  All workgroups of
-    // a column tile on one XCD (consecutive logical ids, one private L2) therefore split the block between them and pull their
-    // slices in with LDS-DMA instructions issued before anything else -- bandwidth-bound and overlapped with the prologue and
-    // the patch staging.  The data lands in this wave's own slots of the (still unused) ring; the real slab DMAs of the same
-    // wave are ordered behind it.  (Not with split-K: a split reads a tap range of every row, not a contiguous block.)
-    if (p.wwarm && p.splitk == 1) {
-        const int nwg = p.tm * p.tn, qx = nwg >> 3, rx = nwg & 7, xcd = (int)blockIdx.x & 7;
-        const int first = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
-        const int cnt = qx + (xcd < rx ? 1 : 0);
-        const int l_lo = max(first, nt_ * p.tm), l_hi = min(first + cnt, (nt_ + 1) * p.tm);
-        const int share = max(l_hi - l_lo, 1), mine = min(max(tlog - l_lo, 0), share - 1);
-        // (with a column gap the physical rows of the tile's first .. last logical column are warmed, gap rows included)
-        const int r_lo = n0 + (n0 >= p.gap_at ? p.gap : 0), c_hi = min(n0 + BN, Nout) - 1, r_hi = c_hi + (c_hi >= p.gap_at ? p.gap : 0);
-        const int blk = (r_hi - r_lo + 1) * ldb * 2;                        // bytes of the block (launcher: < 2^31)
-        const int chunk = ((blk + share - 1) / share + 1023) & ~1023;       // bytes per workgroup, whole wave instructions
-        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w16) + (size_t)r_lo * ldb * 2;
-        const int lo = mine * chunk;
-        int slot = 0;
-        for (int off = wave * 1024; off < chunk && lo + off < blk; off += NW * 1024) {
-            const int a = min(lo + off + lane * 16, blk - 16);
-            ring_dma16(wb + a, ring_lds + (unsigned)((wave * LW + slot % LW) * 1024 + (slot / LW % RING) * SLABB));
-            ++slot;
-        }
-    }
-
     const int it_dep = ntaps * nch;
     const int it_all = gd.nt * it_dep;
     const int it_per = pre ? p.s1_itper : (it_all + p.splitk - 1) / p.splitk;
@@ -384,6 +355,46 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     const int gsz = ntaps * spp;
     const int ngs = pre ? p.s1_ngs : (nch + spp - 1) / spp;
     const int gg0 = (split == 0) ? 0 : (it_begin / it_dep) * ngs + (it_begin % it_dep) / gsz;
+    // ---- first group's patch requested NOW (option ring_early, round 5): the patch is what the first barrier waits for -- a memory round trip
+    // of 5 - 6 k cycles that used to start behind the whole prologue (7 k cycles) -- so its LDS-DMA requests go out before the weight
+    // warm-up, the per-lane slab offsets, the accumulator clears and the entry table; they are drained where the patch used to be staged.
+    // (Round 5's first attempt issued them BEHIND the warm-up and was slower in the step: the two bursts then queue behind each other.)
+    bool early_patch = false;
+    if (p.early && p.dma_patch && gg0 < gd.nt * ngs) {
+        g_jd = (gd.nt == 1) ? 0 : gg0 / ngs;
+        asm volatile("" : "+s"(pgk));
+        stage_patch_dma((gg0 - g_jd * ngs) * spp, std::false_type{});
+        early_patch = true;
+    }
+    // ---- L2 warm-up of this column tile's weight block ------------------------------------------------------------------
+    // The block (BN rows x ldb bf16, contiguous in the packed layout) is streamed by every workgroup of the tile through a
+    // four-deep DMA ring: three slabs (~1.5 k cycles) of look-ahead.  Inside the train step the weights are cold (each layer's
+    // are touched once per time step, tens of MB of other traffic in between) and an L2 miss costs more than the look-ahead:
+    // the in-step gate convolutions ran 5-15 us above their back-to-back time (tests/tools/insitu_tune.py).  All workgroups of
+    // a column tile on one XCD (consecutive logical ids, one private L2) therefore split the block between them and pull their
+    // slices in with LDS-DMA instructions issued before anything else -- bandwidth-bound and overlapped with the prologue and
+    // the patch staging.  The data lands in this wave's own slots of the (still unused) ring; the real slab DMAs of the same
+    // wave are ordered behind it.  (Not with split-K: a split reads a tap range of every row, not a contiguous block.)
+    if (p.wwarm && p.splitk == 1) {
+        const int nwg = p.tm * p.tn, qx = nwg >> 3, rx = nwg & 7, xcd = (int)blockIdx.x & 7;
+        const int first = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
+        const int cnt = qx + (xcd < rx ? 1 : 0);
+        const int l_lo = max(first, nt_ * p.tm), l_hi = min(first + cnt, (nt_ + 1) * p.tm);
+        const int share = max(l_hi - l_lo, 1), mine = min(max(tlog - l_lo, 0), share - 1);
+        // (with a column gap the physical rows of the tile's first .. last logical column are warmed, gap rows included)
+        const int r_lo = n0 + (n0 >= p.gap_at ? p.gap : 0), c_hi = min(n0 + BN, Nout) - 1, r_hi = c_hi + (c_hi >= p.gap_at ? p.gap : 0);
+        const int blk = (r_hi - r_lo + 1) * ldb * 2;                        // bytes of the block (launcher: < 2^31)
+        const int chunk = ((blk + share - 1) / share + 1023) & ~1023;       // bytes per workgroup, whole wave instructions
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w16) + (size_t)r_lo * ldb * 2;
+        const int lo = mine * chunk;
+        int slot = 0;
+        for (int off = wave * 1024; off < chunk && lo + off < blk; off += NW * 1024) {
+            const int a = min(lo + off + lane * 16, blk - 16);
+            ring_dma16(wb + a, ring_lds + (unsigned)((wave * LW + slot % LW) * 1024 + (slot / LW % RING) * SLABB));
+            ++slot;
+        }
+    }
+
 #pragma unroll
     for (int q = 0; q < LW; ++q) {
         const int slot = (wave * LW + q) * 64 + lane;
@@ -475,6 +486,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         const int t_end = ABL(32) ? 0 : min(it_end, e_lo + ntaps * g_slabs) - e_lo;
         if (t_begin >= t_end) continue;
         const int len = t_end - t_begin;
+        if (gg != gg0) early_patch = false;                   // (the early request was for group gg0 only)
         RT(12);
         RTW(1);
         // previous group's patch, ring and table are dead (no DMA in flight here).  Not for the first group: nothing to protect, and
@@ -502,7 +514,8 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
         // same source in one call.  The slab requests queue behind ~40 patch requests per workgroup either way; issued early they only
         // delay the patch, which everything waits for.  Removed.)
         {
-            if (pg.dma_patch) stage_patch_dma(g_first, std::true_type{});
+            if (early_patch) { early_patch = false; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // requested in the prologue
+            else if (pg.dma_patch) stage_patch_dma(g_first, std::true_type{});
             else if (pg.src16) stage_patch(g_first, std::true_type{});
             else stage_patch(g_first, std::false_type{});
             __syncthreads();                                   // table + patch visible
@@ -1019,6 +1032,7 @@ static bool ring_plan(ConvP& p, const SavpConvArgs* a, int nw, int wm, int wn, R
     p.splitk = splitk;
     patch_launch_constants(p, a, phases, tih, nch, spp, tW, splitk);
     p.wwarm = savp_opt(OPT_RING_WWARM) ? 1 : 0;
+    p.early = savp_opt(OPT_RING_EARLY) ? 1 : 0;
     pl.nw = nw; pl.wm = wm; pl.wn = wn; pl.nks = nks; pl.lds = lds;
     pl.grid = dim3((unsigned)(p.tm * p.tn), (unsigned)phases, (unsigned)splitk);
     return true;
