@@ -389,6 +389,31 @@ def test_split_k_scratch_query_is_a_host_side_predicate(hip_lib):
     assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(big)) == 0
 
 
+def test_thin_head_routing_is_a_host_side_predicate(hip_lib):
+    """savp_conv_special (include/savp_hip.h): which calls the problem-specific kernels of csrc/conv_thin.hip take under tile 0 -- round 5's
+    wide -> thin FPROP (scratch-image head 32 -> 4, mask convolution 56 -> 8) and the mask convolution's data gradient (56 <- 8), and the
+    conditions that send a call to the general kernels instead."""
+    from video_prediction_amd import lib
+    hip_lib.savp_conv_special.argtypes = [ctypes.c_void_p]
+    sp = lambda a: hip_lib.savp_conv_special(ctypes.byref(a))
+    head = _conv2d_args(lib, lib.CONV_FPROP, 32, 64, 64, 32, 64, 64, 4, 3, 1, 1)
+    head.act, head.y_sw = lib.ACT_SIGMOID, 56                                  # into a channel slice of the mask convolution's input
+    masks = _conv2d_args(lib, lib.CONV_FPROP, 32, 64, 64, 56, 64, 64, 8, 3, 1, 1)
+    assert sp(head) == 1 and sp(masks) == 1
+    dg = _conv2d_args(lib, lib.CONV_DGRAD, 32, 64, 64, 56, 64, 64, 8, 3, 1, 1)
+    dg.beta = 1
+    assert sp(dg) == 1
+    for field, value in (('Cx', 44), ('Cy', 9), ('precision', 0), ('w_bf16', None), ('src_bf16', 1), ('beta', 1), ('sh', 2)):
+        a = _conv2d_args(lib, lib.CONV_FPROP, 32, 64, 64, 56, 64, 64, 8, 3, 1, 1)
+        setattr(a, field, value)
+        assert sp(a) == 0, field                                                # Cx % 8, Cy <= 8, bf16 precision, packed bf16 weights, fp32 tensors, no accumulation, stride 1
+    dg.Cy = 4                                                                    # the 8-channel kernel is for Cy == 8 exactly ...
+    dg.Cx = 40
+    assert sp(dg) == 0
+    dg.Cx, dg.beta = 32, 0                                                       # ... 32 <- 4 is the RGB-side kernel's problem (round 2)
+    assert sp(dg) == 1
+
+
 def test_bench_dry_run_prints_the_eight_rank_launch_plan():
     """`bench.py --gpus 8 --dry-run` on a box without a GPU: the launcher line the script becomes (= the driver's torch.distributed.run
     line), one core slice per rank, the weak-scaling workload."""
