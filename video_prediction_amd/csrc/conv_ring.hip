@@ -205,6 +205,8 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     // ---- input patch of one slab group (fp32 or bf16 source; zero outside the image, beyond Cred and for images >= N) ----
     auto stage_patch = [&](int cfirst, auto s16c) {
         constexpr bool S16 = decltype(s16c)::value;        // compile-time: a runtime branch inside the loop serialises the loads
+        // (values, not references: a load through pgk behind an asm with a memory clobber would be repeated after every such asm)
+        const unsigned long long magPI = (*pgk).s1_magPI, magC4 = (*pgk).s1_magC4, magPW = (*pgk).s1_magPW, magDm = (*pgk).s1_magDm;
         const int c4n = (spp * CKB) >> 2;
         const int per_img = PH * PW * c4n;
         const int total = ni * per_img;
@@ -218,16 +220,16 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = min(base + u * NT, total - 1);
-                const int im = (int)fastdiv((unsigned)idx, (*pgk).s1_magPI);
+                const int im = (int)fastdiv((unsigned)idx, magPI);
                 const int rem = idx - im * per_img;
-                const int pix = (int)fastdiv((unsigned)rem, (*pgk).s1_magC4);
+                const int pix = (int)fastdiv((unsigned)rem, magC4);
                 const int c = (rem - pix * c4n) << 2;
-                const int pyy = (int)fastdiv((unsigned)pix, (*pgk).s1_magPW);
+                const int pyy = (int)fastdiv((unsigned)pix, magPW);
                 const int pxx = pix - pyy * PW;
                 const int iy = org_h + pyy, ix = org_w + pxx;
                 const int cg = cfirst * CKB + c;
                 const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
+                const int n = (int)fastdiv((unsigned)gi, magDm);
                 const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                 const bool ok = (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN && cg < Cred && gi < nimg &&
                                 (unsigned)dz < (unsigned)gd.srcN;
@@ -265,6 +267,10 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
     // VGPR path above is instruction-bound: 12-22 k cycles of a 62-105 k cycle gate convolution).  The DMAs are drained (vmcnt 0)
     // before the barrier that publishes the patch, so the weight ring's counted waits never see them.
     auto stage_patch_dma = [&](int cfirst, auto drainc) {
+        // kernel arguments of this group as VALUES: read through pgk inside the loops they would be re-loaded (s_load + wait, in a divergent
+        // branch for the zero slot) after every DMA instruction, whose asm carries a memory clobber -- measured: ~400 cycles per DMA instruction
+        const unsigned long long magDm = (*pgk).s1_magDm, magC8 = (*pgk).s1_magC8, magPI8 = (*pgk).s1_magPI8, magP8 = (*pgk).s1_magP8;
+        const unsigned long long zero16 = (unsigned long long)(uintptr_t)(*pgk).zero16;
         if constexpr (NKS >= 3) {
             // Row-wise (round 5; the instantiations with >= 3 k-steps per slab -- the ConvLSTM gate convolutions and the other wide-channel
             // layers): a wave takes whole patch rows (image, patch row = wave-uniform), a row is ceil(P8 / 64) DMA instructions.  Everything
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
 #pragma unroll
             for (int j = 0; j < NJMAX; ++j) {
                 const int sl = j * 64 + lane;
-                const int pxx = (int)fastdiv((unsigned)sl, (*pgk).s1_magC8);
+                const int pxx = (int)fastdiv((unsigned)sl, magC8);
                 const int ch8 = sl - pxx * C8;
                 const int ix = org_w + pxx;
                 const int cg = cfirst * CKB + ch8 * 8;
@@ -299,18 +305,21 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             while (pyy >= PH) { pyy -= PH; ++im; }
             for (int row = wave; row < (ABL(4) ? 0 : rows); row += NW) {
                 const int gi = img0 + im;
-                const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
+                const int n = (int)fastdiv((unsigned)gi, magDm);
                 const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                 const int iy = org_h + pyy;
                 const bool row_ok = (unsigned)iy < (unsigned)gh.srcN && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
                 const long long row_base = (long long)n * s_sn + (long long)dz * s_sd + (long long)iy * s_sh;
                 const unsigned char* rb = src_b + row_base * 2;
                 const unsigned lds_row = patch_lds + (unsigned)(row * P8) * 16u;
+                // (Measured and not kept, round 5: zeroing the slots that hold no data with a store and masking their lanes out of the DMA
+                // instruction instead of gathering them from the 16 zero bytes -- the patch is complete at the same cycle.  What the staging
+                // costs is its instruction stream: ~650 instructions per wave for ~12 DMA instructions, two waves per SIMD.)
 #pragma unroll
                 for (int j = 0; j < NJMAX; ++j) {
                     if (j < nj && j * 64 + lane < P8) {
-                        const void* g = (row_ok && rel[j] >= 0) ? static_cast<const void*>(rb + (long long)rel[j] * 2) : (*pgk).zero16;
-                        ring_dma16(g, lds_row + (unsigned)(j * 1024));
+                        const unsigned long long g = (row_ok && rel[j] >= 0) ? (unsigned long long)(uintptr_t)(rb + (long long)rel[j] * 2) : zero16;
+                        ring_dma16(reinterpret_cast<const void*>((uintptr_t)g), lds_row + (unsigned)(j * 1024));
                     }
                 }
                 pyy += NW;
@@ -326,22 +335,22 @@ __global__ __launch_bounds__(64 * NW, (ring_min_waves<NW, WM, WN, NKS>())) void 
             for (int base = wave * 64; base < (ABL(4) ? 0 : total); base += NT) {
                 const int slot = base + lane;
                 if (slot < total) {
-                    const int im = (int)fastdiv((unsigned)slot, (*pgk).s1_magPI8);
+                    const int im = (int)fastdiv((unsigned)slot, magPI8);
                     const int rem = slot - im * per_img8;
-                    const int pyy = (int)fastdiv((unsigned)rem, (*pgk).s1_magP8);
+                    const int pyy = (int)fastdiv((unsigned)rem, magP8);
                     const int r = rem - pyy * P8;
-                    const int pxx = (int)fastdiv((unsigned)r, (*pgk).s1_magC8);
+                    const int pxx = (int)fastdiv((unsigned)r, magC8);
                     const int ch8 = r - pxx * C8;
                     const int iy = org_h + pyy, ix = org_w + pxx;
                     const int cg = cfirst * CKB + ch8 * 8;
                     const int gi = img0 + im;
-                    const int n = (int)fastdiv((unsigned)gi, (*pgk).s1_magDm);
+                    const int n = (int)fastdiv((unsigned)gi, magDm);
                     const int dz = gd.base + (gi - n * Dm) * gd.mstep + g_jd * gd.jstep;
                     const bool ok = pxx < PW && ch8 < used8 && (unsigned)iy < (unsigned)gh.srcN && (unsigned)ix < (unsigned)gw.srcN &&
                                     cg < Cred && gi < nimg && (unsigned)dz < (unsigned)gd.srcN;
                     const long long off = (long long)n * s_sn + (long long)dz * s_sd + iy * s_sh + ix * s_sw + cg;
-                    const void* g = ok ? static_cast<const void*>(src_b + off * 2) : (*pgk).zero16;
-                    ring_dma16(g, patch_lds + (unsigned)(base * 16));
+                    const unsigned long long g = ok ? (unsigned long long)(uintptr_t)(src_b + off * 2) : zero16;
+                    ring_dma16(reinterpret_cast<const void*>((uintptr_t)g), patch_lds + (unsigned)(base * 16));
                 }
             }
 
