@@ -25,77 +25,79 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# (flag, keyword arguments) in the reference's order, generate.py:20-49; --synthetic_shape is this repository's addition
+_FLAGS = (
+    ('input_dir', dict(type=str, required=True,
+                       help="either a directory containing subdirectories train, val, test, etc, or a directory containing the tfrecords")),
+    ('results_dir', dict(type=str, default='results', help="ignored if output_gif_dir is specified")),
+    ('results_gif_dir', dict(type=str, help="default is results_dir. ignored if output_gif_dir is specified")),
+    ('results_png_dir', dict(type=str, help="default is results_dir. ignored if output_png_dir is specified")),
+    ('output_gif_dir', dict(help="output directory where samples are saved as gifs. default is results_gif_dir/model_fname")),
+    ('output_png_dir', dict(help="output directory where samples are saved as pngs. default is results_png_dir/model_fname")),
+    ('checkpoint', dict(help="directory with checkpoint or checkpoint name (e.g. checkpoint_dir/model-200000)")),
+    ('mode', dict(type=str, choices=['val', 'test'], default='val', help='mode for dataset, val or test.')),
+    ('dataset', dict(type=str, help="dataset class name")),
+    ('dataset_hparams', dict(type=str, help="a string of comma separated list of dataset hyperparameters")),
+    ('model', dict(type=str, help="model class name")),
+    ('model_hparams', dict(type=str, help="a string of comma separated list of model hyperparameters")),
+    ('batch_size', dict(type=int, default=8, help="number of samples in batch")),
+    ('num_samples', dict(type=int, help="number of samples in total (all of them by default)")),
+    ('num_epochs', dict(type=int, default=1)),
+    ('num_stochastic_samples', dict(type=int, default=5)),
+    ('gif_length', dict(type=int, help="default is sequence_length")),
+    ('fps', dict(type=int, default=4)),
+    ('gpu_mem_frac', dict(type=float, default=0, help="fraction of gpu memory to use")),
+    ('seed', dict(type=int, default=7)),
+    ('synthetic_shape', dict(type=str, default='64,64,3', help="H,W,C of --dataset synthetic (not in the reference)")),
+)
+
+
 def build_parser():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--input_dir", type=str, required=True, help="either a directory containing subdirectories "
-                                                                     "train, val, test, etc, or a directory containing "
-                                                                     "the tfrecords")
-    parser.add_argument("--results_dir", type=str, default='results', help="ignored if output_gif_dir is specified")
-    parser.add_argument("--results_gif_dir", type=str, help="default is results_dir. ignored if output_gif_dir is specified")
-    parser.add_argument("--results_png_dir", type=str, help="default is results_dir. ignored if output_png_dir is specified")
-    parser.add_argument("--output_gif_dir", help="output directory where samples are saved as gifs. default is "
-                                                 "results_gif_dir/model_fname")
-    parser.add_argument("--output_png_dir", help="output directory where samples are saved as pngs. default is "
-                                                 "results_png_dir/model_fname")
-    parser.add_argument("--checkpoint", help="directory with checkpoint or checkpoint name (e.g. checkpoint_dir/model-200000)")
-
-    parser.add_argument("--mode", type=str, choices=['val', 'test'], default='val', help='mode for dataset, val or test.')
-
-    parser.add_argument("--dataset", type=str, help="dataset class name")
-    parser.add_argument("--dataset_hparams", type=str, help="a string of comma separated list of dataset hyperparameters")
-    parser.add_argument("--model", type=str, help="model class name")
-    parser.add_argument("--model_hparams", type=str, help="a string of comma separated list of model hyperparameters")
-
-    parser.add_argument("--batch_size", type=int, default=8, help="number of samples in batch")
-    parser.add_argument("--num_samples", type=int, help="number of samples in total (all of them by default)")
-    parser.add_argument("--num_epochs", type=int, default=1)
-
-    parser.add_argument("--num_stochastic_samples", type=int, default=5)
-    parser.add_argument("--gif_length", type=int, help="default is sequence_length")
-    parser.add_argument("--fps", type=int, default=4)
-
-    parser.add_argument("--gpu_mem_frac", type=float, default=0, help="fraction of gpu memory to use")
-    parser.add_argument("--seed", type=int, default=7)
-    parser.add_argument("--synthetic_shape", type=str, default='64,64,3', help="H,W,C of --dataset synthetic (not in the reference)")
+    for name, kw in _FLAGS:
+        parser.add_argument('--' + name, **kw)
     return parser
 
 
+def _side_json(directory, name):
+    """One of the side files train.py leaves beside a checkpoint; a missing hparams file is reported, not fatal (generate.py:68-76)."""
+    try:
+        with open(os.path.join(directory, name)) as f:
+            return json.load(f)
+    except FileNotFoundError:
+        print("%s was not loaded because it does not exist" % name)
+        return {}
+
+
 def resolve_options(args):
-    """generate.py:57-86."""
-    args.results_gif_dir = args.results_gif_dir or args.results_dir
-    args.results_png_dir = args.results_png_dir or args.results_dir
-    dataset_hparams_dict, model_hparams_dict = {}, {}
+    """generate.py:57-86: result directories, and dataset / model / hparams read back from the checkpoint's directory."""
+    for kind in ('gif', 'png'):
+        if not getattr(args, 'results_%s_dir' % kind):
+            setattr(args, 'results_%s_dir' % kind, args.results_dir)
+    hparams = {'dataset': {}, 'model': {}}
     if args.checkpoint:
-        checkpoint_dir = os.path.normpath(args.checkpoint)
-        if not os.path.isdir(args.checkpoint):
-            checkpoint_dir, _ = os.path.split(checkpoint_dir)
-        if not os.path.exists(checkpoint_dir):
-            raise FileNotFoundError(errno.ENOENT, os.strerror(errno.ENOENT), checkpoint_dir)
-        with open(os.path.join(checkpoint_dir, "options.json")) as f:
-            print("loading options from checkpoint %s" % args.checkpoint)
-            options = json.loads(f.read())
-            args.dataset = args.dataset or options['dataset']
-            args.model = args.model or options['model']
-        try:
-            with open(os.path.join(checkpoint_dir, "dataset_hparams.json")) as f:
-                dataset_hparams_dict = json.loads(f.read())
-        except FileNotFoundError:
-            print("dataset_hparams.json was not loaded because it does not exist")
-        try:
-            with open(os.path.join(checkpoint_dir, "model_hparams.json")) as f:
-                model_hparams_dict = json.loads(f.read())
-        except FileNotFoundError:
-            print("model_hparams.json was not loaded because it does not exist")
-        args.output_gif_dir = args.output_gif_dir or os.path.join(args.results_gif_dir, os.path.split(checkpoint_dir)[1])
-        args.output_png_dir = args.output_png_dir or os.path.join(args.results_png_dir, os.path.split(checkpoint_dir)[1])
+        ckpt_dir = os.path.normpath(args.checkpoint)
+        if not os.path.isdir(args.checkpoint):                  # a checkpoint PREFIX (dir/model-200000) names its directory
+            ckpt_dir = os.path.dirname(ckpt_dir)
+        if not os.path.exists(ckpt_dir):
+            raise FileNotFoundError(errno.ENOENT, os.strerror(errno.ENOENT), ckpt_dir)
+        print("loading options from checkpoint %s" % args.checkpoint)
+        with open(os.path.join(ckpt_dir, "options.json")) as f:      # this one is required
+            saved = json.load(f)
+        for key in ('dataset', 'model'):
+            if not getattr(args, key):
+                setattr(args, key, saved[key])
+            hparams[key] = _side_json(ckpt_dir, key + '_hparams.json')
+        leaf = os.path.basename(ckpt_dir)
     else:
-        if not args.dataset:
-            raise ValueError('dataset is required when checkpoint is not specified')
-        if not args.model:
-            raise ValueError('model is required when checkpoint is not specified')
-        args.output_gif_dir = args.output_gif_dir or os.path.join(args.results_gif_dir, 'model.%s' % args.model)
-        args.output_png_dir = args.output_png_dir or os.path.join(args.results_png_dir, 'model.%s' % args.model)
-    return dataset_hparams_dict, model_hparams_dict
+        for key in ('dataset', 'model'):
+            if not getattr(args, key):
+                raise ValueError('%s is required when checkpoint is not specified' % key)
+        leaf = 'model.%s' % args.model
+    for kind in ('gif', 'png'):
+        if not getattr(args, 'output_%s_dir' % kind):
+            setattr(args, 'output_%s_dir' % kind, os.path.join(getattr(args, 'results_%s_dir' % kind), leaf))
+    return hparams['dataset'], hparams['model']
 
 
 def write_png(path, image):
@@ -157,39 +159,30 @@ def main(argv=None):
     inputs = next(batches)
     model.build_graph(inputs, device=device)
 
-    for output_dir in (args.output_gif_dir, args.output_png_dir):
-        if not os.path.exists(output_dir):
-            os.makedirs(output_dir)
-        with open(os.path.join(output_dir, "options.json"), "w") as f:
-            f.write(json.dumps(vars(args), sort_keys=True, indent=4))
-        with open(os.path.join(output_dir, "dataset_hparams.json"), "w") as f:
-            f.write(json.dumps(dataset.hparams.values(), sort_keys=True, indent=4))
-        with open(os.path.join(output_dir, "model_hparams.json"), "w") as f:
-            f.write(json.dumps(model.hparams.values(), sort_keys=True, indent=4))
+    side = (("options.json", vars(args)), ("dataset_hparams.json", dataset.hparams.values()), ("model_hparams.json", model.hparams.values()))
+    for output_dir in (args.output_gif_dir, args.output_png_dir):                             # generate.py:140-148
+        os.makedirs(output_dir, exist_ok=True)
+        for fname, content in side:
+            with open(os.path.join(output_dir, fname), "w") as f:
+                f.write(json.dumps(content, sort_keys=True, indent=4))
     if args.checkpoint:
         model.restore(args.checkpoint)
 
-    sample_ind = 0
-    while inputs is not None:
-        if args.num_samples and sample_ind >= args.num_samples:
-            break
-        print("evaluation samples from %d to %d" % (sample_ind, sample_ind + args.batch_size))
-        context = (inputs['images'] * 255.0).to(torch.uint8).cpu().numpy()                 # [B, T, H, W, C]
-        for stochastic_sample_ind in range(args.num_stochastic_samples):
-            gen_images = model.generate(inputs)['gen_images']                               # [B, T-1, H, W, C]
-            gen_images = (gen_images[:, -future_length:] * 255.0).to(torch.uint8).cpu().numpy()      # only keep the future frames
-            for i, gen_images_ in enumerate(gen_images):
-                frames = list(context[i][:context_frames]) + list(gen_images_)
-                if args.gif_length:
-                    frames = frames[:args.gif_length]
-                pattern = 'gen_image_%%05d_%%02d_%%0%dd.png' % max(2, len(str(len(gen_images_) - 1)))
-                for t, gen_image in enumerate(gen_images_):
-                    write_png(os.path.join(args.output_png_dir, pattern % (sample_ind + i, stochastic_sample_ind, t)), gen_image)
-        sample_ind += args.batch_size
-        try:
-            inputs = next(batches)
-        except StopIteration:
-            inputs = None
+    def to_uint8(x):
+        return (x * 255.0).to(torch.uint8).cpu().numpy()
+
+    first = 0                                                    # index of the batch's first sample (generate.py:154-189)
+    while inputs is not None and not (args.num_samples and first >= args.num_samples):
+        print("evaluation samples from %d to %d" % (first, first + args.batch_size))
+        for draw in range(args.num_stochastic_samples):
+            future = to_uint8(model.generate(inputs)['gen_images'][:, -future_length:])      # [B, T - context, H, W, C]: the future frames only
+            digits = max(2, len(str(future.shape[1] - 1)))
+            for b, clip in enumerate(future):
+                for t, frame in enumerate(clip):
+                    name = 'gen_image_%05d_%02d_%0*d.png' % (first + b, draw, digits, t)
+                    write_png(os.path.join(args.output_png_dir, name), frame)
+        first += args.batch_size
+        inputs = next(batches, None)
 
 
 if __name__ == '__main__':

@@ -104,3 +104,69 @@ def test_png_writer_round_trip(tmp_path):
         rows = zlib.decompress(chunks[b'IDAT'])
         got = np.frombuffer(rows, dtype=np.uint8).reshape(5, 1 + 7 * c)[:, 1:].reshape(5, 7, c)
         assert np.array_equal(got, img)
+
+
+def test_generate_main_loop_file_names_and_side_files(tmp_path, monkeypatch):
+    """scripts/generate.py main() with a stand-in dataset / model on CPU: two batches x two draws, only the future frames written, names
+    gen_image_<sample>_<draw>_<t>.png (generate.py:154-189), the three side JSONs in both output directories (:140-148)."""
+    import types
+    import torch
+    from scripts import train as T_
+    from video_prediction_amd import models as M
+
+    class HP(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def values(self):
+            return dict(self.__dict__)
+
+    class FakeDataset(object):
+        def __init__(self, input_dir, mode, num_epochs, seed, hparams_dict, hparams):
+            self.hparams = HP(context_frames=2, sequence_length=5, time_shift=0)
+
+        def num_examples_per_epoch(self):
+            return 4
+
+        def make_batch(self, batch_size, device=None):
+            for k in range(2):
+                yield {'images': torch.full((batch_size, 5, 4, 6, 3), 0.1 * (k + 1))}
+
+    calls = []
+
+    class FakeModel(object):
+        def __init__(self, mode, hparams_dict, hparams):
+            assert mode == 'test' and hparams_dict['sequence_length'] == 5 and hparams_dict['context_frames'] == 2
+            self.hparams = HP(**hparams_dict)
+
+        def build_graph(self, inputs, device=None):
+            calls.append('build')
+
+        def generate(self, inputs):
+            calls.append('generate')
+            x = inputs['images']
+            ramp = torch.arange(4, dtype=torch.float32).view(1, 4, 1, 1, 1) / 255.0
+            return {'gen_images': x[:, 1:] * 0 + ramp}                      # frame t of the unroll = t / 255
+
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(T_, 'get_dataset_class', lambda name, shape: FakeDataset)
+    monkeypatch.setattr(M, 'get_model_class', lambda name: FakeModel)
+    out = tmp_path / 'res'
+    G.main(['--input_dir', 'none', '--dataset', 'synthetic', '--model', 'savp', '--batch_size', '2', '--num_stochastic_samples', '2',
+            '--results_dir', str(out)])
+    d = out / 'model.savp'
+    names = sorted(p for p in os.listdir(str(d)) if p.endswith('.png'))
+    assert len(names) == 4 * 2 * 3                                            # samples x draws x future frames (5 - 2)
+    assert names[0] == 'gen_image_00000_00_00.png' and names[-1] == 'gen_image_00003_01_02.png'
+    assert calls == ['build'] + ['generate'] * 4
+    for fname in ('options.json', 'dataset_hparams.json', 'model_hparams.json'):
+        assert json.load(open(str(d / fname)))
+    assert json.load(open(str(d / 'options.json')))['num_stochastic_samples'] == 2
+    # the LAST three frames of the unroll are the future ones: pixel value = 1 + t
+    raw = open(str(d / 'gen_image_00002_01_01.png'), 'rb').read()
+    pos = raw.index(b'IDAT')
+    n = struct.unpack('>I', raw[pos - 4:pos])[0]
+    rows = np.frombuffer(zlib.decompress(raw[pos + 4:pos + 4 + n]), dtype=np.uint8).reshape(4, 1 + 6 * 3)
+    assert set(rows[:, 1:].ravel().tolist()) == {2}
+    with pytest.raises(ValueError):
+        G.main(['--input_dir', 'none', '--dataset', 'synthetic', '--model', 'savp', '--batch_size', '3', '--results_dir', str(out)])
