@@ -6,39 +6,33 @@
 loss-weight bookkeeping (:733-852).  The TF graph/session machinery is replaced by an explicit ``train_step``.
 """
 import functools
-import itertools
-from collections import OrderedDict
 
 from ..hparams import HParams
 from . import hparam_defaults
 
 
+# attributes the reference's constructors create empty (base_model.py:60-68, 221-229); callers and subclasses read them
+_BASE_SLOTS = ('inputs', 'gen_images', 'outputs', 'metrics', 'eval_outputs', 'eval_metrics', 'saveable_variables', 'post_init_ops')
+_TRAINABLE_SLOTS = ('gen_images_enc', 'g_losses', 'd_losses', 'g_loss', 'd_loss', 'train_op')
+_REQUIRED_HPARAMS = ('context_frames', 'sequence_length')      # -1 in the defaults = "the dataset has to say" (base_model.py:54-59)
+
+
 class BaseVideoPredictionModel(object):
     def __init__(self, mode='train', hparams_dict=None, hparams=None, num_gpus=None, eval_num_samples=100,
                  eval_num_samples_for_diversity=10, eval_parallel_iterations=1):
-        if mode not in ('train', 'test'):
+        if mode != 'train' and mode != 'test':
             raise ValueError('mode must be train or test, but %s given' % mode)
-        self.mode = mode
-        self.num_gpus = num_gpus
-        self.eval_num_samples = eval_num_samples
-        self.eval_num_samples_for_diversity = eval_num_samples_for_diversity
+        self.mode, self.num_gpus = mode, num_gpus
+        self.eval_num_samples, self.eval_num_samples_for_diversity = eval_num_samples, eval_num_samples_for_diversity
         self.eval_parallel_iterations = eval_parallel_iterations
         self.hparams = self.parse_hparams(hparams_dict, hparams)
-        if self.hparams.context_frames == -1:
-            raise ValueError('Invalid context_frames %r. It might have to be '
-                             'specified.' % self.hparams.context_frames)
-        if self.hparams.sequence_length == -1:
-            raise ValueError('Invalid sequence_length %r. It might have to be '
-                             'specified.' % self.hparams.sequence_length)
+        for name in _REQUIRED_HPARAMS:
+            value = getattr(self.hparams, name)
+            if value == -1:
+                raise ValueError('Invalid %s %r. It might have to be specified.' % (name, value))
         self.deterministic = True
-        self.inputs = None
-        self.gen_images = None
-        self.outputs = None
-        self.metrics = None
-        self.eval_outputs = None
-        self.eval_metrics = None
-        self.saveable_variables = None
-        self.post_init_ops = None
+        for slot in _BASE_SLOTS:
+            setattr(self, slot, None)
 
     def get_default_hparams_dict(self):
         return hparam_defaults.base_defaults()
@@ -47,13 +41,12 @@ class BaseVideoPredictionModel(object):
         return HParams(**self.get_default_hparams_dict())
 
     def parse_hparams(self, hparams_dict, hparams):
-        parsed_hparams = self.get_default_hparams().override_from_dict(hparams_dict or {})
-        if hparams:
-            if not isinstance(hparams, (list, tuple)):
-                hparams = [hparams]
-            for hparam in hparams:
-                parsed_hparams.parse(hparam)
-        return parsed_hparams
+        """defaults <- JSON dict <- one or several ``k=v,...`` strings, in that order (base_model.py:99-109)."""
+        hp = self.get_default_hparams().override_from_dict(hparams_dict or {})
+        strings = [] if not hparams else (list(hparams) if isinstance(hparams, (list, tuple)) else [hparams])
+        for text in strings:
+            hp.parse(text)
+        return hp
 
     def build_graph(self, inputs):
         self.inputs = inputs
@@ -98,19 +91,15 @@ class VideoPredictionModel(BaseVideoPredictionModel):
     def __init__(self, generator_fn, discriminator_fn=None, generator_scope='generator',
                  discriminator_scope='discriminator', aggregate_nccl=False, mode='train', hparams_dict=None,
                  hparams=None, **kwargs):
-        super(VideoPredictionModel, self).__init__(mode, hparams_dict, hparams, **kwargs)
-        self.generator_fn = functools.partial(generator_fn, mode=self.mode, hparams=self.hparams)
-        self.discriminator_fn = functools.partial(discriminator_fn, mode=self.mode, hparams=self.hparams) \
-            if discriminator_fn else None
-        self.generator_scope = generator_scope
-        self.discriminator_scope = discriminator_scope
+        BaseVideoPredictionModel.__init__(self, mode, hparams_dict, hparams, **kwargs)
+
+        def bound(fn):                                          # the plug-ins see the model's mode and hparams (base_model.py:212-216)
+            return functools.partial(fn, mode=self.mode, hparams=self.hparams) if fn else None
+        self.generator_fn, self.discriminator_fn = bound(generator_fn), bound(discriminator_fn)
+        self.generator_scope, self.discriminator_scope = generator_scope, discriminator_scope
         self.aggregate_nccl = aggregate_nccl
-        self.gen_images_enc = None
-        self.g_losses = None
-        self.d_losses = None
-        self.g_loss = None
-        self.d_loss = None
-        self.train_op = None
+        for slot in _TRAINABLE_SLOTS:
+            setattr(self, slot, None)
 
     @property
     def learning_rate(self):
