@@ -1,4 +1,4 @@
-"""Data-parallel host logic on CPU with world_size 2 over gloo: flat-bucket all-reduce, 1/K scaling, rank-0 broadcast,
+"""Data-parallel host logic on CPU with world_size 2 and 4 over gloo: flat-bucket all-reduce, 1/K scaling, rank-0 broadcast,
 batch sharding.  Gradients come from the oracle (the HIP kernels cannot run without a GPU); what is under test is
 video_prediction_amd.parallel.ReplicaGroup and the ParamStore arenas."""
 import os
@@ -57,8 +57,9 @@ def _worker(rank, world, port, q):
     store = ParamStore(specs, vals, 'cpu')
     rg = ReplicaGroup(store, dist)                          # broadcast from rank 0
     rng = np.random.default_rng(0)
-    global_images = torch.tensor(rng.random((3, 2, 32, 32, 3)))     # [T, global B=2, ...]
+    global_images = torch.tensor(rng.random((3, world, 32, 32, 3)))     # [T, global B = one sample per rank, ...]
     mine = rg.shard(global_images, dim=1)
+    assert mine.shape[1] == 1 and torch.equal(mine[:, 0], global_images[:, rank])
     cur = {n: store[n].numpy().copy() for n in store.names()}
     grads = _oracle_grads(hp, cur, mine)
     g = store.groups['g']
@@ -84,15 +85,16 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_replicas_average_gradients_and_stay_identical():
+@pytest.mark.parametrize('world', [2, 4])
+def test_replicas_average_gradients_and_stay_identical(world):
     import multiprocessing
     ctx = multiprocessing.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(2)]
+    results = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -101,7 +103,7 @@ def test_two_replicas_average_gradients_and_stay_identical():
     # the averaged shard gradients equal the single-process gradient of the global batch (per-sample ops only)
     hp, specs, shape = _setup()
     rng = np.random.default_rng(0)
-    global_images = torch.tensor(rng.random((3, 2, 32, 32, 3)))
+    global_images = torch.tensor(rng.random((3, world, 32, 32, 3)))
     ref = _oracle_grads(hp, r0['start_vals'], global_images)
     gmax = max(float(v.abs().max()) for v in ref.values())
     for n, gref in ref.items():
