@@ -515,6 +515,17 @@ int savp_eval_accumulate(void* stream, const float* metric, float* vmin, float* 
 int savp_select_batch(void* stream, const int32_t* cond, const float* x, int64_t x_st, int64_t x_sb, float* out, int64_t o_st,
                       int64_t o_sb, int32_t T, int32_t B, int32_t inner, int32_t mode);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Developer / soak-test aids (debug_ops.hip; no reference counterpart, no product caller): make what a correct launch sequence must never
+ * read adversarial.  savp_debug_poison_lds fills all 160 KB of LDS of every CU with `pattern` (0xFFFFFFFF = NaN as fp32, bf16 and fp64);
+ * `sink` (one uint32 of device memory, or NULL) counts words that did not read back.  savp_debug_fill_u32 fills `words` 32-bit words of
+ * device memory (caller-owned scratch, free allocator blocks).  tests/test_gpu_soak.py, tests/conftest.py (SAVP_POISON=1).
+ * ------------------------------------------------------------------------------------------------------------ */
+int savp_debug_poison_lds(void* stream, uint32_t pattern, void* sink);
+int savp_debug_fill_u32(void* stream, void* p, int64_t words, uint32_t pattern);
+/* reads 64 KB of LDS per workgroup WITHOUT writing it: out2[0] += words equal to `pattern`, out2[1] += words read (two uint64 of device memory) */
+int savp_debug_probe_lds(void* stream, uint32_t pattern, void* out2);
+
 #ifdef __cplusplus
 }
 #endif

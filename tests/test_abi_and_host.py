@@ -389,6 +389,37 @@ def test_split_k_scratch_query_is_a_host_side_predicate(hip_lib):
     assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(big)) == 0
 
 
+def test_weight_gradient_scratch_query_is_the_launchers_own_plan(hip_lib):
+    """Deterministic weight gradients (round 6; include/savp_hip.h SavpConvArgs.ws): every pixel split of a WGRAD launch leaves its dW tiles in
+    its own slice of the caller's scratch and a fold adds the slices in split order.  savp_conv_workspace_bytes asks the SAME planner the
+    launcher runs (conv_wgrad_patch_try(plan) / wgrad_generic_plan): whole slices of taps * Cx * Cy floats, one round of 256 workgroups for
+    the LDS-patch kernel, never an empty split, a bias gradient's rows on top."""
+    from video_prediction_amd import lib
+    # the 32x32 ConvLSTM gate convolution's weight gradient over one timestep of both unrolls: 5x5, 72 -> 128, both operands bf16
+    a = _conv2d_args(lib, lib.CONV_WGRAD, 32, 32, 32, 72, 32, 32, 128, 5, 1, 2)
+    a.src_bf16 = a.out_bf16 = 1
+    nW = 25 * 72 * 128 * 4
+    need = hip_lib.savp_conv_workspace_bytes(ctypes.byref(a))
+    assert need % nW == 0 and 2 <= need // nW <= 256
+    S = need // nW
+    tiles = 32 * 4 * 4                                            # 8x8 pixel tiles: N x (32 / 8)^2
+    per = -(-tiles // S)
+    assert -(-tiles // per) == S                                  # no split is left without tiles
+    # fp32 operands + a bias gradient: each split also keeps one row of Cy floats per wave
+    b = _conv2d_args(lib, lib.CONV_WGRAD, 4, 16, 16, 32, 16, 16, 64, 3, 1, 1)
+    b.bias = 0x500000
+    need_b = hip_lib.savp_conv_workspace_bytes(ctypes.byref(b))
+    row = 9 * 32 * 64
+    assert need_b >= 2 * (row + 4 * 64) * 4                      # (at least the column-sum pass's workspace of the generic path: the larger of the two is reported)
+    # the generic kernel (forced: tile bits 8-9 = 1; exact-fp32 datapath): splitk slices of the im2col GEMM's M x Cy block
+    c = _conv2d_args(lib, lib.CONV_WGRAD, 8, 16, 16, 32, 16, 16, 64, 3, 1, 1, precision=0)
+    c.tile = 0x122
+    need_c = hip_lib.savp_conv_workspace_bytes(ctypes.byref(c))
+    assert need_c % (row * 4) == 0 and need_c // (row * 4) >= 2
+    c.splitk = 1
+    assert hip_lib.savp_conv_workspace_bytes(ctypes.byref(c)) == 0
+
+
 def test_thin_head_routing_is_a_host_side_predicate(hip_lib):
     """savp_conv_special (include/savp_hip.h): which calls the problem-specific kernels of csrc/conv_thin.hip take under tile 0 -- round 5's
     wide -> thin FPROP (scratch-image head 32 -> 4, mask convolution 56 -> 8) and the mask convolution's data gradient (56 <- 8), and the

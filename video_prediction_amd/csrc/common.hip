@@ -128,3 +128,45 @@ void splitk_fold(float* out, const float* part, int splitk, long long n, int bet
     if (vec) hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, part, splitk, n / 4, n, beta, Cd, gap_at, gap);
     else hipLaunchKernelGGL(splitk_fold_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, part, splitk, n, beta, Cd, gap_at, gap);
 }
+
+// ---- deterministic weight gradients (conv_common.h) ------------------------------------------------------------------------------------
+// dW[i] += part[0][i] + part[1][i] + ... in split order: the pixel splits of a weight-gradient launch leave their tiles in slices of the
+// caller's scratch (plain stores) instead of meeting in dW with fp32 atomics, whose arrival order changed the sum's rounding from run to run
+// (round 5: two identical bench runs forked after a few steps through the bf16 rounding of the updated weights).  Eight slices are
+// requested before the first is added: 64 slices of a 1 MB ConvLSTM kernel are 64 MB to read, and a thread that waited for every load
+// before issuing the next would be latency-bound.
+typedef float fold_f4 __attribute__((ext_vector_type(4)));
+template <bool VEC>
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(float* __restrict__ out, const float* __restrict__ part, int nsplit, long long n, long long slice) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if constexpr (VEC) {
+        fold_f4 s = reinterpret_cast<const fold_f4*>(out)[i];
+        const fold_f4* __restrict__ q = reinterpret_cast<const fold_f4*>(part) + i;
+        const long long st4 = slice >> 2;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            fold_f4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(q + (long long)(k + j) * st4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];               // split order: ((s + v0) + v1) + ...
+        }
+        for (; k < nsplit; ++k) s += __builtin_nontemporal_load(q + (long long)k * st4);
+        reinterpret_cast<fold_f4*>(out)[i] = s;
+    } else {
+        float s = out[i];
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * slice + i];
+        out[i] = s;
+    }
+}
+
+void wgrad_fold(float* out, const float* part, int nsplit, long long n, hipStream_t st, long long slice) {
+    if (nsplit < 1 || n <= 0) return;
+    if (slice <= 0) slice = n;
+    const bool vec = (n % 4 == 0) && (slice % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && ((((uintptr_t)part) & 15) == 0);
+    const long long work = vec ? n / 4 : n;
+    const unsigned blocks = (unsigned)((work + 255) / 256);
+    if (vec) hipLaunchKernelGGL(wgrad_fold_kernel<true>, dim3(blocks), dim3(256), 0, st, out, part, nsplit, work, slice);
+    else hipLaunchKernelGGL(wgrad_fold_kernel<false>, dim3(blocks), dim3(256), 0, st, out, part, nsplit, work, slice);
+}

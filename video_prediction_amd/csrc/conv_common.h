@@ -176,6 +176,8 @@ static inline void ablate_init() {}
 // (*rc = SAVP_* status); false = not applicable, the caller falls back to the generic kernel.
 bool conv_patch_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, bool forced, hipStream_t st, int* rc);
 // conv_wgrad_patch.hip: LDS patch WGRAD (2-D stride-1, bf16); same contract.
-bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc);
+bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc, long long* plan_bytes = nullptr);   // plan_bytes: only say how much scratch the call would use
+// common.hip: out[i] += part[0 * slice + i] + part[1 * slice + i] + ... (split order; slice = n when 0): the deterministic weight gradient
+void wgrad_fold(float* out, const float* part, int nsplit, long long n, hipStream_t st, long long slice = 0);
 // conv_ring.hip: LDS patch + LDS-DMA weight ring (+ fused bf16 / statistics epilogue); same contract.
 bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc, bool dry = false);

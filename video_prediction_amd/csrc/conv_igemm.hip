@@ -501,7 +501,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(ConvP p) {
         __syncthreads();
     }
 
-    float* __restrict__ dW = p.out;
+    // deterministic weight gradient (p.part): this split's tile goes to its own slice of the caller's scratch with plain stores and
+    // wgrad_fold adds the slices to dW in split order; without scratch (a C-ABI caller that passed none) the splits meet in dW atomically
+    const bool sliced = p.part != nullptr;
+    float* __restrict__ dW = sliced ? p.part + (long long)zsplit * p.part_sz : p.out;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn0 + j * 32 + l31;
@@ -511,7 +514,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (row < M) unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+                if (row < M) {
+                    if (sliced) dW[(long long)row * Nn + col] = acc[i][j][r];
+                    else unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+                }
             }
     }
 }
@@ -662,7 +668,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
         __syncthreads();
     }
 
-    float* __restrict__ dW = p.out;
+    // deterministic weight gradient (p.part): this split's tile goes to its own slice of the caller's scratch with plain stores and
+    // wgrad_fold adds the slices to dW in split order; without scratch (a C-ABI caller that passed none) the splits meet in dW atomically
+    const bool sliced = p.part != nullptr;
+    float* __restrict__ dW = sliced ? p.part + (long long)zsplit * p.part_sz : p.out;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn0 + j * 32 + l31;
@@ -672,7 +681,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (row < M) unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+                if (row < M) {
+                    if (sliced) dW[(long long)row * Nn + col] = acc[i][j][r];
+                    else unsafeAtomicAdd(dW + (long long)row * Nn + col, acc[i][j][r]);
+                }
             }
     }
 }
@@ -753,6 +765,42 @@ static bool ring_default() {
     return savp_opt(OPT_CONV_RING) != 0;
 }
 
+// Generic (im2col GEMM) weight gradient: tile shape and K splits -- ONE planner for the launcher and savp_conv_workspace_bytes.
+// `splitk` never leaves a split without K tiles (every split's slice of the scratch is then written in full).
+struct WgPlan { int wm, wn, splitk; long long M, ktiles, part_sz; bool va, vb, wbf16; };
+static bool wgrad_generic_plan(const SavpConvArgs* a, bool bf16, int wm, int wn, WgPlan& g) {
+    const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sd % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
+    const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sd % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
+    g.M = (long long)a->kd * a->kh * a->kw * a->Cx;
+    const long long Ktot = (long long)a->N * a->Do * a->Ho * a->Wo;
+    // fastdiv exactness domain: p * d < 2^40 for every (pixel index p, divisor d)
+    if (Ktot <= 0 || (double)Ktot * (double)((long long)a->Do * a->Ho * a->Wo) >= 1099511627776.0) return false;
+    g.va = (a->Cx % 4 == 0) && xs4;
+    g.vb = (a->Cy % 4 == 0) && ys4;
+    if (!wm) {
+        wm = (g.M > 64) ? 2 : 1;
+        wn = (a->Cy > 64) ? 2 : 1;
+    }
+    g.wm = wm; g.wn = wn;
+    const int BM = 64 * wm, BN = 64 * wn;
+    const long long tiles = ((g.M + BM - 1) / BM) * ((a->Cy + BN - 1) / BN);
+    g.wbf16 = bf16 && g.va && g.vb;
+    const int bkt = g.wbf16 ? 64 : BK;
+    g.ktiles = (Ktot + bkt - 1) / bkt;
+    long long splitk = a->splitk;
+    if (splitk <= 0) {
+        long long want = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU
+        long long maxs = g.ktiles / 8 > 0 ? g.ktiles / 8 : 1;     // at least 8 K-tiles per split
+        splitk = want < maxs ? want : maxs;
+    }
+    if (splitk > g.ktiles) splitk = g.ktiles;
+    if (splitk < 1) splitk = 1;
+    const long long per = (g.ktiles + splitk - 1) / splitk;
+    g.splitk = (int)((g.ktiles + per - 1) / per);                 // no empty split
+    g.part_sz = g.M * a->Cy;
+    return true;
+}
+
 extern "C" int64_t savp_conv_workspace_bytes(const SavpConvArgs* a) {
     if (!a) return 0;
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
@@ -773,9 +821,26 @@ extern "C" int64_t savp_conv_workspace_bytes(const SavpConvArgs* a) {
         return S > 1 ? S * block * (long long)sizeof(float) : 0;
     }
     if (a->mode != SAVP_CONV_WGRAD) return 0;
-    const long long thin = conv_thin_workspace_bytes(a);
-    const long long bias = a->bias ? (long long)SAVP_COLSUM_WS_FLOATS * 4 : 0;      // the separate bias-gradient pass (savp_colsum)
-    return thin > bias ? thin : bias;
+    // weight gradient: the per-split slices of the deterministic accumulation (the planner of whichever kernel savp_conv will take), the
+    // RGB-side kernel's partial sums, the separate bias-gradient pass
+    const int algo = (a->tile >> 8) & 3;
+    long long need = 0;
+    const long long thin = algo == 0 ? conv_thin_workspace_bytes(a) : 0;     // geometry only: the RGB-side kernel takes the call when it gets this much scratch
+    if (thin) need = thin;
+    else {
+        int wm = 0, wn = 0;
+        if (a->tile & 0xff) { wm = (a->tile >> 4) & 15; wn = a->tile & 15; if (wm < 1 || wm > 2 || wn < 1 || wn > 2) return 0; }
+        ConvP p;
+        p.bf16 = (a->precision == SAVP_PREC_BF16) ? 1 : 0;
+        int rc = SAVP_OK;
+        long long patch_bytes = 0;
+        WgPlan g;
+        if (algo != 1 && conv_wgrad_patch_try(p, a, nullptr, &rc, &patch_bytes)) need = patch_bytes;
+        else if (algo != 2 && wgrad_generic_plan(a, p.bf16 != 0, wm, wn, g) && g.splitk > 1) need = (long long)g.splitk * g.part_sz * (long long)sizeof(float);
+        const long long bias = a->bias ? (long long)SAVP_COLSUM_WS_FLOATS * 4 : 0;      // the separate bias-gradient pass (savp_colsum) of the generic path
+        if (bias > need) need = bias;
+    }
+    return need;
 }
 
 extern "C" int savp_conv_special(const SavpConvArgs* a) {
@@ -930,30 +995,24 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
             if (algo == 2) return SAVP_EINVAL;
         }
         if (a->src_bf16 || a->out_bf16) return SAVP_EINVAL;    // bf16 operand tensors: only the LDS-patch kernel reads them
-        const long long M = (long long)a->kd * a->kh * a->kw * a->Cx;
-        const long long Ktot = (long long)a->N * a->Do * a->Ho * a->Wo;
-        // fastdiv exactness domain: p * d < 2^40 for every (pixel index p, divisor d)
-        if (Ktot <= 0 || (double)Ktot * (double)((long long)a->Do * a->Ho * a->Wo) >= 1099511627776.0) return SAVP_EINVAL;
-        const bool va = (a->Cx % 4 == 0) && xs4;
-        const bool vb = (a->Cy % 4 == 0) && ys4;
-        if (!wm) {
-            wm = (M > 64) ? 2 : 1;
-            wn = (a->Cy > 64) ? 2 : 1;
-        }
+        WgPlan g;
+        if (!wgrad_generic_plan(a, p.bf16 != 0, wm, wn, g)) return SAVP_EINVAL;
+        wm = g.wm; wn = g.wn;
+        const long long M = g.M, ktiles = g.ktiles;
+        const bool va = g.va, vb = g.vb, wbf16 = g.wbf16;
         const int BM = 64 * wm, BN = 64 * wn;
-        const long long tiles = ((M + BM - 1) / BM) * ((a->Cy + BN - 1) / BN);
-        const bool wbf16 = p.bf16 && va && vb;
-        const int bkt = wbf16 ? 64 : BK;
-        const long long ktiles = (Ktot + bkt - 1) / bkt;
-        int splitk = a->splitk;
-        if (splitk <= 0) {
-            long long want = (512 + tiles - 1) / tiles;           // ~2 workgroups per CU
-            long long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;     // at least 8 K-tiles per split
-            splitk = (int)(want < maxs ? want : maxs);
-            if (splitk < 1) splitk = 1;
+        int splitk = g.splitk;
+        // deterministic accumulation: one slice of dW per split in the caller's scratch, folded in split order (fewer splits if it is small;
+        // no scratch at all: the splits add atomically, in arrival order)
+        p.part = nullptr; p.part_sz = g.part_sz;
+        if (splitk > 1) {
+            const int fit = splitk_fit(a, splitk, p.part_sz);
+            if (fit > 1) {
+                const long long per = (ktiles + fit - 1) / fit;
+                splitk = (int)((ktiles + per - 1) / per);
+                p.part = (float*)a->ws;
+            }
         }
-        if (splitk > ktiles) splitk = (int)ktiles;
-        if (splitk < 1) splitk = 1;
         p.splitk = splitk;
         p.tm = (int)((M + BM - 1) / BM); p.tn = (int)((a->Cy + BN - 1) / BN);
         dim3 grid((unsigned)(p.tm * p.tn * splitk), 1, 1);
@@ -966,6 +1025,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
         else if (wm == 2 && wn == 1) err = launch_wg<2, 1>(p, va, vb, grid, st);
         else if (wm == 1 && wn == 2) err = launch_wg<1, 2>(p, va, vb, grid, st);
         else err = launch_wg<1, 1>(p, va, vb, grid, st);
+        if (p.part && err == hipSuccess) {
+            wgrad_fold(p.out, p.part, splitk, p.part_sz, st);
+            err = hipGetLastError();
+        }
         if (a->bias && err == hipSuccess) {                // bias gradient: column sums of y (separate pass on this path)
             const long long px = (long long)a->Do * a->Ho * a->Wo;
             const bool joint = (a->y_sh == a->Wo * a->y_sw) && (a->Do == 1 || a->y_sd == a->Ho * a->y_sh);

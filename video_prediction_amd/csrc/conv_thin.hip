@@ -509,11 +509,12 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_kernel(ThinP p) {
         bsum.x += __shfl_xor(bsum.x, m); bsum.y += __shfl_xor(bsum.y, m);
         bsum.z += __shfl_xor(bsum.z, m); bsum.w += __shfl_xor(bsum.w, m);
     }
-    if (lane < 8) {
-        atomicAdd(bred + 4 * lane, bsum.x); atomicAdd(bred + 4 * lane + 1, bsum.y);
-        atomicAdd(bred + 4 * lane + 2, bsum.z); atomicAdd(bred + 4 * lane + 3, bsum.w);
+    for (int w = 0; w < 4; ++w) {                                  // the four waves in wave order (an LDS atomic's order is arrival order)
+        if (wave == w && lane < 8) {
+            bred[4 * lane] += bsum.x; bred[4 * lane + 1] += bsum.y; bred[4 * lane + 2] += bsum.z; bred[4 * lane + 3] += bsum.w;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     constexpr int ROW = TAPS * CX * 32 + 32;                       // floats per workspace row: dW then db
     float* __restrict__ wsr = p.ws + (long long)blockIdx.x * ROW;
     for (int e = tid; e < NT32 * 1024; e += 256) {
@@ -524,14 +525,33 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_kernel(ThinP p) {
     if (tid < 32) wsr[TAPS * CX * 32 + tid] = bred[tid];
 }
 
-// out[e] += sum over the workspace rows; grid (ceil(row / 256), G): block y sums rows y, y + G, ...
+// out[e] += sum over the workspace rows, in a fixed order: a block owns 32 consecutive elements; thread (g = tid >> 5, tid & 31) sums rows
+// g, g + 8, ... (eight loads in flight), the eight row groups are added in group order.  One writer per element: no atomics, and the
+// same bits whatever order the workgroups of the gradient kernel finished in.
 __global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ ws, int rows, int row, int ndw, float* dw, float* db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= row) return;
+    __shared__ float part[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     float s = 0.f;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += ws[(long long)r * row + e];
-    if (e < ndw) unsafeAtomicAdd(dw + e, s);
-    else if (db) unsafeAtomicAdd(db + (e - ndw), s);
+    if (e < row) {
+        int r = g;
+        for (; r + 56 < rows; r += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ws[(long long)(r + 8 * j) * row + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < rows; r += 8) s += ws[(long long)r * row + e];
+    }
+    part[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && e < row) {
+        float t = part[0][threadIdx.x];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += part[j][threadIdx.x];
+        if (e < ndw) dw[e] += t;
+        else if (db) db[e - ndw] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -676,9 +696,7 @@ bool conv_thin_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
         if (a->kd == 3) { if (a->Cx == 3) THIN_W(3, 3); else if (a->Cx == 1) THIN_W(3, 1); else THIN_W(3, 4); }
         else { if (a->Cx == 3) THIN_W(1, 3); else if (a->Cx == 1) THIN_W(1, 1); else THIN_W(1, 4); }
 #undef THIN_W
-        const int G = nwg < 16 ? nwg : 16;
-        hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((row + 255) / 256), (unsigned)G), dim3(256), 0, st,
-                           (const float*)ws, nwg, row, ndw, p.dw, p.db);
+        hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((row + 31) / 32)), dim3(256), 0, st, (const float*)ws, nwg, row, ndw, p.dw, p.db);
     } else {
         return false;
     }

@@ -57,6 +57,10 @@ struct WgP {
     int tHW, tW, PT;                   // 8x8 tiles per image (count, columns), total tiles
     unsigned long long magC4, magPW, magTaps, magTHW, magTW, magPP, magDo, magKHW;
     unsigned long long magCG, magCGl;  // divide by the channel groups of a full chunk / of the last chunk (row-group order [tap][group])
+    // deterministic accumulation (round 6): pixel split sp leaves its dW tiles in part + sp * part_sz (plain stores; the launcher adds the slices
+    // to dW in split order, wgrad_fold) and wave w its bias-gradient share in bpart + (sp * NW + w) * Cy.  part == nullptr (a C-ABI caller that
+    // passed no scratch): the splits meet in dW / db with fp32 atomics, in arrival order.
+    float* part; long long part_sz; float* bpart;
 };
 
 // issue order of the MFMA block: in front of MFMA J go the two transpose reads of MFMA J + PD (four when it opens a k-step: + B)
@@ -455,17 +459,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MTW == 4) ? 2 : 1) void wgrad_
         }
         const int c = cy0 + (lane << 2);
         if (lane < 8) {
-            if (c < q.Cy) unsafeAtomicAdd(q.db + c, bsum.x);
-            if (c + 1 < q.Cy) unsafeAtomicAdd(q.db + c + 1, bsum.y);
-            if (c + 2 < q.Cy) unsafeAtomicAdd(q.db + c + 2, bsum.z);
-            if (c + 3 < q.Cy) unsafeAtomicAdd(q.db + c + 3, bsum.w);
+            if (q.bpart) {                                     // this wave's own row of the split's bias slice
+                float* __restrict__ bp = q.bpart + ((long long)sp * NW + wave) * q.Cy;
+                if (c < q.Cy) bp[c] = bsum.x;
+                if (c + 1 < q.Cy) bp[c + 1] = bsum.y;
+                if (c + 2 < q.Cy) bp[c + 2] = bsum.z;
+                if (c + 3 < q.Cy) bp[c + 3] = bsum.w;
+            } else {
+                if (c < q.Cy) unsafeAtomicAdd(q.db + c, bsum.x);
+                if (c + 1 < q.Cy) unsafeAtomicAdd(q.db + c + 1, bsum.y);
+                if (c + 2 < q.Cy) unsafeAtomicAdd(q.db + c + 2, bsum.z);
+                if (c + 3 < q.Cy) unsafeAtomicAdd(q.db + c + 3, bsum.w);
+            }
         }
     }
     // ---- epilogue: acc[i][r] of lane (l31 = column cy, khalf) is row (r&3) + 8 (r>>2) + 4 khalf of row tile i ----------
     const int l31 = lane & 31, khalf = lane >> 5;
     const int cy = cy0 + l31;
     if (cy >= q.Cy) return;
-    float* __restrict__ dW = q.dw;
+    const bool sliced = q.part != nullptr;
+    float* __restrict__ dW = sliced ? q.part + (long long)sp * q.part_sz : q.dw;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         if (i >= nt) break;
@@ -479,7 +492,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MTW == 4) ? 2 : 1) void wgrad_
 #pragma unroll
             for (int r = 8 * hh; r < 8 * hh + 8; ++r) {
                 const int m = (r & 3) + 8 * ((r >> 2) & 1) + 4 * khalf;   // row within the 16-row group
-                if ((ca + cl) * 16 + m < q.Cx) unsafeAtomicAdd(base + (long long)m * q.Cy, acc[i][r]);
+                if ((ca + cl) * 16 + m < q.Cx) {
+                    if (sliced) base[(long long)m * q.Cy] = acc[i][r];
+                    else unsafeAtomicAdd(base + (long long)m * q.Cy, acc[i][r]);
+                }
             }
         }
     }
@@ -506,7 +522,7 @@ static hipError_t launch_wgp_dt(const WgP& q, dim3 grid, size_t lds, hipStream_t
 
 // Returns true when the call was handled (2-D / 3-D, strides <= 2 in the plane and 1 in depth, bf16 precision, channel counts % 4, <= 8 taps per side,
 // >= 64 output pixels per plane, a patch that fits the prefetch registers).
-bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc) {
+bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* rc, long long* plan_bytes) {
     const bool xs4 = (a->x_sn % 4 == 0) && (a->x_sh % 4 == 0) && (a->x_sw % 4 == 0) && aligned16(a->x);
     const bool ys4 = (a->y_sn % 4 == 0) && (a->y_sh % 4 == 0) && (a->y_sw % 4 == 0) && aligned16(a->y);
     if (!(p.bf16 && a->sd == 1 && a->x_sd % 4 == 0 && a->y_sd % 4 == 0 && a->sh <= 2 && a->sw <= 2 && a->Cx % 4 == 0 &&
@@ -569,6 +585,10 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
         if (ovs > 0) s = ovs / ((long long)NB * MC) > 0 ? ovs / ((long long)NB * MC) : 1;
     }
     if (s > q.PT) s = q.PT;
+    {   // no empty split: with per = ceil(PT / S) tiles each, ceil(PT / per) splits have work -- every slice below is written in full
+        const long long per = (q.PT + s - 1) / s;
+        s = (q.PT + per - 1) / per;
+    }
     q.S = (int)s;
     q.magC4 = magic40(cg * 4); q.magPW = magic40(q.PW); q.magTaps = magic40(q.taps);
     q.magCG = magic40(cg); q.magCGl = magic40(q.G16 - (MC - 1) * cg);
@@ -577,6 +597,22 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     if ((double)q.PT * q.tHW >= 1099511627776.0) return false;
     size_t lds = (size_t)2 * a->kd * q.PH * q.pitch * 2 + (size_t)2 * 64 * 32 * 2;
     if (lds > 160 * 1024) return false;
+    // deterministic accumulation: S slices of dW (+ S x NW rows of the bias gradient) in the caller's scratch; too little scratch for two
+    // slices (or none): atomics.  The bound handed to savp_conv_workspace_bytes is this very computation.
+    const long long nW = (long long)q.taps * a->Cx * a->Cy;
+    const long long nB = a->bias ? (long long)nw * a->Cy : 0;
+    if (plan_bytes) {
+        *plan_bytes = q.S > 1 || nB ? (long long)q.S * (nW + nB) * (long long)sizeof(float) : 0;
+        return true;
+    }
+    q.part = nullptr; q.part_sz = nW; q.bpart = nullptr;
+    if ((q.S > 1 || nB) && a->ws && !(((uintptr_t)a->ws) & 15)) {
+        const long long fit = a->ws_bytes / ((nW + nB) * (long long)sizeof(float));
+        if (fit >= q.S) {
+            q.part = (float*)a->ws;
+            if (nB) q.bpart = q.part + (long long)q.S * nW;
+        }
+    }
     // LDS-DMA staging: both operands bf16, no bias gradient, every slot of 8 channels whole and 16-byte aligned in both tensors
     const long long dma_slots = (((long long)a->kd * q.PH * q.pitch + 511) & ~511LL) / 8;
     const size_t lds_dma = (size_t)dma_slots * 8 * 2 * 2 + (size_t)2 * 64 * 32 * 2 + (size_t)256 * 32;     // two buffers + the tile descriptor table
@@ -602,6 +638,7 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
         else if (nw == 8) err = launch_wgp<8, 2, 8, true, true, true>(q, grid, lds, st);
         else if (mtw == 8) err = launch_wgp<4, 8, 8, true, true, true>(q, grid, lds, st);
         else err = launch_wgp<4, 4, 8, true, true, true>(q, grid, lds, st);
+        if (err == hipSuccess && q.part) { wgrad_fold(q.dw, q.part, q.S, nW, st); err = hipGetLastError(); }
         *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
         return true;
     }
@@ -613,6 +650,11 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
     }
     else if (mtw == 8) err = (npf <= 8) ? launch_wgp_dt<4, 8, 8>(q, grid, lds, st, x16, y16) : launch_wgp_dt<4, 8, 16>(q, grid, lds, st, x16, y16);
     else err = (npf <= 8) ? launch_wgp_dt<4, 4, 8>(q, grid, lds, st, x16, y16) : launch_wgp_dt<4, 4, 16>(q, grid, lds, st, x16, y16);
+    if (err == hipSuccess && q.part) {
+        wgrad_fold(q.dw, q.part, q.S, nW, st);
+        if (q.bpart) wgrad_fold(q.db, q.bpart, q.S * nw, a->Cy, st);
+        err = hipGetLastError();
+    }
     *rc = (err == hipSuccess) ? SAVP_OK : SAVP_ELAUNCH;
     return true;
 }

@@ -7,6 +7,7 @@ import ctypes
 
 import torch
 
+from . import debug as _debug
 from . import lib
 from .lib import (c_f32, c_i32, c_i64, c_vp, ptr)
 
@@ -48,7 +49,7 @@ def set_conv_precision(name):
     PRECISION['value'] = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
 
 
-AUTOTUNE = {'enabled': False, 'cache': {}, 'log': [], 'dist': None}
+AUTOTUNE = {'enabled': False, 'cache': {}, 'log': [], 'dist': None, 'rejected': [], 'check_all': False}
 CONV_CALL_LOG = None
 # developer aid (tests/tools/insitu_tune.py): in-step timing of the conv launches of chosen problems and their isolated candidate
 # ranking -- {'mode': 'all' | 'targets' | 'rank', 'targets': set of problem keys, 'events': [(key, e0, e1)], 'ranked': {key: [...]}}
@@ -222,6 +223,17 @@ def _tune(a, mode, dst, w, return_all=False):
         every.append((t, tile, sk))
         if t < best_t:
             best, best_t = (tile, sk), t
+    # Time alone never picks a kernel: the winner (AUTOTUNE['check_all']: every candidate) must reproduce the automatic choice's result on
+    # this very problem, else it is dropped and logged in AUTOTUNE['rejected'] (the failure dump of tests/conftest.py prints that log).
+    bad = []
+    if every and not return_all:
+        check = sorted(every) if AUTOTUNE.get('check_all') else [e for e in every if (e[1], e[2]) == best]
+        check = [e for e in check if (e[1], e[2]) != (0, 0)]
+        if check:
+            bad = _verify_candidates(a, mode, dst, w, [(t_, sk_) for _, t_, sk_ in check])
+            if best in [b[0] for b in bad]:
+                ok = [e for e in sorted(every) if (e[1], e[2]) not in [b[0] for b in bad]] if AUTOTUNE.get('check_all') else []
+                best = (ok[0][1], ok[0][2]) if ok else (0, 0)
     if mode == lib.CONV_WGRAD:
         a.w, a.bias = real_w, real_bias
     else:
@@ -232,9 +244,71 @@ def _tune(a, mode, dst, w, return_all=False):
             a.x = real_dst
         else:
             a.y = real_dst
+    a.ws, a.ws_bytes = None, 0
     if return_all:
         return sorted(every)
+    _tune.last_rejected = bad
     return best or (0, 0)
+
+
+def _verify_candidates(a, mode, dst, w, cfgs):
+    """Run the automatic choice (tile 0, split-K 0) and each (tile, splitk) of `cfgs` on identical, zero-initialised destinations of the
+    call's own addressing and compare everything the call writes (destination, statistics / norm-backward sums).  Returns
+    [((tile, splitk), reason)] for the candidates that differ by more than summation order can explain.  `a` is the argument block as
+    _tune left it (destination / statistics already redirected away from the caller's tensors); restored on return."""
+    fn, st = lib.get().savp_conv, lib.stream()
+    keep = (a.x, a.y, a.w, a.stats, a.nb_ws, a.tile, a.splitk, a.ws, a.ws_bytes, a.beta)
+    if mode == lib.CONV_WGRAD:
+        like, out_bf16 = w, False
+    else:
+        like, out_bf16 = dst, dst.dtype == torch.bfloat16
+    ext = 1 + sum((n - 1) * s_ for n, s_ in zip(like.shape, like.stride()) if n > 0)
+    nst = a.N * (a.Cx if mode == lib.CONV_DGRAD else a.Cy) * 2 if keep[3] else 0
+    nnb = a.N * a.nb_nc * 2 if keep[4] else 0
+
+    def run(cfg):
+        out = torch.zeros(ext, device=like.device, dtype=like.dtype)
+        sts = torch.zeros(max(nst, 1), device=like.device, dtype=torch.float64)
+        nbs = torch.zeros(max(nnb, 1), device=like.device, dtype=torch.float64)
+        if mode == lib.CONV_WGRAD:
+            a.w = out.data_ptr()
+        elif mode == lib.CONV_DGRAD:
+            a.x = out.data_ptr()
+        else:
+            a.y = out.data_ptr()
+        if nst:
+            a.stats = sts.data_ptr()
+        if nnb:
+            a.nb_ws = nbs.data_ptr()
+        a.tile, a.splitk = cfg
+        a.ws, a.ws_bytes = None, 0
+        if mode == lib.CONV_WGRAD or cfg[1] != 1:
+            _conv_scratch(a, like.device)
+        rc = fn(st, ctypes.byref(a))
+        return rc, out, sts, nbs
+
+    def differs(got, ref, tol):
+        g, r = got.double(), ref.double()
+        scale = float(r.abs().max())
+        err = float((g - r).abs().max()) if g.numel() else 0.0
+        if not (err <= tol * max(scale, 1e-30)):        # NaN lands here too
+            return 'max |diff| %.3g against max |ref| %.3g (tol %.1g)' % (err, scale, tol)
+        return None
+
+    bad = []
+    try:
+        rc, ref, ref_st, ref_nb = run((0, 0))
+        if rc != 0:
+            return []
+        tol = 2e-2 if out_bf16 else (1e-2 if a.precision == 1 and mode == lib.CONV_WGRAD else 2e-4)
+        for cfg in cfgs:
+            rc, out, sts, nbs = run(cfg)
+            why = 'rc %d' % rc if rc != 0 else (differs(out, ref, tol) or (nst and differs(sts, ref_st, 1e-3)) or (nnb and differs(nbs, ref_nb, 1e-3)))
+            if why:
+                bad.append((cfg, why))
+    finally:
+        a.x, a.y, a.w, a.stats, a.nb_ws, a.tile, a.splitk, a.ws, a.ws_bytes, a.beta = keep
+    return bad
 
 
 def _conv_scratch(a, device):
@@ -268,6 +342,8 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
         if cfg is None:
             dst = x if mode == lib.CONV_DGRAD else y
             cfg = _tune(a, mode, dst, w)
+            for bad_cfg, why in getattr(_tune, 'last_rejected', []):
+                AUTOTUNE['rejected'].append((key, {'cfg': list(bad_cfg), 'why': why}))
             if AUTOTUNE['dist'] is not None:
                 t = torch.tensor([int(cfg[0]), int(cfg[1])], dtype=torch.int32, device=dst.device)
                 AUTOTUNE['dist'].broadcast(t, src=0)
@@ -368,6 +444,9 @@ class Scratch(object):
             if self.buf is not None:
                 self.retired.append(self.buf)
             self.buf = torch.empty(max(n, 8 << 20), device=self.device, dtype=torch.float32)
+        if _debug.POISON['scratch']:     # developer mode: whoever reads a scratch element it has not written reads NaN
+            _debug.poison_tensor(self.buf)
+            _debug.COUNTS['scratch'] += 1
         return self.buf
 
 
@@ -404,6 +483,10 @@ class ZeroArena(object):
                 raise ValueError('zero arena too small for %d floats' % n)
             self.reset()
         v = self.buf[self.off:self.off + n]
+        if _debug.POISON['arena'] and not torch.cuda.is_current_stream_capturing():
+            _debug.COUNTS['arena'] += 1
+            if bool(v.view(torch.int32).any()):      # developer mode: "all-zero" is a contract, check it (bit pattern: -0.0 counts as dirty)
+                raise RuntimeError('zero arena: slice [%d, %d) handed out dirty' % (self.off, self.off + n))
         self.off += n
         self.hi = max(self.hi, self.off)
         return v

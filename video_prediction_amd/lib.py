@@ -9,6 +9,8 @@ import os
 
 import torch
 
+from . import debug as _debug
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SAVP_LIB') or os.path.join(_HERE, 'libsavp_hip.so')      # SAVP_LIB: developer A/B of two builds
 
@@ -54,7 +56,37 @@ def get():
         _declare(lib)
         _lib = lib
         _forward_env_options(lib)
+    if _debug.POISON['lds']:
+        return _LdsPoisonProxy(_lib)
     return _lib
+
+
+def get_raw():
+    """The library itself, never the debug proxy."""
+    lib = get()
+    return lib._lib if isinstance(lib, _LdsPoisonProxy) else lib
+
+
+class _LdsPoisonProxy(object):
+    """debug.POISON['lds']: every entry point whose first argument is the stream is preceded by savp_debug_poison_lds on that stream, so
+    each kernel of the launch sequence starts on CUs whose LDS holds NaN bit patterns."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        at = getattr(fn, 'argtypes', None)
+        if not name.startswith('savp_') or name.startswith(('savp_debug_', 'savp_prof_')) or not at or at[0] is not c_vp or \
+                name in ('savp_allreduce_bucket',):
+            return fn
+        poison = self._lib.savp_debug_poison_lds
+
+        def call(st, *args):
+            poison(st, _debug.NAN_WORD, None)
+            _debug.COUNTS['lds'] += 1
+            return fn(st, *args)
+        return call
 
 
 # Kernel-selection switches of the library (include/savp_hip.h: savp_set_option).  The library itself never reads the environment;
@@ -344,3 +376,6 @@ class SavpGruArgs(ctypes.Structure):
 for _n in ('savp_convgru_gates_fwd', 'savp_convgru_out_fwd', 'savp_convgru_out_bwd', 'savp_convgru_gates_bwd'):
     register(_n, [c_vp, ctypes.POINTER(SavpGruArgs)])
 register('savp_gan_loss', [c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
+register('savp_debug_poison_lds', [c_vp, ctypes.c_uint32, c_vp])
+register('savp_debug_fill_u32', [c_vp, c_vp, c_i64, ctypes.c_uint32])
+register('savp_debug_probe_lds', [c_vp, ctypes.c_uint32, c_vp])
