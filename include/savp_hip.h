@@ -29,7 +29,8 @@ const char* savp_version(void);
 /* Kernel-selection switches (process-wide; SAVP_EINVAL for an unknown name).  Names and defaults: "conv_ring" 0 (auto algorithm
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1, "ring_dma" 1 (problem-specific kernels / LDS-DMA patch staging of bf16 sources on), "ring_wwarm" 1 (the ring kernel's
  * workgroups pull their column tile's weight block into the XCD's L2 first), "wgp_dma" 1 (weight gradient of two bf16 operands: LDS-DMA
- * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "colsum_2stage" 1,
+ * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "gate_kernel" 1 (the ConvLSTM gate convolution's own kernel
+ * when SavpConvArgs.w_frag is given), "colsum_2stage" 1,
  * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
@@ -137,6 +138,11 @@ typedef struct SavpConvArgs {
     const float *nb_gamma, *nb_beta;                 /* [nb_nc] */
     double* nb_ws;                                   /* [N][nb_nc][2] FLOAT64 (see `stats`) */
     int32_t nb_c0, nb_nc, nb_act; float nb_alpha;    /* nb_act: 0 none, 1 relu, 2 leaky relu (nb_alpha) */
+    /* Round 6, the ConvLSTM gate convolution's own kernel (conv_gate.hip; rnn_ops.py:115-126,143): the weights once more, in MFMA B-fragment
+       order (savp_pack_gate_weights; savp_gate_weights_bytes of them, 16-byte aligned).  Given it, a 2-D 5x5 stride-1 SAME FPROP between dense
+       bf16 tensors with `stats` (bias / act / beta / aux none, Cy % 128 == 0, H == W and (H, Cx) one of the instantiated shapes) takes that
+       kernel whatever `tile` says (option "gate_kernel" 1); NULL or any other problem: the general kernels, as before. */
+    const void* w_frag;
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
@@ -192,7 +198,8 @@ typedef struct SavpInormArgs {
     float* mean; float* rstd;
     int32_t ndy; SavpView dy[4];
     SavpView dx; int32_t dx_beta;
-    float* dgamma; float* dbeta;
+    double* dgamma; double* dbeta; /* FLOAT64 accumulators [C] (8-byte aligned), atomically added to: a sum of fp32 partials is exact in float64, so the
+                                      parameter gradients do not depend on the workgroups' arrival order (round 6); the caller folds them into its fp32 gradients */
     void* ws;                      /* optional scratch [N*C*2] FLOAT64 (8-byte aligned; sums of fp32 partials are exact there, so the statistics do not
                                       depend on the workgroups' arrival order): selects the coalesced two-kernel path for planes of >= "inorm_min_hw" (64) pixels */
     int32_t ws_clean;              /* 1: the caller guarantees ws is all zero (e.g. a slice of an arena cleared once per step),
@@ -237,7 +244,7 @@ typedef struct SavpLstmArgs {
     const float* dc_new;
     float* dgates;
     float* dc_prev;
-    float *dgamma1, *dbeta1, *dgamma2, *dbeta2;
+    double *dgamma1, *dbeta1, *dgamma2, *dbeta2;   /* FLOAT64 accumulators [4F], [4F], [F], [F] (see SavpInormArgs.dgamma) */
     float* ws; int64_t ws_floats;  /* optional workspace, >= N*F*(22 + HW) floats (N*F*HW if ws_stats is given; 8-byte aligned): selects the
                                       coalesced three-pass kernels (F a power of two in [16, 256]); NULL = single fused
                                       kernel (HW <= 1024) */
@@ -359,18 +366,20 @@ int savp_conv_in_act_bwd(void* stream, const SavpConvNormArgs* a);
  * small_ops.hip: z-LSTM over all timesteps (savp_model.py:354-362), reparameterisation + KL
  * (savp_model.py:45-49,711-712; losses.py:57-60), image / GAN / feature-matching losses (losses.py:6-54).
  * Loss entries accumulate the (unweighted) loss value into *loss_out and the weighted gradient into d*.
+ * Round 6: every value that several workgroups add to -- *loss_out, *kl_out, the z-LSTM's dW / db / dc0 / dh0 -- is a FLOAT64 accumulator
+ * (8-byte aligned): fp32 partials summed in float64 are exact, so the result does not depend on the workgroups' arrival order.
  * ------------------------------------------------------------------------------------------------------------ */
 int savp_lstm_z_fwd(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates, float* cs,
                     int32_t T, int32_t B, int32_t nz, float forget_bias);
 int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
-                    const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias);
+                    const float* dh_out, float* dzs, double* dW, double* db, int32_t T, int32_t B, int32_t nz, float forget_bias);
 /* The same with a learned initial state (learn_initial_state, savp_model.py:295-307,344-352): c0 / h0 [nz] are tiled over the batch (NULL =
  * zero); bwd ADDS their gradients (what step 0 hands back, summed over the batch) to dc0 / dh0 [nz] (NULL = not wanted). */
 int savp_lstm_z_fwd_init(void* stream, const float* zs, const float* W, const float* bias, float* hout, float* gates, float* cs,
                          int32_t T, int32_t B, int32_t nz, float forget_bias, const float* c0, const float* h0);
 int savp_lstm_z_bwd_init(void* stream, const float* zs, const float* W, const float* hout, const float* gates, const float* cs,
-                         const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B, int32_t nz, float forget_bias,
-                         const float* c0, const float* h0, float* dc0, float* dh0);
+                         const float* dh_out, float* dzs, double* dW, double* db, int32_t T, int32_t B, int32_t nz, float forget_bias,
+                         const float* c0, const float* h0, double* dc0, double* dh0);
 /* BasicLSTMCell over all timesteps (recurrent encoder of posterior_fn / prior_fn, savp_model.py:31-43,66-76).
  * A [T,B,I+U]: x_t in columns [0,I) (caller), h_{t-1} in [I,I+U) (written by fwd); W [I+U,4U], gate order i,j,f,o.
  * bwd produces dG [T,B,4U] and dA [T,B,I+U] (first I columns = dL/dx); dW = A^T dG and db = colsum(dG) are the caller's GEMM. */
@@ -390,21 +399,21 @@ int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, const float*
 /* KL between two diagonal Gaussians (losses.py:61-67; learn_prior): value into *kl_out (optional), klw-weighted gradient ADDED
  * to dmu1 / dls1 / dmu2 / dls2 (all four or none); ls*_raw are the unclipped log-variances. */
 int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,
-                  const float* ls2_raw, float* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
+                  const float* ls2_raw, double* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
                   float* dls2);
 int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
-                     float* z, float* kl_out);
+                     float* z, double* kl_out);
 int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
                      const float* dz, float klw, float* dmu, float* dls_raw, const float* klw_dev);   /* klw_dev: as lr_t_dev */
 int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride, int32_t p2,
-                 const float* pred, const float* target, float weight, float* loss_out, float* dpred);
+                 const float* pred, const float* target, float weight, double* loss_out, float* dpred);
 /* type 0 LSGAN, 1 GAN (sigmoid cross-entropy), 2 SNGAN (softplus hinge-free form), losses.py:29-54 */
-int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, float* loss_out,
+int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, double* loss_out,
                   float* dlogits, int32_t beta);
-int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out, float* dlogits,
+int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, double* loss_out, float* dlogits,
                     int32_t beta);
 int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,
-                         float* loss_out, float* df0, int32_t beta);
+                         double* loss_out, float* df0, int32_t beta);
 
 /* ------------------------------------------------------------------------------------------------------------
  * weight_prep.hip: packing for the conv kernel, conv_pool2d / upsample_conv2d kernel folding (ops.py:838-842,
@@ -486,7 +495,7 @@ typedef struct SavpGruArgs {
     float* du;
     SavpView dh;
     SavpView drh;
-    float *dgamma, *dbeta;
+    double *dgamma, *dbeta;        /* FLOAT64 accumulators (see SavpInormArgs.dgamma) */
 } SavpGruArgs;
 int savp_convgru_gates_fwd(void* stream, const SavpGruArgs* a);
 int savp_convgru_out_fwd(void* stream, const SavpGruArgs* a);
@@ -514,6 +523,17 @@ int savp_eval_accumulate(void* stream, const float* metric, float* vmin, float* 
 /* base_model.py:170-171: mode 0: out[t,b,:] = cond[b] ? x[t,b,:] : out[t,b,:] ; mode 1: out[t,b,:] += x[t,b,:] */
 int savp_select_batch(void* stream, const int32_t* cond, const float* x, int64_t x_st, int64_t x_sb, float* out, int64_t o_st,
                       int64_t o_sb, int32_t T, int32_t B, int32_t inner, int32_t mode);
+
+/* Fold float64 accumulators into fp32 gradients (round 6): dst[i] += (float) src[i] ; src[i] = 0 for i in idx[0 .. n) (idx NULL: i = 0 .. n-1).
+ * The parameter gradients that many workgroups add to are accumulated in a float64 twin of the gradient arena (SavpInormArgs.dgamma, ...)
+ * and rounded to fp32 once, here, before the optimiser (base_model.py:486-510) or the gradient exchange reads them. */
+int savp_fold_f64(void* stream, const int32_t* idx, int64_t n, double* src, float* dst);
+
+/* Weights of a gate convolution in MFMA B-fragment order (conv_gate.hip): src = the HWIO fp32 master [taps][Cx][Cy] (Cx % 8 == 0, Cy % 32 == 0);
+ * out[cb][ks][lane][j] (bf16) = src[tap][ch8 * 8 + j][cb * 32 + (lane & 31)] for chunk 2 ks + (lane >> 5) = tap * (Cx / 8) + ch8, zero past the last
+ * chunk; savp_gate_weights_bytes(taps, Cx, Cy) bytes (0: shape not supported), 16-byte aligned.  Once per optimiser step, like savp_pack_weights. */
+int64_t savp_gate_weights_bytes(int32_t taps, int32_t Cx, int32_t Cy);
+int savp_pack_gate_weights(void* stream, const float* src, int32_t taps, int32_t Cx, int32_t Cy, void* out);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Developer / soak-test aids (debug_ops.hip; no reference counterpart, no product caller): make what a correct launch sequence must never

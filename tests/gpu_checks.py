@@ -992,6 +992,69 @@ def check_conv_cell(seed=21):
     return out
 
 
+def check_gate_conv_kernel(seed=67):
+    """The gate convolution's own kernel (csrc/conv_gate.hip; rnn_ops.py:115-126,143) at every instantiated (image side, input channels): bf16
+    input [x | z | h], weights in B-fragment order (pack_gate_weights), bf16 gate pre-activations + the instance norm's float64 sums -- against
+    the fp64 cross-correlation of the SAME bf16-rounded operands (so the gate is accumulation error only), against the ring kernel on the same
+    call (option gate_kernel = 0), run twice (bit-identical), and at batch sizes that leave the last 8 x 8 tile pair / column tiles full.  Also:
+    the fragment pack itself, element by element, and what savp_conv_special says."""
+    out = []
+    rng = np.random.default_rng(seed)
+    geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
+    for (N, S, Cx, F) in [(4, 32, 72, 32), (6, 16, 136, 64), (8, 8, 264, 128), (3, 32, 96, 32), (5, 16, 160, 64), (32, 16, 136, 64)]:
+        tag = 'gate_%dx%d_c%d_n%d' % (S, S, Cx, N)
+        x = (rnd(rng, N, S, S, Cx)).float().to(torch.bfloat16)
+        w = (rnd(rng, 5, 5, Cx, 4 * F) * 0.05).float()
+        wq = w.to(torch.bfloat16)
+        ref = TF.conv2d(x.double(), wq.double(), (1, 1), 'SAME')                      # fp64 on the rounded operands
+        ref_s = torch.stack([ref.sum(dim=(1, 2)), (ref ** 2).sum(dim=(1, 2))], dim=-1)
+        wd = dev(w)
+        frag = torch.empty(K.gate_weights_elems(25, Cx, 4 * F), device=DEV, dtype=torch.bfloat16)
+        K.pack_gate_weights(wd, frag)
+        # the pack, element by element: [cb][ks][lane][j] = W[tap][ch8 * 8 + j][cb * 32 + (lane & 31)], chunk 2 ks + (lane >> 5)
+        C8 = Cx // 8
+        KS = (25 * C8 + 1) // 2
+        fr = frag.float().cpu().reshape(4 * F // 32, KS, 64, 8)
+        wf = wq.float().reshape(25, Cx, 4 * F)
+        exp = torch.zeros_like(fr)
+        for ks in range(KS):
+            for half in (0, 1):
+                c = 2 * ks + half
+                if c < 25 * C8:
+                    tap, ch = divmod(c, C8)
+                    blk = wf[tap, ch * 8:ch * 8 + 8, :]                               # [8, Cy]
+                    exp[:, ks, half * 32:(half + 1) * 32, :] = blk.t().reshape(4 * F // 32, 32, 8)
+        out.append((tag + '/pack_exact', float((fr - exp).abs().max()), 0.0))
+        wt = dev(pack_wt(w.double()))
+        xd = x.to(DEV)
+        res = []
+        for rep in range(2):
+            yd = torch.full((N, S, S, 4 * F), float('nan'), device=DEV, dtype=torch.bfloat16)
+            s1 = torch.zeros(N, 4 * F, 2, device=DEV, dtype=torch.float64)
+            a = K._fill_conv_args(lib.CONV_FPROP, geom, xd, yd, wt, None, 0, 0, 0.0, None, 0, 0, 1, wt.to(torch.bfloat16), s1, None, None, frag)
+            assert lib.get().savp_conv_special(ctypes.byref(a)) == 1, tag
+            K.conv(lib.CONV_FPROP, geom, xd, yd, wt, precision=1, w16=wt.to(torch.bfloat16), stats=s1, w_frag=frag)
+            torch.cuda.synchronize()
+            res.append((yd.clone(), s1.clone()))
+        yd, s1 = res[0]
+        out.append((tag + '/gates_vs_fp64', rel_err(yd.float(), ref), 6e-3))          # bf16 rounding of the result: 2^-9 relative to the element
+        out.append((tag + '/stats_sum', rel_err(s1[..., 0], ref_s[..., 0]), 2e-5))      # the sums are taken of the fp32 accumulators
+        out.append((tag + '/stats_sumsq', rel_err(s1[..., 1], ref_s[..., 1]), 2e-5))
+        out.append((tag + '/repeat_bits', float((res[1][0].view(torch.int16) != yd.view(torch.int16)).sum() + (res[1][1] != s1).sum()), 0.0))
+        # the ring kernel on the same call
+        lib.set_option('gate_kernel', 0)
+        try:
+            yr = torch.empty_like(yd)
+            sr = torch.zeros_like(s1)
+            K.conv(lib.CONV_FPROP, geom, xd, yr, wt, precision=1, w16=wt.to(torch.bfloat16), stats=sr, w_frag=frag)
+        finally:
+            lib.set_option('gate_kernel', 1)
+        out.append((tag + '/vs_ring_gates', rel_err(yd.float(), yr.float()), 8e-3))     # both round the same fp32 sums (other order) to bf16
+        out.append((tag + '/vs_ring_stats', rel_err(s1, sr), 2e-5))
+    torch.cuda.synchronize()
+    return out
+
+
 ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_cell', check_conv_cell),
               ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
               ('lstm', check_lstm), ('util', check_util), ('dense', check_dense), ('cdna_composite', check_cdna_composite),

@@ -177,3 +177,9 @@ def test_tiled_z_gradient_and_gapped_gate_dgrad():
 def test_norm_backward_sums_from_the_dgrad_epilogue():
     from tests import gpu_checks
     _run(gpu_checks.check_norm_bwd_stats_epilogue)
+
+
+@pytest.mark.gpu
+def test_gate_convolution_kernel_vs_fp64_and_ring_kernel():
+    from tests import gpu_checks
+    _run(gpu_checks.check_gate_conv_kernel)

@@ -181,3 +181,6 @@ bool conv_wgrad_patch_try(ConvP& p, const SavpConvArgs* a, hipStream_t st, int* 
 void wgrad_fold(float* out, const float* part, int nsplit, long long n, hipStream_t st, long long slice = 0);
 // conv_ring.hip: LDS patch + LDS-DMA weight ring (+ fused bf16 / statistics epilogue); same contract.
 bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t st, int* rc, bool dry = false);
+// conv_gate.hip: the ConvLSTM gate convolution's own kernel (weights in B-fragment order, SavpConvArgs.w_frag); same contract.
+bool conv_gate_applies(const SavpConvArgs* a);
+bool conv_gate_try(const SavpConvArgs* a, hipStream_t st, int* rc);

@@ -844,8 +844,9 @@ extern "C" int64_t savp_conv_workspace_bytes(const SavpConvArgs* a) {
 }
 
 extern "C" int savp_conv_special(const SavpConvArgs* a) {
+    if (a && conv_gate_applies(a)) return 1;                     // whatever `tile` says (SavpConvArgs.w_frag)
     if (!a || ((a->tile >> 8) & 3) != 0) return 0;
-    return (conv_thin_applies(a) || conv_s2dgrad_applies(a)) ? 1 : 0;
+    return (conv_thin_applies(a) || conv_s2dgrad_applies(a) || conv_gate_applies(a)) ? 1 : 0;
 }
 
 extern "C" int savp_conv_stats_ok(const SavpConvArgs* a) {
@@ -915,6 +916,10 @@ extern "C" int savp_conv(void* stream, const SavpConvArgs* a) {
     if (algo == 0 && !gapped && !a->nb_ws && a->mode == SAVP_CONV_DGRAD) {     // 4x4 stride-2 data gradient into a 32-channel activation (conv_s2dgrad.hip)
         int rc = SAVP_OK;
         if (conv_s2dgrad_try(a, st, &rc)) return rc;
+    }
+    if (a->mode == SAVP_CONV_FPROP) {                  // the ConvLSTM gate convolution's own kernel (conv_gate.hip), given its weight pack
+        int rc = SAVP_OK;
+        if (conv_gate_try(a, st, &rc)) return rc;
     }
     if (a->mode == SAVP_CONV_FPROP || a->mode == SAVP_CONV_DGRAD) {
         const bool dg = a->mode == SAVP_CONV_DGRAD;

@@ -57,7 +57,7 @@ struct GruP {
     float* du;                                           // output bwd: d u (post-sigmoid) [N,HW,F]; gates bwd reads it
     float* dh; long long dh_sn, dh_sp;                   // accumulated (+=) gradient of h_prev
     const float* drh; long long drh_sn, drh_sp;          // gates bwd: gradient of the r*h slot
-    float *dgamma, *dbeta;
+    double *dgamma, *dbeta;            // float64 accumulators (savp_hip.h SavpGruArgs)
 };
 
 // ---- gates stage forward: IN over 2F channels (this WG: channels c0..c0+3 of r and of u) ---------------------------

@@ -98,7 +98,7 @@ struct InormP {
     int dy_c0[4], dy_c1[4];         // gradient k covers channels [dy_c0, dy_c1) of the output (default: all C)
     float* dx; long long dx_sn, dx_sp; int dx_beta;
     int dx16;                       // dx is a bf16 tensor (strides in bf16 elements; no dx_beta)
-    float* dgamma; float* dbeta;
+    double* dgamma; double* dbeta;     // float64 accumulators (savp_hip.h SavpInormArgs): sums of fp32 partials are exact there
 };
 
 __global__ __launch_bounds__(NT) void inorm_fwd_kernel(InormP p) {
@@ -461,7 +461,7 @@ struct LstmP {
     float* draw;                                          // fp32 [N,HW,4F] scratch of the raw gate gradients between the passes
     int dgates16;                                         //   (= dgates itself unless dgates16)
     float* dc_prev;                                       // [N,HW,F] contiguous or null
-    float *dg1, *db1, *dg2, *db2;
+    double *dg1, *db1, *dg2, *db2;     // float64 accumulators (savp_hip.h SavpLstmArgs)
 };
 
 __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmP p) {

@@ -70,9 +70,9 @@ __global__ void lstm_z_fwd_kernel(const float* __restrict__ zs, const float* __r
 
 __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __restrict__ W, const float* __restrict__ hout,
                                   const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dh_out,
-                                  float* __restrict__ dzs, float* __restrict__ dW, float* __restrict__ db, int T, int B, int nz,
-                                  float forget_bias, const float* __restrict__ c0, const float* __restrict__ h0, float* __restrict__ dc0,
-                                  float* __restrict__ dh0) {
+                                  float* __restrict__ dzs, double* __restrict__ dW, double* __restrict__ db, int T, int B, int nz,
+                                  float forget_bias, const float* __restrict__ c0, const float* __restrict__ h0, double* __restrict__ dc0,
+                                  double* __restrict__ dh0) {
     __shared__ float sh_dg[4 * MAXNZ], sh_x[2 * MAXNZ], sh_dh[MAXNZ];
     const int b = blockIdx.x, j = threadIdx.x;
     float dWcol[2 * MAXNZ];
@@ -145,17 +145,17 @@ extern "C" int savp_lstm_z_fwd_init(void* stream, const float* zs, const float* 
 }
 
 extern "C" int savp_lstm_z_bwd(void* stream, const float* zs, const float* W, const float* hout, const float* gates,
-                               const float* cs, const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B,
+                               const float* cs, const float* dh_out, float* dzs, double* dW, double* db, int32_t T, int32_t B,
                                int32_t nz, float forget_bias) {
     if (!zs || !W || !hout || !gates || !cs || !dh_out || !dzs || !dW || !db || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_z_bwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, hout, gates, cs, dh_out, dzs, dW,
-                       db, T, B, nz, forget_bias, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       db, T, B, nz, forget_bias, (const float*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr);
     return LAUNCH_OK();
 }
 
 extern "C" int savp_lstm_z_bwd_init(void* stream, const float* zs, const float* W, const float* hout, const float* gates,
-                                    const float* cs, const float* dh_out, float* dzs, float* dW, float* db, int32_t T, int32_t B,
-                                    int32_t nz, float forget_bias, const float* c0, const float* h0, float* dc0, float* dh0) {
+                                    const float* cs, const float* dh_out, float* dzs, double* dW, double* db, int32_t T, int32_t B,
+                                    int32_t nz, float forget_bias, const float* c0, const float* h0, double* dc0, double* dh0) {
     if (!zs || !W || !hout || !gates || !cs || !dh_out || !dzs || !dW || !db || nz < 1 || nz > MAXNZ) return SAVP_EINVAL;
     hipLaunchKernelGGL(lstm_z_bwd_kernel, dim3(B), dim3(4 * nz), 0, (hipStream_t)stream, zs, W, hout, gates, cs, dh_out, dzs, dW,
                        db, T, B, nz, forget_bias, c0, h0, dc0, dh0);
@@ -408,7 +408,7 @@ extern "C" int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, c
 // gradient tensors (the clip passes no gradient outside [-10, 10], like tf.clip_by_value).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void kl_gauss_kernel(long long n, int rows, const float* mu1, const float* ls1_raw, const float* mu2, const float* ls2_raw,
-                                float* kl_out, float klw_host, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
+                                double* kl_out, float klw_host, const float* klw_dev, float* dmu1, float* dls1, float* dmu2,
                                 float* dls2) {
     __shared__ float sh[4];
     const float klw = klw_dev ? *klw_dev : klw_host;
@@ -439,7 +439,7 @@ __global__ void kl_gauss_kernel(long long n, int rows, const float* mu1, const f
 }
 
 extern "C" int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,
-                             const float* ls2_raw, float* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1,
+                             const float* ls2_raw, double* kl_out, float klw, const float* klw_dev, float* dmu1, float* dls1,
                              float* dmu2, float* dls2) {
     if (!mu1 || !ls1_raw || !mu2 || !ls2_raw || rows < 1) return SAVP_EINVAL;
     if (dmu1 && (!dls1 || !dmu2 || !dls2)) return SAVP_EINVAL;
@@ -456,7 +456,7 @@ extern "C" int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float*
 // bwd: dmu = dz + klw*mu/rows ; dls_raw = [ls_raw in [-10,10]] * (dz*eps*0.5*exp(0.5 ls) - 0.5*klw*(1-exp(ls))/rows)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void reparam_fwd_kernel(long long n, int rows, const float* mu, const float* ls_raw, const float* eps, float* ls,
-                                   float* z, float* kl_out) {
+                                   float* z, double* kl_out) {
     __shared__ float sh[4];
     float acc = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -484,7 +484,7 @@ __global__ void reparam_bwd_kernel(long long n, int rows, const float* mu, const
 }
 
 extern "C" int savp_reparam_fwd(void* stream, int64_t n, int32_t rows, const float* mu, const float* ls_raw, const float* eps,
-                                float* ls, float* z, float* kl_out) {
+                                float* ls, float* z, double* kl_out) {
     if (!mu || !ls_raw || !eps || !ls || !z) return SAVP_EINVAL;
     unsigned nb = (unsigned)((n + NT - 1) / NT);
     if (nb > 1024) nb = 1024;
@@ -507,7 +507,7 @@ extern "C" int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const flo
 // l1 / l2 image loss: loss_out += mean(|t-p|) or mean((t-p)^2); dpred += weight * dloss/dpred  (dpred may be null)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void lp_loss_kernel(long long rows, long long row_len, long long p_rs, long long t_rs, int p2, const float* pred,
-                               const float* target, float weight, float* loss_out, float* dpred) {
+                               const float* target, float weight, double* loss_out, float* dpred) {
     __shared__ float sh[4];
     float acc = 0.f;
     const long long n = rows * row_len;
@@ -529,7 +529,7 @@ __global__ void lp_loss_kernel(long long rows, long long row_len, long long p_rs
 }
 
 extern "C" int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride,
-                            int32_t p2, const float* pred, const float* target, float weight, float* loss_out, float* dpred) {
+                            int32_t p2, const float* pred, const float* target, float weight, double* loss_out, float* dpred) {
     // pred/dpred addressed as [rows][row_len] with row stride pred_row_stride (a half of a [T,2B,...] buffer)
     if (!pred || !target || rows < 1 || row_len < 1) return SAVP_EINVAL;
     long long n = (long long)rows * row_len;
@@ -544,7 +544,7 @@ extern "C" int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t
 // constant labels; 2 SNGAN: mean softplus(l) for label 0, mean softplus(-l) for label 1.
 // loss_out += loss ; dlogits (=|+=) weight * dloss/dlogits
 __device__ __forceinline__ float softplus_(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
-__global__ void gan_loss_kernel(int n, int type, const float* logits, float label, float weight, float* loss_out, float* dlogits,
+__global__ void gan_loss_kernel(int n, int type, const float* logits, float label, float weight, double* loss_out, float* dlogits,
                                 int beta) {
     __shared__ float sh[4];
     float acc = 0.f;
@@ -572,7 +572,7 @@ __global__ void gan_loss_kernel(int n, int type, const float* logits, float labe
     if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, t / (float)n);
 }
 
-extern "C" int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, float* loss_out,
+extern "C" int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, double* loss_out,
                              float* dlogits, int32_t beta) {
     if (!logits || n < 1 || type < 0 || type > 2) return SAVP_EINVAL;
     if (type == 2 && label != 0.f && label != 1.f) return SAVP_EINVAL;
@@ -581,7 +581,7 @@ extern "C" int savp_gan_loss(void* stream, int32_t n, int32_t type, const float*
     return LAUNCH_OK();
 }
 
-extern "C" int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, float* loss_out,
+extern "C" int savp_lsgan_loss(void* stream, int32_t n, const float* logits, float label, float weight, double* loss_out,
                                float* dlogits, int32_t beta) {
     return savp_gan_loss(stream, n, 0, logits, label, weight, loss_out, dlogits, beta);
 }
@@ -592,7 +592,7 @@ extern "C" int savp_lsgan_loss(void* stream, int32_t n, const float* logits, flo
 // one wave per position.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void cosine_kernel(long long P, int C, const float* __restrict__ f0, const float* __restrict__ f1,
-                                                    float weight, float eps, float* loss_out, float* df0, int beta) {
+                                                    float weight, float eps, double* loss_out, float* df0, int beta) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float lacc = 0.f;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(NT) void cosine_kernel(long long P, int C, const fl
 // (C = 32, 655k positions) and re-reads the rows three times through dependent loops -- 224 us for 250 MB.
 template <int G>
 __global__ __launch_bounds__(NT) void cosine_vec_kernel(long long P, const float* __restrict__ f0, const float* __restrict__ f1,
-                                                        float weight, float eps, float* loss_out, float* df0, int beta) {
+                                                        float weight, float eps, double* loss_out, float* df0, int beta) {
     __shared__ float sh[4];
     constexpr int C = 4 * G, PW = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NT) void cosine_vec_kernel(long long P, const float
 }
 
 template <int G>
-static void launch_cosine_vec(hipStream_t st, long long P, const float* f0, const float* f1, float weight, float eps, float* loss_out,
+static void launch_cosine_vec(hipStream_t st, long long P, const float* f0, const float* f1, float weight, float eps, double* loss_out,
                               float* df0, int beta) {
     const long long per = 4 * (64 / G);
     unsigned nb = (unsigned)((P + per - 1) / per);
@@ -674,7 +674,7 @@ static void launch_cosine_vec(hipStream_t st, long long P, const float* f0, cons
 }
 
 extern "C" int savp_cosine_distance(void* stream, int64_t P, int32_t C, const float* f0, const float* f1, float weight, float eps,
-                                    float* loss_out, float* df0, int32_t beta) {
+                                    double* loss_out, float* df0, int32_t beta) {
     if (!f0 || !f1 || P < 1 || C < 1) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (((uintptr_t)f0 | (uintptr_t)f1 | (uintptr_t)df0) & 15) == 0;

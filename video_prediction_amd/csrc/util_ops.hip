@@ -80,7 +80,7 @@ extern "C" int savp_tile_channels(void* stream, const float* z, int64_t R, int32
 // colsum: in view [R, HW, C]; per_row: out[r*C+c] (=|+=) scale * sum_p ; else out[c] += scale * sum_{r,p} (atomic).
 // grid = (R, pixel chunks, channel blocks of 64)
 __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ in, long long sn, long long sp, int HW, int C,
-                                                    float scale, float* out, int per_row, int chunk) {
+                                                    float scale, float* out, int per_row, int chunk, float* part) {
     __shared__ float sh[NT];
     const long long r = blockIdx.x;
     const int cb = blockIdx.z * 64;
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ in
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
         float t = (sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]) * scale;
-        if (per_row) unsafeAtomicAdd(out + r * C + c, t);
+        if (part) part[r * C + c] = t;                // deterministic all-row sum: this row's partial, added up in row order by colsum_reduce_kernel
+        else if (per_row) unsafeAtomicAdd(out + r * C + c, t);
         else unsafeAtomicAdd(out + c, t);
     }
 }
@@ -173,13 +174,32 @@ __global__ __launch_bounds__(NT) void colsum_part_kernel(const float* __restrict
     if (pl == 0) *reinterpret_cast<float4*>(part + (long long)blockIdx.x * C + cv * 4) = *reinterpret_cast<const float4*>(sh + threadIdx.x * 4);
 }
 
-// out[c] += scale * sum over rows of part[row][c]; grid (ceil(C / NT), G): block y takes rows y, y + G, ...
+// out[c] += scale * sum over rows of part[row][c], in a fixed order (round 6): a block owns 32 columns; thread (g = tid >> 5, tid & 31) sums
+// rows g, g + 8, ... with eight loads in flight, the eight row groups are added in group order and ONE thread writes the column -- no
+// atomics, the same bits whatever order the partial rows were produced in.
 __global__ __launch_bounds__(NT) void colsum_reduce_kernel(const float* __restrict__ part, int rows, int C, float scale, float* out) {
-    const int c = blockIdx.x * NT + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     float s = 0.f;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += part[(long long)r * C + c];
-    unsafeAtomicAdd(out + c, s * scale);
+    if (c < C) {
+        int r = g;
+        for (; r + 56 < rows; r += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(long long)(r + 8 * j) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < rows; r += 8) s += part[(long long)r * C + c];
+    }
+    sh[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float t = sh[0][threadIdx.x];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += sh[j][threadIdx.x];
+        out[c] += t * scale;
+    }
 }
 
 extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int32_t C, float scale, float* out,
@@ -193,7 +213,7 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
     if (C <= 16 && (C & (C - 1)) == 0 && HW >= 64) {
         const int V = (C >= 4 && (al & 15) == 0) ? 4 : ((C >= 2 && (al & 7) == 0) ? 2 : 1);
         const int per_pass = NT * V / C;
-        const long long per_row_wgs = 4;
+        const long long per_row_wgs = per_row ? 1 : 4;      // per_row: ONE workgroup per row -- a single writer per output, nothing to order
         int chunk = (int)(((HW + per_row_wgs - 1) / per_row_wgs + per_pass - 1) / per_pass * per_pass);   // whole passes
         if (chunk < per_pass) chunk = per_pass;
         dim3 grid((unsigned)R, (unsigned)((HW + chunk - 1) / chunk), 1u);
@@ -218,13 +238,19 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
         static_assert(SAVP_COLSUM_WS_FLOATS >= 1024 * 4 * NT, "workspace covers nwg rows of up to 4*NT channels");
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)rows), dim3(NT), 0, st, (const float*)in.p, (long long)in.sp, P, C, chunk2, ws);
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + NT - 1) / NT), 16u), dim3(NT), 0, st, (const float*)ws, rows, C, scale, out);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + 31) / 32)), dim3(NT), 0, st, (const float*)ws, rows, C, scale, out);
         return LAUNCH_OK();
     }
-    int chunk = 256;
+    // all-row sums of everything else (dense-layer bias gradients: HW = 1, C = 8 / 100 / ...): with caller scratch, one partial row per input row
+    // (one workgroup per (row, 64 channels): plain stores) + the fixed-order reduce -- no atomics, the same bits every run; without scratch the
+    // workgroups add to `out` atomically, in arrival order
+    const bool rows_det = !per_row && ws && (((uintptr_t)ws) & 15) == 0 && (long long)R * C <= ws_floats && R <= 65536;
+    int chunk = (per_row || rows_det) ? HW : 256;          // per_row: one workgroup per (row, 64 channels) -- a single writer per output
     dim3 grid((unsigned)R, (unsigned)((HW + chunk - 1) / chunk), (unsigned)((C + 63) / 64));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)in.p, (long long)in.sn,
-                       (long long)in.sp, HW, C, scale, out, per_row, chunk);
+                       (long long)in.sp, HW, C, scale, out, per_row, chunk, rows_det ? ws : (float*)nullptr);
+    if (rows_det)
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + 31) / 32)), dim3(NT), 0, (hipStream_t)stream, (const float*)ws, (int)R, C, 1.f, out);
     return LAUNCH_OK();
 }
 
@@ -803,5 +829,24 @@ extern "C" int savp_u8_frames_to_f32(void* stream, const uint8_t* in, float* out
     unsigned gx = (unsigned)((frame / 4 + NT - 1) / NT);
     if (gx > 16) gx = 16;
     hipLaunchKernelGGL(u8_frames_kernel, dim3(gx, (unsigned)T, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, in, out, B, T, (long long)frame);
+    return LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fold float64 accumulators into fp32 gradients (round 6): dst[i] += (float) src[i] ; src[i] = 0, for the elements listed in idx (NULL: the
+// first n elements).  The parameter gradients that many workgroups add to (norm gamma / beta, biases, the z-LSTM) are accumulated in a
+// float64 twin of the gradient arena -- exact, hence independent of arrival order -- and rounded to fp32 ONCE, here.
+__global__ __launch_bounds__(NT) void fold_f64_kernel(const int* __restrict__ idx, long long n, double* __restrict__ src, float* __restrict__ dst) {
+    const long long t = (long long)blockIdx.x * NT + threadIdx.x;
+    if (t >= n) return;
+    const long long i = idx ? (long long)idx[t] : t;
+    dst[i] += (float)src[i];
+    src[i] = 0.0;
+}
+
+extern "C" int savp_fold_f64(void* stream, const int32_t* idx, int64_t n, double* src, float* dst) {
+    if (!src || !dst || n < 0) return SAVP_EINVAL;
+    if (n == 0) return SAVP_OK;
+    hipLaunchKernelGGL(fold_f64_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, (const int*)idx, (long long)n, src, dst);
     return LAUNCH_OK();
 }

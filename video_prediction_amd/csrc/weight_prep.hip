@@ -239,7 +239,7 @@ __host__ __device__ __forceinline__ double* sn_acc64(float* ws, long long K, int
 
 // y[k] = sum_c W[k,c] x[c]; one wave per row; optionally accumulates sum_k y[k]^2 into *sq and sum_k y[k]*z[k] into *dotz
 __device__ __forceinline__ void sn_rows_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                             float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx) {
+                                             float xscale, float* __restrict__ y, double* sq, const float* z, double* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sqacc = 0.f, dzacc = 0.f;
     for (long long k = bx * 4LL + wave; k < K; k += (long long)gx * 4) {
@@ -254,13 +254,13 @@ __device__ __forceinline__ void sn_rows_body(const float* __restrict__ W, long l
     }
     if (lane == 0) {
         if (sq) unsafeAtomicAdd(sq, (double)sqacc);
-        if (dotz) unsafeAtomicAdd(dotz, dzacc);
+        if (dotz) unsafeAtomicAdd(dotz, (double)dzacc);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
                                                           float xscale, float* __restrict__ y, double* sq, const float* z,
-                                                          float* dotz) {
+                                                          double* dotz) {
     sn_rows_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
 }
 
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT) void sn_gemv_rows_kernel(const float* __restric
 // channels): LPR lanes x float4 cover one row, a wave covers 64/LPR consecutive rows per pass = 1 KB of contiguous memory,
 // two passes in flight.  (The one-element-per-lane kernel above spends its time in shuffles and exposed load latency.)
 __device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                 float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx) {
+                                                 float xscale, float* __restrict__ y, double* sq, const float* z, double* dotz, int bx, int gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpr = C >> 2, rpw = 64 / lpr;
     const int c4 = lane & (lpr - 1), sub = lane / lpr;
@@ -292,13 +292,13 @@ __device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, lo
     sqacc = wsum(sqacc); dzacc = wsum(dzacc);
     if (lane == 0) {
         if (sq) unsafeAtomicAdd(sq, (double)sqacc);
-        if (dotz) unsafeAtomicAdd(dotz, dzacc);
+        if (dotz) unsafeAtomicAdd(dotz, (double)dzacc);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_vec_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
                                                               float xscale, float* __restrict__ y, double* sq, const float* z,
-                                                              float* dotz) {
+                                                              double* dotz) {
     sn_rows_vec_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x);
 }
 
@@ -309,7 +309,7 @@ static bool sn_vec_ok(const float* W, const float* x, int C) {
 
 // narrow matrices (C <= 16, e.g. the discriminators' final linear [65536, 1]): one THREAD per row
 __device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
-                                                    float xscale, float* __restrict__ y, double* sq, const float* z, float* dotz, int bx, int gx,
+                                                    float xscale, float* __restrict__ y, double* sq, const float* z, double* dotz, int bx, int gx,
                                                     float* sh) {
     float sqacc = 0.f, dzacc = 0.f;
     for (long long k = bx * (long long)NT + threadIdx.x; k < K; k += (long long)gx * NT) {
@@ -324,13 +324,13 @@ __device__ __forceinline__ void sn_rows_narrow_body(const float* __restrict__ W,
     if (threadIdx.x == 0 && sq) unsafeAtomicAdd(sq, (double)t);
     if (dotz) {
         float t2 = block_sum1(dzacc, sh);
-        if (threadIdx.x == 0) unsafeAtomicAdd(dotz, t2);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotz, (double)t2);
     }
 }
 
 __global__ __launch_bounds__(NT) void sn_gemv_rows_narrow_kernel(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
                                                                  float xscale, float* __restrict__ y, double* sq, const float* z,
-                                                                 float* dotz) {
+                                                                 double* dotz) {
     __shared__ float sh[4];
     sn_rows_narrow_body(W, K, C, x, xscale, y, sq, z, dotz, blockIdx.x, gridDim.x, sh);
 }
@@ -419,15 +419,15 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
         unsigned nbn = (unsigned)((K + NT - 1) / NT);
         if (nbn > 1024) nbn = 1024;
         hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64,
-                           (const float*)nullptr, (float*)nullptr);
+                           (const float*)nullptr, (double*)nullptr);
     } else if (sn_vec_ok(W, u, C)) {
         const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);     // rows per block pass pair
         unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
         hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64,
-                           (const float*)nullptr, (float*)nullptr);
+                           (const float*)nullptr, (double*)nullptr);
     } else {
         hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nb), dim3(NT), 0, st, W, (long long)K, C, u, 1.f, a, acc64, (const float*)nullptr,
-                           (float*)nullptr);
+                           (double*)nullptr);
     }
     if (sn_vec_ok(W, W, C)) {
         int rpb = (int)((K + 511) / 512);                    // ~512 blocks, at least one pass of the row slots
@@ -444,13 +444,14 @@ extern "C" int savp_sn_fwd(void* stream, const float* W, int64_t K, int32_t C, c
     return LAUNCH_OK();
 }
 
-// <G, W> -> ws[5]
-__global__ __launch_bounds__(NT) void sn_dot_kernel(const float* __restrict__ G, const float* __restrict__ W, long long n, float* out) {
+// <G, W> -> the backward's float64 accumulator [0] (round 6: the two dot products of the backward are summed in float64 like the forward's
+// sums -- exact, so the discriminator's weight gradients do not depend on the workgroups' arrival order)
+__global__ __launch_bounds__(NT) void sn_dot_kernel(const float* __restrict__ G, const float* __restrict__ W, long long n, double* out) {
     __shared__ float sh[4];
     float acc = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += G[i] * W[i];
     float t = block_sum1(acc, sh);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, t);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, (double)t);
 }
 
 // dW[k,c] (=|+=) G/sigma + alpha*(kappa * v_k * b_c + ga_k * u_c)
@@ -459,8 +460,9 @@ __global__ __launch_bounds__(NT) void sn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ ws, float* __restrict__ dW, int beta) {
     const float sigma = ws[0], na = ws[2], kappa = ws[4];
     const float s = na + SN_EPS;
-    const float alpha = -ws[5] / (sigma * sigma);               // dL/dsigma = -<G,W>/sigma^2
-    const float adotgv = ws[6] * kappa;                          // a . gv
+    const double* bacc = sn_acc64(const_cast<float*>(ws), K, C);   // backward accumulators: [0] = <G, W>, [1] = a . (W b)
+    const float alpha = -(float)bacc[0] / (sigma * sigma);       // dL/dsigma = -<G,W>/sigma^2
+    const float adotgv = (float)bacc[1] * kappa;                 // a . gv
     const float* b = ws + 8;
     const float* a = ws + 8 + 2 * C;
     const float* wb = a + K;                                     // W b
@@ -481,11 +483,12 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
     // ws as left by savp_sn_fwd for the same (W, u).  G = dL/dW_bar [K,C]; dW = dL/dW.
     if (!W || !u || !ws || !G || !dW) return SAVP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    savp_zero_async(ws + 5, 2 * sizeof(float), st);
+    double* bacc = sn_acc64(ws, K, C);                           // the forward's accumulators are dead: [0] = <G, W>, [1] = a . (W b)
+    savp_zero_async(bacc, 2 * sizeof(double), st);
     long long n = (long long)K * C;
     unsigned nb = (unsigned)((n + NT - 1) / NT);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(sn_dot_kernel, dim3(nb), dim3(NT), 0, st, G, W, n, ws + 5);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(nb), dim3(NT), 0, st, G, W, n, bacc);
     float* a = ws + 8 + 2 * C;
     unsigned nr = (unsigned)((K + 3) / 4);
     if (nr > 2048) nr = 2048;
@@ -494,15 +497,15 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
         unsigned nbn = (unsigned)((K + NT - 1) / NT);
         if (nbn > 1024) nbn = 1024;
         hipLaunchKernelGGL(sn_gemv_rows_narrow_kernel, dim3(nbn), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f,
-                           a + K, (double*)nullptr, (const float*)a, ws + 6);
+                           a + K, (double*)nullptr, (const float*)a, bacc + 1);
     } else if (sn_vec_ok(W, ws + 8, C)) {
         const long long passes = (K + (256 / (C >> 2)) * 2 - 1) / ((256 / (C >> 2)) * 2);
         unsigned nbv = (unsigned)(passes < 1024 ? passes : 1024);
         hipLaunchKernelGGL(sn_gemv_rows_vec_kernel, dim3(nbv), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
-                           (double*)nullptr, (const float*)a, ws + 6);
+                           (double*)nullptr, (const float*)a, bacc + 1);
     } else {
         hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(nr), dim3(NT), 0, st, W, (long long)K, C, (const float*)(ws + 8), 1.f, a + K,
-                           (double*)nullptr, (const float*)a, ws + 6);
+                           (double*)nullptr, (const float*)a, bacc + 1);
     }
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nb), dim3(NT), 0, st, G, (long long)K, C, u, (const float*)ws, dW, beta);
     return LAUNCH_OK();
@@ -522,6 +525,11 @@ struct SnBatch { int n; SnB it[SN_MAXB]; };
 __global__ __launch_bounds__(NT) void snb_zero_kernel(SnBatch b, int off, int count_plus_c) {
     const SnB& t = b.it[blockIdx.y];
     const int n = count_plus_c < 0 ? -count_plus_c : count_plus_c + t.C;          // negative: fixed count; else count + C floats
+    if (count_plus_c < 0) {                                                        // backward: its two float64 accumulators (the forward's are dead)
+        double* bacc = sn_acc64(t.ws, t.K, t.C);
+        if (threadIdx.x < 2) bacc[threadIdx.x] = 0.0;
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += NT) t.ws[off + i] = 0.f;
     if (count_plus_c >= 0) {                                                       // forward: the float64 accumulators as well
         double* acc64 = sn_acc64(t.ws, t.K, t.C);
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(NT) void snb_rows_kernel(SnBatch b, int phase) {
     float* y = phase == 0 ? a : a + t.K;
     double* sq = phase == 0 ? sn_acc64(t.ws, t.K, t.C) : nullptr;
     const float* z = phase == 0 ? nullptr : (const float*)a;
-    float* dotz = phase == 0 ? nullptr : t.ws + 6;
+    double* dotz = phase == 0 ? nullptr : sn_acc64(t.ws, t.K, t.C) + 1;
     if (t.C <= 16) {
         const int need = (int)min((t.K + NT - 1) / NT, 1024ll);
         if ((int)blockIdx.x >= need) return;
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(NT) void snb_dot_kernel(SnBatch b) {
     float acc = 0.f;
     for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) acc += t.G[i] * t.W[i];
     const float s = block_sum1(acc, sh);
-    if (threadIdx.x == 0) unsafeAtomicAdd(t.ws + 5, s);
+    if (threadIdx.x == 0) unsafeAtomicAdd(sn_acc64(t.ws, t.K, t.C), (double)s);
 }
 
 __global__ __launch_bounds__(NT) void snb_apply_kernel(SnBatch b) {
@@ -599,8 +607,9 @@ __global__ __launch_bounds__(NT) void snb_apply_kernel(SnBatch b) {
     if ((long long)blockIdx.x * NT >= total) return;
     const float sigma = ws[0], na = ws[2], kappa = ws[4];
     const float s = na + SN_EPS;
-    const float alpha = -ws[5] / (sigma * sigma);
-    const float adotgv = ws[6] * kappa;
+    const double* bacc = sn_acc64(t.ws, K, C);
+    const float alpha = -(float)bacc[0] / (sigma * sigma);
+    const float adotgv = (float)bacc[1] * kappa;
     const float* bv = ws + 8;
     const float* a = ws + 8 + 2 * C;
     const float* wb = a + K;

@@ -66,6 +66,11 @@ def poison_free_blocks(big_gb=8, small_mb=256):
         blocks.append(torch.empty(big_gb * (1 << 28), device='cuda'))
     except RuntimeError:
         pass
+    for mb in (64, 16, 4, 2, 1):                                   # the large pool's mid-sized free blocks (best fit: a 4 MB request re-uses a freed 4 MB block)
+        try:
+            blocks += [torch.empty(mb << 18, device='cuda') for _ in range(8)]
+        except RuntimeError:
+            break
     blocks += [torch.empty(1 << 17, device='cuda') for _ in range(small_mb * 2)]
     blocks += [torch.empty(1 << 8, device='cuda') for _ in range(2048)]
     for b in blocks:

@@ -71,6 +71,11 @@ class ParamGroup(object):
         self.v = self.arena.like()
         self.t = 0
         self._gviews = {}
+        # float64 twin of the gradient arena for everything that many workgroups ADD to (norm gamma / beta, the z-LSTM's kernel / bias,
+        # learned initial states): the kernels accumulate there (a sum of fp32 partials is exact in float64 -- no dependence on arrival
+        # order), fold64() rounds to fp32 once.  Only the variables somebody asked for (grad64) are folded.
+        self.g64 = torch.zeros(self.arena.size, device=device, dtype=torch.float64)
+        self._g64views, self._g64idx, self._g64names = {}, None, []
 
     def param(self, name):
         return self.arena[name]
@@ -80,6 +85,28 @@ class ParamGroup(object):
         if v is None:
             v = self._gviews[name] = self.arena.view_of(self.g, name)
         return v
+
+    def grad64(self, name):
+        """The float64 accumulator of variable `name` (same shape); its content reaches grad(name) with the next fold64()."""
+        v = self._g64views.get(name)
+        if v is None:
+            v = self._g64views[name] = self.arena.view_of(self.g64, name)
+            self._g64names.append(name)
+            self._g64idx = None
+        return v
+
+    def fold64(self):
+        """g += float(g64), g64 = 0 over the variables handed out by grad64(); call before anything reads g (Adam, the gradient exchange,
+        a test).  Safe to call repeatedly (the accumulators are cleared)."""
+        if not self._g64names:
+            return
+        if self._g64idx is None:
+            idx = []
+            for name in self._g64names:
+                off, n, _ = self.arena.offsets[name]
+                idx.append(torch.arange(off, off + n, dtype=torch.int32))
+            self._g64idx = torch.cat(idx).to(self.g.device)
+        K.fold64(self.g64, self.g, self._g64idx)
 
     def zero_grad(self):
         self.g.zero_()
@@ -133,6 +160,9 @@ class ParamStore(object):
     def grad(self, name):
         return self.groups[self.group_of[name]].grad(name)
 
+    def grad64(self, name):
+        return self.groups[self.group_of[name]].grad64(name)
+
     def names(self):
         return list(self.group_of.keys())
 
@@ -160,6 +190,8 @@ class ParamStore(object):
         return OrderedDict((n, self[n].detach().cpu().numpy().copy()) for n in self.specs)
 
     def grads_to_numpy(self):
+        for grp in self.groups.values():
+            grp.fold64()
         return OrderedDict((n, self.grad(n).detach().cpu().numpy().copy()) for n in self.specs if self.group_of[n] != 'aux')
 
 
@@ -248,6 +280,7 @@ class ConvLayer(object):
             self.u_next = torch.empty_like(self.u)
             self.dwf = torch.zeros_like(W)                # dL/dW_bar, then sn_bwd -> master grad
         self.need_wt = self.need_wd = True
+        self.wfrag = None         # enable_gate_pack(): the weights in MFMA B-fragment order for the gate convolution's own kernel (csrc/conv_gate.hip)
         self.prof = None          # list of (start, end) events when bench.py instruments this layer's forward launches
         self.ktimer = None        # kernels.KernelTimer: kernel-only duration of the same launches (ring kernel)
 
@@ -284,6 +317,16 @@ class ConvLayer(object):
             defer_pack.append(entry)
         else:
             K.pack_weights(**entry)
+        if self.wfrag is not None and b16:
+            K.pack_gate_weights(src, self.wfrag)
+
+    def enable_gate_pack(self):
+        """This layer is a ConvLSTM gate convolution (rnn_ops.py:115-126): keep its weights in B-fragment order as well, so that the bf16
+        datapath's forward takes conv_gate_kernel.  No-op for shapes that kernel has no pack for."""
+        if self.kind == 'conv' and not self.padded and not self.sn_u_name:
+            n = K.gate_weights_elems(self.taps, self.cx, self.cy)
+            if n:
+                self.wfrag = torch.empty(n, device=self.W.device, dtype=torch.bfloat16)
 
     def commit_u(self):
         """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
@@ -309,7 +352,7 @@ class ConvLayer(object):
                 return K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16, stats=stats,
                               defer=True)
             return K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats,
-                          defer=True)
+                          defer=True, w_frag=self.wfrag)
         if self.ktimer is not None:
             self.ktimer.arm()
         if self.prof is not None:
@@ -318,7 +361,7 @@ class ConvLayer(object):
         if self.kind == 'up':
             K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16, stats=stats)
         else:
-            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats)
+            K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats, w_frag=self.wfrag)
         if self.prof is not None:
             e1.record()
             self.prof.append((e0, e1))

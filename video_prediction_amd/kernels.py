@@ -103,7 +103,7 @@ def enable_autotune(flag=True):
 
 
 def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, dst_gap=None,
-                    norm_bwd=None):
+                    norm_bwd=None, w_frag=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -147,6 +147,7 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     # WGRAD: `out_bf16` says that the y (output-gradient) operand holds bf16
     a.out_bf16 = int((y if mode == lib.CONV_WGRAD else dst).dtype == torch.bfloat16)
     a.stats = stats.data_ptr() if stats is not None else None
+    a.w_frag = w_frag.data_ptr() if w_frag is not None else None     # the gate convolution's B-fragment pack (pack_gate_weights)
     taps = geom.k[0] * geom.k[1] * geom.k[2]
     if w.numel() != taps * Cx * Cy:
         raise ValueError('weight has %d elements, expected %d' % (w.numel(), taps * Cx * Cy))
@@ -206,10 +207,9 @@ def _tune(a, mode, dst, w, return_all=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for tile, sk in cands:
         a.tile, a.splitk = tile, sk
-        if mode != lib.CONV_WGRAD:
-            a.ws, a.ws_bytes = None, 0
-            if sk != 1:
-                _conv_scratch(a, dst.device)      # the split-K slices (without scratch the candidate would silently run unsplit)
+        a.ws, a.ws_bytes = None, 0
+        if mode == lib.CONV_WGRAD or sk != 1:
+            _conv_scratch(a, dst.device)      # the split-K / weight-gradient slices (without scratch the candidate would run unsplit / atomically)
         if fn(st, ctypes.byref(a)) != 0:
             continue
         t = 1e30
@@ -320,7 +320,7 @@ def _conv_scratch(a, device):
 
 
 def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
-         dst_gap=None, norm_bwd=None, defer=False):
+         dst_gap=None, norm_bwd=None, defer=False, w_frag=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
     destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] float64 (stats_ws: zeroed by the caller)
     receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only); dst_gap = (first, count):
@@ -328,10 +328,8 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     lib.require_device(w, bias, aux)
     lib.require_stats(stats, (norm_bwd or {}).get('ws'))
     lib.require_device_any(x, y)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd)
-    if mode == lib.CONV_WGRAD:           # caller-owned scratch: the RGB-side weight gradient's partial sums
-        _conv_scratch(a, w.device)
-    if AUTOTUNE['enabled'] and tile == 0 and splitk == 0:
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd, w_frag)
+    if AUTOTUNE['enabled'] and tile == 0 and splitk == 0 and not lib.get().savp_conv_special(ctypes.byref(a)):
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
         if a.dst_gap:
@@ -357,14 +355,18 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
                     INSITU['ranked'][key] = _tune(a, mode, x if mode == lib.CONV_DGRAD else y, w, return_all=True)
                     a.tile, a.splitk = cfg
             elif INSITU['mode'] == 'all' or key in INSITU['targets']:
+                if mode == lib.CONV_WGRAD or a.splitk != 1:
+                    _conv_scratch(a, w.device)     # the timed launch is the launch the step makes (split-K / weight-gradient slices included)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
                 e1.record()
                 INSITU['events'].append((key, e0, e1))
                 return
-    if mode != lib.CONV_WGRAD and a.splitk != 1:
-        _conv_scratch(a, w.device)     # split-K slices (deterministic split-K: include/savp_hip.h SavpConvArgs.ws)
+    if mode == lib.CONV_WGRAD or a.splitk != 1:
+        # caller-owned scratch, sized by the library's own planner for the (tile, splitk) just chosen: split-K slices of FPROP / DGRAD,
+        # the per-split dW slices of the deterministic weight gradient (include/savp_hip.h SavpConvArgs.ws)
+        _conv_scratch(a, w.device)
     if CONV_CALL_LOG is not None:      # profiling aid (tests/conv_shape_profile.py): launch order -> problem shape
         CONV_CALL_LOG.append((mode, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, tuple(geom.k), tuple(geom.s), a.tile, a.splitk))
     if defer:                          # the filled argument block (tile / split-K chosen) for a fused-operator entry point; nothing is launched
@@ -404,6 +406,41 @@ def view(t, any_dtype=False):
     v = lib.SavpView()
     v.p, v.sn, v.sp = t.data_ptr(), t.stride(0), sp
     return v
+
+
+class _Acc64(object):
+    """Round 6: everything several workgroups add to -- parameter gradients of the norms, the z-LSTM's dW / db, loss and KL scalars -- is a
+    FLOAT64 accumulator in the C ABI (a sum of fp32 partials is exact there, so the result does not depend on arrival order).  The engine
+    hands over float64 tensors (ParamGroup.grad64, the float64 loss buffer).  A caller that still passes float32 gets the old contract
+    ("accumulates into the tensor") through a zeroed float64 twin that is added back after the launch."""
+
+    def __init__(self, *tensors):
+        self.pairs, self.out = [], []
+        for t in tensors:
+            if t is None:
+                self.out.append(None)
+            elif t.dtype == torch.float64:
+                lib.require_stats(t)
+                self.out.append(t)
+            else:
+                lib.require_device(t)
+                d = torch.zeros(t.shape, dtype=torch.float64, device=t.device)
+                self.pairs.append((t, d))
+                self.out.append(d)
+
+    def ptr(self, i):
+        t = self.out[i]
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+    def addr(self, i):
+        t = self.out[i]
+        return t.data_ptr() if t is not None else None
+
+    def finish(self, deferred=False):
+        if deferred and self.pairs:
+            raise TypeError('a deferred (fused) launch takes float64 accumulators (ParamGroup.grad64)')
+        for t, d in self.pairs:
+            t.add_(d.to(torch.float32))
 
 
 def _hw(t):
@@ -578,10 +615,13 @@ def instnorm_act_bwd(x, gamma, beta, out0, mean, rstd, dys, dx, dgamma, dbeta, d
     a.dx = view(dx, any_dtype=True)
     a.dx_bf16 = _bf16_mask([dx])
     a.dx_beta = int(dx_beta)
-    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    acc = _Acc64(dgamma, dbeta)
+    a.dgamma, a.dbeta = acc.addr(0), acc.addr(1)
     if defer:
+        acc.finish(deferred=True)
         return a
     lib.check(lib.get().savp_instnorm_act_bwd(lib.stream(), ctypes.byref(a)), 'savp_instnorm_act_bwd')
+    acc.finish()
 
 
 def _lstm_args(gates, c_prev, g1, b1, g2, b2, stats, eps, forget_bias):
@@ -662,11 +702,14 @@ def convlstm_gates_bwd(gates, c_prev, g1, b1, g2, b2, stats, dhs, dc_new, dgates
     a.dc_new = dc_new.data_ptr() if dc_new is not None else None
     a.dgates = dgates.data_ptr()
     a.dc_prev = dc_prev.data_ptr() if dc_prev is not None else None
+    acc = _Acc64(*(dparams if not a.no_norm else ()))
     if not a.no_norm:
-        a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = [d.data_ptr() for d in dparams]
+        a.dgamma1, a.dbeta1, a.dgamma2, a.dbeta2 = [acc.addr(i) for i in range(4)]
     if defer:
+        acc.finish(deferred=True)
         return a
     lib.check(lib.get().savp_convlstm_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convlstm_gates_bwd')
+    acc.finish()
 
 
 # ---- one host call per fused operator (include/savp_hip.h, csrc/fused_ops.hip): the two halves are built with defer=True ------------------
@@ -814,6 +857,16 @@ def fill_view(out, value=0.0):
     lib.check(_L().savp_fill_view(lib.stream(), view(out), out.shape[0], _hw(out), out.shape[-1], float(value)), 'savp_fill_view')
 
 
+def fold64(src64, dst32, idx=None):
+    """dst32[i] += float(src64[i]); src64[i] = 0 for the elements listed in idx (int32 device tensor; None: all) -- ParamGroup.fold64."""
+    lib.require_device(dst32)
+    lib.require_stats(src64)
+    if idx is not None:
+        _require_i32(idx)
+    n = idx.numel() if idx is not None else src64.numel()
+    lib.check(_L().savp_fold_f64(lib.stream(), _p(idx), n, _p(src64), _p(dst32)), 'savp_fold_f64')
+
+
 def adam(p, g, m, v, lr_t, beta1, beta2, eps=1e-8, gscale=1.0, lr_t_dev=None):
     """lr_t_dev: optional 1-element device tensor that overrides lr_t (graph replays with a changing rate)."""
     lib.check(_L().savp_adam(lib.stream(), p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr_t), float(beta1), float(beta2),
@@ -918,9 +971,11 @@ def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0, ini
     T, B, nz = zs.shape
     c0, h0 = init if init is not None else (None, None)
     dc0, dh0 = dinit if dinit is not None else (None, None)
-    lib.require_device(c0, h0, dc0, dh0)
-    lib.check(_L().savp_lstm_z_bwd_init(lib.stream(), _p(zs), _p(W), _p(hout), _p(gates), _p(cs), _p(dh_out), _p(dzs), _p(dW), _p(db),
-                                        T, B, nz, float(forget_bias), _p(c0), _p(h0), _p(dc0), _p(dh0)), 'savp_lstm_z_bwd')
+    lib.require_device(c0, h0)
+    acc = _Acc64(dW, db, dc0, dh0)       # float64 accumulators (include/savp_hip.h)
+    lib.check(_L().savp_lstm_z_bwd_init(lib.stream(), _p(zs), _p(W), _p(hout), _p(gates), _p(cs), _p(dh_out), _p(dzs), acc.addr(0), acc.addr(1),
+                                        T, B, nz, float(forget_bias), _p(c0), _p(h0), acc.addr(2), acc.addr(3)), 'savp_lstm_z_bwd')
+    acc.finish()
 
 
 def gru_seq_fwd(A, A2, Wg, bg, Wc, bc, hout, ru, cand, n_in):
@@ -962,16 +1017,20 @@ def kl_gauss(mu1, ls1_raw, mu2, ls2_raw, kl_out=None, klw=0.0, klw_dev=None, gra
     rows = mu1.numel() // mu1.shape[-1]
     g = grads or (None, None, None, None)
     lib.require_device(mu1, ls1_raw, mu2, ls2_raw)
+    acc = _Acc64(kl_out)
     lib.check(_L().savp_kl_gauss(lib.stream(), mu1.numel(), rows, _p(mu1), _p(ls1_raw), _p(mu2), _p(ls2_raw),
-                                 _p(kl_out) if kl_out is not None else None, float(klw),
+                                 acc.addr(0), float(klw),
                                  _p(klw_dev) if klw_dev is not None else None, *[(_p(t) if t is not None else None) for t in g]),
               'savp_kl_gauss')
+    acc.finish()
 
 
 def reparam_fwd(mu, ls_raw, eps, ls, z, kl_out=None):
     rows = mu.numel() // mu.shape[-1]
-    lib.check(_L().savp_reparam_fwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(ls), _p(z), _p(kl_out)),
+    acc = _Acc64(kl_out)
+    lib.check(_L().savp_reparam_fwd(lib.stream(), mu.numel(), rows, _p(mu), _p(ls_raw), _p(eps), _p(ls), _p(z), acc.addr(0)),
               'savp_reparam_fwd')
+    acc.finish()
 
 
 def reparam_bwd(mu, ls_raw, eps, dz, klw, dmu, dls_raw, klw_dev=None):
@@ -987,20 +1046,26 @@ def lp_loss(pred, target, weight, loss_out=None, dpred=None, p2=False):
     assert pred[0].is_contiguous() and target[0].is_contiguous() and target.shape == pred.shape
     if dpred is not None:
         assert dpred.stride() == pred.stride()
+    acc = _Acc64(loss_out)
     lib.check(_L().savp_lp_loss(lib.stream(), rows, row_len, pred.stride(0), target.stride(0), int(p2), _p(pred), _p(target),
-                                float(weight), _p(loss_out), _p(dpred)), 'savp_lp_loss')
+                                float(weight), acc.addr(0), _p(dpred)), 'savp_lp_loss')
+    acc.finish()
 
 
 def lsgan_loss(logits, label, weight, loss_out=None, dlogits=None, beta=0):
-    lib.check(_L().savp_lsgan_loss(lib.stream(), logits.numel(), _p(logits), float(label), float(weight), _p(loss_out), _p(dlogits),
+    acc = _Acc64(loss_out)
+    lib.check(_L().savp_lsgan_loss(lib.stream(), logits.numel(), _p(logits), float(label), float(weight), acc.addr(0), _p(dlogits),
                                    int(beta)), 'savp_lsgan_loss')
+    acc.finish()
 
 
 def cosine_distance(f0, f1, weight, loss_out=None, df0=None, beta=0, eps=1e-10):
     assert f0.is_contiguous() and f1.is_contiguous()
     C = f0.shape[-1]
-    lib.check(_L().savp_cosine_distance(lib.stream(), f0.numel() // C, C, _p(f0), _p(f1), float(weight), float(eps), _p(loss_out),
+    acc = _Acc64(loss_out)
+    lib.check(_L().savp_cosine_distance(lib.stream(), f0.numel() // C, C, _p(f0), _p(f1), float(weight), float(eps), acc.addr(0),
                                         _p(df0), int(beta)), 'savp_cosine_distance')
+    acc.finish()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1029,6 +1094,21 @@ def pack_weights_batch(entries):
             it.Cx, it.Cy = src.shape[-2], src.shape[-1]
             it.T = src.numel() // (it.Cx * it.Cy)
         lib.check(_L().savp_pack_weights_batch(lib.stream(), len(part), arr), 'savp_pack_weights_batch')
+
+
+def gate_weights_elems(taps, Cx, Cy):
+    """bf16 elements of a gate convolution's B-fragment pack (0: the shape has none)."""
+    return int(lib.get().savp_gate_weights_bytes(int(taps), int(Cx), int(Cy))) // 2
+
+
+def pack_gate_weights(src, out):
+    """src HWIO fp32 [..., Cx, Cy] -> out (torch.bfloat16, gate_weights_elems elements): MFMA B-fragment order (csrc/conv_gate.hip)."""
+    lib.require_device(src)
+    Cx, Cy = src.shape[-2], src.shape[-1]
+    taps = src.numel() // (Cx * Cy)
+    if out.dtype != torch.bfloat16 or out.numel() != gate_weights_elems(taps, Cx, Cy):
+        raise ValueError('gate weight pack: expected %d bf16 elements' % gate_weights_elems(taps, Cx, Cy))
+    lib.check(_L().savp_pack_gate_weights(lib.stream(), _p(src), taps, Cx, Cy, _p(out)), 'savp_pack_gate_weights')
 
 
 def fold_pool(inp, out, k, adjoint=False):
@@ -1181,15 +1261,19 @@ def convgru_out_bwd(pre, h, gamma, beta, mean, rstd, u, dys, dpre, du, dh, dgamm
     a.ndy = len(dys)
     _set_views(a.dy, dys)
     a.dpre, a.du, a.dh = _p(dpre), _p(du), view(dh)
-    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    acc = _Acc64(dgamma, dbeta)
+    a.dgamma, a.dbeta = acc.addr(0), acc.addr(1)
     lib.check(_L().savp_convgru_out_bwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_out_bwd')
+    acc.finish()
 
 
 def convgru_gates_bwd(pre, h, gamma, beta, mean, rstd, du, drh, dpre, dh, dgamma, dbeta, eps=1e-6):
     a = _gru_args(pre, h, gamma, beta, mean, rstd, pre.shape[-1] // 2, eps)
     a.du, a.drh, a.dpre, a.dh = _p(du), view(drh), _p(dpre), view(dh)
-    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    acc = _Acc64(dgamma, dbeta)
+    a.dgamma, a.dbeta = acc.addr(0), acc.addr(1)
     lib.check(_L().savp_convgru_gates_bwd(lib.stream(), ctypes.byref(a)), 'savp_convgru_gates_bwd')
+    acc.finish()
 
 
 GAN_TYPES = {'LSGAN': 0, 'GAN': 1, 'SNGAN': 2}
@@ -1197,8 +1281,10 @@ GAN_TYPES = {'LSGAN': 0, 'GAN': 1, 'SNGAN': 2}
 
 def gan_loss(logits, label, weight, gan_loss_type='LSGAN', loss_out=None, dlogits=None, beta=0):
     """losses.gan_loss (losses.py:29-54): value accumulated into loss_out, weighted gradient into dlogits."""
+    acc = _Acc64(loss_out)
     lib.check(_L().savp_gan_loss(lib.stream(), logits.numel(), GAN_TYPES[gan_loss_type], _p(logits), float(label), float(weight),
-                                 _p(loss_out), _p(dlogits), int(beta)), 'savp_gan_loss')
+                                 acc.addr(0), _p(dlogits), int(beta)), 'savp_gan_loss')
+    acc.finish()
 
 
 # ---------------------------------------------------------------------------------------------------------------

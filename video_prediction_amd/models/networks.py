@@ -55,7 +55,7 @@ class PosteriorEncoder(object):
                 L['pre'] = torch.empty(max(M, 1), h, w, cout, device=dev)
                 L['dpre'] = torch.empty(max(M, 1), h, w, cout, device=dev) if train else None
                 L['gamma'], L['beta'] = store[s + 'InstanceNorm/gamma'], store[s + 'InstanceNorm/beta']
-                L['dgamma'], L['dbeta'] = store.grad(s + 'InstanceNorm/gamma'), store.grad(s + 'InstanceNorm/beta')
+                L['dgamma'], L['dbeta'] = store.grad64(s + 'InstanceNorm/gamma'), store.grad64(s + 'InstanceNorm/beta')   # float64 accumulators
                 L['mean'], L['rstd'] = torch.empty(max(M, 1), cout, device=dev), torch.empty(max(M, 1), cout, device=dev)
             self.layers.append(L)
             x = L['y']
@@ -110,7 +110,7 @@ class PosteriorEncoder(object):
         self.z = torch.empty(T1, B, nz, device=dev)
         self.dmu = torch.empty(T1, B, nz, device=dev) if train else None
         self.dls = torch.empty(T1, B, nz, device=dev) if train else None
-        self.kl = torch.zeros(1, device=dev)
+        self.kl = torch.zeros(1, device=dev, dtype=torch.float64)     # float64 accumulator (savp_reparam_fwd / savp_kl_gauss)
         self.convs = [L['conv'] for L in self.layers] + ([self.fc] if self.recurrent else []) + [self.mu_fc, self.ls_fc]
 
     def prep_weights(self):

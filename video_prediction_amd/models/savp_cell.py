@@ -50,7 +50,8 @@ class Act(object):
 class Norm(object):
     def __init__(self, store, scope, T1, N, C, device):
         self.gamma, self.beta = store[scope + 'gamma'], store[scope + 'beta']
-        self.dgamma, self.dbeta = store.grad(scope + 'gamma'), store.grad(scope + 'beta')
+        # float64 accumulators (ParamGroup.grad64): every (sample, channel slab) workgroup of a norm-backward launch adds to them
+        self.dgamma, self.dbeta = store.grad64(scope + 'gamma'), store.grad64(scope + 'beta')
         self.mean = torch.empty(T1, N, C, device=device)
         self.rstd = torch.empty(T1, N, C, device=device)
 
@@ -65,7 +66,7 @@ class ConcatNorm(object):
         self.sizes = [n.gamma.numel() for n in norms]
         C = sum(self.sizes)
         self.gamma, self.beta = torch.empty(C, device=device), torch.empty(C, device=device)
-        self.dgamma, self.dbeta = torch.zeros(C, device=device), torch.zeros(C, device=device)
+        self.dgamma, self.dbeta = torch.zeros(C, device=device, dtype=torch.float64), torch.zeros(C, device=device, dtype=torch.float64)
         self.mean = torch.empty(T1, N, C, device=device)
         self.rstd = torch.empty(T1, N, C, device=device)
 
@@ -79,8 +80,8 @@ class ConcatNorm(object):
     def finish(self):
         off = 0
         for n, c in zip(self.norms, self.sizes):
-            K.axpby(1.0, self.dgamma[off:off + c], 1.0, n.dgamma, n.dgamma)
-            K.axpby(1.0, self.dbeta[off:off + c], 1.0, n.dbeta, n.dbeta)
+            n.dgamma.add_(self.dgamma[off:off + c])          # float64 accumulators on both sides
+            n.dbeta.add_(self.dbeta[off:off + c])
             off += c
         self.dgamma.zero_()
         self.dbeta.zero_()
@@ -224,6 +225,8 @@ class SAVPGenerator(object):
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
                 L['rconv'] = ConvLayer(store, r + 'kernel', (r + 'bias') if self.cell_plain else None, 'conv', (5, 5), (1, 1), (2, 2))
                 if not self.cell_plain:
+                    L['rconv'].enable_gate_pack()      # the gate convolution's own kernel (bf16 datapath, csrc/conv_gate.hip)
+                if not self.cell_plain:
                     L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
                     L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
                 if self.out_norm:
@@ -355,7 +358,7 @@ class SAVPGenerator(object):
             elif self.use_rnn_z:
                 z = prefix + 'lstm_z/basic_lstm_cell/'
                 self.zW, self.zb = store[z + 'kernel'], store[z + 'bias']
-                self.dzW, self.dzb = store.grad(z + 'kernel'), store.grad(z + 'bias')
+                self.dzW, self.dzb = store.grad64(z + 'kernel'), store.grad64(z + 'bias')      # float64 accumulators (one workgroup per sample adds to them)
                 self.z_gates = torch.empty(T1, N, 4 * nz, device=dev)
                 self.z_cs = torch.empty(T1, N, nz, device=dev)
         self.gru = hp.conv_rnn == 'gru'
@@ -367,12 +370,12 @@ class SAVPGenerator(object):
         if self.learn_init:
             k = 0
 
-            def var(shape):
+            def var(shape, acc64=False):
                 nonlocal k
                 name = 'generator/initial_state_%d/initial_state' % k
                 k += 1
                 assert tuple(store[name].shape) == tuple(shape), (name, tuple(store[name].shape), shape)
-                return store[name], (store.grad(name) if g else None)
+                return store[name], ((store.grad64(name) if acc64 else store.grad(name)) if g else None)
             for L in self.layers:
                 if not L['rnn']:
                     continue
@@ -382,8 +385,8 @@ class SAVPGenerator(object):
                     L['c0'] = torch.empty((N,) + hw_f, device=dev)
                 L['h0v'], L['h0g'] = var(hw_f)
             if self.use_rnn_z:
-                self.z_c0, self.z_dc0 = var((nz,))
-                self.z_h0, self.z_dh0 = var((nz,))
+                self.z_c0, self.z_dc0 = var((nz,), acc64=True)    # savp_lstm_z_bwd_init adds to them from every sample's workgroup
+                self.z_h0, self.z_dh0 = var((nz,), acc64=True)
         # ---- merged 3x3 heads on the last decoder layer (SAVP_MERGE_HEADS=0: one launch per head, the reference's structure) ----
         # h6_scratch, h6_masks (and h6_flow / h6_dna_kernel) all read h_last through a 3x3 conv + instance norm + relu: ONE conv with
         # concatenated output channels, ONE instance norm over them, outputs routed by channel range; backward likewise.

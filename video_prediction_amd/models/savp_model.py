@@ -184,7 +184,9 @@ class SAVPEngine(object):
             self.loss_buf_size = max(16, slot + 8)
         self.d_gan = next((d['D'] for d in self.discs if d['kind'] == 'video' and not d['enc']), None)
         self.d_vae = next((d['D'] for d in self.discs if d['kind'] == 'video' and d['enc']), None)
-        self.loss_buf = torch.zeros(getattr(self, 'loss_buf_size', 16), device=self.device)
+        # loss scalars: FLOAT64 accumulators (every workgroup of a loss kernel adds its partial: exact in float64, so the value does not
+        # depend on arrival order); rounded to fp32 once in the step's bookkeeping
+        self.loss_buf = torch.zeros(getattr(self, 'loss_buf_size', 16), device=self.device, dtype=torch.float64)
         self.step = 0
         self.world = 1
         self.dp = False
@@ -524,6 +526,7 @@ class SAVPEngine(object):
                 if last_use[id(D)] == i:
                     # this network's gradients are final: exchange them on the side stream while the next discriminator runs
                     D.finish_weight_grads()
+                    store.groups['d'].fold64()             # float64 accumulators -> fp32 gradients (ParamGroup.grad64)
                     if not return_grads:
                         self._begin_allreduce('d', D.prefix)
             if return_grads:
@@ -582,6 +585,7 @@ class SAVPEngine(object):
         if hp.l2_weight:
             K.lp_loss(pred, target, hp.l2_weight, lb[-1:], dpred, p2=True)
         dzs = self.gen.backward()
+        store.groups['g'].fold64()                         # float64 accumulators of the cell's norms / z-LSTM -> fp32 gradients
         if self.nz and not return_grads:
             # the generator cell's gradients are final after BPTT: exchange them under the encoder's backward pass
             self._begin_allreduce('g', self.gen.prefix_root)
@@ -601,6 +605,7 @@ class SAVPEngine(object):
                 if c1 > 0:
                     add_views([dzs[:c1, B:]], self.dz_post[:c1])
                 self.enc.backward(self.dz_post, klw, kl_weight_dev=self.d_scal[2:3])
+        store.groups['g'].fold64()                         # ... and the encoder's
         if return_grads:
             info['g_grads'] = {n: store.grad(n).clone() for n in store.names() if store.group_of[n] == 'g'}
         self._allreduce('g')
@@ -614,6 +619,7 @@ class SAVPEngine(object):
             self._host_op(self.replicas.sync_aux)    # u vectors: bit-identical replicas (parallel.ReplicaGroup.sync_aux)
         # ---- loss bookkeeping (device scalars; base_model.py:733-852) ----------------------------------------------------------
         d_losses, g_losses = OrderedDict(), OrderedDict()
+        lb = lb.float()                            # the float64 accumulators, rounded once
         for d in discs:
             w, slot, name = d['w'], d['slot'], d['name']
             if not w:
@@ -631,7 +637,7 @@ class SAVPEngine(object):
         if hp.l2_weight:
             g_losses['gen_l2_loss'] = (lb[-1], hp.l2_weight)
         if self.nz and hp.kl_weight:
-            g_losses['gen_kl_loss'] = (self.enc.kl[0], klw)
+            g_losses['gen_kl_loss'] = (self.enc.kl.float()[0], klw)
         info['d_losses'], info['g_losses'] = d_losses, g_losses
         info['d_loss'] = sum(l * w for l, w in d_losses.values()) if d_losses else torch.zeros((), device=self.device)
         # the annealed KL weight is a device scalar here (the graph is replayed with the weight of the current step)
