@@ -175,6 +175,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='(default on one GPU; kept for older command lines)')
     ap.add_argument('--inst-steps', type=int, default=8, help='instrumented eager steps after the timed region (0: none, roofline objects empty)')
     ap.add_argument('--no-f32', action='store_true', help='skip the second object: the exact-fp32 datapath on the same workload')
+    ap.add_argument('--no-workloads', action='store_true', help='skip the `workloads` object: the other single-GPU configs (c1, c4, c5), 20 replayed steps each')
     ap.add_argument('--tuning-table', default=None, help='developer: a tuning table other than the shipped one (A/B of re-tuned entries)')
     ap.add_argument('--retune', action='store_true', help='ignore the shipped tuning table and time every conv problem again')
     ap.add_argument('--save-tuning', default=None, help='write the tuning table found during this run to this path')
@@ -245,7 +246,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def build_engine(precision):
+    def build_engine(precision, cfg=cfg, batch=None, shape=shape, seq=seq):
+        batch = batch or args.batch
         K.set_conv_precision(precision)
         K.enable_autotune(not args.no_autotune)      # tile / split-K selection happens during the warm-up steps
         # shipped table of the BASELINE workload (measured on MI355X by an earlier run of this script with --save-tuning):
@@ -253,11 +255,11 @@ def main():
         table = args.tuning_table or os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_%s.json' % precision)
         if not args.no_autotune and not args.retune and os.path.exists(table):
             K.load_tuning(table)
-        model = make_hparams(args.batch, seq, cfg['context'], cfg['over'])
-        eng = SAVPEngine(model.hparams, shape, args.batch, mode='train', seed=4, device=str(device))
+        model = make_hparams(batch, seq, cfg['context'], cfg['over'])
+        eng = SAVPEngine(model.hparams, shape, batch, mode='train', seed=4, device=str(device))
         if dist is not None:
             eng.attach_process_group(dist)
-        eng.set_images(synthetic_batch(args.batch, 1234 + rank, device, seq, shape))      # inputs resident in HBM before timing
+        eng.set_images(synthetic_batch(batch, 1234 + rank, device, seq, shape))      # inputs resident in HBM before timing
         return eng, model.hparams
 
     def timed_steps(eng, warmup, steps):
@@ -339,6 +341,8 @@ def main():
     tot_flops, tot_s, launches = 0.0, 0.0, 0
     k_flops, k_s, k_launches = 0.0, 0.0, 0
     conv_us_of = {}                               # gate conv layer -> its kernel-only durations (for the cell's kernel-only clock)
+    per_layer = {}                                # variable scope of the layer -> its mean kernel-only duration / fraction of the peak
+    gate_native = 0                               # how many of the timed layers ran the gate convolution's own kernel (csrc/conv_gate.hip)
     for layer, fl in inst:
         for e0, e1 in prof_lists[id(layer)]:
             tot_s += e0.elapsed_time(e1) * 1e-3
@@ -349,6 +353,14 @@ def main():
             k_s += us * 1e-6
             k_flops += fl
             k_launches += 1
+        if conv_us_of[id(layer)]:
+            mean_us = sum(conv_us_of[id(layer)]) / len(conv_us_of[id(layer)])
+            from video_prediction_amd import lib as _lib0
+            native = bool(getattr(layer, 'wfrag', None) is not None and args.precision == 'bf16' and _lib0.get_option('gate_kernel'))
+            gate_native += int(native)
+            per_layer[layer.kernel_name.split('/')[-3] if layer.kernel_name.count('/') >= 3 else layer.kernel_name] = {
+                'avg_us': mean_us, 'gflop': fl / 1e9, 'frac': fl / mean_us / 1e6 / PEAK_TFLOPS[args.precision],
+                'kernel': 'conv_gate_kernel' if native else ('conv_ring_kernel' if args.precision == 'bf16' else 'conv_fd_kernel')}
         ktimers[id(layer)].close()
         layer.prof = None
         layer.ktimer = None
@@ -425,7 +437,13 @@ def main():
                      'traffic_unit': ('HBM bytes per launch, mean of the 5 layers (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
                                      'read from %s -- a counter pass of the same kernel sources + tuning tables (source id %s), not collected by this '
                                      'run); algorithmic bytes: avg_algorithmic_bytes_five_layers of the same file' % (traffic_src, src_id)) if traffic is not None else traffic_note,
-                     'kernel': '%s, ConvLSTM gate conv FPROP x5 layers' % ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'),
+                     'kernel': '%s, ConvLSTM gate conv FPROP x%d layers' % (
+                         ('conv_gate_kernel (csrc/conv_gate.hip: shape-specialised, LDS patch by LDS-DMA, weights in B-fragment order straight from L2, one K slice per wave, '
+                          'bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)' + ('' if gate_native == len(per_layer) else
+                          ' on %d of the layers, conv_ring_kernel on the others' % gate_native)) if (args.precision == 'bf16' and gate_native) else
+                         ('conv_ring_kernel (LDS patch + LDS-DMA weight ring, bf16 MFMA, fused cell epilogue: bf16 gates + instance-norm statistics)'
+                          if args.precision == 'bf16' else 'conv_fd_kernel (implicit GEMM, fp32 MFMA)'), len(per_layer)),
+                     'per_layer': per_layer,
                      'launches_timed': launches, 'avg_launch_us': (tot_s / launches * 1e6) if launches else None, 'clock': clock,
                      'avg_launch_us_with_gaps': gaps_us,
                      'measured_on': '%d instrumented eager steps after the timed region' % INST_STEPS},
@@ -494,6 +512,40 @@ def main():
             K.set_conv_precision(args.precision)
         except Exception as ex:            # never lose the headline line to the second datapath
             result['f32'] = {'error': repr(ex)}
+    if world == 1 and not args.no_workloads and args.config == 'c2' and args.precision == 'bf16' and not args.eager:
+        # The other single-GPU configurations of BASELINE.json (configs[0], [3], [4] at their per-GPU batch), AFTER the headline's timed region:
+        # each a fresh engine, 3 untimed steps (untuned conv problems are timed there), then 20 steps replayed as the captured hipGraph between
+        # synchronisations -- the same clock as the headline.  Parity of these very steps at these shapes: tests/test_gpu_model.py
+        # (test_the_replayed_bench_step_is_the_eager_step_and_matches_the_golden[c4|c5], test_config_c1_...).
+        result['workloads'] = {}
+        step_tflop_of = {'c2': 0.684, 'c4': 1.004, 'c5': 4.81}
+        for name in ('c1', 'c4', 'c5'):
+            wc = CONFIGS[name]
+            try:
+                try:
+                    del engine
+                except NameError:
+                    pass
+                torch.cuda.empty_cache()
+                engw, hpw = build_engine('bf16', cfg=wc, batch=wc['batch'], shape=wc['shape'], seq=wc['seq'])
+                engw.use_graph = True
+                kw = 20
+                dtw, infow = timed_steps(engw, 3, kw)
+                obj = {'metric': 'train frames/sec, %s seq%d SAVP' % (wc['name'], wc['seq']), 'value': wc['batch'] * wc['seq'] * kw / dtw, 'unit': 'frames/s',
+                       'ms_per_step': dtw / kw * 1e3, 'steps': kw, 'warmup': 3, 'dtype': 'bf16', 'data': 'synthetic', 'n_gpus': 1,
+                       'submission': 'hipGraph replay' if (engw.graph is not None and engw.graph.segments == 1) else 'eager launches',
+                       'config': {'workload': '%s: %s, seq=%d, context=%d, nz=%d, batch=%d per GPU' % (name, wc['name'], wc['seq'], wc['context'], hpw.nz, wc['batch'])},
+                       'losses': {'d_loss': float(infow['d_loss']), 'g_loss': float(infow['g_loss'])},
+                       'conv_problems_tuned_live': len(K.AUTOTUNE['log']), 'tuner_rejected': len(K.AUTOTUNE['rejected'])}
+                if name in step_tflop_of:
+                    tfw = step_tflop_of[name] * wc['batch'] * kw / dtw
+                    obj['roofline_step'] = {'tflop_per_sequence': step_tflop_of[name], 'achieved': tfw, 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+                                            'frac': tfw / PEAK_TFLOPS['bf16']}
+                result['workloads'][name] = obj
+                del engw
+            except Exception as ex:        # never lose the headline line to an extra workload
+                result['workloads'][name] = {'error': repr(ex)}
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == 'c2':     # the CPU sample has the c2 workload's shape
             try:

@@ -30,8 +30,8 @@ const char* savp_version(void);
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1, "ring_dma" 1 (problem-specific kernels / LDS-DMA patch staging of bf16 sources on), "ring_wwarm" 1 (the ring kernel's
  * workgroups pull their column tile's weight block into the XCD's L2 first), "wgp_dma" 1 (weight gradient of two bf16 operands: LDS-DMA
  * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "gate_kernel" 1 (the ConvLSTM gate convolution's own kernel
- * when SavpConvArgs.w_frag is given), "colsum_2stage" 1,
- * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy" (0). */
+ * when SavpConvArgs.w_frag is given), "gate_wwarm" 1 (its workgroups touch their column tile's weight block into the XCD's L2 first), "colsum_2stage" 1,
+ * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy", "gate_alt" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
 
@@ -531,7 +531,8 @@ int savp_fold_f64(void* stream, const int32_t* idx, int64_t n, double* src, floa
 
 /* Weights of a gate convolution in MFMA B-fragment order (conv_gate.hip): src = the HWIO fp32 master [taps][Cx][Cy] (Cx % 8 == 0, Cy % 32 == 0);
  * out[cb][ks][lane][j] (bf16) = src[tap][ch8 * 8 + j][cb * 32 + (lane & 31)] for chunk 2 ks + (lane >> 5) = tap * (Cx / 8) + ch8, zero past the last
- * chunk; savp_gate_weights_bytes(taps, Cx, Cy) bytes (0: shape not supported), 16-byte aligned.  Once per optimiser step, like savp_pack_weights. */
+ * chunk, followed by 8 KB of zeros (the kernel's look-ahead reads past the last column block); savp_gate_weights_bytes(taps, Cx, Cy) bytes in all
+ * (0: shape not supported), 16-byte aligned.  Once per optimiser step, like savp_pack_weights. */
 int64_t savp_gate_weights_bytes(int32_t taps, int32_t Cx, int32_t Cy);
 int savp_pack_gate_weights(void* stream, const float* src, int32_t taps, int32_t Cx, int32_t Cy, void* out);
 

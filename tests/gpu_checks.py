@@ -1014,7 +1014,9 @@ def check_gate_conv_kernel(seed=67):
         # the pack, element by element: [cb][ks][lane][j] = W[tap][ch8 * 8 + j][cb * 32 + (lane & 31)], chunk 2 ks + (lane >> 5)
         C8 = Cx // 8
         KS = (25 * C8 + 1) // 2
-        fr = frag.float().cpu().reshape(4 * F // 32, KS, 64, 8)
+        npack = (4 * F // 32) * KS * 64 * 8
+        out.append((tag + '/pack_pad_zero', float(frag[npack:].float().abs().max()), 0.0))      # 8 k-steps of readable zeros behind the pack
+        fr = frag[:npack].float().cpu().reshape(4 * F // 32, KS, 64, 8)
         wf = wq.float().reshape(25, Cx, 4 * F)
         exp = torch.zeros_like(fr)
         for ks in range(KS):

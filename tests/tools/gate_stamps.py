@@ -23,8 +23,9 @@ for (S, Cx, F) in [(32, 72, 32), (16, 136, 64), (8, 264, 128)]:
     K.pack_gate_weights(w, frag)
     y = torch.empty(N, S, S, 4 * F, device='cuda', dtype=torch.bfloat16)
     st = torch.zeros(N, 4 * F, 2, device='cuda', dtype=torch.float64)
-    for opt in (1, 0):
-        lib.set_option('gate_kernel', opt)
+    for opt in (1, 2, 0):
+        lib.set_option('gate_kernel', 1 if opt else 0)
+        lib.set_option('gate_alt', 1 if opt == 2 else 0)
         run = lambda: K.conv(lib.CONV_FPROP, geom, x, y, wt, precision=1, w16=wt.to(torch.bfloat16), stats=st, w_frag=frag)
         w16 = wt.to(torch.bfloat16)
         run = lambda: K.conv(lib.CONV_FPROP, geom, x, y, wt, precision=1, w16=w16, stats=st, w_frag=frag)
@@ -38,16 +39,18 @@ for (S, Cx, F) in [(32, 72, 32), (16, 136, 64), (8, 264, 128)]:
         e1.synchronize()
         flops = 2.0 * N * S * S * 4 * F * 25 * Cx
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print(json.dumps({'shape': [S, Cx, F], 'kernel': 'gate' if opt else 'ring', 'us_back_to_back': round(us, 2), 'frac_of_2.5PF': round(flops / us / 1e6 / 2500, 3)}), flush=True)
+        print(json.dumps({'shape': [S, Cx, F], 'kernel': {1: 'gate', 2: 'gate_alt', 0: 'ring'}[opt], 'us_back_to_back': round(us, 2), 'frac_of_2.5PF': round(flops / us / 1e6 / 2500, 3)}), flush=True)
     lib.set_option('gate_kernel', 1)
-    if hasattr(L, 'savp_debug_gate_times'):
-        for blk in (0, 100):
-            L.savp_debug_gate_block(blk)
-            run()
-            torch.cuda.synchronize()
-            buf = (ctypes.c_ulonglong * 32)()
-            L.savp_debug_gate_times(buf)
-            for wv in range(4):
-                t = [buf[wv * 8 + i] for i in range(8)]
-                print(json.dumps({'shape': [S, Cx, F], 'block': blk, 'wave': wv, 'total': t[7] - t[0],
-                                  'phases': {names[i]: t[i + 1] - t[i] for i in range(7)}}), flush=True)
+    for alt in ((0, 1) if hasattr(L, 'savp_debug_gate_times') else ()):
+        lib.set_option('gate_alt', alt)
+        for blk in (100,):
+                L.savp_debug_gate_block(blk)
+                run()
+                torch.cuda.synchronize()
+                buf = (ctypes.c_ulonglong * 32)()
+                L.savp_debug_gate_times(buf)
+                for wv in range(4):
+                    t = [buf[wv * 8 + i] for i in range(8)]
+                    print(json.dumps({'shape': [S, Cx, F], 'alt': alt, 'block': blk, 'wave': wv, 'total': t[7] - t[0],
+                                      'phases': {names[i]: t[i + 1] - t[i] for i in range(7)}}), flush=True)
+    lib.set_option('gate_alt', 0)

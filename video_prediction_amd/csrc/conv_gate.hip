@@ -24,6 +24,7 @@
 #include "conv_common.h"
 #include "opts.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 extern thread_local hipEvent_t g_savp_prof_start;     // common.hip: savp_prof_arm
 extern thread_local hipEvent_t g_savp_prof_stop;
@@ -35,6 +36,7 @@ struct GateP {
     double* stats;                // [N][Cy][2] float64 sum / sum of squares (atomically added to), may be null
     const void* zero16;           // 16 zero bytes in global memory (source of halo slots)
     int N, Cy, mtiles, ntiles;
+    int wwarm;                    // touch the column tile's weight block first (option "gate_wwarm")
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_gate_zero[4] = {0u, 0u, 0u, 0u};
@@ -50,6 +52,13 @@ extern "C" int savp_debug_gate_block(int b) { return hipMemcpyToSymbol(HIP_SYMBO
 #define GT(i) do {} while (0)
 #endif
 
+// lane l copies 4 bytes from its own global address to LDS byte address lds_dst + 4 l: the L2 warm-up's "touch" (one 128-byte line per lane)
+__device__ __forceinline__ void gate_touch4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // lane l copies 16 bytes from its own global address to LDS byte address lds_dst + 16 l (as conv_ring.hip's ring_dma16)
 __device__ __forceinline__ void gate_dma16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -57,16 +66,17 @@ __device__ __forceinline__ void gate_dma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int S, int CIN, int TN, int NWN>
+template <int S, int CIN, int TM, int TN, int NWN>
 struct GateCfg {
     static constexpr int KH = 5, KW = 5, PAD = 2, TAPS = KH * KW;
-    static constexpr int KSPLIT = 4 / NWN;                      // K slices per workgroup (4 waves)
+    static constexpr int KSPLIT = 4 / NWN;                      // K slices per workgroup: the four waves are NWN column groups x KSPLIT K slices
+    static constexpr int PIX = 32 * TM;                         // pixels per workgroup tile (128 or 256)
     static constexpr int C8 = CIN / 8;                          // 8-channel chunks per pixel
     static constexpr int C8P = (C8 & 1) ? C8 : C8 + 1;          // ... in LDS (odd: conflict-free fragment reads)
     static constexpr int PXB = C8P * 16;                        // LDS bytes per pixel
     static constexpr int TC = S >= 16 ? 16 : 8;                 // tile columns
-    static constexpr int TR = 8;                                // tile rows per image
-    static constexpr int NI = 128 / (TR * TC);                  // images per tile (1, or 2 at 8 x 8)
+    static constexpr int TR = (S * S >= PIX) ? PIX / TC : S;    // tile rows per image
+    static constexpr int NI = PIX / (TR * TC);                  // images per tile
     static constexpr int PR = TR + 2 * PAD, PC = TC + 2 * PAD;  // patch rows / columns per image
     static constexpr int RPAD = (256 - (4 * PXB) % 256) % 256;
     static constexpr int RP = PC * PXB + RPAD;                  // patch row pitch: == TC * PXB (mod 256)
@@ -74,32 +84,55 @@ struct GateCfg {
     static constexpr int PATCHB = NI * IMGB;
     static constexpr int NCH = TAPS * C8;                       // chunks of the reduction
     static constexpr int KS = (NCH + 1) / 2;                    // k-steps (two chunks each)
-    static constexpr int ETABB = ((2 * KS * 4) + 15) & ~15;
-    static constexpr int NC = 32 * TN * NWN;                    // output columns per workgroup
-    static constexpr int NCP = NC + 4;                          // fp32 tile row pitch (floats)
-    static constexpr int TILEB = 128 * NCP * 4;
-    static constexpr int STATB = NI * (256 / NC) * NC * 2 * 4;  // [image][row group][column][2] fp32 partial sums
-    static constexpr int EPIB = (KSPLIT == 4 ? 2 : 1) * TILEB + STATB;
-    static constexpr int LDSB = (PATCHB + ETABB) > EPIB ? (PATCHB + ETABB) : EPIB;
+    static constexpr int KPAD = 8;                              // k-steps of look-ahead past the end that must be READABLE (weights: zero pad of the pack; table: replicas)
+    static constexpr int ETABB = ((2 * (KS + KPAD) * 4) + 15) & ~15;
+    static constexpr int NCW = 32 * TN;                         // output columns per wave
+    static constexpr int NC = NCW * NWN;                        // output columns per workgroup
+    static constexpr int TILEB = 32 * 32 * 4;                   // one MFMA tile of fp32, in the accumulator's own (register, lane) layout
+    static constexpr int XB = (KSPLIT > 1 ? TM / 2 : 0) * TN * TILEB;   // exchange buffer of one wave (round 1: half of its tiles)
+    static constexpr int TP = NC / 2 + 4;                       // bf16 staging: dwords per pixel row (16-byte aligned rows)
+    static constexpr int STGB = PIX * TP * 4;
+    static constexpr int STATB = KSPLIT * NC * 2 * 4;           // [K slice][column][2] fp32 partial sums
+    static constexpr int EPIB = (4 * XB > STGB ? 4 * XB : STGB) + STATB;
+    static constexpr int WARMB = 256;                           // landing area of the L2 warm-up's touches (never read)
+    static constexpr int LDSB = (PATCHB + ETABB + WARMB) > EPIB ? (PATCHB + ETABB + WARMB) : EPIB;
     static constexpr int TPI = NI == 1 ? (S / TR) * (S / TC) : 1;   // tiles per image
     static constexpr int PPR = PC * C8P;                        // 16-byte pieces per patch row
     static constexpr int NJ = (PPR + 63) / 64;                  // DMA instructions per patch row
-    static_assert(CIN % 8 == 0 && S % TR == 0 && S % TC == 0 && (NWN == 1 || NWN == 2 || NWN == 4) && 256 % NC == 0, "shape");
+    // A fragments: MFMA row tile i of lane (l31, khalf) sits at a0 + AOFF(i): 32 consecutive tile pixels = 32 / TC tile rows
+    static constexpr int aoff(int i) { return ((i * 32) / (TR * TC)) * IMGB + (((i * 32) % (TR * TC)) / TC) * RP; }
+    static_assert(CIN % 8 == 0 && S % TC == 0 && S % TR == 0 && (TM == 4 || TM == 8) && (TN == 1 || TN == 2) && (NWN == 1 || NWN == 2) && TR * TC * NI == PIX && 32 % TC == 0, "shape");
     static_assert(LDSB <= 160 * 1024, "LDS");
 };
 
-template <int S, int CIN, int TN, int NWN>
-__global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
+// issue order of one k-step: the TM fragment reads (+ the table read) and the TN weight loads of LATER k-steps are spread between this k-step's
+// TM x TN MFMAs.  One wave per SIMD issues in order: loads issued as a block in front of the MFMAs leave the matrix pipe idle meanwhile
+// (measured on the first version of this kernel: 47 cycles per MFMA instead of 32 with every load ablated but the A reads).
+template <int TM, int TN, int I>
+__device__ __forceinline__ void gate_sched() {
+    constexpr int M = TM * TN, ND = TM + 1, NV = TN;
+    if constexpr (I < M) {
+        constexpr int d = (ND * (I + 1)) / M - (ND * I) / M;     // LDS reads in front of MFMA I
+        constexpr int v = (NV * (I + 1)) / M - (NV * I) / M;     // global loads in front of MFMA I
+        if constexpr (d > 0) __builtin_amdgcn_sched_group_barrier(0x100, d, 0);
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x020, v, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        gate_sched<TM, TN, I + 1>();
+    }
+}
+
+template <int S, int CIN, int TM, int TN, int NWN>
+__global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160 * 1024 ? 2 : 1)) void conv_gate_kernel(GateP p) {
     GT(0);
-    using G = GateCfg<S, CIN, TN, NWN>;
-    constexpr int TM = 4;                                       // 32-pixel MFMA row tiles per wave: all 128 pixels of the tile
-    constexpr int KS = G::KS, KSPLIT = G::KSPLIT, NC = G::NC, NCP = G::NCP;
+    using G = GateCfg<S, CIN, TM, TN, NWN>;
+    constexpr int KS = G::KS, NC = G::NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     unsigned char* patch = gsm;
     unsigned* etab = reinterpret_cast<unsigned*>(gsm + G::PATCHB);          // [2 KS] byte offset of chunk c inside a pixel's 5 x 5 window
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = wave % NWN, kq = wave / NWN;
+    const int nw = wave % NWN, kq = wave / NWN;                             // this wave's column group and K slice
+    constexpr int KSPLIT = G::KSPLIT;
     const int l31 = lane & 31, khalf = lane >> 5;
 
     // ---- which tile: column tiles outermost, so that the workgroups of one column tile (same weights) share an XCD's L2 ------------------
@@ -115,6 +148,26 @@ __global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
         img0 = mt * G::NI; ty0 = 0; tx0 = 0;
     }
 
+    // ---- L2 warm-up of this column tile's weight block (as conv_ring_kernel's ring_wwarm).  Inside the train step the pack is cold (each layer's
+    //      weights are read once per time step, hundreds of MB of other traffic in between) and the main loop streams it with four k-steps of
+    //      look-ahead: latency-bound on every miss.  The workgroups of a column tile on one XCD (consecutive logical ids, one private L2) split
+    //      the block and touch their share -- one 128-byte line per lane, 8 KB per wave instruction, everything in flight at once, under the
+    //      patch staging.  Measured in the step (profiles/r06_gate_kernel.md): the 8 x 8 layer (6.8 MB of weights) 27.4 -> ... us.
+    if (p.wwarm) {
+        const int nwg = p.mtiles * p.ntiles, qx = nwg >> 3, rx = nwg & 7, xcd = (int)blockIdx.x & 7;
+        const int first = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
+        const int cnt = qx + (xcd < rx ? 1 : 0);
+        const int l_lo = max(first, nt * p.mtiles), l_hi = min(first + cnt, (nt + 1) * p.mtiles);
+        const int share = max(l_hi - l_lo, 1), mine = min(max(logical - l_lo, 0), share - 1);
+        constexpr int BLK = TN * NWN * KS * 1024;                                     // bytes of the column tile's block (contiguous in the pack)
+        const int chunk = ((BLK + share - 1) / share + 8191) & ~8191;           // bytes per workgroup, whole wave instructions
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.wfrag) + (size_t)(n0 / 32) * KS * 1024;
+        const unsigned warm_lds = (unsigned)(uintptr_t)(gsm + G::PATCHB + G::ETABB);
+        for (int off = wave * 8192; off < chunk && mine * chunk + off < BLK; off += 4 * 8192) {
+            const int a = min(mine * chunk + off + lane * 128, BLK - 4);
+            gate_touch4(wb + a, warm_lds);
+        }
+    }
     // ---- input patch by LDS-DMA: a wave takes whole patch rows; what depends on the lane is the same for every row -------------------------
     {
         const unsigned patch_lds = (unsigned)(uintptr_t)patch;
@@ -146,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
     }
     GT(1);
     // ---- chunk table: chunk c = (tap, 8-channel chunk) -> byte offset inside a pixel's window (chunks past the end: weights are zero) ---------
-    for (int c = tid; c < 2 * KS; c += 256) {
+    for (int c = tid; c < 2 * (KS + G::KPAD); c += 256) {
         const int cc = c < G::NCH ? c : 0;
         const int tap = cc / G::C8, ch = cc - tap * G::C8;
         etab[c] = (unsigned)((tap / G::KW) * G::RP + (tap % G::KW) * G::PXB + ch * 16);
@@ -154,25 +207,26 @@ __global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
 
     // ---- this wave's K slice and its B stream ---------------------------------------------------------------------------------------------------
     constexpr int KSW = (KS + KSPLIT - 1) / KSPLIT;
-    const int ks0 = kq * KSW, ks1 = min(KS, ks0 + KSW);
+    const int ks0 = kq * KSW, ks1 = min(KS, ks0 + KSW);          // (KS >= 4 * 3: every slice has work)
     const uint4* __restrict__ bsrc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bsrc[j] = p.wfrag + ((long long)(n0 / 32 + nw * TN + j) * KS) * 64 + lane;
+#ifdef SAVP_GATE_PF
+    constexpr int PF = SAVP_GATE_PF;
+#else
     constexpr int PF = 4;                                       // k-steps of B look-ahead
+#endif
+#ifndef SAVP_GATE_ABL
+#define SAVP_GATE_ABL 0                                         // developer timing builds (wrong results): 1 = no B loads in the loop, 2 = no A loads, 4 = no MFMAs
+#endif
     uint4 bq[PF][TN];
 #pragma unroll
     for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bq[u][j] = bsrc[j][(long long)min(ks0 + u, ks1 - 1) * 64];
+        for (int j = 0; j < TN; ++j) bq[u][j] = bsrc[j][(long long)(ks0 + u) * 64];      // (past the slice: the next slice's / the pack's zero pad, never used)
 
-    // ---- A addressing: MFMA row r of row tile i is tile pixel i * 32 + r = (image, tile row, tile column) -----------------------------------------
-    unsigned abase[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int pix = i * 32 + l31;
-        const int im = pix / (G::TR * G::TC), rr = pix - im * (G::TR * G::TC);
-        abase[i] = (unsigned)(im * G::IMGB + (rr / G::TC) * G::RP + (rr % G::TC) * G::PXB);
-    }
+    // ---- A addressing: lane (l31, khalf) of row tile i reads its pixel's window at a0 + aoff(i) + chunk offset --------------------------------------
+    const unsigned a0 = (unsigned)((l31 / G::TC) * G::RP + (l31 % G::TC) * G::PXB);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -186,141 +240,194 @@ __global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
     __syncthreads();                                            // patch + table visible to every wave
     GT(3);
 
-    // ---- main loop: no barrier, no LDS write; A fragments one k-step ahead, B fragments PF k-steps ahead ---------------------------------------
+    // ---- main loop: no barrier, no LDS write; A fragments one k-step ahead, B fragments PF k-steps ahead, chunk offsets two ahead -----------------
     bf16x8 af[2][TM];
-    // the chunk offset of k-step k + 1 is read from the table one step before the A loads that use it (a wave issues in order: an LDS round trip
-    // between the table read and the fragment reads would sit in front of the k-step's MFMAs and idle the matrix pipe)
     auto load_a = [&](bf16x8 (&dst)[TM], unsigned off) {
+        const unsigned char* a = patch + a0 + off;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(patch + abase[i] + off);
+        for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(a + G::aoff(i));
     };
     const unsigned* etl = etab + khalf;
-    unsigned off_next = 0;
-    if (ks0 < ks1) {
-        load_a(af[0], etl[2 * ks0]);
-        off_next = etl[2 * min(ks0 + 1, ks1 - 1)];
-    }
-    for (int ks = ks0; ks < ks1; ks += PF) {
+    load_a(af[0], etl[2 * ks0]);
+    unsigned off_next = etl[2 * (ks0 + 1)];
+    // one k-step: no conditionals, no index clamps -- what is fetched past the end of the slice (the next slice's fragments, the zero pad behind
+    // the pack, the table's replicas) is valid memory and never used.  Every scalar instruction between two MFMAs takes an issue slot of the
+    // wave's single in-order stream (MI355X guide: about five besides the MFMA are free).
+    auto kstep = [&](int k, auto uc, auto steadyc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool STEADY = decltype(steadyc)::value;
+        if (!(SAVP_GATE_ABL & 2)) {
+            load_a(af[(u + 1) & 1], off_next);
+            off_next = etl[2 * (k + 2)];
+        }
+        bf16x8 bf[TN];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int k = ks + u;
-            if (k < ks1) {
-                if (k + 1 < ks1) {
-                    load_a(af[(u + 1) & 1], off_next);
-                    off_next = etl[2 * min(k + 2, ks1 - 1)];
-                }
-                bf16x8 bf[TN];
+        for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, bq[u % PF][j]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, bq[u][j]);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][i], bf[j], acc[i][j], 0, 0, 0);
-                if (k + PF < ks1) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bq[u][j] = bsrc[j][(long long)(k + PF) * 64];
-                }
+            for (int j = 0; j < TN; ++j) {
+                if (!(SAVP_GATE_ABL & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][i], bf[j], acc[i][j], 0, 0, 0);
+                else asm volatile("" :: "v"(af[u & 1][i]), "v"(bf[j]));
             }
+        if (!(SAVP_GATE_ABL & 1)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[u % PF][j] = bsrc[j][(long long)(k + PF) * 64];
+        }
+        if constexpr (STEADY) gate_sched<TM, TN, 0>();
+    };
+    using U0 = std::integral_constant<int, 0>; using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>; using U3 = std::integral_constant<int, 3>;
+    static_assert(PF == 4 || PF == 2 || PF == 8, "the loop is unrolled four k-steps");
+    int k = ks0;
+    if constexpr (PF == 4 || PF == 2 || PF == 8) {
+        for (; k + 4 <= ks1; k += 4) {
+            kstep(k, U0{}, std::true_type{});
+            kstep(k + 1, U1{}, std::true_type{});
+            kstep(k + 2, U2{}, std::true_type{});
+            kstep(k + 3, U3{}, std::true_type{});
         }
     }
-
+    // the last one to three k-steps of the slice
+    if (k < ks1) { kstep(k, U0{}, std::false_type{}); ++k; }
+    if (k < ks1) { kstep(k, U1{}, std::false_type{}); ++k; }
+    if (k < ks1) { kstep(k, U2{}, std::false_type{}); ++k; }
     GT(4);
-    // ---- the K slices meet in LDS in a FIXED order: ((k0 + k1) + (k2 + k3)) -------------------------------------------------------------------------
-    __syncthreads();                                            // every wave is done with the patch
-    float* bufA = reinterpret_cast<float*>(gsm);
-    float* bufB = reinterpret_cast<float*>(gsm + (KSPLIT == 4 ? G::TILEB : 0));
-    float* stat = reinterpret_cast<float*>(gsm + (KSPLIT == 4 ? 2 : 1) * G::TILEB);
-    const int wc0 = nw * 32 * TN;
-    auto put = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    buf[row * NCP + wc0 + j * 32 + l31] = acc[i][j][r];
-                }
-    };
-    auto add = [&](const float* buf) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    acc[i][j][r] += buf[row * NCP + wc0 + j * 32 + l31];
-                }
-    };
-    float* fin = bufA;
-    if constexpr (KSPLIT == 1) {
-        put(bufA);
-        __syncthreads();
-    } else if constexpr (KSPLIT == 2) {
-        if (kq == 1) put(bufA);
-        __syncthreads();
-        if (kq == 0) { add(bufA); put(bufA); }
-        __syncthreads();
-    } else {
-        if (kq == 1) put(bufA);
-        if (kq == 3) put(bufB);
-        __syncthreads();
-        if (kq == 0) add(bufA);
-        if (kq == 2) add(bufB);
-        __syncthreads();
-        if (kq == 2) put(bufA);
-        __syncthreads();
-        if (kq == 0) { add(bufA); put(bufB); }
-        __syncthreads();
-        fin = bufB;
-    }
 
+    // ---- the four K slices meet in LDS: a reduce-scatter over MFMA row tiles in the accumulators' own (register, lane) layout -- lane-linear
+    //      16-byte LDS accesses, no transposition -- in a FIXED order, ((k0 + k1) + (k2 + k3)) for every element.  Round 1: the pairs (0, 1) and
+    //      (2, 3) swap halves of their row tiles; round 2: (0, 2) and (1, 3) swap halves of what they kept.  Afterwards wave kq holds the finished
+    //      row tiles [FIN0, FIN0 + TM / 4).
+    __syncthreads();                                            // every wave is done with the patch
+    constexpr int TMH = TM / 2, TMQ = TM / 4;
+    float4* xbuf = reinterpret_cast<float4*>(gsm);              // [wave][tile][4][64 lanes] float4
+    // (row-tile ranges are COMPILE-TIME in every branch below: the accumulators are registers, a run-time tile index would turn every access
+    //  into a chain of selects -- the first version of this epilogue spilled 241 VGPRs)
+    auto xput = [&](int wslot, auto ilo_c, auto ni_c) {         // this wave's row tiles [ILO, ILO + NI) -> its slot
+        constexpr int ILO = decltype(ilo_c)::value, NI_ = decltype(ni_c)::value;
+        float4* dst = xbuf + (size_t)wslot * (G::XB / 16) + lane;
+#pragma unroll
+        for (int i = ILO; i < ILO + NI_; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    dst[(((i - ILO) * TN + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);      // tile by tile: hoisting every tile's moves first is what spills
+                }
+    };
+    auto xadd = [&](int wslot, auto ilo_c, auto ni_c) {         // row tiles [ILO, ILO + NI) += the partner's slot
+        constexpr int ILO = decltype(ilo_c)::value, NI_ = decltype(ni_c)::value;
+        const float4* src = xbuf + (size_t)wslot * (G::XB / 16) + lane;
+#pragma unroll
+        for (int i = ILO; i < ILO + NI_; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = src[(((i - ILO) * TN + j) * 4 + g) * 64];
+                    acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w;
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    using IC0 = std::integral_constant<int, 0>; using ICH = std::integral_constant<int, TMH>; using ICQ = std::integral_constant<int, TMQ>;
+    using ICHQ = std::integral_constant<int, TMH + TMQ>;
+    const int odd = kq & 1, hi = kq >> 1;
+    // round 1 (partner: the same column group's other K slice of the pair): even slices keep the first half of the row tiles, odd ones the second
+    if (!odd) xput(wave, ICH{}, ICH{}); else xput(wave, IC0{}, ICH{});
+    __syncthreads();
+    if (!odd) xadd(wave ^ NWN, IC0{}, ICH{}); else xadd(wave ^ NWN, ICH{}, ICH{});
+    __syncthreads();                                            // round 1's slots are read
+    if constexpr (KSPLIT == 4) {
+        // round 2: slices 0 / 1 keep the first quarter of the half they hold, slices 2 / 3 the second
+        if (!odd && !hi) xput(wave, ICQ{}, ICQ{});                  // slice 0 holds [0, TMH): keeps [0, TMQ), sends [TMQ, TMH)
+        else if (!odd && hi) xput(wave, IC0{}, ICQ{});              // slice 2 holds [0, TMH): keeps [TMQ, TMH), sends [0, TMQ)
+        else if (odd && !hi) xput(wave, ICHQ{}, ICQ{});             // slice 1 holds [TMH, TM): keeps [TMH, TMH + TMQ), sends the rest
+        else xput(wave, ICH{}, ICQ{});                              // slice 3 holds [TMH, TM): keeps [TMH + TMQ, TM), sends [TMH, TMH + TMQ)
+        __syncthreads();
+        if (!odd && !hi) xadd(wave ^ 2, IC0{}, ICQ{});
+        else if (!odd && hi) xadd(wave ^ 2, ICQ{}, ICQ{});
+        else if (odd && !hi) xadd(wave ^ 2, ICH{}, ICQ{});
+        else xadd(wave ^ 2, ICHQ{}, ICQ{});
+        __syncthreads();                                        // the exchange buffers are dead: staging may overwrite them
+    }
     GT(5);
-    // ---- epilogue, all four waves: bf16 rows as 16-byte pieces ------------------------------------------------------------------------------------
+
+    // ---- epilogue, per wave on its finished row tiles [FIN, FIN + TMQ): the instance norm's sums of the fp32 values, bf16 rows through LDS ----------
+    float* stat = reinterpret_cast<float*>(gsm + (4 * G::XB > G::STGB ? 4 * G::XB : G::STGB));      // [wave][column][2]
+    unsigned* T = reinterpret_cast<unsigned*>(gsm);             // [PIX][TP] dwords (bf16 pairs)
+    constexpr int TMF = TM / KSPLIT;                            // finished row tiles per wave
+    auto finish = [&](auto fin_c) {
+        constexpr int FIN = decltype(fin_c)::value;
+        const bool oddl = lane & 1;
+#pragma unroll
+        for (int i = FIN; i < FIN + TMF; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cp = (nw * G::NCW + 32 * j + (l31 & ~1)) >> 1;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float e = acc[i][j][2 * m], o = acc[i][j][2 * m + 1];
+                    const float en = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, e), 0xB1, 0xF, 0xF, true));
+                    const float on = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, o), 0xB1, 0xF, 0xF, true));
+                    // even lane: row of register 2m, columns (own, neighbour); odd lane: row of register 2m + 1, (neighbour, own)
+                    const int r = 2 * m + (oddl ? 1 : 0);
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    T[row * G::TP + cp] = oddl ? __builtin_bit_cast(unsigned, bf16x2{(__bf16)on, (__bf16)o}) : __builtin_bit_cast(unsigned, bf16x2{(__bf16)e, (__bf16)en});
+                }
+            }
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float sm = 0.f, q = 0.f;
+#pragma unroll
+                for (int i = FIN; i < FIN + TMF; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sm += v; q += v * v; }
+                sm += __shfl_xor(sm, 32); q += __shfl_xor(q, 32);
+                if (khalf == 0) { stat[(kq * NC + nw * G::NCW + 32 * j + l31) * 2] = sm; stat[(kq * NC + nw * G::NCW + 32 * j + l31) * 2 + 1] = q; }
+            }
+        }
+    };
+    if constexpr (KSPLIT == 4) {
+        if (!odd && !hi) finish(IC0{});
+        else if (!odd && hi) finish(ICQ{});
+        else if (odd && !hi) finish(ICH{});
+        else finish(ICHQ{});
+    } else {
+        if (!odd) finish(IC0{}); else finish(ICH{});
+    }
+    __syncthreads();
+    GT(6);
     {
-        constexpr int CH = NC / 8;                              // pieces per pixel
-        for (int idx = tid; idx < 128 * CH; idx += 256) {
+        constexpr int CH = NC / 8;                              // 16-byte pieces per pixel
+        for (int idx = tid; idx < G::PIX * CH; idx += 256) {
             const int pix = idx / CH, c8 = idx - pix * CH;
             const int im = pix / (G::TR * G::TC), rr = pix - im * (G::TR * G::TC);
             const int n = img0 + im;
             if (n >= p.N) continue;
             const int oy = ty0 + rr / G::TC, ox = tx0 + rr % G::TC;
-            const float4 a = *reinterpret_cast<const float4*>(fin + pix * NCP + c8 * 8);
-            const float4 b = *reinterpret_cast<const float4*>(fin + pix * NCP + c8 * 8 + 4);
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            uint4 v;
-            v.x = __builtin_bit_cast(unsigned, bf16x2{(__bf16)a.x, (__bf16)a.y});
-            v.y = __builtin_bit_cast(unsigned, bf16x2{(__bf16)a.z, (__bf16)a.w});
-            v.z = __builtin_bit_cast(unsigned, bf16x2{(__bf16)b.x, (__bf16)b.y});
-            v.w = __builtin_bit_cast(unsigned, bf16x2{(__bf16)b.z, (__bf16)b.w});
+            const uint4 v = *reinterpret_cast<const uint4*>(T + pix * G::TP + c8 * 4);
             unsigned short* dst = p.y + (((long long)n * S + oy) * S + ox) * (long long)p.Cy + n0 + c8 * 8;
             *reinterpret_cast<uint4*>(dst) = v;
         }
     }
-    GT(6);
-    // ---- ... and the instance norm's sums (of the fp32 values, as conv_ring_kernel's cell epilogue): column sums over an image's rows in a fixed
-    //      order, ONE float64 atomic per (image, channel, workgroup) -- exact, hence independent of the workgroups' arrival order
+    // the waves' partial sums in row order (wave w finished row tiles [FIN(w), FIN(w) + TMQ): FIN = 0, TMH, TMQ, TMH + TMQ for w = 0 .. 3), ONE float64
+    // atomic per (image, channel, workgroup) -- exact, hence independent of the workgroups' arrival order
     if (p.stats) {
-        constexpr int RG = 256 / NC;                            // row groups
-        constexpr int RPI = 128 / G::NI;                        // tile rows (pixels) per image
-        const int col = tid % NC, rg = tid / NC;
-#pragma unroll
-        for (int im = 0; im < G::NI; ++im) {
-            float s = 0.f, q = 0.f;
-            for (int r = rg; r < RPI; r += RG) { const float v = fin[(im * RPI + r) * NCP + col]; s += v; q += v * v; }
-            stat[((im * RG + rg) * NC + col) * 2] = s;
-            stat[((im * RG + rg) * NC + col) * 2 + 1] = q;
-        }
-        __syncthreads();
+        constexpr int WPI = KSPLIT / G::NI;                     // K slices (= row blocks) per image, in row order: 0, 2, 1, 3 (KSPLIT 4) or 0, 1
         for (int i = tid; i < G::NI * NC * 2; i += 256) {
             const int im = i / (NC * 2), rem = i - im * (NC * 2);
             const int n = img0 + im;
             if (n >= p.N) continue;
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < RG; ++g) t += stat[(im * RG + g) * NC * 2 + rem];
+            for (int o = 0; o < WPI; ++o) {
+                const int ord = im * WPI + o;                   // position in row order -> K slice
+                const int q_ = KSPLIT == 4 ? (((ord & 1) << 1) | (ord >> 1)) : ord;
+                t += stat[q_ * NC * 2 + rem];
+            }
             unsafeAtomicAdd(p.stats + ((long long)n * p.Cy + n0 + (rem >> 1)) * 2 + (rem & 1), (double)t);
         }
     }
@@ -328,12 +435,15 @@ __global__ __launch_bounds__(256, 1) void conv_gate_kernel(GateP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+#define GATE_PACK_PAD_KSTEPS 8        // == GateCfg::KPAD: k-steps of zeros behind the pack that the kernel's look-ahead may read
 // weights in B-fragment order: out[cb][ks][lane][j] = W[tap][ch8 * 8 + j][cb * 32 + (lane & 31)] with chunk c = 2 ks + (lane >> 5) = tap * C8 + ch8
 // (zero past the last chunk).  src: HWIO fp32 [taps][Cx][Cy] (the master variable).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_gate_weights_kernel(const float* __restrict__ src, int taps, int Cx, int Cy, uint4* __restrict__ out) {
     const int C8 = Cx >> 3, nch = taps * C8, KS = (nch + 1) >> 1;
     const long long total = (long long)(Cy >> 5) * KS * 64;
+    for (long long t = total + (long long)blockIdx.x * 256 + threadIdx.x; t < total + GATE_PACK_PAD_KSTEPS * 64; t += (long long)gridDim.x * 256)
+        out[t] = make_uint4(0u, 0u, 0u, 0u);                    // the readable pad behind the last column block (conv_gate_kernel's look-ahead)
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
         const int lane = (int)(t & 63);
         const long long r = t >> 6;
@@ -354,12 +464,12 @@ __global__ __launch_bounds__(256) void pack_gate_weights_kernel(const float* __r
 extern "C" int64_t savp_gate_weights_bytes(int32_t taps, int32_t Cx, int32_t Cy) {
     if (taps < 1 || Cx < 8 || (Cx & 7) || Cy < 32 || (Cy & 31)) return 0;
     const long long KS = ((long long)taps * (Cx >> 3) + 1) >> 1;
-    return (long long)(Cy >> 5) * KS * 64 * 16;
+    return ((long long)(Cy >> 5) * KS + GATE_PACK_PAD_KSTEPS) * 64 * 16;
 }
 
 extern "C" int savp_pack_gate_weights(void* stream, const float* src, int32_t taps, int32_t Cx, int32_t Cy, void* out) {
     if (!src || !out || !savp_gate_weights_bytes(taps, Cx, Cy) || (((uintptr_t)out) & 15)) return SAVP_EINVAL;
-    const long long total = savp_gate_weights_bytes(taps, Cx, Cy) / 16;
+    const long long total = savp_gate_weights_bytes(taps, Cx, Cy) / 16 - GATE_PACK_PAD_KSTEPS * 64;
     unsigned nb = (unsigned)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_gate_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, taps, Cx, Cy, (uint4*)out);
@@ -369,32 +479,35 @@ extern "C" int savp_pack_gate_weights(void* stream, const float* src, int32_t ta
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-template <int S, int CIN, int TN, int NWN>
+template <int S, int CIN, int TM, int TN, int NWN>
 static hipError_t launch_gate(const GateP& p, hipStream_t st) {
-    using G = GateCfg<S, CIN, TN, NWN>;
+    using G = GateCfg<S, CIN, TM, TN, NWN>;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_gate_kernel<S, CIN, TN, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB);
+        hipFuncSetAttribute((const void*)conv_gate_kernel<S, CIN, TM, TN, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB);
         attr = true;
     }
     const dim3 grid((unsigned)(p.mtiles * p.ntiles));
     if (g_savp_prof_start) {            // bench.py's kernel-only clock (savp_prof_arm): the dispatch's own begin / end stamps
-        hipExtLaunchKernelGGL((conv_gate_kernel<S, CIN, TN, NWN>), grid, dim3(256), G::LDSB, st, g_savp_prof_start, g_savp_prof_stop, 0, p);
+        hipExtLaunchKernelGGL((conv_gate_kernel<S, CIN, TM, TN, NWN>), grid, dim3(256), G::LDSB, st, g_savp_prof_start, g_savp_prof_stop, 0, p);
         g_savp_prof_start = g_savp_prof_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((conv_gate_kernel<S, CIN, TN, NWN>), grid, dim3(256), G::LDSB, st, p);
+        hipLaunchKernelGGL((conv_gate_kernel<S, CIN, TM, TN, NWN>), grid, dim3(256), G::LDSB, st, p);
     }
     return hipGetLastError();
 }
 
-// Which (image side, input channels) have an instantiation: the gate convolutions of the shipped recipes at 64 x 64 (c2: nz = 8; c4 KTH: nz = 32).  TN / NWN: a 128-pixel x NC-column workgroup tile, NC chosen so that one launch is about one round of 256 workgroups at
-// N = 32 images.
-#define GATE_SHAPES(X)                                                                                   \
-    X(32, 72, 2, 2) X(16, 136, 2, 1) X(8, 264, 1, 1)     /* BAIR 64 x 64, nz = 8: F = 32 / 64 / 128 */    \
-    X(32, 96, 2, 2) X(16, 160, 2, 1)                     /* KTH 64 x 64, nz = 32 (its 8 x 8 layer, 288 channels: the patch of two images exceeds 160 KB) */
+// Which (image side, input channels) have an instantiation: the gate convolutions of the shipped recipes at 64 x 64 (c2: nz = 8; c4 KTH: nz = 32).
+// (TM, TN): a workgroup owns 32 TM pixels x 32 TN columns, each of its four waves one K slice of that whole tile.  What the shapes are chosen
+// for: ONE round of 256 workgroups at N = 32 images, and as little weight traffic per MFMA as that allows -- the L2 -> CU path delivers ~37 B/clk/CU
+// to this access pattern (measured with the MFMAs ablated), and a 128-pixel tile needs 32 of them at the matrix pipe's full rate.
+#define GATE_SHAPES(X)                                                                                                    \
+    X(32, 72, 8, 1, 2, 0) X(16, 136, 4, 1, 1, 0) X(8, 264, 4, 1, 1, 0)     /* BAIR 64 x 64, nz = 8: F = 32 / 64 / 128 */   \
+    X(32, 96, 8, 1, 2, 0) X(16, 160, 4, 1, 1, 0)                           /* KTH 64 x 64, nz = 32 (its 8 x 8 layer, 288 channels: the patch of two images exceeds 160 KB) */ \
+    X(32, 72, 8, 1, 1, 1) X(16, 136, 8, 1, 1, 2) X(32, 96, 8, 1, 1, 1) X(16, 160, 8, 1, 1, 2)      /* developer A/B (option "gate_alt": bit 0 the 32 x 32 layers, bit 1 the 16 x 16 layers) */
 
 static bool gate_shape_ok(const SavpConvArgs* a) {
-#define X(S_, C_, TN_, NWN_) if (a->H == S_ && a->Cx == C_) return true;
+#define X(S_, C_, TM_, TN_, NWN_, ALT_) if (a->H == S_ && a->Cx == C_) return true;
     GATE_SHAPES(X)
 #undef X
     return false;
@@ -413,7 +526,6 @@ bool conv_gate_applies(const SavpConvArgs* a) {
           a->y_sh == (long long)a->W * a->Cy && a->y_sn == (long long)a->H * a->W * a->Cy && aligned16(a->x) && aligned16(a->y) && aligned16(a->w_frag)))
         return false;
     if ((a->Cy & 127) || a->N < 1 || (a->stats && (((uintptr_t)a->stats) & 7))) return false;
-    if (a->H == 8 && (a->N & 1)) return false;                  // an 8 x 8 tile holds two whole images
     return gate_shape_ok(a);
 }
 
@@ -425,15 +537,19 @@ bool conv_gate_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
     if (!zero_of[dev_ord] && hipGetSymbolAddress((void**)&zero_of[dev_ord], HIP_SYMBOL(g_gate_zero)) != hipSuccess) { *rc = SAVP_ELAUNCH; return true; }
     GateP p;
     p.x = (const unsigned short*)a->x; p.wfrag = (const uint4*)a->w_frag; p.y = (unsigned short*)a->y; p.stats = (double*)a->stats;
-    p.zero16 = zero_of[dev_ord]; p.N = a->N; p.Cy = a->Cy;
+    p.zero16 = zero_of[dev_ord]; p.N = a->N; p.Cy = a->Cy; p.wwarm = savp_opt(OPT_GATE_WWARM);
     hipError_t err = hipErrorInvalidValue;
-#define X(S_, C_, TN_, NWN_)                                                                             \
-    if (a->H == S_ && a->Cx == C_) {                                                                     \
-        using G = GateCfg<S_, C_, TN_, NWN_>;                                                            \
-        p.mtiles = G::NI == 1 ? a->N * G::TPI : a->N / G::NI; p.ntiles = a->Cy / G::NC;                  \
-        err = launch_gate<S_, C_, TN_, NWN_>(p, st);                                                     \
-    } else
-    GATE_SHAPES(X) {}
+    const int alt = savp_opt(OPT_GATE_ALT);
+    bool done = false;
+#define X(S_, C_, TM_, TN_, NWN_, ALT_)                                                                  \
+    if (!done && a->H == S_ && a->Cx == C_ && (want ? (ALT_ & want) != 0 : ALT_ == 0)) {                 \
+        using G = GateCfg<S_, C_, TM_, TN_, NWN_>;                                                       \
+        p.mtiles = G::NI == 1 ? a->N * G::TPI : (a->N + G::NI - 1) / G::NI; p.ntiles = a->Cy / G::NC;    \
+        err = launch_gate<S_, C_, TM_, TN_, NWN_>(p, st);                                                \
+        done = true;                                                                                     \
+    }
+    { const int want = alt; GATE_SHAPES(X) }
+    { const int want = 0; GATE_SHAPES(X) }               // (no alternative instantiation for this shape: the shipped one)
 #undef X
     *rc = err == hipSuccess ? SAVP_OK : SAVP_ELAUNCH;
     return true;
