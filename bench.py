@@ -403,7 +403,7 @@ def main():
     traffic, traffic_src, traffic_alg, traffic_note = None, None, None, None
     from video_prediction_amd import lib as _lib
     src_id = _lib.source_id()
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
         pmc_path = os.path.join(ROOT, 'profiles', '%s_convlstm_cell_pmc_%s.json' % (rnd, args.precision))
         if os.path.exists(pmc_path) and args.batch == 16 and args.config == 'c2':
             try:
@@ -465,7 +465,7 @@ def main():
     # kernel time by family: not measurable from inside the run; quoted from the committed rocprofv3 kernel stats of the SAME kernel
     # sources + tuning tables (tests/tools/kernel_families.py stamps the source id), else left out
     if args.config == 'c2' and args.batch == 16:
-        for rnd in ('r05', 'r04'):
+        for rnd in ('r06', 'r05', 'r04'):
             fam_path = os.path.join(ROOT, 'profiles', '%s_kernel_families.json' % rnd)
             try:
                 fam = json.load(open(fam_path))

@@ -30,7 +30,7 @@ const char* savp_version(void);
  * prefers the LDS-DMA ring kernel), "s2dgrad" 1, "thin" 1, "lstm_fused" 1, "ring_dma" 1 (problem-specific kernels / LDS-DMA patch staging of bf16 sources on), "ring_wwarm" 1 (the ring kernel's
  * workgroups pull their column tile's weight block into the XCD's L2 first), "wgp_dma" 1 (weight gradient of two bf16 operands: LDS-DMA
  * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "gate_kernel" 1 (the ConvLSTM gate convolution's own kernel
- * when SavpConvArgs.w_frag is given), "gate_wwarm" 1 (its workgroups touch their column tile's weight block into the XCD's L2 first), "colsum_2stage" 1,
+ * when SavpConvArgs.w_frag is given), "gate_cell" 1 (savp_convlstm_cell_fwd: the whole cell in one launch where a tile holds whole images), "gate_wwarm" 1 (its workgroups touch their column tile's weight block into the XCD's L2 first), "colsum_2stage" 1,
  * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy", "gate_alt" (0). */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
@@ -143,6 +143,10 @@ typedef struct SavpConvArgs {
        bf16 tensors with `stats` (bias / act / beta / aux none, Cy % 128 == 0, H == W and (H, Cx) one of the instantiated shapes) takes that
        kernel whatever `tile` says (option "gate_kernel" 1); NULL or any other problem: the general kernels, as before. */
     const void* w_frag;
+    /* ... and in the INTERLEAVED column order (savp_pack_gate_weights(interleave = 1): local column l of a 32-column block = gate l & 3 of channel
+       l >> 2).  Only savp_convlstm_cell_fwd reads it: given it, the 16 x 16 and 8 x 8 layers' whole cell -- convolution, IN(4F), gates, IN(F), h --
+       is ONE launch (option "gate_cell" 1); savp_conv ignores it. */
+    const void* w_frag_il;
 } SavpConvArgs;
 
 int savp_conv(void* stream, const SavpConvArgs* args);
@@ -534,7 +538,7 @@ int savp_fold_f64(void* stream, const int32_t* idx, int64_t n, double* src, floa
  * chunk, followed by 8 KB of zeros (the kernel's look-ahead reads past the last column block); savp_gate_weights_bytes(taps, Cx, Cy) bytes in all
  * (0: shape not supported), 16-byte aligned.  Once per optimiser step, like savp_pack_weights. */
 int64_t savp_gate_weights_bytes(int32_t taps, int32_t Cx, int32_t Cy);
-int savp_pack_gate_weights(void* stream, const float* src, int32_t taps, int32_t Cx, int32_t Cy, void* out);
+int savp_pack_gate_weights(void* stream, const float* src, int32_t taps, int32_t Cx, int32_t Cy, void* out, int32_t interleave);   /* interleave: see SavpConvArgs.w_frag_il */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Developer / soak-test aids (debug_ops.hip; no reference counterpart, no product caller): make what a correct launch sequence must never

@@ -1057,6 +1057,80 @@ def check_gate_conv_kernel(seed=67):
     return out
 
 
+def check_one_launch_cell(seed=71):
+    """savp_convlstm_cell_fwd as ONE kernel (csrc/conv_gate.hip, CELL instantiations; rnn_ops.py:137-171): the 16 x 16 and 8 x 8 ConvLSTM layers,
+    weights in the interleaved fragment order, against the fp64 oracle of the whole cell on the bf16-rounded operands -- gate tensor (bf16, the
+    backward pass reads it), c', h' into up to four destinations (fp32 and bf16, contiguous and channel slices of wider buffers), the four saved
+    statistics vectors -- with and without a previous state, an odd batch at 8 x 8 (the last tile's second image is absent), and against the
+    two-launch path of the same entry (option gate_cell = 0); the launch count is checked through the statistics workspace, which only the
+    two-launch path fills."""
+    out = []
+    rng = np.random.default_rng(seed)
+    geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
+    for (N, S, Cx, F, zero_state, nh) in [(3, 16, 136, 64, False, 3), (5, 8, 264, 128, False, 4), (2, 8, 264, 128, True, 1), (2, 16, 160, 64, False, 2)]:
+        tag = 'cell1_%dx%d_c%d_n%d' % (S, S, Cx, N)
+        x = rnd(rng, N, S, S, Cx).float().to(torch.bfloat16)
+        w = (rnd(rng, 5, 5, Cx, 4 * F) * 0.05).float()
+        c = rnd(rng, N, S, S, F)
+        g1, b1 = rnd(rng, 4 * F) * 0.3 + 1, rnd(rng, 4 * F) * 0.3
+        g2, b2 = rnd(rng, F) * 0.3 + 1, rnd(rng, F) * 0.3
+        gates = TF.conv2d(x.double(), w.to(torch.bfloat16).double(), (1, 1), 'SAME')
+        # the cell reads the bf16-ROUNDED gate tensor with the statistics of the unrounded one (as the two-launch path): the oracle on the rounded
+        # tensor differs from that by the rounding's effect on mean / variance, far below the gates
+        gq = gates.float().to(torch.bfloat16).double()
+        cz = torch.zeros_like(c) if zero_state else c
+        cn, hn = _ref_lstm_gates(gq, cz, g1, b1, g2, b2)
+        wd = dev(w)
+        wt = dev(pack_wt(w.double()))
+        w16 = wt.to(torch.bfloat16)
+        n_el = K.gate_weights_elems(25, Cx, 4 * F)
+        frag, frag_il = torch.empty(n_el, device=DEV, dtype=torch.bfloat16), torch.empty(n_el, device=DEV, dtype=torch.bfloat16)
+        K.pack_gate_weights(wd, frag)
+        K.pack_gate_weights(wd, frag_il, interleave=True)
+        xd = x.to(DEV)
+        p = [dev(t) for t in (g1, b1, g2, b2)]
+        res = {}
+        for mode in (1, 0):
+            lib.set_option('gate_cell', mode)
+            try:
+                yd = torch.full((N, S, S, 4 * F), float('nan'), device=DEV, dtype=torch.bfloat16)
+                ws, s1 = K.lstm_stats_ws(torch.device(DEV), N, F)
+                ws.zero_()
+                c_new = torch.full((N, S, S, F), float('nan'), device=DEV)
+                wide = torch.full((N, S, S, 3 * F + 8), float('nan'), device=DEV, dtype=torch.bfloat16)      # a consumer's [.. | h | ..] buffer
+                hs = [torch.full((N, S, S, F), float('nan'), device=DEV), wide[..., 8:8 + F],
+                      torch.full((N, S, S, F), float('nan'), device=DEV, dtype=torch.bfloat16), wide[..., 8 + F:8 + 2 * F]][:nh]
+                stats = [torch.full((N, 4 * F), float('nan'), device=DEV), torch.full((N, 4 * F), float('nan'), device=DEV),
+                         torch.full((N, F), float('nan'), device=DEV), torch.full((N, F), float('nan'), device=DEV)]
+                lws = torch.empty(K.lstm_ws_floats(N, S * S, F), device=DEV)
+                ca = K.conv(lib.CONV_FPROP, geom, xd, yd, wt, precision=1, w16=w16, stats=s1, w_frag=frag, w_frag_il=frag_il, defer=True)
+                ga = K.convlstm_gates_fwd(yd, None if zero_state else dev(c), p[0], p[1], p[2], p[3], c_new, hs, stats, ws=lws, stats1=ws, defer=True)
+                K.convlstm_cell_fwd(ca, ga)
+                torch.cuda.synchronize()
+                res[mode] = dict(y=yd.float().cpu(), c=c_new.cpu(), h=[h.float().cpu() for h in hs], st=[t.cpu() for t in stats],
+                                 one_launch=bool(float(s1.abs().sum()) == 0.0))
+            finally:
+                lib.set_option('gate_cell', 1)
+        out.append((tag + '/is_one_launch', 0.0 if (res[1]['one_launch'] and not res[0]['one_launch']) else 1.0, 0.0))
+        r = res[1]
+        out.append((tag + '/gates_bf16', rel_err(r['y'], gates), 6e-3))
+        out.append((tag + '/c', rel_err(r['c'], cn), 2e-2))
+        for k, h in enumerate(r['h']):
+            out.append((tag + '/h%d' % k, rel_err(h, hn), 2e-2))
+        m1 = gates.mean(dim=(1, 2))
+        v1 = gates.var(dim=(1, 2), unbiased=False)
+        out.append((tag + '/mean1', rel_err(r['st'][0], m1), 1e-4))
+        out.append((tag + '/rstd1', rel_err(r['st'][1], 1.0 / torch.sqrt(v1 + 1e-6)), 1e-3))
+        # against the two-launch path (another tile split of the same sums: bf16 rounding flips, nothing more)
+        t = res[0]
+        out.append((tag + '/vs_two_launch_c', rel_err(r['c'], t['c']), 2e-2))
+        out.append((tag + '/vs_two_launch_h', max(rel_err(a_, b_) for a_, b_ in zip(r['h'], t['h'])), 2e-2))
+        out.append((tag + '/vs_two_launch_mean2', rel_err(r['st'][2], t['st'][2]), 5e-3))
+        out.append((tag + '/vs_two_launch_rstd2', rel_err(r['st'][3], t['st'][3]), 5e-3))
+    torch.cuda.synchronize()
+    return out
+
+
 ALL_CHECKS = [('conv', check_conv), ('conv_bf16', check_conv_bf16), ('conv_cell', check_conv_cell),
               ('conv_views', check_conv_views_and_epilogues), ('inorm', check_inorm),
               ('lstm', check_lstm), ('util', check_util), ('dense', check_dense), ('cdna_composite', check_cdna_composite),

@@ -183,3 +183,9 @@ def test_norm_backward_sums_from_the_dgrad_epilogue():
 def test_gate_convolution_kernel_vs_fp64_and_ring_kernel():
     from tests import gpu_checks
     _run(gpu_checks.check_gate_conv_kernel)
+
+
+@pytest.mark.gpu
+def test_convlstm_cell_forward_as_one_launch_vs_oracle_and_two_launch_path():
+    from tests import gpu_checks
+    _run(gpu_checks.check_one_launch_cell)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from video_prediction_amd import lib
 
-FAMILIES = (('ring conv (FPROP / DGRAD, LDS patch + DMA weight ring)', ('conv_ring',)), ('RGB-side / thin / stride-2 DGRAD convs', ('thin_fprop', 'wthin_', 'thin8', 's2dgrad')),
+FAMILIES = (('gate conv FPROP (conv_gate_kernel: weights in B-fragment order from L2)', ('conv_gate_kernel',)), ('ring conv (FPROP / DGRAD, LDS patch + DMA weight ring)', ('conv_ring',)), ('RGB-side / thin / stride-2 DGRAD convs', ('thin_fprop', 'wthin_', 'thin8', 's2dgrad')),
             ('weight gradients', ('wgrad',)),
             ('ConvLSTM gate block', ('lstm_fused', 'lstm_fwd', 'lstm_bwd', 'lstm_gates')), ('instance norm', ('inorm',)),
             ('generic conv (implicit GEMM)', ('conv_fd',)), ('patch conv', ('conv_patch',)), ('CDNA + composite', ('cdna', 'composite')),

@@ -29,8 +29,15 @@ def run():
     w = torch.randn(k * k * Cx * Cy, device='cuda') * 0.05
     st = torch.zeros(N, Cy, 2, device='cuda', dtype=torch.float64) if cell else None
     geom = K.ConvGeom((k, k), (1, 1), (k // 2, k // 2))
+    frag = None
+    if cell and mode == lib.CONV_FPROP and k == 5 and x.dtype == torch.bfloat16 and os.environ.get('GATE', '1') == '1':
+        # what the engine launches since round 6: the gate convolution's own kernel, given the B-fragment pack (ConvLayer.enable_gate_pack)
+        n = K.gate_weights_elems(k * k, Cx, Cy)
+        if n:
+            frag = torch.empty(n, device='cuda', dtype=torch.bfloat16)
+            K.pack_gate_weights(w.reshape(k, k, Cx, Cy), frag)
     for _ in range(6):
-        K.conv(mode, geom, x, y, w, tile=tile, w16=w.to(torch.bfloat16), splitk=0 if tile == 0 else int(os.environ.get('SK', '1')), stats=st)
+        K.conv(mode, geom, x, y, w, tile=tile, w16=w.to(torch.bfloat16), splitk=0 if tile == 0 else int(os.environ.get('SK', '1')), stats=st, w_frag=frag)
     torch.cuda.synchronize()
 
 

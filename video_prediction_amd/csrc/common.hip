@@ -41,7 +41,7 @@ extern "C" int savp_prof_elapsed_us(void* start, void* stop, float* us) {
 // ---- options (opts.h) ----------------------------------------------------------------------------------------
 static struct { const char* name; int value; } g_opts[OPT_COUNT] = {
     {"conv_ring", 0}, {"s2dgrad", 1}, {"thin", 1}, {"wgp_cfg", 0}, {"wgp_split", 0}, {"inorm_min_hw", 64}, {"colsum_2stage", 1},
-    {"dense_legacy", 0}, {"cdna_legacy", 0}, {"lstm_fused", 1}, {"ring_dma", 1}, {"lstm_q", 0}, {"ring_wwarm", 1}, {"wgp_dma", 1}, {"ring_early", 1}, {"gate_kernel", 1}, {"gate_alt", 0}, {"gate_wwarm", 1},
+    {"dense_legacy", 0}, {"cdna_legacy", 0}, {"lstm_fused", 1}, {"ring_dma", 1}, {"lstm_q", 0}, {"ring_wwarm", 1}, {"wgp_dma", 1}, {"ring_early", 1}, {"gate_kernel", 1}, {"gate_alt", 0}, {"gate_cell", 1}, {"gate_wwarm", 1},
 };
 int savp_opt(int id) { return g_opts[id].value; }
 extern "C" int savp_set_option(const char* name, int value) {

@@ -184,3 +184,5 @@ bool conv_ring_try(ConvP& p, const SavpConvArgs* a, int wm, int wn, hipStream_t 
 // conv_gate.hip: the ConvLSTM gate convolution's own kernel (weights in B-fragment order, SavpConvArgs.w_frag); same contract.
 bool conv_gate_applies(const SavpConvArgs* a);
 bool conv_gate_try(const SavpConvArgs* a, hipStream_t st, int* rc);
+struct SavpConvLstmCellArgs;
+bool conv_gate_cell_try(const SavpConvLstmCellArgs* c, hipStream_t st, int* rc);   // the whole cell forward in one launch (w_frag_il)

@@ -11,6 +11,8 @@
 #include <stdint.h>
 #include "savp_hip.h"
 
+bool conv_gate_cell_try(const SavpConvLstmCellArgs* c, hipStream_t st, int* rc);      // conv_gate.hip
+
 // BasicConv2DLSTMCell.call (rnn_ops.py:137-171), forward: gates = conv2d([x | z | h], W); IN(4F); i, j, f, o; c', h'.
 extern "C" int savp_convlstm_cell_fwd(void* stream, const SavpConvLstmCellArgs* a) {
     if (!a || a->conv.mode != SAVP_CONV_FPROP) return SAVP_EINVAL;
@@ -24,6 +26,11 @@ extern "C" int savp_convlstm_cell_fwd(void* stream, const SavpConvLstmCellArgs* 
     // the `stats` epilogue sums the accumulators WITHOUT the bias and the gate block reads them as sums around 0 (rnn_ops.py:122-125: the gate
     // convolution has no bias when a normaliser follows): a biased convolution here would silently shift the mean
     if (c.stats && c.bias) return SAVP_EINVAL;
+    {   // the whole cell as ONE kernel where the gate convolution's tile holds whole images (conv_gate.hip, SavpConvArgs.w_frag_il): both instance
+        // norms' statistics are then workgroup-local -- no grid-wide dependency, no second launch
+        int rc1 = SAVP_OK;
+        if (conv_gate_cell_try(a, (hipStream_t)stream, &rc1)) return rc1;
+    }
     int rc = savp_conv(stream, &c);
     if (rc != SAVP_OK) return rc;
     return savp_convlstm_gates_fwd(stream, &g);

@@ -21,6 +21,7 @@ enum SavpOptId {
     OPT_RING_EARLY,        // ring kernel: the first slab group's DMA-staged patch is requested at the top of the prologue (1)
     OPT_GATE_KERNEL,       // the ConvLSTM gate convolution takes conv_gate.hip when SavpConvArgs.w_frag is given (1)
     OPT_GATE_ALT,          // developer: conv_gate.hip's alternative tile instantiations (0)
+    OPT_GATE_CELL,         // savp_convlstm_cell_fwd runs the whole cell in ONE launch where conv_gate.hip's tile holds whole images (1)
     OPT_GATE_WWARM,        // conv_gate.hip: workgroups of a column tile touch its weight block into their XCD's L2 first (1)
     OPT_COUNT
 };

@@ -281,6 +281,7 @@ class ConvLayer(object):
             self.dwf = torch.zeros_like(W)                # dL/dW_bar, then sn_bwd -> master grad
         self.need_wt = self.need_wd = True
         self.wfrag = None         # enable_gate_pack(): the weights in MFMA B-fragment order for the gate convolution's own kernel (csrc/conv_gate.hip)
+        self.wfrag_il = None      # ... and with interleaved gate columns: the whole cell forward in one launch (savp_convlstm_cell_fwd)
         self.prof = None          # list of (start, end) events when bench.py instruments this layer's forward launches
         self.ktimer = None        # kernels.KernelTimer: kernel-only duration of the same launches (ring kernel)
 
@@ -319,14 +320,18 @@ class ConvLayer(object):
             K.pack_weights(**entry)
         if self.wfrag is not None and b16:
             K.pack_gate_weights(src, self.wfrag)
+            if self.wfrag_il is not None:
+                K.pack_gate_weights(src, self.wfrag_il, interleave=True)
 
-    def enable_gate_pack(self):
+    def enable_gate_pack(self, cell=False):
         """This layer is a ConvLSTM gate convolution (rnn_ops.py:115-126): keep its weights in B-fragment order as well, so that the bf16
         datapath's forward takes conv_gate_kernel.  No-op for shapes that kernel has no pack for."""
         if self.kind == 'conv' and not self.padded and not self.sn_u_name:
             n = K.gate_weights_elems(self.taps, self.cx, self.cy)
             if n:
                 self.wfrag = torch.empty(n, device=self.W.device, dtype=torch.bfloat16)
+                if cell and self.cy % 32 == 0:
+                    self.wfrag_il = torch.empty(n, device=self.W.device, dtype=torch.bfloat16)
 
     def commit_u(self):
         """The reference's UPDATE_OP ``u.assign(u_final)`` (ops.py:1046-1048)."""
@@ -352,7 +357,7 @@ class ConvLayer(object):
                 return K.conv(lib.CONV_DGRAD, self.geom, y, x, self.wd, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wd16, stats=stats,
                               defer=True)
             return K.conv(lib.CONV_FPROP, self.geom, x, y, self.wt, bias=b, beta=beta, act=act, alpha=alpha, w16=self.wt16, stats=stats,
-                          defer=True, w_frag=self.wfrag)
+                          defer=True, w_frag=self.wfrag, w_frag_il=self.wfrag_il)
         if self.ktimer is not None:
             self.ktimer.arm()
         if self.prof is not None:

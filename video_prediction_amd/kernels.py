@@ -103,7 +103,7 @@ def enable_autotune(flag=True):
 
 
 def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16=None, stats=None, dst_gap=None,
-                    norm_bwd=None, w_frag=None):
+                    norm_bwd=None, w_frag=None, w_frag_il=None):
     a = lib.SavpConvArgs()
     a.mode = mode
     N, D, H, W, Cx, a.x_sn, a.x_sd, a.x_sh, a.x_sw = _nd(x)
@@ -148,6 +148,7 @@ def _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, ti
     a.out_bf16 = int((y if mode == lib.CONV_WGRAD else dst).dtype == torch.bfloat16)
     a.stats = stats.data_ptr() if stats is not None else None
     a.w_frag = w_frag.data_ptr() if w_frag is not None else None     # the gate convolution's B-fragment pack (pack_gate_weights)
+    a.w_frag_il = w_frag_il.data_ptr() if w_frag_il is not None else None     # ... with interleaved gate columns (the one-launch cell)
     taps = geom.k[0] * geom.k[1] * geom.k[2]
     if w.numel() != taps * Cx * Cy:
         raise ValueError('weight has %d elements, expected %d' % (w.numel(), taps * Cx * Cy))
@@ -320,7 +321,7 @@ def _conv_scratch(a, device):
 
 
 def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, splitk=0, tile=0, precision=None, w16=None, stats=None,
-         dst_gap=None, norm_bwd=None, defer=False, w_frag=None):
+         dst_gap=None, norm_bwd=None, defer=False, w_frag=None, w_frag_il=None):
     """mode FPROP: y = F(x) ; DGRAD: x = F^T(y) ; WGRAD: w += x (*) y.  See include/savp_hip.h.  A torch.bfloat16 source /
     destination tensor selects the ring kernel's bf16 activation paths; `stats` [N, C_dst, 2] float64 (stats_ws: zeroed by the caller)
     receives the destination's per-(sample, channel) sum / sum of squares (bf16 destination only); dst_gap = (first, count):
@@ -328,7 +329,7 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
     lib.require_device(w, bias, aux)
     lib.require_stats(stats, (norm_bwd or {}).get('ws'))
     lib.require_device_any(x, y)
-    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd, w_frag)
+    a = _fill_conv_args(mode, geom, x, y, w, bias, beta, act, alpha, aux, splitk, tile, precision, w16, stats, dst_gap, norm_bwd, w_frag, w_frag_il)
     if AUTOTUNE['enabled'] and tile == 0 and splitk == 0 and not lib.get().savp_conv_special(ctypes.byref(a)):
         key = (mode, a.precision, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, geom.k, geom.s, geom.p, a.act, a.beta,
                a.x_sw, a.y_sw, bias is not None, w16 is not None, a.src_bf16, a.out_bf16, stats is not None)
@@ -1101,14 +1102,15 @@ def gate_weights_elems(taps, Cx, Cy):
     return int(lib.get().savp_gate_weights_bytes(int(taps), int(Cx), int(Cy))) // 2
 
 
-def pack_gate_weights(src, out):
-    """src HWIO fp32 [..., Cx, Cy] -> out (torch.bfloat16, gate_weights_elems elements): MFMA B-fragment order (csrc/conv_gate.hip)."""
+def pack_gate_weights(src, out, interleave=False):
+    """src HWIO fp32 [..., Cx, Cy] -> out (torch.bfloat16, gate_weights_elems elements): MFMA B-fragment order (csrc/conv_gate.hip).
+    interleave: the gate columns [i | j | f | o] regrouped per 8 channels (SavpConvArgs.w_frag_il: the one-launch cell)."""
     lib.require_device(src)
     Cx, Cy = src.shape[-2], src.shape[-1]
     taps = src.numel() // (Cx * Cy)
     if out.dtype != torch.bfloat16 or out.numel() != gate_weights_elems(taps, Cx, Cy):
         raise ValueError('gate weight pack: expected %d bf16 elements' % gate_weights_elems(taps, Cx, Cy))
-    lib.check(_L().savp_pack_gate_weights(lib.stream(), _p(src), taps, Cx, Cy, _p(out)), 'savp_pack_gate_weights')
+    lib.check(_L().savp_pack_gate_weights(lib.stream(), _p(src), taps, Cx, Cy, _p(out), int(bool(interleave))), 'savp_pack_gate_weights')
 
 
 def fold_pool(inp, out, k, adjoint=False):

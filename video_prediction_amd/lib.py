@@ -37,7 +37,7 @@ class SavpConvArgs(ctypes.Structure):
         ('dst_gap_at', c_i32), ('dst_gap', c_i32),
         ('nb_x', c_vp), ('nb_x_sn', c_i64), ('nb_x_sp', c_i64), ('nb_mean', c_vp), ('nb_rstd', c_vp), ('nb_gamma', c_vp), ('nb_beta', c_vp),
         ('nb_ws', c_vp), ('nb_c0', c_i32), ('nb_nc', c_i32), ('nb_act', c_i32), ('nb_alpha', c_f32),
-        ('w_frag', c_vp),
+        ('w_frag', c_vp), ('w_frag_il', c_vp),
     ]
 
 
@@ -93,7 +93,7 @@ class _LdsPoisonProxy(object):
 # Kernel-selection switches of the library (include/savp_hip.h: savp_set_option).  The library itself never reads the environment;
 # for A/B runs the host forwards SAVP_<NAME>=<int> here, once, when the library is loaded.
 OPTION_NAMES = ('conv_ring', 's2dgrad', 'thin', 'wgp_cfg', 'wgp_split', 'inorm_min_hw', 'colsum_2stage', 'dense_legacy', 'cdna_legacy',
-                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm', 'wgp_dma', 'ring_early', 'gate_kernel', 'gate_alt', 'gate_wwarm')
+                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm', 'wgp_dma', 'ring_early', 'gate_kernel', 'gate_alt', 'gate_cell', 'gate_wwarm')
 
 
 def set_option(name, value):
@@ -379,7 +379,7 @@ for _n in ('savp_convgru_gates_fwd', 'savp_convgru_out_fwd', 'savp_convgru_out_b
     register(_n, [c_vp, ctypes.POINTER(SavpGruArgs)])
 register('savp_gan_loss', [c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_fold_f64', [c_vp, c_vp, c_i64, c_vp, c_vp])
-register('savp_pack_gate_weights', [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp])
+register('savp_pack_gate_weights', [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32])
 register('savp_debug_poison_lds', [c_vp, ctypes.c_uint32, c_vp])
 register('savp_debug_fill_u32', [c_vp, c_vp, c_i64, ctypes.c_uint32])
 register('savp_debug_probe_lds', [c_vp, ctypes.c_uint32, c_vp])

@@ -225,7 +225,9 @@ class SAVPGenerator(object):
                 L['dc'] = [torch.empty(N, h_, w_, f, device=dev), torch.empty(N, h_, w_, f, device=dev)] if g else None
                 L['rconv'] = ConvLayer(store, r + 'kernel', (r + 'bias') if self.cell_plain else None, 'conv', (5, 5), (1, 1), (2, 2))
                 if not self.cell_plain:
-                    L['rconv'].enable_gate_pack()      # the gate convolution's own kernel (bf16 datapath, csrc/conv_gate.hip)
+                    # the gate convolution's own kernel (bf16 datapath, csrc/conv_gate.hip); where a tile holds whole images (planes of <= 256
+                    # pixels) also the interleaved pack: savp_convlstm_cell_fwd then runs the whole cell forward as one launch
+                    L['rconv'].enable_gate_pack(cell=bool(L['fused']) and h_ * w_ <= 256)
                 if not self.cell_plain:
                     L['n1'] = Norm(store, r + 'input_transform_forget_output/', T1, N, 4 * f, dev)
                     L['n2'] = Norm(store, r + 'state/', T1, N, f, dev)
