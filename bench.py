@@ -375,6 +375,7 @@ def main():
     # weights in bf16 mode) and FLOPs (2*M*N*K of the gate conv) per cell launch-set, against both roofs.
     cell_s, cell_flops, cell_bytes, cell_n = 0.0, 0.0, 0.0, 0
     ck_s, ck_flops, ck_bytes, ck_n = 0.0, 0.0, 0.0, 0          # the same cells on the kernel-only clock: gate conv + gate block durations
+    two_launch_gate_us = {}
     for L in cells:
         h_, w_ = L['hw']
         cin, f = L['a'].v.shape[-1], L['f']
@@ -388,6 +389,7 @@ def main():
             cell_bytes += wbytes + abytes
             cell_n += 1
         g_us = gate_timers[id(L)].durations_us()
+        two_launch_gate_us[id(L)] = g_us
         c_us = conv_us_of.get(id(L['rconv']), [])
         if g_us and len(g_us) == len(c_us):
             ck_s += (sum(g_us) + sum(c_us)) * 1e-6
@@ -397,6 +399,41 @@ def main():
         gate_timers[id(L)].close()
         L['cell_prof'] = None
         L['gate_ktimer'] = None
+    # ... and the cell the way the timed region runs it: where the gate convolution's tile holds whole images (16 x 16, 8 x 8) the whole cell
+    # forward is ONE kernel (csrc/conv_gate.hip, CELL instantiations); a second set of instrumented steps times that kernel by its own dispatch
+    # stamps, the other layers as gate conv + gate block as above.
+    one_s, one_flops, one_n, one_layers = 0.0, 0.0, 0, 0
+    if INST_STEPS and args.precision == 'bf16':
+        fused_layers = [L for L in cells if getattr(L['rconv'], 'wfrag_il', None) is not None]
+        if fused_layers:
+            ct = {id(L): K.KernelTimer() for L in fused_layers}
+            for L in fused_layers:
+                L['cell_ktimer'] = ct[id(L)]
+            sync()
+            for _ in range(max(1, INST_STEPS // 2)):
+                engine.train_step()
+            sync()
+            for L in cells:
+                h_, w_ = L['hw']
+                cin, f = L['a'].v.shape[-1], L['f']
+                fl = 2.0 * engine.N * h_ * w_ * (4 * f) * (25 * cin)
+                if id(L) in ct:
+                    us = ct[id(L)].durations_us()
+                    ct[id(L)].close()
+                    L['cell_ktimer'] = None
+                    if us:
+                        one_s += sum(us) * 1e-6; one_flops += fl * len(us); one_n += len(us); one_layers += 1
+            # two-launch layers enter with the mean of their (gate conv + gate block) pairs measured above
+            two = [L for L in cells if id(L) not in ct]
+            for L in two:
+                c_us = conv_us_of.get(id(L['rconv']), [])
+                g_us = two_launch_gate_us.get(id(L), [])
+                if c_us and len(c_us) == len(g_us):
+                    h_, w_ = L['hw']
+                    cin, f = L['a'].v.shape[-1], L['f']
+                    fl = 2.0 * engine.N * h_ * w_ * (4 * f) * (25 * cin)
+                    k = len(c_us)
+                    one_s += (sum(c_us) + sum(g_us)) * 1e-6; one_flops += fl * k; one_n += k
     # HBM traffic of the same kernel / shapes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (FETCH_SIZE x2 on gfx950 per
     # MI355X_MICROARCH.md).  bench.py cannot collect counters itself: the number is read from the committed PMC pass of the
     # round (profiles/, written by tests/tools/collect_profiles.sh on the same build) and labelled with its source.
@@ -455,6 +492,10 @@ def main():
                                           'avg_cell_us': (ck_s / ck_n * 1e6) if ck_n else None, 'cells_timed': ck_n,
                                           'mfma_frac': (ck_flops / ck_s / 1e12 / PEAK_TFLOPS[args.precision]) if ck_s else None,
                                           'hbm_frac': (ck_bytes / ck_s / 1e9 / 8000.0) if ck_s else None},
+                          'as_timed': {'what': 'the cell as the timed region runs it: ONE kernel per cell on %d of the %d layers (16 x 16 and 8 x 8: conv_gate_kernel CELL '
+                                               'instantiations, dispatch stamps), gate conv + gate block on the others' % (one_layers, len(cells)),
+                                       'avg_cell_us': (one_s / one_n * 1e6) if one_n else None, 'cells_timed': one_n,
+                                       'mfma_frac': (one_flops / one_s / 1e12 / PEAK_TFLOPS[args.precision]) if one_s else None},
                           'mfma': {'achieved': (cell_flops / cell_s / 1e12) if cell_s else None, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                                    'frac': (cell_flops / cell_s / 1e12 / PEAK_TFLOPS[args.precision]) if cell_s else None},
                           'hbm': {'achieved': (cell_bytes / cell_s / 1e9) if cell_s else None, 'peak': 8000.0, 'unit': 'GB/s',

@@ -116,6 +116,15 @@ def write_png(path, image):
         f.write(png)
 
 
+def write_gif(path, frames, fps):
+    """frames uint8 [T, H, W, 1 | 3] -> an animated GIF at `fps`, looping (the reference's save_gif through moviepy, utils/ffmpeg_gif.py /
+    generate.py:170-176; here Pillow's GIF encoder: adaptive palette per frame)."""
+    from PIL import Image
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    imgs = [Image.fromarray(f[..., 0], 'L') if f.shape[-1] == 1 else Image.fromarray(f, 'RGB') for f in frames]
+    imgs[0].save(path, save_all=True, append_images=imgs[1:], duration=max(1, int(round(1000.0 / max(fps, 1)))), loop=0)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     import torch
@@ -174,10 +183,16 @@ def main(argv=None):
     first = 0                                                    # index of the batch's first sample (generate.py:154-189)
     while inputs is not None and not (args.num_samples and first >= args.num_samples):
         print("evaluation samples from %d to %d" % (first, first + args.batch_size))
+        context = to_uint8(inputs['images'][:, :context_frames])                                  # [B, context, H, W, C]
         for draw in range(args.num_stochastic_samples):
             future = to_uint8(model.generate(inputs)['gen_images'][:, -future_length:])      # [B, T - context, H, W, C]: the future frames only
             digits = max(2, len(str(future.shape[1] - 1)))
             for b, clip in enumerate(future):
+                # generate.py:170-176: context frames + generated frames as one GIF, truncated to --gif_length, at --fps
+                frames = np.concatenate([context[b], clip], axis=0)
+                if args.gif_length:
+                    frames = frames[:args.gif_length]
+                write_gif(os.path.join(args.output_gif_dir, 'gen_image_%05d_%02d.gif' % (first + b, draw)), frames, args.fps)
                 for t, frame in enumerate(clip):
                     name = 'gen_image_%05d_%02d_%0*d.png' % (first + b, draw, digits, t)
                     write_png(os.path.join(args.output_png_dir, name), frame)

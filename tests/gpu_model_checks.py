@@ -480,6 +480,7 @@ def check_cell_options():
     cases = [('learn_init', dict(learn_initial_state=True)),
              ('learn_init_gru', dict(learn_initial_state=True, conv_rnn='gru')),
              ('abl_rnn', dict(ablation_rnn=True)),
+             ('abl_rnn_learn_init', dict(ablation_rnn=True, learn_initial_state=True)),      # no state to learn: the flag does nothing (savp_model.py:269-307)
              ('abl_cell_norm', dict(ablation_conv_rnn_norm=True)),
              ('cell_norm_none', dict(conv_rnn_norm_layer='none')),
              ('rnn_gru', dict(rnn='gru', use_e_rnn=True, nef=16))]

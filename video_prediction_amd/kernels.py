@@ -882,6 +882,8 @@ def cdna_kernels_fwd(raw, kern, kh, kw, K):
 
 
 def cdna_kernels_bwd(raw, dkern, draw, kh, kw, K):
+    """dkern: the FLOAT64 accumulator [N, kh * kw, K] cdna_apply_bwd filled (include/savp_hip.h: savp_cdna_kernels_bwd)."""
+    lib.require_stats(dkern)             # a float32 buffer here (the pre-round-5 contract) would be read as float64: twice its size
     lib.check(_L().savp_cdna_kernels_bwd(lib.stream(), _p(raw), _p(dkern), _p(draw), raw.shape[0], kh, kw, K),
               'savp_cdna_kernels_bwd')
 
@@ -907,6 +909,7 @@ def cdna_apply_bwd(img, kern, dout, dimg, dkern, kh, kw, K, dimg_beta=0):
     if dimg is not None:
         a.dimg = view(dimg)
     a.dimg_beta = int(dimg_beta)
+    lib.require_stats(dkern)             # FLOAT64 [N, kh * kw, K], zeroed by the caller: the kernel adds float64 atomics over twice a float32 buffer's size
     a.dkern = _p(dkern)
     lib.check(_L().savp_cdna_apply_bwd(lib.stream(), ctypes.byref(a)), 'savp_cdna_apply_bwd')
 

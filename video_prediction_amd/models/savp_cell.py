@@ -123,8 +123,8 @@ class SAVPGenerator(object):
         # ablation_rnn (savp_model.py:272-291,426-429,466-474,502-509): no recurrent state anywhere -- every conv-RNN becomes conv2d 5x5
         # (+ tiled z) -> norm -> ReLU under scope conv_h<i>, the latent's cell becomes dense + tanh under scope fc_z
         self.abl_rnn = bool(hp.ablation_rnn)
-        if self.abl_rnn and hp.learn_initial_state:
-            raise ValueError('learn_initial_state has no state to learn under ablation_rnn')
+        # (learn_initial_state under ablation_rnn: the reference's state_size then holds no conv_rnn_states / rnn_z_state entries, so no
+        #  initial_state variables exist -- savp_model.py:269-307 -- and the flag does nothing; variables.py creates none either)
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
@@ -368,7 +368,7 @@ class SAVPGenerator(object):
         # `generator/initial_state_<i>/initial_state` (i = position in nest.flatten of {'conv_rnn_states': [...], 'rnn_z_state': ...}: layer
         # order, LSTM tuples as (c, h), the latent cell last), tiled over the batch; both unrolls (N = 2B) share them.  Forward: a broadcast
         # copy into step 0's state slots; backward: what step 0 hands back, summed over the batch.
-        self.learn_init = bool(hp.learn_initial_state)
+        self.learn_init = bool(hp.learn_initial_state) and not self.abl_rnn
         if self.learn_init:
             k = 0
 
@@ -579,7 +579,12 @@ class SAVPGenerator(object):
                     ca = (L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1, defer=True)
                           if (FUSED_ENTRIES and cp is None and gk is None and K.fused_ok()) else None)
                     if ca is not None:
+                        ck = L.get('cell_ktimer')            # bench.py: the one-launch cell's own begin / end stamps (the kernel takes the armed pair)
+                        if ck is not None:
+                            ck.arm()
                         K.convlstm_cell_fwd(ca, K.convlstm_gates_fwd(*gargs, eps=EPS_IN, ws=self._lstm_ws(L), stats1=stats1, defer=True))
+                        if ck is not None:
+                            ck.taken()
                     else:
                         L['rconv'].forward(a.v[t], L['gates'].v[t], use_bias=False, stats=s1)
                         if gk is not None:
