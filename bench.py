@@ -468,6 +468,7 @@ def main():
                                 'one Adam step on the L1 loss per train step') % (args.config, cfg['name'], seq, cfg['context'], hp.nz, args.batch),
                    'global_batch': world * args.batch, 'seq_len': seq, 'parallelism': 'dp%d' % world,
                    'sequences_per_s': world * args.batch * args.steps / dt,
+                   'conv_problems_tuned_live': len(K.AUTOTUNE['log']), 'tuner_rejected': len(K.AUTOTUNE['rejected']),
                    'submission': mode, 'eager_ms_per_step': eager_ms, 'host_issue_ms_per_step': host_issue_ms, 'instrumented_ms_per_step': inst_ms},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_TFLOPS[args.precision]) if achieved else None, 'traffic': traffic, 'algorithmic_bytes': traffic_alg,
@@ -568,6 +569,7 @@ def main():
                 except NameError:
                     pass
                 torch.cuda.empty_cache()
+                tuned0, rej0 = len(K.AUTOTUNE['log']), len(K.AUTOTUNE['rejected'])
                 engw, hpw = build_engine('bf16', cfg=wc, batch=wc['batch'], shape=wc['shape'], seq=wc['seq'])
                 engw.use_graph = True
                 kw = 20
@@ -577,7 +579,7 @@ def main():
                        'submission': 'hipGraph replay' if (engw.graph is not None and engw.graph.segments == 1) else 'eager launches',
                        'config': {'workload': '%s: %s, seq=%d, context=%d, nz=%d, batch=%d per GPU' % (name, wc['name'], wc['seq'], wc['context'], hpw.nz, wc['batch'])},
                        'losses': {'d_loss': float(infow['d_loss']), 'g_loss': float(infow['g_loss'])},
-                       'conv_problems_tuned_live': len(K.AUTOTUNE['log']), 'tuner_rejected': len(K.AUTOTUNE['rejected'])}
+                       'conv_problems_tuned_live': len(K.AUTOTUNE['log']) - tuned0, 'tuner_rejected': len(K.AUTOTUNE['rejected']) - rej0}
                 if name in step_tflop_of:
                     tfw = step_tflop_of[name] * wc['batch'] * kw / dtw
                     obj['roofline_step'] = {'tflop_per_sequence': step_tflop_of[name], 'achieved': tfw, 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',

@@ -14,7 +14,13 @@ python bench.py --steps 2 --warmup 2 --no-f32 --no-cpu-baseline --inst-steps 1 >
 bash tests/tools/collect_profiles.sh $TAG 2>&1 | tail -12
 echo "collect done $(( $(date +%s)-t0 ))s"
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+python -m video_prediction_amd.debug > $O/${TAG}_box_fingerprint.json 2>/dev/null
 timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_full_gputest.log 2>&1; echo "gputest rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/${TAG}_full_gputest.log
+# the same suite with every allocation, the caller-owned scratch and all of LDS NaN-poisoned before each launch, the zero arena checked (video_prediction_amd/debug.py)
+SAVP_POISON=1 timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_full_gputest_poisoned.log 2>&1; echo "poisoned gputest rc=$? $(( $(date +%s)-t0 ))s"; tail -3 $O/${TAG}_full_gputest_poisoned.log
+cp gpurun_out/pytest_evidence/soak_*.json gpurun_out/r06_replay_vs_eager_*.json $O/ 2>/dev/null
+# two default-shaped bench runs in ONE lease: identical `losses` (the step is bit-reproducible)
+for i in 1 2; do timeout 300 python bench.py --steps 40 --no-f32 --no-cpu-baseline --no-workloads --inst-steps 0 > $O/${TAG}_bench_repeat_$i.json 2>/dev/null; python -c "import json; d=json.load(open('$O/${TAG}_bench_repeat_$i.json')); print('repeat $i', d['ms_per_step'], d['losses'])"; done
 timeout 600 python bench.py --config c4 --steps 60 --warmup 5 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_c4_kth.json 2> $O/c4.err; echo "c4 rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-200 $O/${TAG}_bench_c4_kth.json
 timeout 600 python bench.py --config c5 --steps 40 --warmup 5 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_c5_128.json 2> $O/c5.err; echo "c5 rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-200 $O/${TAG}_bench_c5_128.json
 timeout 600 python bench.py --config c1 --steps 100 --warmup 5 --no-f32 --no-cpu-baseline > $O/${TAG}_bench_c1_det.json 2> $O/c1.err; echo "c1 rc=$? $(( $(date +%s)-t0 ))s"; cut -c1-200 $O/${TAG}_bench_c1_det.json

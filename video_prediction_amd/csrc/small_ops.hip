@@ -81,6 +81,13 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
     float dbj = 0.f;
     float dc_next = 0.f;
     if (j < nz) sh_dh[j] = 0.f;           // dh carried from t+1
+    // W in LDS (rows padded by one float: thread j reads row j), staged ONCE: inside the time loop the 4 nz global loads per step and thread were
+    // a serial chain of L1 round trips -- 278 us for this one launch in the step (profiles/r06_kernel_stats.csv).  nz <= 32; larger: global.
+    __shared__ float wsh[64 * 129];
+    const bool w_lds = nz <= 32;
+    const int wp = 4 * nz + 1;
+    if (w_lds)
+        for (int i = j; i < 2 * nz * 4 * nz; i += 4 * nz) wsh[(i / (4 * nz)) * wp + (i % (4 * nz))] = W[i];
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
         const long long o = (long long)t * B + b;
@@ -111,7 +118,8 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
         // dx = W dgate : thread i < 2nz computes sum_j W[i][j] * dg[j]
         if (j < 2 * nz) {
             float s = 0.f;
-            for (int q = 0; q < 4 * nz; ++q) s += W[j * 4 * nz + q] * sh_dg[q];
+            if (w_lds) { for (int q = 0; q < 4 * nz; ++q) s += wsh[j * wp + q] * sh_dg[q]; }
+            else { for (int q = 0; q < 4 * nz; ++q) s += W[j * 4 * nz + q] * sh_dg[q]; }
             if (j < nz) dzs[o * nz + j] = s;
             else sh_dh[j - nz] = s;
         }
