@@ -195,6 +195,12 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
             const bool row_ok = (unsigned)iy < (unsigned)S && n < p.N;
             const unsigned char* rb = xb + ((long long)n * S + iy) * (long long)(S * CIN * 2);
             const unsigned lds_row = patch_lds + (unsigned)(im * G::IMGB + py * G::RP);
+            if (!row_ok) {                                      // a row of padding (above / below the image, an absent image): plain LDS stores of zeros --
+#pragma unroll                                                  // a DMA instruction fetching 64 x the same 16 zero bytes costs 100 - 200 issue cycles
+                for (int j = 0; j < G::NJ; ++j)
+                    if (j * 64 + lane < G::PPR) *reinterpret_cast<uint4*>(patch + im * G::IMGB + py * G::RP + (j * 64 + lane) * 16) = make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < G::NJ; ++j) {
                 if (j * 64 + lane < G::PPR) {
@@ -218,11 +224,9 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
     const uint4* __restrict__ bsrc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bsrc[j] = p.wfrag + ((long long)(n0 / 32 + nw * TN + j) * KS) * 64 + lane;
-#ifdef SAVP_GATE_PF
-    constexpr int PF = SAVP_GATE_PF;
-#else
-    constexpr int PF = 4;                                       // k-steps of B look-ahead
-#endif
+    // k-steps of B look-ahead (= the unroll of the main loop, the slots of the register ring): about 1 000 cycles of MFMA work either way -- a
+    // k-step is 8 MFMAs (256 cycles) with 256-pixel tiles, 4 (128 cycles) with 128-pixel tiles, and an L2 hit under load takes 500 - 900
+    constexpr int PF = (TM * TN >= 8) ? 4 : 8;
 #ifndef SAVP_GATE_ABL
 #define SAVP_GATE_ABL 0                                         // developer timing builds (wrong results): 1 = no B loads in the loop, 2 = no A loads, 4 = no MFMAs
 #endif
@@ -285,20 +289,19 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
     };
     using U0 = std::integral_constant<int, 0>; using U1 = std::integral_constant<int, 1>;
     using U2 = std::integral_constant<int, 2>; using U3 = std::integral_constant<int, 3>;
-    static_assert(PF == 4, "the loop is unrolled four k-steps and the B ring has four slots");
+    using U4 = std::integral_constant<int, 4>; using U5 = std::integral_constant<int, 5>;
+    using U6 = std::integral_constant<int, 6>; using U7 = std::integral_constant<int, 7>;
+    static_assert(PF == 4 || PF == 8, "the loop is unrolled PF k-steps: the B ring's slots are compile-time registers");
     int k = ks0;
-    {
-        for (; k + 4 <= ks1; k += 4) {
-            kstep(k, U0{}, std::true_type{});
-            kstep(k + 1, U1{}, std::true_type{});
-            kstep(k + 2, U2{}, std::true_type{});
-            kstep(k + 3, U3{}, std::true_type{});
-        }
+    auto body = [&](auto... us) { (kstep(k + decltype(us)::value, us, std::true_type{}), ...); };
+    auto tail = [&](auto... us) { ((k < ks1 ? (kstep(k, us, std::false_type{}), ++k, 0) : 0), ...); };      // the last PF - 1 k-steps at most
+    if constexpr (PF == 4) {
+        for (; k + 4 <= ks1; k += 4) body(U0{}, U1{}, U2{}, U3{});
+        tail(U0{}, U1{}, U2{});
+    } else {
+        for (; k + 8 <= ks1; k += 8) body(U0{}, U1{}, U2{}, U3{}, U4{}, U5{}, U6{}, U7{});
+        tail(U0{}, U1{}, U2{}, U3{}, U4{}, U5{}, U6{});
     }
-    // the last one to three k-steps of the slice
-    if (k < ks1) { kstep(k, U0{}, std::false_type{}); ++k; }
-    if (k < ks1) { kstep(k, U1{}, std::false_type{}); ++k; }
-    if (k < ks1) { kstep(k, U2{}, std::false_type{}); ++k; }
     GT(4);
 
     // ---- the four K slices meet in LDS: a reduce-scatter over MFMA row tiles in the accumulators' own (register, lane) layout -- lane-linear
