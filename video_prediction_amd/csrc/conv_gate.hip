@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
 #pragma unroll
             for (int i = 0; i < TMFc; ++i)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) cp[i * 4 + m] = cpb[(long long)(erow(i, m) % HWI) * p.cp_sp];
+                for (int m = 0; m < 4; ++m) cp[i * 4 + m] = cpb[(erow(i, m) % HWI) * (int)p.cp_sp];
         } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) cp[e] = 0.f;
@@ -457,8 +457,11 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
         }
         const int first_of_image = (((im * WPI) & 1) << 1) | ((im * WPI) >> 1);
         if (live && kq == first_of_image && khalf == 0) { p.mean1[(long long)n * 4 * F + pc] = mu; p.rstd1[(long long)n * 4 * F + pc] = rs; }
-        // every lane activates its own gate: sigmoid(x) = 1 / (1 + exp(-x)) (f: x + forget_bias); j: tanh(x) = copysign((1 - e) / (1 + e), x), e = exp(-2 |x|)
-        const float sc = rs * ga1, sh = be1 - mu * rs * ga1 + (g == 2 ? p.forget_bias : 0.f);
+        // every lane activates its own gate, branch-free: sigmoid(y) = 1 / (1 + 2^(-y log2 e)) with y = x (i, o), x + forget_bias (f), 2 x (j: tanh(x) =
+        // 2 sigmoid(2 x) - 1); the instance norm's scale / shift, the factor and log2 e are folded into ONE fma per element
+        const float kk = g == 1 ? 2.f : 1.f;
+        const float sc = -1.4426950408889634f * kk * rs * ga1, sh = -1.4426950408889634f * kk * (be1 - mu * rs * ga1 + (g == 2 ? p.forget_bias : 0.f));
+        const float oa = kk, ob = 1.f - kk;                      // a = sigmoid * oa + ob
         float cpre[NE], so[NE];
         float s2 = 0.f, q2 = 0.f;
 #pragma unroll
@@ -468,10 +471,8 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
                 float a4[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float x = xq[i][4 * m + t] * sc + sh;
-                    const float e = __expf(g == 1 ? -2.f * fabsf(x) : -x);
-                    const float rc = __builtin_amdgcn_rcpf(1.f + e);
-                    a4[t] = g == 1 ? copysignf((1.f - e) * rc, x) : rc;
+                    const float e = __builtin_amdgcn_exp2f(xq[i][4 * m + t] * sc + sh);      // 2^(-y log2 e) = exp(-y); +inf for very negative y: rcp -> 0
+                    a4[t] = __builtin_amdgcn_rcpf(1.f + e) * oa + ob;
                 }
                 // 4 x 4 transpose inside the quad: gate k of this lane's element (register 4 m + g) = lane k's a4[g]
                 float gk[4];
@@ -529,18 +530,19 @@ __global__ __launch_bounds__(256, (2 * GateCfg<S, CIN, TM, TN, NWN>::LDSB <= 160
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k >= p.nh) break;
+                const int hsp = (int)p.h_sp[k];                  // (pixel strides of the destinations fit 31 bits: launcher)
                 if ((p.h16 >> k) & 1) {
                     unsigned short* __restrict__ hb = reinterpret_cast<unsigned short*>(p.h[k]) + (long long)n * p.h_sn[k] + cch;
 #pragma unroll
                     for (int i = 0; i < TMFc; ++i)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) hb[(long long)(erow(i, m) % HWI) * p.h_sp[k]] = __builtin_bit_cast(unsigned short, (__bf16)hv[i * 4 + m]);
+                        for (int m = 0; m < 4; ++m) hb[(erow(i, m) % HWI) * hsp] = __builtin_bit_cast(unsigned short, (__bf16)hv[i * 4 + m]);
                 } else {
                     float* __restrict__ hb = reinterpret_cast<float*>(p.h[k]) + (long long)n * p.h_sn[k] + cch;
 #pragma unroll
                     for (int i = 0; i < TMFc; ++i)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) hb[(long long)(erow(i, m) % HWI) * p.h_sp[k]] = hv[i * 4 + m];
+                        for (int m = 0; m < 4; ++m) hb[(erow(i, m) % HWI) * hsp] = hv[i * 4 + m];
                 }
             }
         }
@@ -786,6 +788,9 @@ bool conv_gate_cell_try(const SavpConvLstmCellArgs* c, hipStream_t st, int* rc) 
     if (g->no_norm || !g->gates_bf16 || g->F * 4 != a->Cy || g->N != a->N || g->HW != a->H * a->W || g->nh < 0 || g->nh > 4 || !g->gamma1 || !g->beta1 ||
         !g->gamma2 || !g->beta2 || !g->c_new || !g->mean1 || !g->rstd1 || !g->mean2 || !g->rstd2 || (g->F & 7))
         return false;
+    if (g->c_prev.sp * (long long)g->HW >= (1ll << 31)) return false;
+    for (int i = 0; i < g->nh; ++i)
+        if (g->h[i].sp * (long long)g->HW >= (1ll << 31)) return false;
     static const void* zero_of[64] = {nullptr};
     int dev_ord = 0;
     if (hipGetDevice(&dev_ord) != hipSuccess || dev_ord < 0 || dev_ord >= 64) dev_ord = 0;
