@@ -533,6 +533,18 @@ int savp_select_batch(void* stream, const int32_t* cond, const float* x, int64_t
  * and rounded to fp32 once, here, before the optimiser (base_model.py:486-510) or the gradient exchange reads them. */
 int savp_fold_f64(void* stream, const int32_t* idx, int64_t n, double* src, float* dst);
 
+/* The robot-state recurrence of the action / state-conditioned cell (savp_model.py:411-422, 655-658, 684-685), all T steps in one launch
+ * (state_pred.hip; it involves the actions and states only, so it is hoisted out of the per-frame loop like the latent's LSTMCell):
+ *     state_t = gt[t, n] ? states_in[t, n] : gen_{t-1, n}  (gen_{-1} = 0) ;   gen_t = [actions_t | state_t] . W + b
+ * actions [T, N, na] (NULL when na == 0), states_in [T, N, ns], gt int32 [T, N], W [(na + ns), ns], b [ns]; writes sa [T, N, na + ns] =
+ * [actions_t | state_t] (what the cell tiles beside the latent -- under stop_gradient, :421-422) and gen [T, N, ns].  na + ns <= 32.
+ * _bwd: dgen [T, N, ns] holds dL/dgen of the state loss (base_model.py:758-762) and is replaced by the total gradient (the step after
+ * hands its state's gradient back where it took the prediction); dW / db: float64, += , one workgroup in a fixed order. */
+int savp_state_pred_fwd(void* stream, int32_t T, int32_t N, int32_t na, int32_t ns, const float* actions, const float* states_in,
+                        const int32_t* gt, const float* W, const float* b, float* sa, float* gen);
+int savp_state_pred_bwd(void* stream, int32_t T, int32_t N, int32_t na, int32_t ns, const int32_t* gt, const float* W, const float* sa,
+                        float* dgen, double* dW, double* db);
+
 /* Weights of a gate convolution in MFMA B-fragment order (conv_gate.hip): src = the HWIO fp32 master [taps][Cx][Cy] (Cx % 8 == 0, Cy % 32 == 0);
  * out[cb][ks][lane][j] (bf16) = src[tap][ch8 * 8 + j][cb * 32 + (lane & 31)] for chunk 2 ks + (lane >> 5) = tap * (Cx / 8) + ch8, zero past the last
  * chunk, followed by 8 KB of zeros (the kernel's look-ahead reads past the last column block); savp_gate_weights_bytes(taps, Cx, Cy) bytes in all

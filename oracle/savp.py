@@ -266,7 +266,7 @@ def _conv_rnn_layer(vs, idx, conv_rnn_h, conv_rnn_states, new_conv_rnn_states, f
     return h
 
 
-def savp_cell_zero_state(images, hp, zs=None, vs=None):
+def savp_cell_zero_state(images, hp, zs=None, vs=None, n_states=0):
     """SAVPCell.zero_state, savp_model.py:263-308,344-352.
 
     learn_initial_state (:295-307): the conv-RNN states and the rnn_z state are variables `initial_state_<i>/initial_state`, i = position in
@@ -318,6 +318,8 @@ def savp_cell_zero_state(images, hp, zs=None, vs=None):
             st['rnn_z_state'] = (c0, h0)
         else:                                                                    # GRUCell: the state is h (:288-291)
             st['rnn_z_state'] = initial((hp.nz,))
+    if n_states:
+        st['gen_state'] = torch.zeros(B, n_states, dtype=dt)                     # state_size['gen_state'] (:291-292), never learned (:295-297)
     return st
 
 
@@ -337,6 +339,17 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
     image = torch.where(gt, image_in, states['gen_image'])                   # :406
     last_images = states['last_images'][1:] + [image]                         # :407
 
+    # :411-422: the robot state follows the same schedule as the image (ground truth, else the cell's own prediction); actions and the
+    # (stop-gradient) state join the latent in every tile-concatenated slice, state_pred sees actions and state with their gradient
+    state_action, sa_z = [], []
+    if 'states' in inputs:
+        state = torch.where(ground_truth_t.reshape(B, 1), inputs['states'], states['gen_state'])     # :412
+    if 'actions' in inputs:
+        state_action.append(inputs['actions'])
+        sa_z.append(inputs['actions'])
+    if 'states' in inputs:
+        state_action.append(state)
+        sa_z.append(state.detach())                                              # tf.stop_gradient (:421-422)
     state_action_z = None
     rnn_z_state = None
     if 'zs' in inputs:
@@ -357,6 +370,8 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
             state_action_z = rnn_z
         else:
             state_action_z = inputs['zs']
+    if sa_z:                                                                     # concat(state_action_z, axis=-1) (:436-444)
+        state_action_z = torch.cat(sa_z + ([state_action_z] if state_action_z is not None else []), dim=-1)
 
     def add_z(h):
         if state_action_z is None:
@@ -500,6 +515,11 @@ def savp_cell_call(vs, inputs, states, all_images, ground_truth_t, hp):
                   'conv_rnn_states': new_conv_rnn_states}
     if rnn_z_state is not None:
         new_states['rnn_z_state'] = rnn_z_state
+    if 'states' in inputs:                                                       # :655-658,666-667,684-685
+        v = vs.sub('state_pred')
+        gen_state = ops.dense(torch.cat(state_action, dim=-1), v['dense/kernel'], v['dense/bias'])
+        outputs['gen_states'] = gen_state
+        new_states['gen_state'] = gen_state
     return outputs, new_states
 
 
@@ -518,12 +538,15 @@ def generator_given_z_fn(vs, inputs, mode, hp, ground_truth_sampling=None):
     ground_truth = torch.cat([torch.ones(hp.context_frames, B, dtype=torch.bool),
                               torch.as_tensor(ground_truth_sampling, dtype=torch.bool)], dim=0)   # :333-334
     cell_vs = vs.sub('rnn').sub('savp_cell')
-    states = savp_cell_zero_state(images, hp, zs, vs)
+    cond = {k: inputs[k][:T1] for k in ('actions', 'states') if k in inputs}   # maybe_pad_or_slice of every input (:690-691)
+    states = savp_cell_zero_state(images, hp, zs, vs, n_states=cond['states'].shape[-1] if 'states' in cond else 0)
     outs = []
     for t in range(T1):
         step_in = {'images': images[t]}
         if zs is not None:
             step_in['zs'] = zs[t]
+        for k, v in cond.items():
+            step_in[k] = v[t]
         o, states = savp_cell_call(cell_vs, step_in, states, images, ground_truth[t], hp)
         outs.append(o)
     outputs = OrderedDict()
@@ -672,9 +695,11 @@ def _z_heads(vs, h):
 
 
 def posterior_fn(vs, inputs, hp):
-    """savp_model.py:21-51 (no actions)."""
+    """savp_model.py:21-51; actions are tile-concatenated to the frame pairs (:24-26)."""
     images = inputs['images']
     image_pairs = torch.cat([images[:-1], images[1:]], dim=-1)
+    if 'actions' in inputs:
+        image_pairs = ops.tile_concat([image_pairs, inputs['actions'][..., None, None, :]], axis=-1)
     T1, B = image_pairs.shape[:2]
     flat = image_pairs.reshape((T1 * B,) + tuple(image_pairs.shape[2:]))
     h = encoder(vs, flat, nef=hp.nef, n_layers=hp.n_layers, norm_layer=hp.norm_layer).reshape(T1, B, -1)
@@ -689,6 +714,12 @@ def prior_fn(vs, inputs, hp):
     images = inputs['images']
     c = hp.context_frames
     image_pairs = torch.cat([images[:c - 1], images[1:c]], dim=-1)
+    if 'actions' in inputs:
+        # :57-59: tile_concat broadcasts size-1 dimensions only (ops.py:995-1000), so the reference fails here unless the actions
+        # cover exactly the context pairs (context_frames == sequence_length); restated, not repaired
+        if inputs['actions'].shape[0] != image_pairs.shape[0]:
+            raise AssertionError('tile_concat: %d action steps against %d context frame pairs' % (inputs['actions'].shape[0], image_pairs.shape[0]))
+        image_pairs = ops.tile_concat([image_pairs, inputs['actions'][..., None, None, :]], axis=-1)
     Tc, B = image_pairs.shape[:2]
     flat = image_pairs.reshape((Tc * B,) + tuple(image_pairs.shape[2:]))
     h = encoder(vs, flat, nef=hp.nef, n_layers=hp.n_layers, norm_layer=hp.norm_layer).reshape(Tc, B, -1)

@@ -93,6 +93,9 @@ def generator_loss_fn(hp, inputs, outputs, kl_w):
         losses['gen_l1_loss'] = (l1_loss(gen_images, target_images), hp.l1_weight)
     if hp.l2_weight:
         losses['gen_l2_loss'] = (l2_loss(gen_images, target_images), hp.l2_weight)
+    if getattr(hp, 'state_weight', 0):                                                       # base_model.py:758-762
+        gen_states = outputs.get('gen_states_enc', outputs['gen_states'])
+        losses['gen_state_loss'] = (l2_loss(gen_states, inputs['states'][1:]), hp.state_weight)
     for infix, w, wf_l2, wf_cd, sfx, nm in (
             ('_image_sn', hp.image_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),
             ('_video_sn', hp.video_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),

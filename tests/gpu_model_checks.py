@@ -37,6 +37,23 @@ def synth(hp, B, H, W, C, seed=0, smooth=True):
     return torch.tensor(np.concatenate(frames, axis=0))            # [T,B,H,W,C] fp64
 
 
+def synth_cond(hp, B, cond, seed=0):
+    """Seeded actions [T-1, B, na] / states [T, B, ns] (fp64, time-major) for the action / state-conditioned cell; {} when cond == (0, 0)."""
+    na, ns = cond
+    rng = np.random.default_rng(1000 + seed)
+    T = hp.sequence_length
+    out = {}
+    if na:
+        out['actions'] = torch.tensor(rng.standard_normal((T - 1, B, na)))
+    if ns:
+        out['states'] = torch.tensor(np.cumsum(0.3 * rng.standard_normal((T, B, ns)), axis=0))
+    return out
+
+
+def _to_dev(cond_inputs):
+    return {k: v.float().to(DEV) for k, v in cond_inputs.items()}
+
+
 def make_noise(hp, B, seed=1, sampling=True):
     T1 = hp.sequence_length - 1
     rng = np.random.default_rng(seed)
@@ -57,11 +74,11 @@ def make_noise(hp, B, seed=1, sampling=True):
     return noise
 
 
-def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, **over):
+def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, cond=(0, 0), **over):
     hpd = dict(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none' if nz == 0 else 'inverse_sigmoid')
     hpd.update(over)
     hp = make_hparams(**hpd)
-    specs = V.variable_specs(hp, (H, W, C), mode='test')
+    specs = V.variable_specs(hp, (H, W, C), mode='test', cond=cond)
     vals = V.init_variables(specs, seed=4)
     # perturb norm params / biases so that they matter
     rng = np.random.default_rng(9)
@@ -76,12 +93,13 @@ def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, *
             vals[k] = (vals[k] * 3).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
     noise = make_noise(hp, B, sampling=True)
+    ci = synth_cond(hp, B, cond, seed)
     P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
     with torch.no_grad():
-        ref = OS.generator_fn(OS.Scope(P).sub('generator'), {'images': images}, 'train', hp, noise)
-    eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, device=DEV)
+        ref = OS.generator_fn(OS.Scope(P).sub('generator'), dict(ci, images=images), 'train', hp, noise)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, device=DEV, cond=cond)
     eng.mode = 'train'          # honour the injected scheduled-sampling mask like mode='train' does
-    eng.set_images(images.float().to(DEV), time_major=True)
+    eng.set_images(dict(_to_dev(ci), images=images.float().to(DEV)), time_major=True)
     eng.prep_generator_weights()
     gen = eng.forward_generator(noise, collect_masks=True)
     torch.cuda.synchronize()
@@ -114,6 +132,10 @@ def check_generator_forward(nz=0, B=2, T=5, H=64, W=64, C=3, seed=0, tag=None, *
     if nz and hp.learn_prior:
         out.append((tag + '/zs_mu_prior', rel(eng.prior.mu, ref['zs_mu_prior']), 1e-4))
         out.append((tag + '/zs_log_sigma_sq_prior', rel(eng.prior.ls, ref['zs_log_sigma_sq_prior']), 1e-4))
+    if cond[1]:
+        out.append((tag + '/gen_states', rel(g.gen_states.v[:, lo:], ref['gen_states']), 1e-5))
+        if nz:
+            out.append((tag + '/gen_states_enc', rel(g.gen_states.v[:, :B], ref['gen_states_enc']), 1e-5))
     return out
 
 
@@ -123,7 +145,7 @@ def _l2rel(got, ref):
     return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
 
 
-def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='train', abs_floor=2e-5, **over):
+def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='train', abs_floor=2e-5, cond=(0, 0), **over):
     """One (or two) sess.run(train_op) equivalents.  Gradients are compared per variable in relative L2 against the
     fp64 oracle; the yardstick for "within fp32 tolerance" is the SAME oracle evaluated in fp32 on the CPU: the HIP
     path must be within max(20x that error, 2e-3).  (LeakyReLU/ReLU kinks make a few discriminator gradients
@@ -133,7 +155,7 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
                video_sn_gan_weight=0.1, vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
     hpd.update(over)
     hp = make_hparams(**hpd)
-    specs = V.variable_specs(hp, (H, W, C), mode='train')
+    specs = V.variable_specs(hp, (H, W, C), mode='train', cond=cond)
     vals = V.init_variables(specs, seed=4)
     rng = np.random.default_rng(9)
     for k in vals:
@@ -144,12 +166,15 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
         elif k.endswith('initial_state'):        # learn_initial_state: zero-initialised in the reference; perturbed so that they matter
             vals[k] = (0.3 * rng.standard_normal(vals[k].shape)).astype(np.float32)
         elif k.endswith('kernel') and k.startswith('generator'):
-            vals[k] = (vals[k] * 3).astype(np.float32)
+            vals[k] = (vals[k] * (30 if 'state_pred' in k else 3)).astype(np.float32)
     images = synth(hp, B, H, W, C, seed)
+    ci = synth_cond(hp, B, cond, seed)
+    inputs64 = dict(ci, images=images)
+    inputs32 = {k: v.float() for k, v in inputs64.items()}
     P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
     st = OT.init_opt_state(P)
-    eng = SAVPEngine(hp, (H, W, C), B, mode='train', values=vals, device=DEV)
-    eng.set_images(images.float().to(DEV), time_major=True)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='train', values=vals, device=DEV, cond=cond)
+    eng.set_images(dict(_to_dev(ci), images=images.float().to(DEV)), time_major=True)
     out = []
     for it in range(steps):
         noise = make_noise(hp, B, seed=100 + it, sampling=True)
@@ -157,10 +182,10 @@ def check_train_step(B=2, T=6, H=64, W=64, C=3, nz=8, steps=2, seed=0, tag='trai
         if it == 0:
             P32 = {k: v.float() for k, v in P.items()}
             n32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in noise.items()}
-            _, _, info32 = OT.train_step(P32, OT.init_opt_state(P32), {'images': images.float()}, hp, n32,
+            _, _, info32 = OT.train_step(P32, OT.init_opt_state(P32), inputs32, hp, n32,
                                          noise.get('d_indices_pre'), noise.get('d_indices_post'), step=it)
         P_before = P
-        P, st, info_ref = OT.train_step(P, st, {'images': images}, hp, noise, noise.get('d_indices_pre'), noise.get('d_indices_post'),
+        P, st, info_ref = OT.train_step(P, st, inputs64, hp, noise, noise.get('d_indices_pre'), noise.get('d_indices_post'),
                                         step=it)
         info = eng.train_step(noise, return_grads=(it == 0))
         torch.cuda.synchronize()
@@ -469,6 +494,91 @@ def check_eval_best_of_n(B=2, T=6, H=32, W=32, C=3, num_samples=4):
     for k in r:
         res.append(('metrics_fn/' + k, rel(m[k], r[k]), 2e-3))
     return res
+
+
+def check_action_conditioned():
+    """The action / state-conditioned cell (savp_model.py:24-26,411-444,655-661; base_model.py:758-762), forward (fp32 datapath vs the
+    fp64 oracle) and through one train step with the state loss on: actions + states with the latent (tiled width 16: every channel
+    count stays aligned), BAIR's use_state shapes (4 actions + 3 states + nz 8 = 15 tiled channels: odd channel counts everywhere),
+    actions only on the deterministic model (nz = 0), and where_add = 'input'."""
+    res = []
+    cases = [('a4s4', (4, 4), 8, dict(state_weight=1.0)),
+             ('a4s3_bair_use_state', (4, 3), 8, dict(state_weight=1.0)),
+             ('a4_det', (4, 0), 0, dict()),
+             ('a2s2_where_input', (2, 2), 8, dict(state_weight=0.5, where_add='input'))]
+    for tag, cond, nz, over in cases:
+        over_f = {k: v for k, v in over.items() if k != 'state_weight'}
+        res += check_generator_forward(nz=nz, B=2, T=5, tag='gen_fwd_' + tag, cond=cond, **over_f)
+        if nz:
+            res += check_train_step(B=2, T=5, nz=nz, steps=1, tag='train_' + tag, cond=cond, **over)
+        else:
+            res += check_train_step(B=2, T=5, nz=0, steps=1, tag='train_' + tag, cond=cond, kl_weight=0.0, video_sn_vae_gan_weight=0.0,
+                                    vae_gan_feature_cdist_weight=0.0, **over)
+    res += check_action_conditioned_bf16((4, 4), 'a4s4')
+    res += check_action_conditioned_bf16((4, 3), 'a4s3_bair_use_state')
+    return res
+
+
+def check_action_conditioned_bf16(cond, tag, B=2, T=5, H=64, W=64, C=3):
+    """The conditioned cell on the bf16 datapath (bench default) against the SAME engine on the exact-fp32 datapath (itself held to the
+    oracle above), one train step from identical variables / inputs / noise: the gates of check_train_recipe_shapes' bf16 arm (losses 2e-2 /
+    6e-2 of max(|ref|, 0.05), frames 5e-2 absolute, per-variable gradients 0.25 relative L2 with the 2e-3-of-gmax absolute floor); the
+    state recurrence involves no convolution and must agree to fp32 rounding."""
+    from video_prediction_amd import kernels as K
+    hp = make_hparams(context_frames=2, sequence_length=T, clip_length=4, nz=8, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
+                      l2_weight=0.0, kl_weight=1.0, kl_anneal='none', video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
+                      vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0, state_weight=1.0)
+    specs = V.variable_specs(hp, (H, W, C), mode='train', cond=cond)
+    vals = V.init_variables(specs, seed=4)
+    rng = np.random.default_rng(9)
+    for k in vals:
+        if k.endswith('gamma'):
+            vals[k] = (1 + 0.2 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('bias'):
+            vals[k] = (0.1 * rng.standard_normal(vals[k].shape)).astype(np.float32)
+        elif k.endswith('kernel') and k.startswith('generator'):
+            vals[k] = (vals[k] * (30 if 'state_pred' in k else 3)).astype(np.float32)
+    images = synth(hp, B, H, W, C, 0)
+    ci = synth_cond(hp, B, cond, 0)
+    noise = make_noise(hp, B, seed=100, sampling=True)
+    runs = {}
+    for prec in ('f32', 'bf16'):
+        K.set_conv_precision(prec)
+        try:
+            eng = SAVPEngine(hp, (H, W, C), B, mode='train', values=vals, device=DEV, cond=cond)
+            eng.set_images(dict(_to_dev(ci), images=images.float().to(DEV)), time_major=True)
+            info = eng.train_step(noise, return_grads=True)
+            torch.cuda.synchronize()
+            runs[prec] = (info, eng.gen.gen.v.double().cpu(), eng.gen.gen_states.v.double().cpu())
+        finally:
+            K.set_conv_precision('f32')
+    (ref, gen_r, gs_r), (got, gen_g, gs_g) = runs['f32'], runs['bf16']
+    t = 'cond_bf16_%s' % tag
+    out = []
+
+    def lrel(a, b):
+        return abs(float(a) - float(b)) / max(abs(float(b)), 0.05)
+    out.append((t + '/d_loss', lrel(got['d_loss'], ref['d_loss']), 2e-2))
+    out.append((t + '/g_loss', lrel(got['g_loss'], ref['g_loss']), 2e-2))
+    for nm, (l, w) in got['g_losses'].items():
+        out.append((t + '/' + nm, lrel(l, ref['g_losses'][nm][0]), 6e-2))
+    out.append((t + '/gen_images_abs', float((gen_g - gen_r).abs().max()), 5e-2))
+    out.append((t + '/gen_states', rel(gs_g, gs_r), 1e-5))
+    for grp, key in (('d', 'd_grads'), ('g', 'g_grads')):
+        gmax = max(float(v.abs().max()) for v in ref[key].values())
+        worst, wname = 0.0, ''
+        for name, gref in ref[key].items():
+            g_ = got[key][name]
+            if float(gref.abs().max()) < 1e-9 * gmax:
+                e, tol = float(g_.abs().max()) / gmax, 1e-2
+            else:
+                e, tol = _l2rel(g_, gref), 0.25
+                if float((g_.double() - gref.double()).abs().max()) <= 2e-3 * gmax:
+                    e = min(e, tol)
+            if e / tol > worst:
+                worst, wname = e / tol, name
+        out.append((t + '/%s_grads_worst_err_over_tol[%s]' % (grp, wname.split('/', 1)[-1][-36:]), worst, 1.0))
+    return out
 
 
 def check_cell_options():

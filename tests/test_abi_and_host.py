@@ -290,24 +290,39 @@ def test_allreduce_bucket_entry_point_validates_its_arguments(hip_lib):
     assert hip_lib.savp_allreduce_bucket(0x1000, None, 0x2000, 0) == 0
 
 
-def test_action_and_state_inputs_are_refused_not_ignored():
-    """SAVPCell.call consumes inputs['actions'] / ['states'] (reference savp_model.py:413-421,655-658); the HIP path is action-free,
-    so every entry that takes the dataset's inputs dict raises instead of running as if the keys were absent."""
+def test_conditioning_inputs_are_read_off_the_inputs_dict_and_pix_distribs_are_refused_not_ignored():
+    """SAVPCell.call consumes inputs['actions'] / ['states'] (reference savp_model.py:413-421,655-658): the model is built for the widths
+    the inputs dict carries (round 6; GPU parity: test_gpu_model.py::test_action_and_state_conditioned_cell_vs_oracle).  inputs['pix_distribs']
+    (:408-410,647-653) is not on the HIP path: every entry that takes the dataset's inputs dict raises instead of running as if the key
+    were absent."""
     import numpy as np
     import pytest
     from video_prediction_amd.models import get_model_class
     from video_prediction_amd.models import savp_model as M
+    from video_prediction_amd import variables as V
     images = np.zeros((2, 4, 64, 64, 3), np.float32)
     model = get_model_class('savp')(mode='test', hparams_dict=dict(context_frames=2, sequence_length=4))
-    for key in ('actions', 'states'):
-        inputs = {'images': images, key: np.zeros((2, 4, 4), np.float32)}
-        with pytest.raises(NotImplementedError, match=key):
-            model.build_graph(inputs)
-        with pytest.raises(NotImplementedError, match=key):
-            M.generator_fn(inputs, 'test', model.hparams)
-        with pytest.raises(NotImplementedError, match=key):
-            M.SAVPEngine.set_images(None, inputs)
-    M.refuse_conditioning_inputs({'images': images, 'actions': None})       # an absent / None entry is the action-free case
+    inputs = {'images': images, 'pix_distribs': np.zeros((2, 4, 64, 64, 1), np.float32)}
+    with pytest.raises(NotImplementedError, match='pix_distribs'):
+        model.build_graph(inputs)
+    with pytest.raises(NotImplementedError, match='pix_distribs'):
+        M.generator_fn(inputs, 'test', model.hparams)
+    with pytest.raises(NotImplementedError, match='pix_distribs'):
+        M.SAVPEngine.set_images(None, inputs)
+    M.refuse_conditioning_inputs({'images': images, 'pix_distribs': None})       # an absent / None entry is fine
+    assert M.cond_of({'images': images}) == (0, 0)
+    assert M.cond_of({'images': images, 'actions': np.zeros((2, 3, 4), np.float32), 'states': np.zeros((2, 4, 3), np.float32)}) == (4, 3)
+    assert M.cond_of({'images': images, 'actions': None, 'states': np.zeros((2, 4, 5), np.float32)}) == (0, 5)
+    # the variable table of the conditioned model: BAIR with use_state (4 actions, 3 states, nz = 8)
+    specs = V.variable_specs(model.hparams, (64, 64, 3), mode='test', cond=(4, 3))
+    assert specs['generator/rnn/savp_cell/h0/conv_pool2d/kernel'][0] == (5, 5, 6 + 15, 32)
+    assert specs['generator/rnn/savp_cell/lstm_h0/basic_conv2dlstm_cell/kernel'][0] == (5, 5, 32 + 15 + 32, 128)
+    assert specs['generator/encoder/layer_1/conv2d/kernel'][0] == (4, 4, 6 + 4, 64)
+    assert specs['generator/rnn/savp_cell/state_pred/dense/kernel'][0] == (7, 3)
+    # state_weight without states: the reference reads inputs['states'] (base_model.py:758-760)
+    hp = get_model_class('savp')(mode='train', hparams_dict=dict(context_frames=2, sequence_length=4, state_weight=1.0)).hparams
+    with pytest.raises(KeyError):
+        M.SAVPEngine(hp, (64, 64, 3), 2, mode='train', device='cpu')
 
 
 def test_fused_operator_entries_refuse_halves_that_do_not_fit(hip_lib):

@@ -76,6 +76,13 @@ def test_cell_options_no_shipped_recipe_sets_vs_oracle():
     _assert_ok(G.check_cell_options())
 
 
+def test_action_and_state_conditioned_cell_vs_oracle():
+    """inputs['actions'] / inputs['states'] (savp_model.py:24-26,411-444,655-661; base_model.py:758-762): forward and train-step parity of
+    the conditioned cell, including BAIR's use_state widths (4 + 3 + nz 8 = 15 tiled channels) and the state loss."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_action_conditioned())
+
+
 def test_config_c1_deterministic_b4_t12_forward_and_train_vs_oracle():
     """BASELINE configs[0] at its own shape (not scaled): deterministic generator, nz=0, B=4, T=12, 64x64x3, the
     ours_deterministic_l1 recipe."""
@@ -404,6 +411,49 @@ def test_checkpoint_save_restore_round_trip(tmp_path):
     ga = a.engine.generate(noise).clone()
     gb = b.engine.generate(noise)
     assert float((ga - gb).abs().max()) <= 2e-4          # same weights; the norm statistics are summed atomically (order noise, amplified by the recurrence)
+
+
+def test_model_class_with_actions_and_states_trains_generates_and_checkpoints(tmp_path):
+    """The reference's scripts hand the dataset's inputs dict to build_graph / train_step (scripts/train.py:160-176): with 'actions' and
+    'states' in it (BAIR with use_state: 4 + 3) the model is built conditioned, trains with the state loss (three eager + one replayed step),
+    generates, reports gen_states through generator_fn, and its checkpoint carries state_pred/dense under the reference's names."""
+    from video_prediction_amd.models import get_model_class
+    from video_prediction_amd.models import savp_model as SM
+    Model = get_model_class('savp')
+    hp = dict(context_frames=2, sequence_length=6, nz=8, clip_length=4, state_weight=1e-4, video_sn_gan_weight=0.1, video_sn_vae_gan_weight=0.1)
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 6
+    inputs = {'images': torch.rand(B, T, 64, 64, 3, generator=g).cuda(), 'actions': torch.randn(B, T - 1, 4, generator=g).cuda(),
+              'states': torch.randn(B, T, 3, generator=g).cuda()}
+    m = Model(mode='train', hparams_dict=hp)
+    m.build_graph(inputs)
+    assert m.engine.cond == (4, 3)
+    names = set(m.engine.store.names())
+    assert {'generator/rnn/savp_cell/state_pred/dense/kernel', 'generator/rnn/savp_cell/state_pred/dense/bias'} <= names
+    losses = []
+    for _ in range(4):
+        info = m.train_step(inputs)
+        losses.append(float(info['g_losses']['gen_state_loss'][0]))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[0] > 0
+    with pytest.raises(KeyError):
+        m.train_step({'images': inputs['images'], 'actions': inputs['actions']})      # the structure is fixed by build_graph
+    out = m.generate(inputs)
+    assert tuple(out['gen_images'].shape) == (B, T - 1, 64, 64, 3) and bool(torch.isfinite(out['gen_images']).all())
+    tm = {k: v.transpose(0, 1).contiguous() for k, v in inputs.items()}
+    o = SM.generator_fn(tm, 'test', m.hparams, engine=m.engine)
+    assert tuple(o['gen_states'].shape) == (T - 1, B, 3) and tuple(o['gen_states_enc'].shape) == (T - 1, B, 3)
+    # within the context the cell sees the true state: gen_state_t = [a_t | s_t] W + b
+    W = m.engine.store['generator/rnn/savp_cell/state_pred/dense/kernel']
+    b = m.engine.store['generator/rnn/savp_cell/state_pred/dense/bias']
+    want = torch.cat([tm['actions'][0], tm['states'][0]], -1) @ W + b
+    assert float((o['gen_states'][0] - want).abs().max()) < 1e-5
+    m.save(str(tmp_path / 'model-4'))
+    m2 = Model(mode='train', hparams_dict=hp)
+    m2.build_graph(inputs)
+    m2.restore(str(tmp_path))
+    for n in names:
+        assert torch.equal(m.engine.store[n], m2.engine.store[n]), n
 
 
 def test_plugin_functions_public_signatures_keys_and_shapes():

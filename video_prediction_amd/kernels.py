@@ -372,7 +372,17 @@ def conv(mode, geom, x, y, w, bias=None, beta=0, act=0, alpha=0.0, aux=None, spl
         CONV_CALL_LOG.append((mode, a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, tuple(geom.k), tuple(geom.s), a.tile, a.splitk))
     if defer:                          # the filled argument block (tile / split-K chosen) for a fused-operator entry point; nothing is launched
         return a
-    lib.check(lib.get().savp_conv(lib.stream(), ctypes.byref(a)), 'savp_conv')
+    rc = lib.get().savp_conv(lib.stream(), ctypes.byref(a))
+    if rc:
+        lib.check(rc, 'savp_conv(%s)' % describe_conv(a))
+
+
+def describe_conv(a):
+    """One line naming a convolution problem (for error messages and logs)."""
+    return ('%s N=%d in=%dx%dx%dx%d out=%dx%dx%dx%d k=%dx%dx%d s=%dx%dx%d prec=%s x=%s%s y=%s%s tile=0x%x splitk=%d act=%d beta=%d bias=%d' %
+            (('fprop', 'dgrad', 'wgrad')[a.mode], a.N, a.D, a.H, a.W, a.Cx, a.Do, a.Ho, a.Wo, a.Cy, a.kd, a.kh, a.kw, a.sd, a.sh, a.sw,
+             'bf16' if a.precision == 1 else 'f32', 'bf16' if a.src_bf16 else 'f32', '/sw%d' % a.x_sw, 'bf16' if a.out_bf16 else 'f32',
+             '/sw%d' % a.y_sw, a.tile, a.splitk, a.act, a.beta, 1 if a.bias else 0))
 
 
 def conv_stats_ok(mode, geom, x, y, w, bias=None, w16=None, dst_gap=None, norm_bwd=None):
@@ -866,6 +876,34 @@ def fold64(src64, dst32, idx=None):
         _require_i32(idx)
     n = idx.numel() if idx is not None else src64.numel()
     lib.check(_L().savp_fold_f64(lib.stream(), _p(idx), n, _p(src64), _p(dst32)), 'savp_fold_f64')
+
+
+def state_pred_fwd(actions, states_in, gt, W, b, sa, gen):
+    """savp_model.py:411-422,655-658: the robot-state recurrence over all T steps.  actions [T,N,na] or None, states_in [T,N,ns], gt int32
+    [T,N]; fills sa [T,N,na+ns] = [actions_t | state_t] and gen [T,N,ns]."""
+    T, N, ns = states_in.shape
+    na = actions.shape[-1] if actions is not None else 0
+    for t_ in (actions, states_in, W, b, sa, gen):
+        if t_ is not None:
+            lib.require_device(t_)
+            assert t_.is_contiguous() and t_.dtype == torch.float32
+    _require_i32(gt)
+    assert gt.is_contiguous() and tuple(gt.shape) == (T, N) and tuple(W.shape) == (na + ns, ns) and tuple(sa.shape) == (T, N, na + ns)
+    assert tuple(gen.shape) == (T, N, ns) and (actions is None or tuple(actions.shape[:2]) == (T, N))
+    lib.check(_L().savp_state_pred_fwd(lib.stream(), T, N, na, ns, _p(actions), _p(states_in), _p(gt), _p(W), _p(b), _p(sa), _p(gen)),
+              'savp_state_pred_fwd')
+
+
+def state_pred_bwd(gt, W, sa, dgen, dW64, db64):
+    """dgen [T,N,ns]: dL/dgen_state of the loss in, total gradient out; dW64 / db64 float64, accumulated."""
+    T, N, ns = dgen.shape
+    na = sa.shape[-1] - ns
+    lib.require_stats(dW64)
+    lib.require_stats(db64)
+    _require_i32(gt)
+    assert dgen.is_contiguous() and sa.is_contiguous() and dW64.numel() == (na + ns) * ns and db64.numel() == ns
+    lib.check(_L().savp_state_pred_bwd(lib.stream(), T, N, na, ns, _p(gt), _p(W), _p(sa), _p(dgen), _p(dW64), _p(db64)),
+              'savp_state_pred_bwd')
 
 
 def adam(p, g, m, v, lr_t, beta1, beta2, eps=1e-8, gscale=1.0, lr_t_dev=None):

@@ -22,12 +22,17 @@ class PosteriorEncoder(object):
     prior=True builds prior_fn (:54-85) under its own scope: the convolutional encoder sees only the context_frames-1 context
     pairs, the remaining sequence_length-context_frames feature rows are zeros, and the recurrent tail is always present."""
 
-    def __init__(self, store, hp, image_shape, B, train=True, prefix='generator/encoder/', prior=False):
+    def __init__(self, store, hp, image_shape, B, train=True, prefix='generator/encoder/', prior=False, n_actions=0):
         H, W, C = image_shape
         self.hp, self.store = hp, store
         self.T1 = T1 = hp.sequence_length - 1
         self.prior = prior
         self.Tc = Tc = (hp.context_frames - 1) if prior else T1           # steps whose frame pair is encoded
+        self.na = na = int(n_actions)                                     # inputs['actions'] tiled behind the frame pair (savp_model.py:24-26,57-59)
+        if prior and na and Tc != T1:
+            # prior_fn tile-concatenates T-1 action steps to context_frames-1 frame pairs: ops.tile_concat only broadcasts size-1
+            # dimensions (ops.py:995-1000), the reference's graph construction fails
+            raise ValueError('learn_prior with actions: %d action steps against %d context frame pairs (savp_model.py:56-59)' % (T1, Tc))
         self.B, self.M, self.R = B, Tc * B, T1 * B
         M, R = self.M, self.R
         dev = store.device
@@ -38,10 +43,10 @@ class PosteriorEncoder(object):
         if self.recurrent and hp.rnn not in ('lstm', 'gru'):
             raise NotImplementedError(hp.rnn)                                  # savp_model.py:40-41
         self.gru = bool(self.recurrent and hp.rnn == 'gru')
-        self.pairs = torch.zeros(max(M, 1), H, W, 2 * C, device=dev)
+        self.pairs = torch.zeros(max(M, 1), H, W, 2 * C + na, device=dev)
         self.C = C
         self.layers = []
-        cin, h, w = 2 * C, H, W
+        cin, h, w = 2 * C + na, H, W
         x = self.pairs
         for i in range(hp.n_layers):
             cout = hp.nef * min(2 ** i, 4)
@@ -119,15 +124,20 @@ class PosteriorEncoder(object):
     def _head_input(self):
         return self.hout.reshape(self.R, -1) if self.recurrent else self.feat
 
-    def forward(self, images, eps, kl=True):
-        """images [T,B,H,W,C] contiguous; eps [T1,B,nz].  Returns z [T1,B,nz] = mu + sigma*eps (and fills mu, ls; kl=True also
-        accumulates KL(q || N(0,1)) into self.kl -- the learned-prior KL is taken by the caller with kernels.kl_gauss)."""
+    def forward(self, images, eps, kl=True, actions=None):
+        """images [T,B,H,W,C] contiguous; eps [T1,B,nz]; actions [T1,B,na] when built with n_actions.  Returns z [T1,B,nz] = mu +
+        sigma*eps (and fills mu, ls; kl=True also accumulates KL(q || N(0,1)) into self.kl -- the learned-prior KL is taken by the
+        caller with kernels.kl_gauss)."""
         T1, B, C, M, R, Tc = self.T1, self.B, self.C, self.M, self.R, self.Tc
         if M:
             a = images[:Tc].reshape((M,) + tuple(images.shape[2:]))
             b = images[1:Tc + 1].reshape((M,) + tuple(images.shape[2:]))
             copy_view(a, [self.pairs[..., 0:C]])                                   # image_pairs = concat([x_t, x_t+1])  :23
             copy_view(b, [self.pairs[..., C:2 * C]])
+            if self.na:                                                            # tile_concat([image_pairs, actions[..., None, None, :]])  :24-26
+                if actions is None:
+                    raise ValueError('this encoder was built for inputs with actions')
+                K.tile_channels(actions[:Tc].reshape(M, self.na), self.pairs[..., 2 * C:2 * C + self.na])
             for L in self.layers:
                 if not L['normed']:
                     L['conv'].forward(L['x'], L['y'], act=lib.ACT_LRELU, alpha=0.2)            # networks.py:18-19

@@ -88,7 +88,9 @@ class ConcatNorm(object):
 
 
 class SAVPGenerator(object):
-    def __init__(self, store, hp, image_shape, N, train=True, prefix='generator/rnn/savp_cell/'):
+    def __init__(self, store, hp, image_shape, N, train=True, prefix='generator/rnn/savp_cell/', cond=(0, 0)):
+        """cond = (n_actions, n_states): widths of inputs['actions'] / inputs['states'] (savp_model.py:411-444): [actions_t | state_t]
+        joins the latent in every tile-concatenated slice, the next state is predicted by `state_pred/dense` (:655-658)."""
         H, W, C = image_shape
         self.hp, self.store, self.N, self.H, self.W, self.C = hp, store, N, H, W, C
         self._ones = None
@@ -127,6 +129,11 @@ class SAVPGenerator(object):
         #  initial_state variables exist -- savp_model.py:269-307 -- and the flag does nothing; variables.py creates none either)
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
+        self.na, self.ns = na, ns = int(cond[0]), int(cond[1])
+        self.cw = cw = na + ns                 # conditioning columns in front of the latent: state_action_z = [actions | state | z]
+        self.zw = zw = cw + nz                 # width of every tiled slice
+        if cw > 32:
+            raise NotImplementedError('actions + states wider than 32 (csrc/state_pred.hip keeps them in registers)')
         # where the latent is tile-concatenated (savp_model.py:456-470,492-506): 'all' = the input of every down / upsample conv and of
         # every conv-RNN; 'input' = the first encoder conv only; 'middle' = the first decoder conv only
         # use_tile_concat=False (savp_model.py:458-460,470-471,495-496,506-507 -> _maybe_tile_concat_layer :983-993, rnn_ops.py:128-135,
@@ -136,7 +143,7 @@ class SAVPGenerator(object):
         # z, the `dense/kernel` / `weights` variables and z itself get zero gradients.  The layers therefore run without z channels and
         # those variables keep their (zero-initialised) gradients; pinned against the oracle, which computes the sums literally.
         tile = bool(hp.use_tile_concat)
-        zr = nz if (hp.where_add == 'all' and tile) else 0              # z channels in a conv-RNN's input [x | z | h]
+        zr = zw if (hp.where_add == 'all' and tile) else 0              # tiled channels in a conv-RNN's input [x | actions state z | h]
         g = train
         # bf16 storage of tensors whose ONLY readers are convolutions of the bf16 datapath (round 4; the cell input [x | z | h] and the
         # gate gradient have been stored this way since round 3): the inputs of the down / upsample convolutions behind layer 0, the
@@ -157,7 +164,7 @@ class SAVPGenerator(object):
             L = {'f': f, 'rnn': use_rnn, 'idx': i, 'dec': i >= self.ne}
             s = prefix + 'h%d/' % i
             j_dec = i - len(enc_specs)
-            zc = nz if (tile and (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0) or
+            zc = zw if (tile and (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0) or
                                   (hp.where_add == 'middle' and j_dec == 0))) else 0
             L['zc'], L['zr'] = zc, zr
             if i < self.ne:
@@ -181,7 +188,11 @@ class SAVPGenerator(object):
                 L['conv'] = ConvLayer(store, s + 'upsample_conv2d/kernel', s + 'upsample_conv2d/bias', 'up', (3, 3), (2, 2),
                                       (same_pad_before(6, 2, h_), same_pad_before(6, 2, w_)))
             L['hw'] = (h_, w_)
-            L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g, grad_dtype=a16 if f % 8 == 0 else torch.float32)
+            # (a decoder layer whose input keeps an odd channel count -- conditioning widths that are no multiple of 8 -- stays fp32 on both
+            #  sides: the weight gradient of an upsample conv reads the input as its `dy` operand, and only whole 4-channel groups ride
+            #  the bf16-operand kernel)
+            pre16 = f % 8 == 0 and (i < self.ne or L['in'].v.dtype == torch.bfloat16 or not self.act16)
+            L['pre'] = Act((T1, N, h_, w_, f), dev, grad=g, grad_dtype=a16 if pre16 else torch.float32)
             L['norm'] = Norm(store, s + 'InstanceNorm/', T1, N, f, dev)
             if use_rnn and self.abl_rnn:
                 r = prefix + 'conv_h%d/' % i
@@ -237,7 +248,7 @@ class SAVPGenerator(object):
                 # The data gradient of the gate convolution leaves the tiled-z channels of [x | z | h] out (their gradient is a per-sample
                 # sum, taken once over all timesteps from region sums of the gate gradient: csrc/tiled_z.hip), which keeps its column count
                 # on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256).  bf16 datapath (the ring kernel owns the column gap).
-                L['zless'] = bool(g and zr and L['fused'] and os.environ.get('SAVP_ZLESS_DGRAD', '1') == '1' and
+                L['zless'] = bool(g and zr and not cw and L['fused'] and os.environ.get('SAVP_ZLESS_DGRAD', '1') == '1' and
                                   K.tiled_z_ok(h_, w_, 4 * f, zr, L['rconv'].geom))
                 if L['zless']:
                     L['weff'] = torch.empty(25, 4 * f, 8, device=dev)
@@ -336,6 +347,17 @@ class SAVPGenerator(object):
         self.gen = Act((T1, N, H, W, C), dev, grad=g, zero_grad=True)
         self.dimg_cdna = torch.empty(N, H, W, C, device=dev) if g else None
 
+        # ---- actions / states (savp_model.py:411-422,655-658) -----------------------------------------------------
+        # saz [T1, N, zw] = what every slice tiles: [actions_t | state_t | rnn_z_t]; the state recurrence (state_t = ground truth or the
+        # previous step's prediction, gen_state_t = dense([actions_t | state_t])) involves no image, so one launch runs all steps
+        # (csrc/state_pred.hip) before the unroll.  The tiled copy is under stop_gradient (:421-422): only the state loss reaches state_pred.
+        self.saz = torch.zeros(T1, N, zw, device=dev) if cw else None
+        if ns:
+            s_ = prefix + 'state_pred/dense/'
+            self.spW, self.spb = store[s_ + 'kernel'], store[s_ + 'bias']
+            self.dspW, self.dspb = (store.grad64(s_ + 'kernel'), store.grad64(s_ + 'bias')) if g else (None, None)
+            self.sa = torch.zeros(T1, N, cw, device=dev)
+            self.gen_states = Act((T1, N, ns), dev, grad=g, zero_grad=True)
         # ---- z path -------------------------------------------------------------------------------------------
         if nz:
             self.zs = Act((T1, N, nz), dev, grad=g)
@@ -450,13 +472,24 @@ class SAVPGenerator(object):
         f = L['f']
         return [buf.g[t][..., off:off + f] for buf, off in L['routes']]
 
-    def forward(self, images, zs=None, gt_mask=None, collect_masks=False):
+    def forward(self, images, zs=None, gt_mask=None, collect_masks=False, actions=None, states=None):
         """images [T>=T1, N, H, W, C] device fp32 (frame t feeds step t); zs [T1, N, nz]; gt_mask int32 [T1, N]
-        (1 = take the ground-truth frame: self.ground_truth of savp_model.py:333-334).  Fills self.gen.v."""
+        (1 = take the ground-truth frame: self.ground_truth of savp_model.py:333-334); actions [T1, N, na] / states [>=T1, N, ns] when
+        the generator was built with cond.  Fills self.gen.v (and self.gen_states.v)."""
         T1, N, C = self.T1, self.N, self.C
         nz = self.nz
         self.images = images
         self.gt_mask = gt_mask
+        cw, na = self.cw, self.na
+        if cw:
+            if (na and actions is None) or (self.ns and states is None):
+                raise ValueError('this generator was built for inputs with actions / states (cond=%r)' % ((na, self.ns),))
+            if self.ns:
+                K.state_pred_fwd(actions[:T1].contiguous() if na else None, states[:T1].contiguous(), gt_mask, self.spW, self.spb, self.sa,
+                                 self.gen_states.v)
+                self.saz[..., :cw].copy_(self.sa)
+            else:
+                self.saz[..., :na].copy_(actions[:T1])
         if nz:
             self.zs.v.copy_(zs)
             if self.use_rnn_z and self.abl_rnn:           # tanh(dense(z)) (savp_model.py:426-429)
@@ -470,14 +503,18 @@ class SAVPGenerator(object):
                              init=(self.z_c0, self.z_h0) if self.learn_init else None)
             else:
                 self.rnn_z.v.copy_(self.zs.v)
-            zflat = self.rnn_z.v.reshape(T1 * N, nz)
+            if cw:
+                self.saz[..., cw:].copy_(self.rnn_z.v)
+        if self.zw:
+            zw = self.zw
+            zflat = (self.saz if cw else self.rnn_z.v).reshape(T1 * N, zw)
             for L in self.layers:
                 b = L['in']
                 if L['zc']:
-                    K.tile_channels(zflat, b.flat(b.v)[..., L['zoff_in']:L['zoff_in'] + nz])
+                    K.tile_channels(zflat, b.flat(b.v)[..., L['zoff_in']:L['zoff_in'] + zw])
                 if L['rnn'] and L['zr']:
                     a = L['a']
-                    K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + nz])
+                    K.tile_channels(zflat, a.flat(a.v)[..., L['f']:L['f'] + zw])
         if self.learn_init:                # step 0's state slots <- the learned initial states, tiled over the batch
             for L in self.layers:
                 if L['rnn']:
@@ -698,8 +735,9 @@ class SAVPGenerator(object):
             ws = self._lstm_ws_buf = torch.empty(max(need, K.lstm_ws_floats(self.N, self.H * self.W // 4, 32)), device=L["gates"].v.device)
         return ws
 
-    def backward(self):
-        """BPTT.  Expects self.gen.g (zero-initialised each step by the caller) to hold dL/dgen_images.
+    def backward(self, state_grad=False):
+        """BPTT.  Expects self.gen.g (zero-initialised each step by the caller) to hold dL/dgen_images (and, with state_grad,
+        self.gen_states.g to hold dL/dgen_states).
         Accumulates every generator-cell weight gradient into the store and returns dL/dzs [T1, N, nz] (or None)."""
         T1, N, C, nz = self.T1, self.N, self.C, self.nz
         ngf = self.hp.ngf
@@ -878,15 +916,19 @@ class SAVPGenerator(object):
         self.masks_out.backward_weights(hl.flat(maskin.v)[..., 0:self.mask_cin], hl.flat(self.logits.g))
         for c in self.convs:
             c.finish_weight_grad()
+        # ---- state prediction: the state loss's gradient (the caller left it in gen_states.g) through the recurrence ----------
+        if self.ns and state_grad:
+            K.state_pred_bwd(self.gt_mask, self.spW, self.sa, self.gen_states.g, self.dspW, self.dspb)
         # ---- z path ----------------------------------------------------------------------------------------------
         if not nz:
             return None
         drz = self.rnn_z.g
         drz.zero_()
+        cw = self.cw                     # the conditioning columns of each tiled slice are inputs / under stop_gradient: skipped
         for L in self.layers:
             b = L['in']
             if L['zc']:
-                K.colsum(b.flat(b.g)[..., L['zoff_in']:L['zoff_in'] + nz], drz, per_row=True)
+                K.colsum(b.flat(b.g)[..., L['zoff_in'] + cw:L['zoff_in'] + cw + nz], drz, per_row=True)
             if L['rnn'] and L['zr'] and L.get('zless'):
                 # z gradient of the gate convolution from the gate gradients of all timesteps (the DGRADs left those channels out)
                 gt = L['gates']
@@ -894,7 +936,7 @@ class SAVPGenerator(object):
                 K.tiled_z_grad(gt.flat(gt.g), L['weff'], drz.reshape(T1 * N, nz), beta=1)
             elif L['rnn'] and L['zr']:
                 a = L['a']
-                K.colsum(a.flat(a.g)[..., L['f']:L['f'] + nz], drz, per_row=True)
+                K.colsum(a.flat(a.g)[..., L['f'] + cw:L['f'] + cw + nz], drz, per_row=True)
         if self.use_rnn_z and self.abl_rnn:               # tanh(dense(z)) backward: d pre = d rnn_z * (1 - rnn_z^2)
             dpre = self.fcz_pre.g.reshape(T1, N, nz)
             torch.mul(self.rnn_z.v, self.rnn_z.v, out=dpre)

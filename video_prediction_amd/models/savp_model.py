@@ -121,18 +121,25 @@ class SAVPEngine(object):
 
     # loss terms of base_model.py:733-829 that need inputs / networks outside the SAVP hot path (VGG features, robot states,
     # auto-encoder outputs): accepting them silently would train a different model than the recipe asks for
-    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'state_weight', 'tv_weight', 'z_l1_weight')
+    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'tv_weight', 'z_l1_weight')
 
-    def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0', base_seed=0, rank=0):
+    def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0', base_seed=0, rank=0,
+                 cond=(0, 0)):
+        """cond = (n_actions, n_states): the widths of inputs['actions'] [B, T-1, na] / inputs['states'] [B, T, ns] when the dataset
+        supplies them (the action / state-conditioned model, savp_model.py:24-26,411-444,655-661; base_model.py:758-762)."""
         self.hp, self.mode, self.B = hp, mode, batch_size
         bad = [k for k in self.UNSUPPORTED_WEIGHTS if getattr(hp, k, 0)]
         if bad and mode == 'train':
             raise NotImplementedError('loss weights not covered by the HIP path: %s' % ', '.join(bad))
+        self.na, self.ns = int(cond[0]), int(cond[1])
+        self.cond = (self.na, self.ns)
+        if getattr(hp, 'state_weight', 0) and mode == 'train' and not self.ns:
+            raise KeyError('states')               # base_model.py:758-760 reads inputs['states'] whenever state_weight is set
         self.base_seed, self.rank = int(base_seed), int(rank)
         self.image_shape = tuple(image_shape)
         self.device = torch.device(device)
         self.train = mode == 'train'
-        specs = V.variable_specs(hp, image_shape, mode=mode)
+        specs = V.variable_specs(hp, image_shape, mode=mode, cond=self.cond)
         if values is None:
             values = V.init_variables(specs, seed=seed)
         self.store = ParamStore(specs, values, self.device)
@@ -141,8 +148,13 @@ class SAVPEngine(object):
         self.T, self.T1 = hp.sequence_length, hp.sequence_length - 1
         H, W, C = image_shape
         self.N = N = 2 * B if self.nz else B
-        self.gen = SAVPGenerator(self.store, hp, image_shape, N, train=self.train)
-        self.enc = PosteriorEncoder(self.store, hp, image_shape, B, train=self.train) if self.nz else None
+        self.gen = SAVPGenerator(self.store, hp, image_shape, N, train=self.train, cond=self.cond)
+        self.enc = PosteriorEncoder(self.store, hp, image_shape, B, train=self.train, n_actions=self.na) if self.nz else None
+        # conditioning inputs, time-major; both unrolls (N = 2B: posterior half, prior half) see the same actions / states
+        self.actions_tm = torch.zeros(self.T1, B, self.na, device=self.device) if self.na else None
+        self.actions_n = (torch.zeros(self.T1, N, self.na, device=self.device) if self.nz else self.actions_tm) if self.na else None
+        self.states_tm = torch.zeros(self.T, B, self.ns, device=self.device) if self.ns else None
+        self.states_n = (torch.zeros(self.T, N, self.ns, device=self.device) if self.nz else self.states_tm) if self.ns else None
         self.images_tm = torch.empty(self.T, B, H, W, C, device=self.device)
         self.images_n = torch.empty(self.T, N, H, W, C, device=self.device) if self.nz else self.images_tm
         self.zs_all = torch.zeros(self.T1, N, self.nz, device=self.device) if self.nz else None
@@ -155,7 +167,8 @@ class SAVPEngine(object):
             raise ValueError('clip_length=%d needs sequence_length >= %d (got %d)' % (hp.clip_length, hp.clip_length + 1, self.T))
         # learned prior (prior_fn, savp_model.py:54-85,717-721): its own encoder + recurrent tail under scope generator/prior
         self.learn_prior = bool(self.nz and hp.learn_prior)
-        self.prior = (PosteriorEncoder(self.store, hp, image_shape, B, train=self.train, prefix='generator/prior/', prior=True)
+        self.prior = (PosteriorEncoder(self.store, hp, image_shape, B, train=self.train, prefix='generator/prior/', prior=True,
+                                       n_actions=self.na)
                       if self.learn_prior else None)
         # (discriminator, loss weight, loss-name infix, operates on the posterior ('_enc') unroll?, clip index keys)
         self.discs = []
@@ -265,11 +278,31 @@ class SAVPEngine(object):
             self._host_op(lambda: self.replicas.finish_allreduce(group))
 
     # -- input staging -------------------------------------------------------------------------------------------------
+    def set_conditioning(self, actions=None, states=None, time_major=False):
+        """actions [B, T-1, na] / states [B, T, ns] (reference layout; [T, B, ...] if time_major), sliced to the model's sequence length
+        (tf_utils.maybe_pad_or_slice, savp_model.py:690-691)."""
+        for name, x, buf, buf_n, steps in (('actions', actions, self.actions_tm, self.actions_n, self.T1),
+                                          ('states', states, self.states_tm, self.states_n, self.T)):
+            if buf is None:
+                if x is not None:
+                    raise ValueError("inputs[%r] given to a model built without it (build_graph fixes the input structure)" % name)
+                continue
+            if x is None:
+                raise KeyError(name)
+            x = x if time_major else x.transpose(0, 1)
+            if x.shape[0] < steps or tuple(x.shape[1:]) != tuple(buf.shape[1:]):
+                raise ValueError('inputs[%r]: expected %d steps of %r, got %r' % (name, steps, tuple(buf.shape[1:]), tuple(x.shape)))
+            buf.copy_(x[:steps])
+            if buf_n is not buf:
+                buf_n[:, :self.B].copy_(buf)
+                buf_n[:, self.B:].copy_(buf)
+
     def set_images(self, images, time_major=False):
-        """images: device fp32 [B,T,H,W,C] (reference layout) or [T,B,H,W,C] if time_major; or the dataset's inputs dict
-        (its 'images' entry is taken; 'actions' / 'states' are refused, see refuse_conditioning_inputs)."""
+        """images: device fp32 [B,T,H,W,C] (reference layout) or [T,B,H,W,C] if time_major; or the dataset's inputs dict ('images' and,
+        for a model built with cond, 'actions' / 'states'; 'pix_distribs' is refused, see refuse_conditioning_inputs)."""
         if isinstance(images, dict):
             refuse_conditioning_inputs(images)
+            self.set_conditioning(images.get('actions'), images.get('states'), time_major=time_major)
             images = images['images']
         T = self.T
         if time_major:
@@ -381,12 +414,12 @@ class SAVPEngine(object):
         gt = self.d_gt
         if self.nz:
             eps = self.d_eps
-            z_post = self.enc.forward(self.images_tm, eps, kl=not self.learn_prior)
+            z_post = self.enc.forward(self.images_tm, eps, kl=not self.learn_prior, actions=self.actions_tm)
             nzv = self.nz
             copy_view(z_post.reshape(T1, B, nzv), [self.zs_all[:, :B]])
             if self.learn_prior:
                 # zs_prior = mu_p + sigma_p * eps for ALL steps (:717-721); KL(posterior || learned prior) (base_model.py:825-828)
-                z_prior = self.prior.forward(self.images_tm, self.d_prior_eps, kl=False)
+                z_prior = self.prior.forward(self.images_tm, self.d_prior_eps, kl=False, actions=self.actions_tm)
                 copy_view(z_prior, [self.zs_all[:, B:]])
                 K.kl_gauss(self.enc.mu, self.enc.ls_raw, self.prior.mu, self.prior.ls_raw, kl_out=self.enc.kl)
             else:
@@ -395,8 +428,9 @@ class SAVPEngine(object):
                 if c1 > 0:
                     copy_view(z_post[:c1], [self.zs_all[:c1, B:]])
                 copy_view(self.d_prior, [self.zs_all[c1:, B:]])
-            return self.gen.forward(self.images_n, self.zs_all, gt, collect_masks=collect_masks)
-        return self.gen.forward(self.images_n, None, gt, collect_masks=collect_masks)
+            return self.gen.forward(self.images_n, self.zs_all, gt, collect_masks=collect_masks, actions=self.actions_n,
+                                    states=self.states_n)
+        return self.gen.forward(self.images_n, None, gt, collect_masks=collect_masks, actions=self.actions_n, states=self.states_n)
 
     # -- one sess.run(train_op) --------------------------------------------------------------------------------------------
     def _d_clips(self, D, phase, key_real, key_fake, fake_half, lo_real, lo_fake):
@@ -584,7 +618,13 @@ class SAVPEngine(object):
             K.lp_loss(pred, target, hp.l1_weight, lb[-2:-1], dpred, p2=False)
         if hp.l2_weight:
             K.lp_loss(pred, target, hp.l2_weight, lb[-1:], dpred, p2=True)
-        dzs = self.gen.backward()
+        state_w = getattr(hp, 'state_weight', 0) if self.ns else 0
+        if state_w:
+            # gen_state_loss = l2_loss(gen_states(_enc), inputs['states'][1:]) (base_model.py:758-762): the posterior half where there is one
+            gs = self.gen.gen_states
+            gs.g.zero_()
+            K.lp_loss(gs.v[:, :B], self.states_tm[1:self.T], state_w, lb[-3:-2], gs.g[:, :B], p2=True)
+        dzs = self.gen.backward(state_grad=bool(state_w))
         store.groups['g'].fold64()                         # float64 accumulators of the cell's norms / z-LSTM -> fp32 gradients
         if self.nz and not return_grads:
             # the generator cell's gradients are final after BPTT: exchange them under the encoder's backward pass
@@ -636,6 +676,8 @@ class SAVPEngine(object):
             g_losses['gen_l1_loss'] = (lb[-2], hp.l1_weight)
         if hp.l2_weight:
             g_losses['gen_l2_loss'] = (lb[-1], hp.l2_weight)
+        if state_w:
+            g_losses['gen_state_loss'] = (lb[-3], state_w)
         if self.nz and hp.kl_weight:
             g_losses['gen_kl_loss'] = (self.enc.kl.float()[0], klw)
         info['d_losses'], info['g_losses'] = d_losses, g_losses
@@ -759,14 +801,20 @@ _ENGINES = {}
 
 
 def refuse_conditioning_inputs(inputs):
-    """SAVPCell.call concatenates inputs['actions'] / inputs['states'] into every layer and predicts the next state
-    (savp_model.py:413-421,655-658; generator_fn slices them at :702-703).  The HIP path is the action-free one of
-    BASELINE.json's north_star: a batch that carries them is refused instead of being run as if they were not there."""
-    if isinstance(inputs, dict):
-        for k in ('actions', 'states'):
-            if inputs.get(k) is not None:
-                raise NotImplementedError("inputs[%r] given: action- / state-conditioned SAVP cells (reference savp_model.py:413-421,"
-                                          "655-658) are not on the MI355X hot path; drop the key (action-free model) to proceed" % k)
+    """inputs['pix_distribs'] (savp_model.py:252-255,408-410,647-653: designated-pixel distributions pushed through the predicted
+    transformations, a visual-servoing output no training loss reads) is not on the MI355X path: a batch that carries it is refused
+    instead of being run as if it were not there.  'actions' / 'states' are handled (cond_of)."""
+    if isinstance(inputs, dict) and inputs.get('pix_distribs') is not None:
+        raise NotImplementedError("inputs['pix_distribs'] given: the pixel-distribution outputs of SAVPCell (reference savp_model.py:"
+                                  "408-410,647-653) are not on the MI355X hot path; drop the key to proceed")
+
+
+def cond_of(inputs):
+    """(n_actions, n_states) of an inputs dict -- the structure SAVPCell reads off `inputs` (savp_model.py:256-257,291-292,416-422)."""
+    if not isinstance(inputs, dict):
+        return (0, 0)
+    a, s_ = inputs.get('actions'), inputs.get('states')
+    return (int(a.shape[-1]) if a is not None else 0, int(s_.shape[-1]) if s_ is not None else 0)
 
 
 def _engine_for(inputs, mode, hparams, engine=None):
@@ -775,24 +823,25 @@ def _engine_for(inputs, mode, hparams, engine=None):
     if engine is not None:
         return engine
     T, B = images.shape[:2]
-    key = (id(hparams), mode, tuple(images.shape))
+    cond = cond_of(inputs)
+    key = (id(hparams), mode, tuple(images.shape), cond)
     eng = _ENGINES.get(key)
     if eng is None:
         eng = _ENGINES[key] = SAVPEngine(hparams, tuple(images.shape[2:]), B, mode='train' if mode == 'train' else 'test',
-                                         device=images.device)
+                                         device=images.device, cond=cond)
     return eng
 
 
 def posterior_fn(inputs, hparams, engine=None, noise=None):
     """savp_model.py:21-51.  inputs['images'] time-major [T,B,H,W,C] on the device."""
     eng = _engine_for(inputs, 'test', hparams, engine)
-    eng.set_images(inputs['images'], time_major=True)
+    eng.set_images(inputs, time_major=True)
     eng.enc.prep_weights()
     nz = hparams.nz
     eps = (noise or {}).get('eps')
     if eps is None:
         eps = torch.zeros(eng.T1, eng.B, nz)
-    eng.enc.forward(eng.images_tm, eps.to(eng.device, torch.float32))
+    eng.enc.forward(eng.images_tm, eps.to(eng.device, torch.float32), actions=eng.actions_tm)
     return {'zs_mu': eng.enc.mu, 'zs_log_sigma_sq': eng.enc.ls}
 
 
@@ -801,19 +850,19 @@ def prior_fn(inputs, hparams, engine=None, noise=None):
     if not hparams.learn_prior:
         raise ValueError('prior_fn needs hparams.learn_prior=True (the prior network is not instantiated otherwise)')
     eng = _engine_for(inputs, 'test', hparams, engine)
-    eng.set_images(inputs['images'], time_major=True)
+    eng.set_images(inputs, time_major=True)
     eng.prior.prep_weights()
     eps = (noise or {}).get('prior_eps')
     if eps is None:
         eps = torch.zeros(eng.T1, eng.B, hparams.nz)
-    eng.prior.forward(eng.images_tm, eps.to(eng.device, torch.float32), kl=False)
+    eng.prior.forward(eng.images_tm, eps.to(eng.device, torch.float32), kl=False, actions=eng.actions_tm)
     return {'zs_mu': eng.prior.mu, 'zs_log_sigma_sq': eng.prior.ls}
 
 
 def generator_fn(inputs, mode, hparams, engine=None, noise=None):
     """savp_model.py:699-768 (without the visualisation-only gen_images_samples unroll :745-767)."""
     eng = _engine_for(inputs, mode, hparams, engine)
-    eng.set_images(inputs['images'], time_major=True)
+    eng.set_images(inputs, time_major=True)
     if noise is None:
         noise = eng.default_noise()
     eng.prep_generator_weights()
@@ -829,6 +878,8 @@ def generator_fn(inputs, mode, hparams, engine=None, noise=None):
     outputs['masks'] = masks[:, lo:]
     gt = eng._gt_mask(noise)
     outputs['ground_truth_sampling_mean'] = gt[hparams.context_frames:, lo:].float().mean()
+    if eng.ns:
+        outputs['gen_states'] = g.gen_states.v[:, lo:]             # savp_model.py:666-667
     if eng.learn_prior:
         outputs['zs_mu_prior'] = eng.prior.mu                    # savp_model.py:735 (keys get the '_prior' suffix)
         outputs['zs_log_sigma_sq_prior'] = eng.prior.ls
@@ -839,6 +890,8 @@ def generator_fn(inputs, mode, hparams, engine=None, noise=None):
         outputs['transformed_images_enc'] = timgs[:, :B]
         outputs['masks_enc'] = masks[:, :B]
         outputs['ground_truth_sampling_mean_enc'] = gt[hparams.context_frames:, :B].float().mean()
+        if eng.ns:
+            outputs['gen_states_enc'] = g.gen_states.v[:, :B]
     return outputs
 
 
@@ -889,13 +942,15 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         return super(SAVPVideoPredictionModel, self).parse_hparams(hparams_dict, hparams)
 
     def build_graph(self, inputs, values=None, seed=4, device='cuda:0'):
-        """inputs: {'images': [B,T,H,W,C] device tensor} (batch-major like the reference's dataset iterator)."""
+        """inputs: {'images': [B,T,H,W,C] device tensor, optionally 'actions': [B,T-1,na], 'states': [B,T,ns]} (batch-major like the
+        reference's dataset iterator).  As in the reference the input STRUCTURE is fixed here: a model built with actions / states
+        expects them in every later batch."""
         refuse_conditioning_inputs(inputs)
         super(SAVPVideoPredictionModel, self).build_graph(inputs)
         images = inputs['images']
         B = images.shape[0]
         self.engine = SAVPEngine(self.hparams, tuple(images.shape[2:]), B, mode=self.mode, values=values, seed=seed,
-                                 device=device)
+                                 device=device, cond=cond_of(inputs))
         self.saveable_variables = self.engine.store.names()
         self.post_init_ops = []
         self.outputs = {}
@@ -910,7 +965,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         if inputs is not None:
             refuse_conditioning_inputs(inputs)
             self.inputs = inputs
-        self.engine.set_images(self.inputs['images'])
+        self.engine.set_images(self.inputs)
         info = self.engine.train_step(noise)
         self.d_losses, self.g_losses = info['d_losses'], info['g_losses']
         self.d_loss, self.g_loss = info['d_loss'], info['g_loss']
@@ -921,7 +976,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         if inputs is not None:
             refuse_conditioning_inputs(inputs)
             self.inputs = inputs
-        self.engine.set_images(self.inputs['images'])
+        self.engine.set_images(self.inputs)
         gen = self.engine.generate(noise)
         lo = self.engine.B if self.engine.nz else 0
         self.outputs['gen_images'] = gen[:, lo:].transpose(0, 1)
@@ -933,7 +988,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         """base_model.py:113-130 on the current inputs (psnr / mse / ssim; lpips needs external weights)."""
         if inputs is not None:
             self.inputs = inputs
-            self.engine.set_images(self.inputs['images'])
+            self.engine.set_images(self.inputs)
         self.metrics = self.engine.metrics()
         return self.metrics
 
@@ -942,7 +997,7 @@ class SAVPVideoPredictionModel(VideoPredictionModel):
         """base_model.py:132-227: best / mean / worst of num_samples prior samples per sequence (time-major tensors)."""
         if inputs is not None:
             self.inputs = inputs
-            self.engine.set_images(self.inputs['images'])
+            self.engine.set_images(self.inputs)
         self.eval_outputs, self.eval_metrics = self.engine.eval_outputs_and_metrics(num_samples or self.eval_num_samples, noises)
         return self.eval_outputs, self.eval_metrics
 

@@ -67,11 +67,17 @@ def uses_discriminator(hp):
                 hp.images_sn_gan_weight or hp.images_sn_vae_gan_weight)
 
 
-def generator_variable_specs(hp, image_shape):
-    """name -> (shape, init) for everything under scope 'generator/'."""
+def generator_variable_specs(hp, image_shape, cond=(0, 0)):
+    """name -> (shape, init) for everything under scope 'generator/'.
+
+    cond = (n_actions, n_states): widths of inputs['actions'] / inputs['states'] when the dataset supplies them (savp_model.py:24-26,
+    413-444: tiled into the encoder's frame pairs and, beside the latent, into every tile-concatenated slice of the cell; :655-658: the
+    next state is a dense layer of [actions | state])."""
     H, W, C = image_shape
     specs = OrderedDict()
     nz = hp.nz
+    na, ns = int(cond[0]), int(cond[1])
+    zw = nz + na + ns                 # width of state_action_z (savp_model.py:414-444): [actions | stop_gradient(state) | z]
     def rnn_cell_specs(scope, n_in, u):
         """savp_model.py:36-41,354-362: 'lstm' = BasicLSTMCell / LSTMCell(name='basic_lstm_cell') -- kernel [in + u, 4u] with get_variable's
         default initializer (glorot-uniform), zero bias; 'gru' = tf.contrib.rnn.GRUCell (default name 'gru_cell') -- gates/{kernel [in + u,
@@ -90,7 +96,7 @@ def generator_variable_specs(hp, image_shape):
     def encoder_specs(p, recurrent):
         """networks.encoder + the optional recurrent tail + the two heads under scope p (savp_model.py:21-51 posterior_fn with
         use_e_rnn, :54-85 prior_fn which always has the tail)."""
-        cin = 2 * C
+        cin = 2 * C + na                                                           # frame pair + tiled actions (savp_model.py:23-26,56-59)
         for i in range(hp.n_layers):
             cout = hp.nef * min(2 ** i, 4)
             s = p + 'layer_%d/' % (i + 1)
@@ -124,7 +130,7 @@ def generator_variable_specs(hp, image_shape):
     elif nz and hp.use_rnn_z:
         rnn_cell_specs(p + '%s_z/' % hp.rnn, nz, nz)                                # scope '%s_z' % rnn (savp_model.py:426)
     tile = hp.use_tile_concat
-    zc = nz if tile else 0          # channels added by tile_concat
+    zc = zw if tile else 0          # channels added by tile_concat
     enc, dec = layer_specs(hp.ngf, H, W)
 
     def norm(scope, c):
@@ -141,8 +147,8 @@ def generator_variable_specs(hp, image_shape):
             # savp_model.py:474-478 / :510-513: conv2d 5x5 (+ dense(z) without tile_concat) -> norm_layer -> activation, scope conv_h<i>
             specs[scope + 'conv2d/kernel'] = ((5, 5, cin, f), 'tn0.02')
             specs[scope + 'conv2d/bias'] = ((f,), 'zeros')
-            if add_z and nz and not tile:
-                specs[scope + 'dense/kernel'] = ((nz, f), 'tn0.02')
+            if add_z and zw and not tile:
+                specs[scope + 'dense/kernel'] = ((zw, f), 'tn0.02')
             norm(scope, f)
             return
         if getattr(hp, 'ablation_conv_rnn_norm', False) and hp.conv_rnn_norm_layer != 'none':
@@ -152,8 +158,8 @@ def generator_variable_specs(hp, image_shape):
         if hp.conv_rnn == 'lstm':
             s = scope + 'basic_conv2dlstm_cell/'
             specs[s + 'kernel'] = ((5, 5, cin + f, 4 * f), 'tn0.02')
-            if add_z and nz and not tile:
-                specs[s + 'weights'] = ((nz, 4 * f), 'tn0.02')
+            if add_z and zw and not tile:
+                specs[s + 'weights'] = ((zw, 4 * f), 'tn0.02')
             if not cell_norm:
                 specs[s + 'bias'] = ((4 * f,), 'zeros')
             else:
@@ -165,9 +171,9 @@ def generator_variable_specs(hp, image_shape):
             s = scope + 'conv2dgru_cell/'
             specs[s + 'gates/kernel'] = ((5, 5, cin + f, 2 * f), 'tn0.02')
             specs[s + 'candidate/kernel'] = ((5, 5, cin + 2 * f, f), 'tn0.02')
-            if add_z and nz and not tile:
-                specs[s + 'gates/weights'] = ((nz, 2 * f), 'tn0.02')
-                specs[s + 'candidate/weights'] = ((nz, f), 'tn0.02')
+            if add_z and zw and not tile:
+                specs[s + 'gates/weights'] = ((zw, 2 * f), 'tn0.02')
+                specs[s + 'candidate/weights'] = ((zw, f), 'tn0.02')
             if not cell_norm:
                 specs[s + 'gates/bias'] = ((2 * f,), 'ones')
                 specs[s + 'candidate/bias'] = ((f,), 'zeros')
@@ -185,14 +191,14 @@ def generator_variable_specs(hp, image_shape):
         s = p + 'h%d/' % i
         cx = 2 * C if i == 0 else prev
         k = 5 if i == 0 else 3
-        add_z = bool(nz) and (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0))
+        add_z = bool(zw) and (hp.where_add == 'all' or (hp.where_add == 'input' and i == 0))
         specs[s + 'conv_pool2d/kernel'] = ((k, k, cx + (zc if add_z else 0), f), 'tn0.02')
         specs[s + 'conv_pool2d/bias'] = ((f,), 'zeros')
         if add_z and not tile:
-            specs[s + 'dense/kernel'] = ((nz, f), 'tn0.02')
+            specs[s + 'dense/kernel'] = ((zw, f), 'tn0.02')
         norm(s, f)
         if use_rnn:
-            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, i), f, f, bool(nz) and hp.where_add == 'all')
+            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, i), f, f, bool(zw) and hp.where_add == 'all')
         layer_out.append(f)
         prev = f
     ne = len(enc)
@@ -200,14 +206,14 @@ def generator_variable_specs(hp, image_shape):
         li = ne + i
         s = p + 'h%d/' % li
         cx = prev if i == 0 else prev + layer_out[ne - i - 1]
-        add_z = bool(nz) and (hp.where_add == 'all' or (hp.where_add == 'middle' and i == 0))
+        add_z = bool(zw) and (hp.where_add == 'all' or (hp.where_add == 'middle' and i == 0))
         specs[s + 'upsample_conv2d/kernel'] = ((3, 3, cx + (zc if add_z else 0), f), 'tn0.02')
         specs[s + 'upsample_conv2d/bias'] = ((f,), 'zeros')
         if add_z and not tile:
-            specs[s + 'dense/kernel'] = ((nz, f), 'tn0.02')
+            specs[s + 'dense/kernel'] = ((zw, f), 'tn0.02')
         norm(s, f)
         if use_rnn:
-            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, li), f, f, bool(nz) and hp.where_add == 'all')
+            conv_rnn(p + '%s_h%d/' % ('conv' if ablation_rnn else hp.conv_rnn, li), f, f, bool(zw) and hp.where_add == 'all')
         layer_out.append(f)
         prev = f
     nl = len(layer_out)
@@ -252,6 +258,9 @@ def generator_variable_specs(hp, image_shape):
         cin = hp.ngf + (nm * C if hp.dependent_mask else 0)
         specs[p + 'masks/conv2d/kernel'] = ((3, 3, cin, nm), 'tn0.02')
         specs[p + 'masks/conv2d/bias'] = ((nm,), 'zeros')
+    if ns:
+        specs[p + 'state_pred/dense/kernel'] = ((na + ns, ns), 'tn0.02')            # savp_model.py:655-658
+        specs[p + 'state_pred/dense/bias'] = ((ns,), 'zeros')
     if getattr(hp, 'learn_initial_state', False):
         # savp_model.py:295-307: one variable per entry of nest.flatten({'conv_rnn_states': [...], 'rnn_z_state': ...}) -- dict keys sorted,
         # LSTM state tuples as (c, h) -- created where the cell is constructed (scope `generator/`, not `generator/rnn/savp_cell/`)
@@ -338,8 +347,8 @@ def discriminator_variable_specs(hp, image_shape):
     return specs
 
 
-def variable_specs(hp, image_shape, mode='train'):
-    specs = generator_variable_specs(hp, image_shape)
+def variable_specs(hp, image_shape, mode='train', cond=(0, 0)):
+    specs = generator_variable_specs(hp, image_shape, cond)
     if mode == 'train':
         specs.update(discriminator_variable_specs(hp, image_shape))
     return specs
