@@ -291,6 +291,8 @@ def main():
     if engine.use_graph and engine.graph is not None:
         nseg = engine.graph.segments
         mode = 'hipGraph replay' if nseg == 1 else 'hipGraph replay in %d segments, collectives issued between them' % nseg
+        if nseg == 1 and getattr(engine, 'graph_collectives', False):
+            mode = 'hipGraph replay, collectives captured in the graph (SAVP_GRAPH_COLLECTIVES=1)'
     eager_ms = None
     host_issue_ms = None
     INST_STEPS = max(0, args.inst_steps)
@@ -530,6 +532,7 @@ def main():
         result['config']['dist'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                                     'allreduce_chunks_issued': st['chunks'], 'allreduce_elements': st['elements'], 'aux_broadcasts': st['aux_broadcasts'],
                                     'side_stream': engine.replicas.comm_stream is not None, 'binding': binding,
+                                    'collectives_in_graph': bool(getattr(engine, 'graph_collectives', False)),
                                     'ranks_seen_by_backend': dist.get_world_size(), 'allreduce_bytes_per_step': 4 * st['elements'] // max(1, args.warmup + args.steps + INST_STEPS)}
     if dist is not None and os.environ.get('SAVP_BENCH_CHECK_REPLICAS', '0') == '1':
         result['replicas_identical'] = bool(engine.replicas.checksum_identical())      # collective: every rank calls it

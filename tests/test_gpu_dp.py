@@ -225,14 +225,16 @@ def test_live_tuning_choice_is_rank0s_on_every_replica():
 
 
 # ---- RCCL itself, at world size 1 (the one transport a one-GPU box cannot exercise between ranks) -----------------------------------
-def _rccl_world1_worker(port, q):
-    """One rank, backend 'nccl' (= RCCL), collectives FORCED: attach_process_group(force=True) keeps the rank-0 broadcast, the
+def _rccl_world1_worker(port, q, captured=False):
+    """(captured: SAVP_GRAPH_COLLECTIVES=1 -- the collectives are captured into the step's one hipGraph.)
+    One rank, backend 'nccl' (= RCCL), collectives FORCED: attach_process_group(force=True) keeps the rank-0 broadcast, the
     side-stream chunked all-reduce, the u broadcast and the event chaining in the step although a sum over one replica is the
     identity.  Engine A: forced collectives + segmented hipGraph replay.  Engine B: plain single-process engine, eager."""
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['SAVP_GRAPH_COLLECTIVES'] = '1' if captured else '0'
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1)
@@ -300,6 +302,36 @@ def test_rccl_world_size_one_forced_collectives_and_segmented_replay_equal_the_p
         tot += float(d.sum())
         cnt += d.size
     assert tot / cnt <= 0.2 * hp.lr, tot / cnt           # four Adam steps (each moves a variable by ~lr): a small fraction of one step
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_captured_into_the_steps_one_hipgraph_at_world_size_one():
+    """SAVP_GRAPH_COLLECTIVES=1 (round-5 verdict item 7): the side-stream all-reduces, the u broadcast and their event fork / join are
+    captured with the kernels, so a replica replays ONE hipGraph per step instead of 8 segments with 7 host actions between them
+    (profiles/r06_graph_collectives_probe.json: -2.5 % per step at world size 1).  Forced collectives at world size 1: four steps must
+    reproduce the plain engine's.  Opt-in: no N > 1 lease exists to validate the replayed RCCL kernels across ranks."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q, True))
+    p.start()
+    r = _get(q, [p], 800)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert r['backend'] == 'nccl' and r['active'] and r['dp'] and r['side_stream'] and r['same']
+    assert r['segments'] == 1 and r['host_ops'] == 0, (r['segments'], r['host_ops'])
+    # host-side counters see the eager step and the capture only (replays issue no host call): 2 x (4 chunks, 1 broadcast)
+    assert r['stats']['chunks'] == 2 * 4 and r['stats']['aux_broadcasts'] == 2, r['stats']
+    hp = _setup(False)[0]
+    for i, ((da, ga), (db, gb)) in enumerate(zip(r['la'], r['lb'])):
+        tol = 2e-5 if i == 0 else 2e-3
+        assert abs(da - db) <= tol * max(abs(db), 1e-3) and abs(ga - gb) <= tol * max(abs(gb), 1e-3), (i, r['la'], r['lb'])
+    tot = cnt = 0.0
+    for name, pb in r['pb'].items():
+        d = np.abs(pb.astype(np.float64) - r['pa'][name])
+        tot += float(d.sum())
+        cnt += d.size
+    assert tot / cnt <= 0.2 * hp.lr, tot / cnt
 
 
 def _bucket_worker(q):

@@ -203,6 +203,7 @@ class SAVPEngine(object):
         self.step = 0
         self.world = 1
         self.dp = False
+        self.graph_collectives = False
         self._rec = None
         self.dist = None
         # per-step inputs drawn on the host are staged into these persistent device buffers BEFORE the kernels of the step
@@ -234,6 +235,10 @@ class SAVPEngine(object):
         self.dist = dist_module
         self.world = self.replicas.world
         self.dp = self.replicas.active          # the step carries collectives (world > 1, or forced)
+        # Collectives inside the step's hipGraph (one graph launch per step instead of 8 segments + 7 host actions): opt-in, validated at
+        # world size 1 only (tests/test_gpu_dp.py, tests/tools/ab_calls/graph_collectives_probe.py) -- no N > 1 lease exists to show that
+        # every rank's replayed graph issues its RCCL kernels in a compatible order, and a hang there would cost the scaling run.
+        self.graph_collectives = self.dp and os.environ.get('SAVP_GRAPH_COLLECTIVES', '0') == '1'
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
         self.graph = None                       # a step captured without the collectives is not this engine's step any more
         # Segmented replay pays when the collectives are stream-ordered (RCCL).  Under a backend whose collectives block the host
@@ -258,9 +263,12 @@ class SAVPEngine(object):
         """A host-side action between launches of the step (a collective on the side stream, an event wait).  Eager step: done
         now.  While the step is being captured (_StepProgram): closes the current hipGraph segment, is recorded as the action
         to perform between this segment and the next one, and a new segment is opened."""
-        if self._rec is not None:
+        if self._rec is not None and not self.graph_collectives:
             self._rec.host_op(fn)
         else:
+            # eager step -- or SAVP_GRAPH_COLLECTIVES=1: the action runs while the step is being captured, so the RCCL call on the side
+            # stream and its event fork / join become nodes of the ONE hipGraph the step is replayed as (ProcessGroupNCCL issues
+            # ncclAllReduce on torch's current stream: a capturing stream records it)
             fn()
 
     def _begin_allreduce(self, group, prefix):
