@@ -89,14 +89,32 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
     if (w_lds)
         for (int i = j; i < 2 * nz * 4 * nz; i += 4 * nz) wsh[(i / (4 * nz)) * wp + (i % (4 * nz))] = W[i];
     __syncthreads();
+    // every global operand of step t is independent of the recurrence: the loads of step t - 1 are issued before step t's arithmetic and its
+    // three barriers (one exposed L2 round trip per step was most of this launch: 228 us for 29 steps of a 32-wide cell)
+    struct StepIn { float gi, gj, gf, go, c, cprev, dh, z, hprev; };
+    auto load_step = [&](int t) {
+        StepIn r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (j < nz && t >= 0) {
+            const long long o = (long long)t * B + b;
+            r.gi = gates[o * 4 * nz + j]; r.gj = gates[o * 4 * nz + nz + j]; r.gf = gates[o * 4 * nz + 2 * nz + j];
+            r.go = gates[o * 4 * nz + 3 * nz + j];
+            r.c = cs[o * nz + j];
+            r.cprev = t > 0 ? cs[(o - B) * nz + j] : (c0 ? c0[j] : 0.f);
+            r.dh = dh_out[o * nz + j];
+            r.z = zs[o * nz + j];
+            r.hprev = t > 0 ? hout[(o - B) * nz + j] : (h0 ? h0[j] : 0.f);
+        }
+        return r;
+    };
+    StepIn cur = load_step(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const long long o = (long long)t * B + b;
+        const StepIn nxt = load_step(t - 1);
         if (j < nz) {
-            float gi = gates[o * 4 * nz + j], gj = gates[o * 4 * nz + nz + j], gf = gates[o * 4 * nz + 2 * nz + j],
-                  go = gates[o * 4 * nz + 3 * nz + j];
-            float c = cs[o * nz + j];
-            float cprev = t > 0 ? cs[(o - B) * nz + j] : (c0 ? c0[j] : 0.f);
-            float dh = dh_out[o * nz + j] + sh_dh[j];
+            float gi = cur.gi, gj = cur.gj, gf = cur.gf, go = cur.go;
+            float c = cur.c;
+            float cprev = cur.cprev;
+            float dh = cur.dh + sh_dh[j];
             float so = sigm(go), tc = tanh_(c);
             float dc = dh * so * (1.f - tc * tc) + dc_next;
             float si = sigm(gi), tj = tanh_(gj), sf = sigm(gf + forget_bias);
@@ -105,9 +123,10 @@ __global__ void lstm_z_bwd_kernel(const float* __restrict__ zs, const float* __r
             sh_dg[2 * nz + j] = dc * cprev * sf * (1.f - sf);
             sh_dg[3 * nz + j] = dh * tc * so * (1.f - so);
             dc_next = dc * sf;
-            sh_x[j] = zs[o * nz + j];
-            sh_x[nz + j] = t > 0 ? hout[(o - B) * nz + j] : (h0 ? h0[j] : 0.f);
+            sh_x[j] = cur.z;
+            sh_x[nz + j] = cur.hprev;
         }
+        cur = nxt;
         __syncthreads();
         const float dgj = sh_dg[j];
         dbj += dgj;

@@ -289,10 +289,16 @@ __device__ __forceinline__ void sn_rows_vec_body(const float* __restrict__ W, lo
             if (kb < K) { y[kb] = sb; sqacc += sb * sb; if (z) dzacc += sb * z[kb]; }
         }
     }
+    // one float64 atomic per WORKGROUP and accumulator: every launch of this body adds into ONE address per matrix, and same-address
+    // atomics retire one at a time (measured: the batched launch over a discriminator's eight matrices took 62 us with one atomic per
+    // wave of 1024 workgroups -- 20 MB of weights are 5 us of HBM time)
+    __shared__ float sn_part[2][4];
     sqacc = wsum(sqacc); dzacc = wsum(dzacc);
-    if (lane == 0) {
-        if (sq) unsafeAtomicAdd(sq, (double)sqacc);
-        if (dotz) unsafeAtomicAdd(dotz, (double)dzacc);
+    if (lane == 0) { sn_part[0][wave] = sqacc; sn_part[1][wave] = dzacc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sq) unsafeAtomicAdd(sq, (double)(sn_part[0][0] + sn_part[0][1]) + (double)(sn_part[0][2] + sn_part[0][3]));
+        if (dotz) unsafeAtomicAdd(dotz, (double)(sn_part[1][0] + sn_part[1][1]) + (double)(sn_part[1][2] + sn_part[1][3]));
     }
 }
 
@@ -352,6 +358,29 @@ __global__ __launch_bounds__(NT) void sn_gemv_cols_kernel(const float* __restric
     sn_cols_body(W, K, C, x, y, rows_per_block, blockIdx.x);
 }
 
+// narrow matrices (C <= 16: the discriminators' final linear layer, [65536, 1]): every thread walks rows, the block reduces per column
+__device__ __forceinline__ void sn_cols_narrow_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
+                                                    double* __restrict__ y, int rows_per_block, int bx, float* sh4) {
+    const long long k0 = (long long)bx * rows_per_block;
+    const long long k1 = min(K, k0 + rows_per_block);
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (long long k = k0 + threadIdx.x; k < k1; k += NT) {
+        const float xv = x[k];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) acc[c] += W[k * C + c] * xv;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < C) {                                       // C is uniform: every thread takes the same branches (barriers inside block_sum1)
+            const float t = block_sum1(acc[c], sh4);
+            if (threadIdx.x == 0) unsafeAtomicAdd(y + c, (double)t);
+        }
+    }
+}
+
 // vectorised variant (C = 4 * LPR, LPR a power of two <= 64): thread = (column quad, row slot), float4 loads of full rows,
 // LDS reduction over the row slots, one atomic per column and block
 __device__ __forceinline__ void sn_cols_vec_body(const float* __restrict__ W, long long K, int C, const float* __restrict__ x,
@@ -361,7 +390,16 @@ __device__ __forceinline__ void sn_cols_vec_body(const float* __restrict__ W, lo
     const long long k0 = (long long)bx * rows_per_block;
     const long long k1 = min(K, k0 + rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long k = k0 + sub; k < k1; k += slots) {
+    long long k = k0 + sub;
+    for (; k + 3 * slots < k1; k += 4 * slots) {            // four rows in flight per thread (the loop is latency-bound otherwise)
+        float4 w[4];
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = *reinterpret_cast<const float4*>(W + (k + j * slots) * C + c4 * 4); xv[j] = x[k + j * slots]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc.x += w[j].x * xv[j]; acc.y += w[j].y * xv[j]; acc.z += w[j].z * xv[j]; acc.w += w[j].w * xv[j]; }
+    }
+    for (; k < k1; k += slots) {
         const float4 w = *reinterpret_cast<const float4*>(W + k * C + c4 * 4);
         const float xv = x[k];
         acc.x += w.x * xv; acc.y += w.y * xv; acc.z += w.z * xv; acc.w += w.w * xv;
@@ -521,6 +559,14 @@ extern "C" int savp_sn_bwd(void* stream, const float* W, int64_t K, int32_t C, c
 #define SN_MAXB 16
 struct SnB { const float* W; long long K; int C; const float* u; float* ws; float* u_new; const float* G; float* dW; int beta; int vec; };
 struct SnBatch { int n; SnB it[SN_MAXB]; };
+// Workgroups per matrix of the batched products.  Each workgroup ends in float64 atomics on the matrix's accumulators (one address for
+// |W u|^2, C addresses for W^T a): few workgroups with several rows in flight each, not one workgroup per handful of rows.
+#ifndef SNB_ROW_BLOCKS
+#define SNB_ROW_BLOCKS 256
+#endif
+#ifndef SNB_COL_BLOCKS
+#define SNB_COL_BLOCKS 128
+#endif
 
 __global__ __launch_bounds__(NT) void snb_zero_kernel(SnBatch b, int off, int count_plus_c) {
     const SnB& t = b.it[blockIdx.y];
@@ -548,16 +594,16 @@ __global__ __launch_bounds__(NT) void snb_rows_kernel(SnBatch b, int phase) {
     const float* z = phase == 0 ? nullptr : (const float*)a;
     double* dotz = phase == 0 ? nullptr : sn_acc64(t.ws, t.K, t.C) + 1;
     if (t.C <= 16) {
-        const int need = (int)min((t.K + NT - 1) / NT, 1024ll);
+        const int need = (int)min((t.K + NT - 1) / NT, (long long)SNB_ROW_BLOCKS);
         if ((int)blockIdx.x >= need) return;
         sn_rows_narrow_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need, sh);
     } else if (t.vec) {
         const int rp = (256 / (t.C >> 2)) * 2;
-        const int need = (int)min((t.K + rp - 1) / rp, 1024ll);
+        const int need = (int)min((t.K + rp - 1) / rp, (long long)SNB_ROW_BLOCKS);
         if ((int)blockIdx.x >= need) return;
         sn_rows_vec_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need);
     } else {
-        const int need = (int)min((t.K + 3) / 4, 1024ll);
+        const int need = (int)min((t.K + 3) / 4, (long long)SNB_ROW_BLOCKS);
         if ((int)blockIdx.x >= need) return;
         sn_rows_body(t.W, t.K, t.C, x, 1.f, y, sq, z, dotz, blockIdx.x, need);
     }
@@ -569,13 +615,17 @@ __global__ __launch_bounds__(NT) void snb_cols_kernel(SnBatch b) {
     const SnB& t = b.it[blockIdx.y];
     const float* a = t.ws + 8 + 2 * t.C;
     if (t.vec) {
-        int rpb = (int)((t.K + 511) / 512);
+        int rpb = (int)((t.K + SNB_COL_BLOCKS - 1) / SNB_COL_BLOCKS);
         const int slots = NT / (t.C >> 2);
         if (rpb < 4 * slots) rpb = 4 * slots;
         if ((long long)blockIdx.x * rpb >= t.K) return;
         sn_cols_vec_body(t.W, t.K, t.C, a, sn_acc64(t.ws, t.K, t.C) + 1, rpb, blockIdx.x, sh);
+    } else if (t.C <= 16) {
+        const int rpb = (int)max((long long)NT, (t.K + SNB_COL_BLOCKS - 1) / SNB_COL_BLOCKS);
+        if ((long long)blockIdx.x * rpb >= t.K) return;
+        sn_cols_narrow_body(t.W, t.K, t.C, a, sn_acc64(t.ws, t.K, t.C) + 1, rpb, blockIdx.x, reinterpret_cast<float*>(sh));
     } else {
-        const int rpb = (int)max(64ll, (t.K + 511) / 512);
+        const int rpb = (int)max(64ll, (t.K + SNB_COL_BLOCKS - 1) / SNB_COL_BLOCKS);
         if ((long long)blockIdx.x * rpb >= t.K) return;
         sn_cols_body(t.W, t.K, t.C, a, sn_acc64(t.ws, t.K, t.C) + 1, rpb, blockIdx.x);
     }
@@ -643,8 +693,8 @@ extern "C" int savp_sn_fwd_batch(void* stream, int32_t n, const SavpSnItem* item
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(snb_zero_kernel, dim3(1, n), dim3(NT), 0, st, b, 0, 8);            // ws[0 .. 8 + C)
-    hipLaunchKernelGGL(snb_rows_kernel, dim3(1024, n), dim3(NT), 0, st, b, 0);
-    hipLaunchKernelGGL(snb_cols_kernel, dim3(512, n), dim3(NT), 0, st, b);
+    hipLaunchKernelGGL(snb_rows_kernel, dim3(SNB_ROW_BLOCKS, n), dim3(NT), 0, st, b, 0);
+    hipLaunchKernelGGL(snb_cols_kernel, dim3(SNB_COL_BLOCKS, n), dim3(NT), 0, st, b);
     hipLaunchKernelGGL(snb_finalize_kernel, dim3(1, n), dim3(NT), 0, st, b);
     return LAUNCH_OK();
 }
@@ -655,8 +705,8 @@ extern "C" int savp_sn_bwd_batch(void* stream, int32_t n, const SavpSnItem* item
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(snb_zero_kernel, dim3(1, n), dim3(NT), 0, st, b, 5, -2);           // ws[5], ws[6]
-    hipLaunchKernelGGL(snb_dot_kernel, dim3(1024, n), dim3(NT), 0, st, b);
-    hipLaunchKernelGGL(snb_rows_kernel, dim3(1024, n), dim3(NT), 0, st, b, 1);
+    hipLaunchKernelGGL(snb_dot_kernel, dim3(SNB_ROW_BLOCKS, n), dim3(NT), 0, st, b);
+    hipLaunchKernelGGL(snb_rows_kernel, dim3(SNB_ROW_BLOCKS, n), dim3(NT), 0, st, b, 1);
     hipLaunchKernelGGL(snb_apply_kernel, dim3(2048, n), dim3(NT), 0, st, b);
     return LAUNCH_OK();
 }
