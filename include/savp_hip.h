@@ -400,6 +400,12 @@ int savp_gru_seq_fwd(void* stream, float* A, float* A2, const float* Wg, const f
                      float* ru, float* cand, int32_t T, int32_t B, int32_t I, int32_t U);
 int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, const float* Wc, const float* ru, const float* cand, const float* dh_out,
                      float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U);
+/* ... from a caller-supplied initial state h0 [U] (learn_initial_state with the GRU latent cell, savp_model.py:288-291,344-352) and its
+ * gradient dh0 [U] (float64, += : one workgroup per sample adds what step 0 hands back). */
+int savp_gru_seq_fwd_init(void* stream, float* A, float* A2, const float* Wg, const float* bg, const float* Wc, const float* bc, float* hout,
+                          float* ru, float* cand, int32_t T, int32_t B, int32_t I, int32_t U, const float* h0);
+int savp_gru_seq_bwd_init(void* stream, const float* A, const float* Wg, const float* Wc, const float* ru, const float* cand, const float* dh_out,
+                          float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U, double* dh0);
 /* KL between two diagonal Gaussians (losses.py:61-67; learn_prior): value into *kl_out (optional), klw-weighted gradient ADDED
  * to dmu1 / dls1 / dmu2 / dls2 (all four or none); ls*_raw are the unclipped log-variances. */
 int savp_kl_gauss(void* stream, int64_t n, int32_t rows, const float* mu1, const float* ls1_raw, const float* mu2,

@@ -589,6 +589,7 @@ def check_cell_options():
     res = []
     cases = [('learn_init', dict(learn_initial_state=True)),
              ('learn_init_gru', dict(learn_initial_state=True, conv_rnn='gru')),
+             ('learn_init_rnn_gru', dict(learn_initial_state=True, rnn='gru')),          # the latent's GRUCell from a learned state (round 6)
              ('abl_rnn', dict(ablation_rnn=True)),
              ('abl_rnn_learn_init', dict(ablation_rnn=True, learn_initial_state=True)),      # no state to learn: the flag does nothing (savp_model.py:269-307)
              ('abl_cell_norm', dict(ablation_conv_rnn_norm=True)),

@@ -311,14 +311,15 @@ extern "C" int savp_lstm_seq_bwd(void* stream, const float* A, const float* W, c
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void gru_seq_fwd_kernel(float* __restrict__ A, float* __restrict__ A2, const float* __restrict__ Wg, const float* __restrict__ bg,
                                    const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ hout,
-                                   float* __restrict__ ru, float* __restrict__ cand, int T, int B, int I, int U) {
+                                   float* __restrict__ ru, float* __restrict__ cand, int T, int B, int I, int U,
+                                   const float* __restrict__ h0) {
     extern __shared__ float sh_gru[];
     const int K = I + U;
     float* sh_a = sh_gru;               // [K]  [x_t | h_{t-1}]
     float* sh_ru = sh_gru + K;          // [2U]
     float* sh_rh = sh_ru + 2 * U;       // [U]
     const int b = blockIdx.x, j = threadIdx.x;
-    if (j < U) sh_a[I + j] = 0.f;
+    if (j < U) sh_a[I + j] = h0 ? h0[j] : 0.f;       // learn_initial_state: the variable, tiled over the batch (savp_model.py:344-352)
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const long long o = (long long)t * B + b;
@@ -354,7 +355,8 @@ __global__ void gru_seq_fwd_kernel(float* __restrict__ A, float* __restrict__ A2
 
 __global__ void gru_seq_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Wg, const float* __restrict__ Wc,
                                    const float* __restrict__ ru, const float* __restrict__ cand, const float* __restrict__ dh_out,
-                                   float* __restrict__ dGg, float* __restrict__ dGc, float* __restrict__ dA, int T, int B, int I, int U) {
+                                   float* __restrict__ dGg, float* __restrict__ dGc, float* __restrict__ dA, int T, int B, int I, int U,
+                                   double* __restrict__ dh0) {
     extern __shared__ float sh_gru[];
     const int K = I + U;
     float* sh_dgc = sh_gru;             // [U]
@@ -407,6 +409,8 @@ __global__ void gru_seq_bwd_kernel(const float* __restrict__ A, const float* __r
         }
         __syncthreads();
     }
+    // gradient of the learned initial state: what step 0 hands back, summed over the batch (float64: one workgroup per sample adds)
+    if (dh0 && j < U) unsafeAtomicAdd(dh0 + j, (double)sh_dh[j]);
 }
 
 extern "C" int savp_gru_seq_fwd(void* stream, float* A, float* A2, const float* Wg, const float* bg, const float* Wc, const float* bc,
@@ -416,7 +420,15 @@ extern "C" int savp_gru_seq_fwd(void* stream, float* A, float* A2, const float* 
     if (nt > 1024) return SAVP_EINVAL;
     // (threads beyond 2U would index past the gate arrays: the launch uses exactly 2U threads -- any count is legal, waves are padded)
     hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(B), dim3(2 * U), (size_t)(I + U + 3 * U) * sizeof(float), (hipStream_t)stream, A, A2, Wg, bg,
-                       Wc, bc, hout, ru, cand, T, B, I, U);
+                       Wc, bc, hout, ru, cand, T, B, I, U, (const float*)nullptr);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_gru_seq_fwd_init(void* stream, float* A, float* A2, const float* Wg, const float* bg, const float* Wc, const float* bc,
+                                     float* hout, float* ru, float* cand, int32_t T, int32_t B, int32_t I, int32_t U, const float* h0) {
+    if (!A || !A2 || !Wg || !bg || !Wc || !bc || !hout || !ru || !cand || !h0 || U < 1 || U > 512 || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(B), dim3(2 * U), (size_t)(I + U + 3 * U) * sizeof(float), (hipStream_t)stream, A, A2, Wg, bg,
+                       Wc, bc, hout, ru, cand, T, B, I, U, h0);
     return LAUNCH_OK();
 }
 
@@ -424,7 +436,16 @@ extern "C" int savp_gru_seq_bwd(void* stream, const float* A, const float* Wg, c
                                 const float* dh_out, float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U) {
     if (!A || !Wg || !Wc || !ru || !cand || !dh_out || !dGg || !dGc || !dA || U < 1 || U > 512 || I < 1 || I + U > 4096) return SAVP_EINVAL;
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(B), dim3(2 * U), (size_t)(6 * U + I) * sizeof(float), (hipStream_t)stream, A, Wg, Wc, ru,
-                       cand, dh_out, dGg, dGc, dA, T, B, I, U);
+                       cand, dh_out, dGg, dGc, dA, T, B, I, U, (double*)nullptr);
+    return LAUNCH_OK();
+}
+
+extern "C" int savp_gru_seq_bwd_init(void* stream, const float* A, const float* Wg, const float* Wc, const float* ru, const float* cand,
+                                     const float* dh_out, float* dGg, float* dGc, float* dA, int32_t T, int32_t B, int32_t I, int32_t U,
+                                     double* dh0) {
+    if (!A || !Wg || !Wc || !ru || !cand || !dh_out || !dGg || !dGc || !dA || !dh0 || U < 1 || U > 512 || I < 1 || I + U > 4096) return SAVP_EINVAL;
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(B), dim3(2 * U), (size_t)(6 * U + I) * sizeof(float), (hipStream_t)stream, A, Wg, Wc, ru,
+                       cand, dh_out, dGg, dGc, dA, T, B, I, U, dh0);
     return LAUNCH_OK();
 }
 

@@ -1020,19 +1020,30 @@ def lstm_z_bwd(zs, W, hout, gates, cs, dh_out, dzs, dW, db, forget_bias=1.0, ini
     acc.finish()
 
 
-def gru_seq_fwd(A, A2, Wg, bg, Wc, bc, hout, ru, cand, n_in):
-    """GRUCell over time (include/savp_hip.h): A [T,B,I+U] with x in [..., :I]; fills A[..., I:], A2, hout, ru, cand."""
+def gru_seq_fwd(A, A2, Wg, bg, Wc, bc, hout, ru, cand, n_in, h0=None):
+    """GRUCell over time (include/savp_hip.h): A [T,B,I+U] with x in [..., :I]; fills A[..., I:], A2, hout, ru, cand.  h0 [U]: the initial
+    state (learn_initial_state; None: zeros)."""
     T, B, Kd = A.shape
     U = Kd - n_in
-    lib.require_device(A, A2, Wg, bg, Wc, bc, hout, ru, cand)
+    lib.require_device(A, A2, Wg, bg, Wc, bc, hout, ru, cand, h0)
+    if h0 is not None:
+        lib.check(_L().savp_gru_seq_fwd_init(lib.stream(), _p(A), _p(A2), _p(Wg), _p(bg), _p(Wc), _p(bc), _p(hout), _p(ru), _p(cand), T, B, n_in,
+                                             U, _p(h0)), 'savp_gru_seq_fwd_init')
+        return
     lib.check(_L().savp_gru_seq_fwd(lib.stream(), _p(A), _p(A2), _p(Wg), _p(bg), _p(Wc), _p(bc), _p(hout), _p(ru), _p(cand), T, B, n_in, U),
               'savp_gru_seq_fwd')
 
 
-def gru_seq_bwd(A, Wg, Wc, ru, cand, dh_out, dGg, dGc, dA, n_in):
+def gru_seq_bwd(A, Wg, Wc, ru, cand, dh_out, dGg, dGc, dA, n_in, dh0=None):
+    """dh0 [U] float64: the initial state's gradient, accumulated (learn_initial_state)."""
     T, B, Kd = A.shape
     U = Kd - n_in
     lib.require_device(A, Wg, Wc, ru, cand, dh_out, dGg, dGc, dA)
+    if dh0 is not None:
+        lib.require_stats(dh0)
+        lib.check(_L().savp_gru_seq_bwd_init(lib.stream(), _p(A), _p(Wg), _p(Wc), _p(ru), _p(cand), _p(dh_out), _p(dGg), _p(dGc), _p(dA), T, B,
+                                             n_in, U, _p(dh0)), 'savp_gru_seq_bwd_init')
+        return
     lib.check(_L().savp_gru_seq_bwd(lib.stream(), _p(A), _p(Wg), _p(Wc), _p(ru), _p(cand), _p(dh_out), _p(dGg), _p(dGc), _p(dA), T, B, n_in, U),
               'savp_gru_seq_bwd')
 

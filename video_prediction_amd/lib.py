@@ -321,6 +321,8 @@ register('savp_kl_gauss', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f
 register('savp_lstm_z_bwd', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32])
 register('savp_gru_seq_fwd', [c_vp] * 10 + [c_i32] * 4)
 register('savp_gru_seq_bwd', [c_vp] * 10 + [c_i32] * 4)
+register('savp_gru_seq_fwd_init', [c_vp] * 10 + [c_i32] * 4 + [c_vp])
+register('savp_gru_seq_bwd_init', [c_vp] * 10 + [c_i32] * 4 + [c_vp])
 register('savp_lstm_z_fwd_init', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp])
 register('savp_lstm_z_bwd_init', [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp])
 register('savp_reparam_fwd', [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])

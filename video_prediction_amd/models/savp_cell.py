@@ -118,8 +118,6 @@ class SAVPGenerator(object):
             raise NotImplementedError('dilation_rate != (1, 1)')
         if hp.nz and hp.use_rnn_z and hp.rnn not in ('lstm', 'gru') and not hp.ablation_rnn:
             raise NotImplementedError(hp.rnn)                                  # savp_model.py:360-361
-        if hp.nz and hp.use_rnn_z and hp.rnn == 'gru' and hp.learn_initial_state:
-            raise NotImplementedError('learn_initial_state with the GRU latent cell')
         if hp.where_add not in ('input', 'all', 'middle'):
             raise ValueError('Invalid where_add %s' % hp.where_add)                      # savp_model.py:176-177
         # ablation_rnn (savp_model.py:272-291,426-429,466-474,502-509): no recurrent state anywhere -- every conv-RNN becomes conv2d 5x5
@@ -408,7 +406,9 @@ class SAVPGenerator(object):
                     L['c0v'], L['c0g'] = var(hw_f)
                     L['c0'] = torch.empty((N,) + hw_f, device=dev)
                 L['h0v'], L['h0g'] = var(hw_f)
-            if self.use_rnn_z:
+            if self.use_rnn_z and hp.rnn == 'gru':               # GRUCell: the state is h alone (savp_model.py:288-291)
+                self.z_h0, self.z_dh0 = var((nz,), acc64=True)
+            elif self.use_rnn_z:
                 self.z_c0, self.z_dc0 = var((nz,), acc64=True)    # savp_lstm_z_bwd_init adds to them from every sample's workgroup
                 self.z_h0, self.z_dh0 = var((nz,), acc64=True)
         # ---- merged 3x3 heads on the last decoder layer (SAVP_MERGE_HEADS=0: one launch per head, the reference's structure) ----
@@ -497,7 +497,8 @@ class SAVPGenerator(object):
                 torch.tanh(self.fcz_pre.v.reshape(T1, N, nz), out=self.rnn_z.v)
             elif self.use_rnn_z and self.hp.rnn == 'gru':
                 self.zA[..., :nz].copy_(self.zs.v)
-                K.gru_seq_fwd(self.zA, self.zA2, self.zg.W, self.zg.bias, self.zc.W, self.zc.bias, self.rnn_z.v, self.z_ru, self.z_cand, nz)
+                K.gru_seq_fwd(self.zA, self.zA2, self.zg.W, self.zg.bias, self.zc.W, self.zc.bias, self.rnn_z.v, self.z_ru, self.z_cand, nz,
+                              h0=self.z_h0 if self.learn_init else None)
             elif self.use_rnn_z:
                 K.lstm_z_fwd(self.zs.v, self.zW, self.zb, self.rnn_z.v, self.z_gates, self.z_cs,
                              init=(self.z_c0, self.z_h0) if self.learn_init else None)
@@ -948,7 +949,8 @@ class SAVPGenerator(object):
             return self.zs.g
         if self.use_rnn_z and self.hp.rnn == 'gru':
             R = T1 * N
-            K.gru_seq_bwd(self.zA, self.zg.W, self.zc.W, self.z_ru, self.z_cand, drz, self.z_dGg, self.z_dGc, self.z_dA, nz)
+            K.gru_seq_bwd(self.zA, self.zg.W, self.zc.W, self.z_ru, self.z_cand, drz, self.z_dGg, self.z_dGc, self.z_dA, nz,
+                          dh0=self.z_dh0 if self.learn_init else None)
             self.zg.backward_weights(self.zA.reshape(R, 1, 1, 2 * nz), self.z_dGg.reshape(R, 1, 1, 2 * nz))
             self.zc.backward_weights(self.zA2.reshape(R, 1, 1, 2 * nz), self.z_dGc.reshape(R, 1, 1, nz))
             self.zs.g.copy_(self.z_dA[..., :nz])
