@@ -417,6 +417,11 @@ int savp_reparam_bwd(void* stream, int64_t n, int32_t rows, const float* mu, con
                      const float* dz, float klw, float* dmu, float* dls_raw, const float* klw_dev);   /* klw_dev: as lr_t_dev */
 int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t pred_row_stride, int64_t target_row_stride, int32_t p2,
                  const float* pred, const float* target, float weight, double* loss_out, float* dpred);
+/* Total variation of the predicted flows (base_model.py:763-769, tv_weight with transformation = 'flow'): flows = n_img images [H, W, C = 2 nk]
+ * (element strides img_stride / px_stride); loss_out (float64) += s1 sum |f[y+1] - f[y]| + s2 sum |f[x+1] - f[x]| over these images (s1, s2: the
+ * means' 1 / count over the WHOLE sequence); dflows (same addressing, may be NULL) += weight * gradient.  One call per time step inside BPTT. */
+int savp_tv_loss(void* stream, const float* flows, int32_t n_img, int32_t H, int32_t W, int32_t C, int64_t img_stride, int64_t px_stride,
+                 float s1, float s2, float weight, double* loss_out, float* dflows);
 /* type 0 LSGAN, 1 GAN (sigmoid cross-entropy), 2 SNGAN (softplus hinge-free form), losses.py:29-54 */
 int savp_gan_loss(void* stream, int32_t n, int32_t type, const float* logits, float label, float weight, double* loss_out,
                   float* dlogits, int32_t beta);

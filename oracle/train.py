@@ -96,6 +96,12 @@ def generator_loss_fn(hp, inputs, outputs, kl_w):
     if getattr(hp, 'state_weight', 0):                                                       # base_model.py:758-762
         gen_states = outputs.get('gen_states_enc', outputs['gen_states'])
         losses['gen_state_loss'] = (l2_loss(gen_states, inputs['states'][1:]), hp.state_weight)
+    if getattr(hp, 'tv_weight', 0):                                                          # base_model.py:763-769
+        gen_flows = outputs.get('gen_flows_enc', outputs['gen_flows'])                       # [T, B, H, W, 2, nk]
+        d1 = gen_flows[..., 1:, :, :, :] - gen_flows[..., :-1, :, :, :]
+        d2 = gen_flows[..., :, 1:, :, :] - gen_flows[..., :, :-1, :, :]
+        # sum over the multiple transformations but take the mean for the other dimensions
+        losses['gen_tv_loss'] = (d1.abs().sum(dim=(-2, -1)).mean() + d2.abs().sum(dim=(-2, -1)).mean(), hp.tv_weight)
     for infix, w, wf_l2, wf_cd, sfx, nm in (
             ('_image_sn', hp.image_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),
             ('_video_sn', hp.video_sn_gan_weight, hp.gan_feature_l2_weight, hp.gan_feature_cdist_weight, '', 'gan'),

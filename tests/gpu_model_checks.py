@@ -581,6 +581,12 @@ def check_action_conditioned_bf16(cond, tag, B=2, T=5, H=64, W=64, C=3):
     return out
 
 
+def check_flow_tv_loss():
+    """tv_weight with transformation = 'flow' (base_model.py:763-769): total variation of the predicted flows, value and gradient through
+    one train step (fp32 datapath vs the fp64 oracle)."""
+    return check_train_step(B=2, T=5, nz=8, steps=1, tag='train_flow_tv', transformation='flow', tv_weight=0.05)
+
+
 def check_cell_options():
     """The options of SAVPCell that no shipped recipe sets, each forward (fp32 datapath vs the fp64 oracle) and through one train step:
     learn_initial_state (savp_model.py:295-307,344-352), ablation_rnn (:272-291,426-429,466-474,502-509), ablation_conv_rnn_norm

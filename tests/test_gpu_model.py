@@ -83,6 +83,12 @@ def test_action_and_state_conditioned_cell_vs_oracle():
     _assert_ok(G.check_action_conditioned())
 
 
+def test_flow_total_variation_loss_vs_oracle():
+    """tv_weight (base_model.py:763-769) on the flow transformation's outputs: loss value and every gradient of one train step."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_flow_tv_loss())
+
+
 def test_config_c1_deterministic_b4_t12_forward_and_train_vs_oracle():
     """BASELINE configs[0] at its own shape (not scaled): deterministic generator, nz=0, B=4, T=12, 64x64x3, the
     ours_deterministic_l1 recipe."""

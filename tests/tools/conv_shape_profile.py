@@ -13,12 +13,12 @@ def run():
     os.environ['SAVP_GRAPH'] = '0'
     K.set_conv_precision('bf16'); K.enable_autotune(True)
     K.load_tuning(os.path.join(ROOT, 'video_prediction_amd', 'tuning_gfx950_bf16.json'))
-    B, T = 16, 30
+    B, T, HW_ = int(os.environ.get('B', 16)), int(os.environ.get('T', 30)), int(os.environ.get('HW', 64))     # c5: B=8 HW=128
     hp = make_hparams(context_frames=2, sequence_length=T, batch_size=B, lr=2e-4, beta1=0.5, beta2=0.999, l1_weight=100.0,
                       l2_weight=0.0, kl_weight=1.0, video_sn_vae_gan_weight=0.1, video_sn_gan_weight=0.1,
                       vae_gan_feature_cdist_weight=10.0, gan_feature_cdist_weight=0.0)
-    eng = SAVPEngine(hp, (64, 64, 3), B, mode='train')
-    eng.set_images(torch.rand(T, B, 64, 64, 3, device='cuda:0'), time_major=True)
+    eng = SAVPEngine(hp, (HW_, HW_, 3), B, mode='train')
+    eng.set_images(torch.rand(T, B, HW_, HW_, 3, device='cuda:0'), time_major=True)
     for _ in range(2):
         eng.train_step()
     torch.cuda.synchronize()

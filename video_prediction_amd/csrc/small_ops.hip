@@ -588,6 +588,48 @@ extern "C" int savp_lp_loss(void* stream, int64_t rows, int64_t row_len, int64_t
     return LAUNCH_OK();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Total variation of the predicted flows (base_model.py:763-769, tv_weight; transformation = 'flow'):
+//   loss = mean_{t,b,y<H-1,x} sum_c |f[y+1,x,c] - f[y,x,c]| + mean_{t,b,y,x<W-1} sum_c |f[y,x+1,c] - f[y,x,c]|,  c over the 2 * nk flow channels.
+// One launch per time step (the flow gradient of a step is complete only inside BPTT): s1 / s2 = 1 / (T B (H-1) W), 1 / (T B H (W-1)) of the WHOLE
+// sequence; loss_out (float64) += this step's share; dflows += weight * d loss / d f  (tf.abs: sign(0) = 0).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn_(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+__global__ void tv_loss_kernel(const float* __restrict__ f, int n_img, int H, int W, int C, long long img_stride, long long px_stride, float s1,
+                               float s2, float weight, double* loss_out, float* __restrict__ df) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const long long total = (long long)n_img * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long long n = r / H;
+        const float* q = f + n * img_stride + ((long long)y * W + x) * px_stride + c;
+        const float v = *q;
+        float g = 0.f;
+        if (y + 1 < H) { const float d = q[(long long)W * px_stride] - v; acc += fabsf(d) * s1; g -= sgn_(d) * s1; }
+        if (y > 0) g += sgn_(v - q[-(long long)W * px_stride]) * s1;
+        if (x + 1 < W) { const float d = q[px_stride] - v; acc += fabsf(d) * s2; g -= sgn_(d) * s2; }
+        if (x > 0) g += sgn_(v - q[-px_stride]) * s2;
+        if (df) df[n * img_stride + ((long long)y * W + x) * px_stride + c] += weight * g;
+    }
+    const float t = block_sum1(acc, sh);
+    if (threadIdx.x == 0 && loss_out) unsafeAtomicAdd(loss_out, (double)t);
+}
+
+extern "C" int savp_tv_loss(void* stream, const float* flows, int32_t n_img, int32_t H, int32_t W, int32_t C, int64_t img_stride, int64_t px_stride,
+                            float s1, float s2, float weight, double* loss_out, float* dflows) {
+    if (!flows || n_img < 1 || H < 2 || W < 2 || C < 1) return SAVP_EINVAL;
+    const long long total = (long long)n_img * H * W * C;
+    unsigned nb = (unsigned)((total + NT - 1) / NT);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(tv_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, flows, n_img, H, W, C, (long long)img_stride,
+                       (long long)px_stride, s1, s2, weight, loss_out, dflows);
+    return LAUNCH_OK();
+}
+
 // GAN losses on logits [n] (losses.py:29-54).  type 0 LSGAN: mean((l-label)^2); 1 GAN: mean sigmoid cross-entropy with
 // constant labels; 2 SNGAN: mean softplus(l) for label 0, mean softplus(-l) for label 1.
 // loss_out += loss ; dlogits (=|+=) weight * dloss/dlogits

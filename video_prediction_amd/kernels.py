@@ -1105,6 +1105,19 @@ def lp_loss(pred, target, weight, loss_out=None, dpred=None, p2=False):
     acc.finish()
 
 
+def tv_loss(flows, n_channels, s1, s2, weight, loss_out=None, dflows=None):
+    """base_model.py:763-769 on the flows of some images: flows view [n, H, W, >= n_channels] (channel-contiguous, any image / pixel stride);
+    loss_out float64 [1] += s1 * sum |d/dy| + s2 * sum |d/dx|; dflows (same strides) += weight * gradient."""
+    lib.require_device_any(flows)
+    assert flows.dtype == torch.float32 and flows.dim() == 4 and flows.stride(3) == 1 and flows.stride(1) == flows.shape[2] * flows.stride(2)
+    if dflows is not None:
+        assert dflows.stride() == flows.stride() and dflows.dtype == torch.float32
+    lib.require_stats(loss_out)
+    n, H, W, _ = flows.shape
+    lib.check(_L().savp_tv_loss(lib.stream(), _p(flows), n, H, W, int(n_channels), flows.stride(0), flows.stride(2), float(s1), float(s2),
+                                float(weight), _p(loss_out), _p(dflows)), 'savp_tv_loss')
+
+
 def lsgan_loss(logits, label, weight, loss_out=None, dlogits=None, beta=0):
     acc = _Acc64(loss_out)
     lib.check(_L().savp_lsgan_loss(lib.stream(), logits.numel(), _p(logits), float(label), float(weight), acc.addr(0), _p(dlogits),

@@ -381,6 +381,7 @@ for _n in ('savp_convgru_gates_fwd', 'savp_convgru_out_fwd', 'savp_convgru_out_b
     register(_n, [c_vp, ctypes.POINTER(SavpGruArgs)])
 register('savp_gan_loss', [c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32])
 register('savp_fold_f64', [c_vp, c_vp, c_i64, c_vp, c_vp])
+register('savp_tv_loss', [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp])
 register('savp_state_pred_fwd', [c_vp, c_i32, c_i32, c_i32, c_i32] + [c_vp] * 7)
 register('savp_state_pred_bwd', [c_vp, c_i32, c_i32, c_i32, c_i32] + [c_vp] * 6)
 register('savp_pack_gate_weights', [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32])

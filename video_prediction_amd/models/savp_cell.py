@@ -127,6 +127,7 @@ class SAVPGenerator(object):
         #  initial_state variables exist -- savp_model.py:269-307 -- and the flag does nothing; variables.py creates none either)
         self.nz = nz = hp.nz
         self.use_rnn_z = bool(nz and hp.use_rnn_z)
+        self.tv = None                       # (weight, leading samples the loss covers, float64 [1] accumulator): set by the engine for tv_weight
         self.na, self.ns = na, ns = int(cond[0]), int(cond[1])
         self.cw = cw = na + ns                 # conditioning columns in front of the latent: state_action_z = [actions | state | z]
         self.zw = zw = cw + nz                 # width of every tiled slice
@@ -762,6 +763,11 @@ class SAVPGenerator(object):
             else:
                 if self.tf == 'flow':
                     K.image_warp_bwd(in0.v[t][..., 0:C], self.tf_raw.v[t], dslot, self.tf_raw.g[t], self.dimg_cdna, self.nk)
+                    if self.tv is not None:          # total-variation loss of the flows (base_model.py:763-769): this step's share + gradient
+                        w_tv, rows, acc = self.tv
+                        s1 = 1.0 / (T1 * rows * (self.H - 1) * self.W)
+                        s2 = 1.0 / (T1 * rows * self.H * (self.W - 1))
+                        K.tv_loss(self.tf_raw.v[t][:rows], 2 * self.nk, s1, s2, w_tv, acc, self.tf_raw.g[t][:rows])
                 else:
                     K.dna_apply_bwd(in0.v[t][..., 0:C], self.tf_raw.v[t], self.dna_kern[t], dslot, self.tf_raw.g[t],
                                     self.dimg_cdna, self.kh, self.kw, self.nk)

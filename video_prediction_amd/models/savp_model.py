@@ -121,7 +121,7 @@ class SAVPEngine(object):
 
     # loss terms of base_model.py:733-829 that need inputs / networks outside the SAVP hot path (VGG features, robot states,
     # auto-encoder outputs): accepting them silently would train a different model than the recipe asks for
-    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'tv_weight', 'z_l1_weight')
+    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'z_l1_weight')
 
     def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0', base_seed=0, rank=0,
                  cond=(0, 0)):
@@ -135,6 +135,8 @@ class SAVPEngine(object):
         self.cond = (self.na, self.ns)
         if getattr(hp, 'state_weight', 0) and mode == 'train' and not self.ns:
             raise KeyError('states')               # base_model.py:758-760 reads inputs['states'] whenever state_weight is set
+        if getattr(hp, 'tv_weight', 0) and mode == 'train' and hp.transformation != 'flow':
+            raise KeyError('gen_flows')            # base_model.py:763-764: only the flow transformation has that output (savp_model.py:668-669)
         self.base_seed, self.rank = int(base_seed), int(rank)
         self.image_shape = tuple(image_shape)
         self.device = torch.device(device)
@@ -632,6 +634,9 @@ class SAVPEngine(object):
             gs = self.gen.gen_states
             gs.g.zero_()
             K.lp_loss(gs.v[:, :B], self.states_tm[1:self.T], state_w, lb[-3:-2], gs.g[:, :B], p2=True)
+        tv_w = getattr(hp, 'tv_weight', 0)
+        # gen_tv_loss (base_model.py:763-769) is taken step by step inside BPTT, where each step's flow gradient is complete
+        self.gen.tv = (tv_w, B, lb[-4:-3]) if tv_w else None
         dzs = self.gen.backward(state_grad=bool(state_w))
         store.groups['g'].fold64()                         # float64 accumulators of the cell's norms / z-LSTM -> fp32 gradients
         if self.nz and not return_grads:
@@ -686,6 +691,8 @@ class SAVPEngine(object):
             g_losses['gen_l2_loss'] = (lb[-1], hp.l2_weight)
         if state_w:
             g_losses['gen_state_loss'] = (lb[-3], state_w)
+        if tv_w:
+            g_losses['gen_tv_loss'] = (lb[-4], tv_w)
         if self.nz and hp.kl_weight:
             g_losses['gen_kl_loss'] = (self.enc.kl.float()[0], klw)
         info['d_losses'], info['g_losses'] = d_losses, g_losses
