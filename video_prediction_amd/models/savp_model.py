@@ -119,9 +119,11 @@ class SAVPEngine(object):
     """All device state of one SAVP replica: variables, generator unroll (batch 2B: posterior + prior), posterior
     encoder, the two video discriminators; implements one training step and inference."""
 
-    # loss terms of base_model.py:733-829 that need inputs / networks outside the SAVP hot path (VGG features, robot states,
-    # auto-encoder outputs): accepting them silently would train a different model than the recipe asks for
-    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight', 'z_l1_weight')
+    # loss terms of base_model.py:733-829 that need networks / outputs the SAVP generator does not have (VGG features; `gen_features` and
+    # `gen_images_dec` are outputs of other model families: the reference's loss_fn raises KeyError for them on SAVP): accepting them
+    # silently would train a different model than the recipe asks for.  (z_l1_weight is a declared hyper-parameter no loss reads,
+    # base_model.py:398: accepted and without effect here as there.)
+    UNSUPPORTED_WEIGHTS = ('vgg_cdist_weight', 'feature_l2_weight', 'ae_l2_weight')
 
     def __init__(self, hp, image_shape, batch_size, mode='train', values=None, seed=4, device='cuda:0', base_seed=0, rank=0,
                  cond=(0, 0)):
