@@ -31,7 +31,9 @@ const char* savp_version(void);
  * workgroups pull their column tile's weight block into the XCD's L2 first), "wgp_dma" 1 (weight gradient of two bf16 operands: LDS-DMA
  * staging), "ring_early" 1 (ring kernel: the first patch is requested at the top of the prologue), "gate_kernel" 1 (the ConvLSTM gate convolution's own kernel
  * when SavpConvArgs.w_frag is given), "gate_cell" 1 (savp_convlstm_cell_fwd: the whole cell in one launch where a tile holds whole images), "gate_wwarm" 1 (its workgroups touch their column tile's weight block into the XCD's L2 first), "colsum_2stage" 1,
- * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy", "gate_alt" (0). */
+ * "inorm_min_hw" 64, and the developer overrides "wgp_cfg", "wgp_split", "lstm_q", "dense_legacy", "cdna_legacy", "gate_alt" (0).
+ * "splitk_reduced" is a counter, not a switch: the number of convolution calls so far whose requested split-K count was cut (or dropped) because
+ * SavpConvArgs.ws was absent or too small (savp_conv_workspace_bytes says how much a call can use); set it to 0 to reset. */
 int savp_set_option(const char* name, int32_t value);
 int savp_get_option(const char* name, int32_t* value);
 

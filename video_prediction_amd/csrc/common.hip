@@ -41,9 +41,10 @@ extern "C" int savp_prof_elapsed_us(void* start, void* stop, float* us) {
 // ---- options (opts.h) ----------------------------------------------------------------------------------------
 static struct { const char* name; int value; } g_opts[OPT_COUNT] = {
     {"conv_ring", 0}, {"s2dgrad", 1}, {"thin", 1}, {"wgp_cfg", 0}, {"wgp_split", 0}, {"inorm_min_hw", 64}, {"colsum_2stage", 1},
-    {"dense_legacy", 0}, {"cdna_legacy", 0}, {"lstm_fused", 1}, {"ring_dma", 1}, {"lstm_q", 0}, {"ring_wwarm", 1}, {"wgp_dma", 1}, {"ring_early", 1}, {"gate_kernel", 1}, {"gate_alt", 0}, {"gate_cell", 1}, {"gate_wwarm", 1},
+    {"dense_legacy", 0}, {"cdna_legacy", 0}, {"lstm_fused", 1}, {"ring_dma", 1}, {"lstm_q", 0}, {"ring_wwarm", 1}, {"wgp_dma", 1}, {"ring_early", 1}, {"gate_kernel", 1}, {"gate_alt", 0}, {"gate_cell", 1}, {"gate_wwarm", 1}, {"splitk_reduced", 0},
 };
 int savp_opt(int id) { return g_opts[id].value; }
+void savp_opt_count(int id) { ++g_opts[id].value; }
 extern "C" int savp_set_option(const char* name, int value) {
     if (!name) return SAVP_EINVAL;
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -81,8 +82,9 @@ extern "C" int savp_allreduce_bucket(void* comm, void* stream, void* buf, int64_
 // ---- deterministic split-K (conv_common.h) --------------------------------------------------------------------------------------
 int splitk_fit(const SavpConvArgs* a, int want, long long block_elems) {
     if (want <= 1) return 1;
-    if (!a->ws || a->ws_bytes <= 0 || block_elems <= 0 || (((uintptr_t)a->ws) & 15)) return 1;
+    if (!a->ws || a->ws_bytes <= 0 || block_elems <= 0 || (((uintptr_t)a->ws) & 15)) { savp_opt_count(OPT_SPLITK_REDUCED); return 1; }
     const long long fit = a->ws_bytes / (block_elems * (long long)sizeof(float));
+    if (fit < want) savp_opt_count(OPT_SPLITK_REDUCED);          // the scratch holds fewer slices than asked for: visible in the option table
     if (fit < 2) return 1;
     return want < fit ? want : (int)fit;
 }

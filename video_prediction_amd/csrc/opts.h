@@ -23,10 +23,12 @@ enum SavpOptId {
     OPT_GATE_ALT,          // developer: conv_gate.hip's alternative tile instantiations (0)
     OPT_GATE_CELL,         // savp_convlstm_cell_fwd runs the whole cell in ONE launch where conv_gate.hip's tile holds whole images (1)
     OPT_GATE_WWARM,        // conv_gate.hip: workgroups of a column tile touch its weight block into their XCD's L2 first (1)
+    OPT_SPLITK_REDUCED,    // counter, not a switch: calls whose requested split-K count was cut (or dropped) because the caller's scratch was too small
     OPT_COUNT
 };
 
 int savp_opt(int id);
+void savp_opt_count(int id);       // += 1 (counters among the options: readable / resettable through savp_get_option / savp_set_option)
 
 #ifdef __HIPCC__
 // Touch every 64-byte line of the kernel-argument segment with one scalar load each and wait for all of them once.  The

@@ -93,7 +93,7 @@ class _LdsPoisonProxy(object):
 # Kernel-selection switches of the library (include/savp_hip.h: savp_set_option).  The library itself never reads the environment;
 # for A/B runs the host forwards SAVP_<NAME>=<int> here, once, when the library is loaded.
 OPTION_NAMES = ('conv_ring', 's2dgrad', 'thin', 'wgp_cfg', 'wgp_split', 'inorm_min_hw', 'colsum_2stage', 'dense_legacy', 'cdna_legacy',
-                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm', 'wgp_dma', 'ring_early', 'gate_kernel', 'gate_alt', 'gate_cell', 'gate_wwarm')
+                'lstm_fused', 'ring_dma', 'lstm_q', 'ring_wwarm', 'wgp_dma', 'ring_early', 'gate_kernel', 'gate_alt', 'gate_cell', 'gate_wwarm', 'splitk_reduced')
 
 
 def set_option(name, value):
