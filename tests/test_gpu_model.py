@@ -76,6 +76,36 @@ def test_cell_options_no_shipped_recipe_sets_vs_oracle():
     _assert_ok(G.check_cell_options())
 
 
+def test_conditioned_generator_vs_committed_golden_vectors():
+    """The action / state-conditioned HIP generator vs tests/golden/gen_cond_32x32.npz (fp64 oracle outputs, make_golden.py::golden_conditioned):
+    both unrolls' frames, the predicted states under scheduled sampling, the posterior means."""
+    from tests.gpu_model_checks import make_hparams
+    from video_prediction_amd import variables as V
+    from video_prediction_amd.models.savp_model import SAVPEngine
+    d = np.load(os.path.join(HERE, 'golden', 'gen_cond_32x32.npz'))
+    images = d['images']
+    T, B, H, W, C = images.shape
+    cond = (d['actions'].shape[-1], d['states'].shape[-1])
+    hp = make_hparams(context_frames=2, sequence_length=T, nz=8, schedule_sampling='inverse_sigmoid')
+    vals = V.init_variables(V.variable_specs(hp, (H, W, C), mode='test', cond=cond), seed=4)
+    for k in vals:
+        if 'state_pred' in k and k.endswith('kernel'):
+            vals[k] = (vals[k] * 30).astype(np.float32)
+    eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, cond=cond)
+    eng.mode = 'train'                       # honour the injected scheduled-sampling draws
+    eng.set_images({'images': torch.tensor(images).cuda(), 'actions': torch.tensor(d['actions']).cuda(), 'states': torch.tensor(d['states']).cuda()},
+                   time_major=True)
+    noise = {'eps': torch.tensor(d['eps']), 'prior': torch.tensor(d['prior']), 'ground_truth_sampling': torch.tensor(d['gts']),
+             'ground_truth_sampling_enc': torch.tensor(d['gts_enc'])}
+    eng.prep_generator_weights()
+    gen = eng.forward_generator(noise).cpu().double().numpy()
+    gs = eng.gen.gen_states.v.cpu().double().numpy()
+    assert np.abs(gen[:, B:] - d['gen_images']).max() <= 1e-4 and np.abs(gen[:, :B] - d['gen_images_enc']).max() <= 1e-4
+    scale = np.abs(d['gen_states']).max()
+    assert np.abs(gs[:, B:] - d['gen_states']).max() <= 1e-5 * scale and np.abs(gs[:, :B] - d['gen_states_enc']).max() <= 1e-5 * scale
+    assert np.abs(eng.enc.mu.cpu().double().numpy() - d['zs_mu_enc']).max() <= 1e-4
+
+
 def test_action_and_state_conditioned_cell_vs_oracle():
     """inputs['actions'] / inputs['states'] (savp_model.py:24-26,411-444,655-661; base_model.py:758-762): forward and train-step parity of
     the conditioned cell, including BAIR's use_state widths (4 + 3 + nz 8 = 15 tiled channels) and the state loss."""
