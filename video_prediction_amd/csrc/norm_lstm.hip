@@ -47,6 +47,9 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#ifndef INORM_U
+#define INORM_U 2            // pixel rows per trip (measured in the step: 1 -> 46.39 ms, 2 -> 45.66, 4 -> 45.76, 8 -> 45.94: more rows cost occupancy); of the instance-norm streaming loops (loads of a trip in flight together)
+#endif
 // four consecutive elements at element index idx of a tensor that holds fp32 or (is16) bf16
 __device__ __forceinline__ float4 ld4x(const float* base, long long idx, int is16) {
     if (is16) {
@@ -253,16 +256,28 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const double*
     }
     const float4 g = ld4(p.gamma + c4 * 4), b = ld4(p.beta + c4 * 4);
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
-    for (int px = p0 + prow; px < p1; px += rows) {
-        float4 v = ld4(x + (long long)px * p.x_sp + c4 * 4);
-        float4 o;
-        o.x = act_fwd((v.x - m[0]) * r[0] * g.x + b.x, p.act, p.alpha);
-        o.y = act_fwd((v.y - m[1]) * r[1] * g.y + b.y, p.act, p.alpha);
-        o.z = act_fwd((v.z - m[2]) * r[2] * g.z + b.z, p.act, p.alpha);
-        o.w = act_fwd((v.w - m[3]) * r[3] * g.w + b.w, p.act, p.alpha);
-        for (int kq = 0; kq < p.nout; ++kq)
-            if (c4 * 4 >= p.o_c0[kq] && c4 * 4 < p.o_c1[kq])
-                st4x(p.out[kq], (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + (c4 * 4 - p.o_c0[kq]), o, p.o16[kq]);
+    // INORM_U pixel rows per trip, every load of the trip issued before the first store (the destinations may alias the source as far as the
+    // compiler knows, so a one-pixel loop exposes a full memory round trip per pixel)
+    for (int px0 = p0 + prow; px0 < p1; px0 += INORM_U * rows) {
+        float4 v[INORM_U];
+#pragma unroll
+        for (int j = 0; j < INORM_U; ++j) {
+            const int px = px0 + j * rows;
+            v[j] = ld4(x + (long long)(px < p1 ? px : px0) * p.x_sp + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < INORM_U; ++j) {
+            const int px = px0 + j * rows;
+            if (px >= p1) break;
+            float4 o;
+            o.x = act_fwd((v[j].x - m[0]) * r[0] * g.x + b.x, p.act, p.alpha);
+            o.y = act_fwd((v[j].y - m[1]) * r[1] * g.y + b.y, p.act, p.alpha);
+            o.z = act_fwd((v[j].z - m[2]) * r[2] * g.z + b.z, p.act, p.alpha);
+            o.w = act_fwd((v[j].w - m[3]) * r[3] * g.w + b.w, p.act, p.alpha);
+            for (int kq = 0; kq < p.nout; ++kq)
+                if (c4 * 4 >= p.o_c0[kq] && c4 * 4 < p.o_c1[kq])
+                    st4x(p.out[kq], (long long)n * p.o_sn[kq] + (long long)px * p.o_sp[kq] + (c4 * 4 - p.o_c0[kq]), o, p.o16[kq]);
+        }
     }
 }
 
@@ -282,6 +297,36 @@ __device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c
     return d;
 }
 
+// the same for INORM_U pixel rows px0, px0 + rows, ... (rows past p1 re-read px0 and are ignored by the caller): all loads first
+__device__ __forceinline__ void inorm_dz_batch(const InormP& p, int n, int px0, int rows, int p1, int c0, const float* x, const float m[4],
+                                               const float r[4], const float4 g, const float4 bt, float4 (&d)[INORM_U], float4 (&xh)[INORM_U]) {
+    float4 v[INORM_U];
+    int pxs[INORM_U];
+#pragma unroll
+    for (int j = 0; j < INORM_U; ++j) {
+        pxs[j] = px0 + j * rows < p1 ? px0 + j * rows : px0;
+        v[j] = ld4(x + (long long)pxs[j] * p.x_sp + c0);
+        d[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int k = 0; k < p.ndy; ++k) {
+        if (c0 < p.dy_c0[k] || c0 >= p.dy_c1[k]) continue;
+        const float* base = p.dy[k] + (long long)n * p.dy_sn[k] + (c0 - p.dy_c0[k]);
+        float4 t[INORM_U];
+#pragma unroll
+        for (int j = 0; j < INORM_U; ++j) t[j] = ld4(base + (long long)pxs[j] * p.dy_sp[k]);
+#pragma unroll
+        for (int j = 0; j < INORM_U; ++j) { d[j].x += t[j].x; d[j].y += t[j].y; d[j].z += t[j].z; d[j].w += t[j].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < INORM_U; ++j) {
+        xh[j].x = (v[j].x - m[0]) * r[0]; xh[j].y = (v[j].y - m[1]) * r[1]; xh[j].z = (v[j].z - m[2]) * r[2]; xh[j].w = (v[j].w - m[3]) * r[3];
+        d[j].x *= act_grad_from_out((v[j].x - m[0]) * r[0] * g.x + bt.x, p.act, p.alpha);
+        d[j].y *= act_grad_from_out((v[j].y - m[1]) * r[1] * g.y + bt.y, p.act, p.alpha);
+        d[j].z *= act_grad_from_out((v[j].z - m[2]) * r[2] * g.z + bt.z, p.act, p.alpha);
+        d[j].w *= act_grad_from_out((v[j].w - m[3]) * r[3] * g.w + bt.w, p.act, p.alpha);
+    }
+}
+
 __global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, double* ws) {
     extern __shared__ float sh[];
     const int n = blockIdx.y, C = p.C, C4 = C / 4;
@@ -294,10 +339,15 @@ __global__ __launch_bounds__(NT) void inorm_bwd_stats_kernel(InormP p, double* w
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
     if (prow < rows)
-        for (int px = p0 + prow; px < p1; px += rows) {
-            float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, x, m, r, gm, bt, xh);
-            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
-            q.x += d.x * xh.x; q.y += d.y * xh.y; q.z += d.z * xh.z; q.w += d.w * xh.w;
+        for (int px0 = p0 + prow; px0 < p1; px0 += INORM_U * rows) {
+            float4 xh[INORM_U], d[INORM_U];
+            inorm_dz_batch(p, n, px0, rows, p1, c4 * 4, x, m, r, gm, bt, d, xh);
+#pragma unroll
+            for (int j = 0; j < INORM_U; ++j) {           // same per-thread order of additions as a one-pixel loop
+                if (px0 + j * rows >= p1) break;
+                s.x += d[j].x; s.y += d[j].y; s.z += d[j].z; s.w += d[j].w;
+                q.x += d[j].x * xh[j].x; q.y += d[j].y * xh[j].y; q.z += d[j].z * xh[j].z; q.w += d[j].w * xh[j].w;
+            }
         }
     if (prow < rows) {
         float* d = sh + prow * 2 * C + c4 * 4;
@@ -336,17 +386,23 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(InormP p, const dou
     const float4 g = ld4(p.gamma + c4 * 4), bt = ld4(p.beta + c4 * 4);
     float* dx = p.dx + (p.dx16 ? 0 : (long long)n * p.dx_sn + c4 * 4);
     const int p0 = blockIdx.x * p.chunk, p1 = min(p.HW, p0 + p.chunk);
-    for (int px = p0 + prow; px < p1; px += rows) {
-        float4 xh; float4 d = inorm_dz(p, n, px, c4 * 4, x, m, r, g, bt, xh);
-        float4 o;
-        o.x = g.x * r[0] * (d.x - s1[0] - xh.x * s2[0]);
-        o.y = g.y * r[1] * (d.y - s1[1] - xh.y * s2[1]);
-        o.z = g.z * r[2] * (d.z - s1[2] - xh.z * s2[2]);
-        o.w = g.w * r[3] * (d.w - s1[3] - xh.w * s2[3]);
-        if (p.dx16) { st4x(dx, (long long)n * p.dx_sn + (long long)px * p.dx_sp + c4 * 4, o, 1); continue; }
-        float* qq = dx + (long long)px * p.dx_sp;
-        if (p.dx_beta) { float4 t = ld4(qq); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-        st4(qq, o);
+    for (int px0 = p0 + prow; px0 < p1; px0 += INORM_U * rows) {
+        float4 xh[INORM_U], d[INORM_U];
+        inorm_dz_batch(p, n, px0, rows, p1, c4 * 4, x, m, r, g, bt, d, xh);
+#pragma unroll
+        for (int j = 0; j < INORM_U; ++j) {
+            const int px = px0 + j * rows;
+            if (px >= p1) break;
+            float4 o;
+            o.x = g.x * r[0] * (d[j].x - s1[0] - xh[j].x * s2[0]);
+            o.y = g.y * r[1] * (d[j].y - s1[1] - xh[j].y * s2[1]);
+            o.z = g.z * r[2] * (d[j].z - s1[2] - xh[j].z * s2[2]);
+            o.w = g.w * r[3] * (d[j].w - s1[3] - xh[j].w * s2[3]);
+            if (p.dx16) { st4x(dx, (long long)n * p.dx_sn + (long long)px * p.dx_sp + c4 * 4, o, 1); continue; }
+            float* qq = dx + (long long)px * p.dx_sp;
+            if (p.dx_beta) { float4 t = ld4(qq); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+            st4(qq, o);
+        }
     }
 }
 
