@@ -721,7 +721,7 @@ __global__ __launch_bounds__(NT) void cosine_kernel(long long P, int C, const fl
 // (C = 32, 655k positions) and re-reads the rows three times through dependent loops -- 224 us for 250 MB.
 template <int G>
 __global__ __launch_bounds__(NT) void cosine_vec_kernel(long long P, const float* __restrict__ f0, const float* __restrict__ f1,
-                                                        float weight, float eps, double* loss_out, float* df0, int beta) {
+                                                        float weight, float eps, double* loss_out, float* __restrict__ df0, int beta) {
     __shared__ float sh[4];
     constexpr int C = 4 * G, PW = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
