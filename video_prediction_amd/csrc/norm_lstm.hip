@@ -281,23 +281,9 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(InormP p, const double*
     }
 }
 
-__device__ __forceinline__ float4 inorm_dz(const InormP& p, int n, int px, int c0, const float* x, const float m[4], const float r[4],
-                                           const float4 g, const float4 bt, float4& xh) {
-    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < p.ndy; ++k) {
-        if (c0 < p.dy_c0[k] || c0 >= p.dy_c1[k]) continue;
-        float4 t = ld4(p.dy[k] + (long long)n * p.dy_sn[k] + (long long)px * p.dy_sp[k] + (c0 - p.dy_c0[k]));
-        d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
-    }
-    float4 v = ld4(x + (long long)px * p.x_sp + c0);
-    xh.x = (v.x - m[0]) * r[0]; xh.y = (v.y - m[1]) * r[1]; xh.z = (v.z - m[2]) * r[2]; xh.w = (v.w - m[3]) * r[3];
-    // activation mask from the pre-activation (same expression as the forward apply pass): y > 0 <=> z > 0
-    d.x *= act_grad_from_out((v.x - m[0]) * r[0] * g.x + bt.x, p.act, p.alpha); d.y *= act_grad_from_out((v.y - m[1]) * r[1] * g.y + bt.y, p.act, p.alpha);
-    d.z *= act_grad_from_out((v.z - m[2]) * r[2] * g.z + bt.z, p.act, p.alpha); d.w *= act_grad_from_out((v.w - m[3]) * r[3] * g.w + bt.w, p.act, p.alpha);
-    return d;
-}
-
-// the same for INORM_U pixel rows px0, px0 + rows, ... (rows past p1 re-read px0 and are ignored by the caller): all loads first
+// dz = dL/d(normalised pre-activation) of INORM_U pixel rows px0, px0 + rows, ... of this thread's four channels (rows past p1 re-read px0 and
+// are ignored by the caller): the sum of the gradient views that cover the channels, times the activation's derivative (the mask is recomputed from
+// the pre-activation: y > 0 <=> z > 0), and xhat.  All loads of the trip are issued before anything is computed.
 __device__ __forceinline__ void inorm_dz_batch(const InormP& p, int n, int px0, int rows, int p1, int c0, const float* x, const float m[4],
                                                const float r[4], const float4 g, const float4 bt, float4 (&d)[INORM_U], float4 (&xh)[INORM_U]) {
     float4 v[INORM_U];
