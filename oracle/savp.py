@@ -784,12 +784,14 @@ def discriminator_fn(vs, inputs, outputs, mode, hp, indices, sn_state=None):
 
 
 def generator_fn(vs, inputs, mode, hp, noise=None):
-    """savp_model.py:699-768 (the gen_images_samples visualisation unroll :745-767 is not on the train path and is
-    omitted).
+    """savp_model.py:699-768.  The gen_images_samples visualisation unroll (:745-767, num_samples draws from the prior per sequence,
+    not on the train path) is run only when its draws are injected (noise['samples_prior'] / ['samples_prior_eps']).
 
     noise: {'eps': [T-1,B,nz], 'prior': [T-context,B,nz], 'ground_truth_sampling': bool [T-1-context,B],
             'ground_truth_sampling_enc': same for the posterior unroll}  (each unroll builds its own
-    SAVPCell, hence its own Bernoulli draw: savp_model.py:693,730,732).
+    SAVPCell, hence its own Bernoulli draw: savp_model.py:693,730,732);
+           'samples_prior': [T-context, S, B, nz] (or, learn_prior, 'samples_prior_eps': [T-1, S, B, nz]) and optionally
+           'samples_ground_truth_sampling': bool [T-1-context, S*B] for the samples unroll.
     """
     noise = noise or {}
     if hp.nz == 0:
@@ -818,4 +820,21 @@ def generator_fn(vs, inputs, mode, hp, noise=None):
         outputs[k + '_enc'] = v
     for k, v in gen_post.items():
         outputs[k + '_enc'] = v
+    if 'samples_prior' in noise or 'samples_prior_eps' in noise:                            # :745-767
+        if hp.learn_prior:
+            eps_s = noise['samples_prior_eps']                                              # [T-1, S, B, nz]
+            zs_s = outputs_prior['zs_mu'][:, None] + torch.sqrt(torch.exp(outputs_prior['zs_log_sigma_sq']))[:, None] * eps_s
+        else:
+            pr = noise['samples_prior']                                                     # [T-context, S, B, nz]
+            S = pr.shape[1]
+            zs_s = torch.cat([zs_posterior[:hp.context_frames - 1][:, None].expand(-1, S, -1, -1), pr], dim=0)
+        S = zs_s.shape[1]
+        inputs_s = {k: v[:, None].expand((v.shape[0], S) + tuple(v.shape[1:])).reshape((v.shape[0], S * v.shape[1]) + tuple(v.shape[2:]))
+                    for k, v in inputs.items()}                                             # tile along a new axis 1, flatten(1, 2)
+        inputs_s['zs'] = zs_s.reshape((zs_s.shape[0], S * zs_s.shape[2], zs_s.shape[3]))
+        gen_s = generator_given_z_fn(vs, inputs_s, mode, hp, noise.get('samples_ground_truth_sampling'))['gen_images']
+        B = inputs['images'].shape[1]
+        gen_s = torch.stack([gen_s[:, i * B:(i + 1) * B] for i in range(S)], dim=-1)         # tf.split(axis=1) + stack(axis=-1)
+        outputs['gen_images_samples'] = gen_s
+        outputs['gen_images_samples_avg'] = gen_s.mean(dim=-1)
     return outputs

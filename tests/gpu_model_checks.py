@@ -581,6 +581,37 @@ def check_action_conditioned_bf16(cond, tag, B=2, T=5, H=64, W=64, C=3):
     return out
 
 
+def check_generator_samples(B=1, T=4, S=2, H=64, W=64, C=3, nz=8):
+    """generator_fn's visualisation unroll (savp_model.py:745-767): S draws from the prior per sequence -> gen_images_samples
+    [T-1, B, H, W, C, S] and their mean, plug-in function vs the oracle with the draws injected."""
+    from video_prediction_amd.models import savp_model as SM
+    out = []
+    for learn_prior in (False, True):
+        over = dict(learn_prior=True, use_e_rnn=True, nef=16) if learn_prior else {}
+        hp = make_hparams(context_frames=2, sequence_length=T, nz=nz, schedule_sampling='none', num_samples=S, **over)
+        vals = V.init_variables(V.variable_specs(hp, (H, W, C), mode='test'), seed=4)
+        images = synth(hp, B, H, W, C, 0)
+        noise = make_noise(hp, B, sampling=False)
+        rng = np.random.default_rng(77)
+        if learn_prior:
+            noise['samples_prior_eps'] = torch.tensor(rng.standard_normal((T - 1, S, B, nz)))
+        else:
+            noise['samples_prior'] = torch.tensor(rng.standard_normal((T - hp.context_frames, S, B, nz)))
+        P = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
+        with torch.no_grad():
+            ref = OS.generator_fn(OS.Scope(P).sub('generator'), {'images': images}, 'test', hp, noise)
+        eng = SAVPEngine(hp, (H, W, C), B, mode='test', values=vals, device=DEV)
+        got = SM.generator_fn({'images': images.float().to(DEV)}, 'test', hp, engine=eng, noise=noise)
+        torch.cuda.synchronize()
+        tag = 'gen_samples_%s' % ('learned_prior' if learn_prior else 'unit_prior')
+        assert tuple(got['gen_images_samples'].shape) == (T - 1, B, H, W, C, S)
+        out.append((tag + '/gen_images_samples', rel(got['gen_images_samples'], ref['gen_images_samples']), 1e-3))
+        out.append((tag + '/gen_images_samples_avg', rel(got['gen_images_samples_avg'], ref['gen_images_samples_avg']), 1e-3))
+        out.append((tag + '/gen_images_after_the_samples', rel(got['gen_images'], ref['gen_images']), 1e-3))      # the views still hold the main unroll
+        out.append((tag + '/gen_images_enc_after_the_samples', rel(got['gen_images_enc'], ref['gen_images_enc']), 1e-3))
+    return out
+
+
 def check_flow_tv_loss():
     """tv_weight with transformation = 'flow' (base_model.py:763-769): total variation of the predicted flows, value and gradient through
     one train step (fp32 datapath vs the fp64 oracle)."""

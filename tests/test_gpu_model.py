@@ -113,6 +113,12 @@ def test_action_and_state_conditioned_cell_vs_oracle():
     _assert_ok(G.check_action_conditioned())
 
 
+def test_generator_fn_prior_samples_unroll_vs_oracle():
+    """generator_fn's gen_images_samples / gen_images_samples_avg (savp_model.py:745-767), unit-variance and learned prior."""
+    from tests import gpu_model_checks as G
+    _assert_ok(G.check_generator_samples())
+
+
 def test_flow_total_variation_loss_vs_oracle():
     """tv_weight (base_model.py:763-769) on the flow transformation's outputs: loss value and every gradient of one train step."""
     from tests import gpu_model_checks as G

@@ -876,8 +876,10 @@ def prior_fn(inputs, hparams, engine=None, noise=None):
     return {'zs_mu': eng.prior.mu, 'zs_log_sigma_sq': eng.prior.ls}
 
 
-def generator_fn(inputs, mode, hparams, engine=None, noise=None):
-    """savp_model.py:699-768 (without the visualisation-only gen_images_samples unroll :745-767)."""
+def generator_fn(inputs, mode, hparams, engine=None, noise=None, samples=False):
+    """savp_model.py:699-768.  samples=True (or injected draws noise['samples_prior'] [T-context, S, B, nz] / ['samples_prior_eps']
+    [T-1, S, B, nz]) also runs the visualisation unroll of :745-767: hparams.num_samples draws from the prior per sequence ->
+    gen_images_samples [T-1, B, H, W, C, S] and their mean gen_images_samples_avg (one more unroll per draw: not on the train path)."""
     eng = _engine_for(inputs, mode, hparams, engine)
     eng.set_images(inputs, time_major=True)
     if noise is None:
@@ -909,6 +911,27 @@ def generator_fn(inputs, mode, hparams, engine=None, noise=None):
         outputs['ground_truth_sampling_mean_enc'] = gt[hparams.context_frames:, :B].float().mean()
         if eng.ns:
             outputs['gen_states_enc'] = g.gen_states.v[:, :B]
+    if eng.nz and (samples or 'samples_prior' in noise or 'samples_prior_eps' in noise):
+        # the prior half of one more 2B unroll per draw (the posterior half repeats the posterior unroll above: same eps, same schedule)
+        key = 'samples_prior_eps' if eng.learn_prior else 'samples_prior'
+        draws = noise.get(key)
+        if draws is None:
+            S = int(hparams.num_samples)
+            gen_ = torch.Generator().manual_seed(eng._noise_seed(eng.step, stream=3))
+            T0 = eng.T1 if eng.learn_prior else eng.T - hparams.context_frames
+            draws = torch.randn(T0, S, B, eng.nz, generator=gen_)
+        draws = torch.as_tensor(draws, dtype=torch.float32)
+        S = draws.shape[1]
+        gts = noise.get('samples_ground_truth_sampling')
+        outs = []
+        for i in range(S):
+            n_i = dict(noise)
+            n_i['prior_eps' if eng.learn_prior else 'prior'] = draws[:, i]
+            n_i['ground_truth_sampling'] = None if gts is None else torch.as_tensor(gts)[:, i * B:(i + 1) * B]
+            outs.append(eng.forward_generator(n_i)[:, B:].clone())
+        outputs['gen_images_samples'] = torch.stack(outs, dim=-1)                            # savp_model.py:762-765
+        outputs['gen_images_samples_avg'] = outputs['gen_images_samples'].mean(dim=-1)
+        eng.forward_generator(noise, collect_masks=True)          # leave the engine's buffers as the main unrolls wrote them (the views above)
     return outputs
 
 
