@@ -151,7 +151,11 @@ class SyntheticVideoDataset(object):
         g = torch.Generator().manual_seed(1234 + 7919 * rank + (0 if self.mode == 'train' else 1))
         T = self.hparams.sequence_length
         while True:
-            yield {'images': torch.rand((batch_size, T) + self.image_shape, generator=g).to(device)}
+            batch = {'images': torch.rand((batch_size, T) + self.image_shape, generator=g).to(device)}
+            if self.hparams.use_state:          # the robot datasets' extra inputs (softmotion_dataset.py:62-64): 3-d end-effector states, 4-d actions
+                batch['states'] = torch.randn(batch_size, T, 3, generator=g).cumsum(1).mul(0.1).to(device)
+                batch['actions'] = torch.randn(batch_size, T - 1, 4, generator=g).to(device)
+            yield batch
 
 
 def get_dataset_class(name, synthetic_shape):
@@ -298,7 +302,7 @@ def main(argv=None):
             # eval summary (train.py:264-265,301-305): best / mean / worst of eval_num_samples prior samples on a validation batch
             print("recording eval summary")
             _, metrics = model.eval_outputs_and_metrics_fn(next(val_iter))
-            model.engine.set_images(inputs['images'])
+            model.engine.set_images(inputs)                     # back to the training batch (images and, if the model has them, actions / states)
             if chief:
                 summaries.write(json.dumps(dict({k: float(v.mean()) for k, v in metrics.items()}, global_step=global_step,
                                                 tag='eval_summary_1')) + '\n')

@@ -562,6 +562,34 @@ def test_train_and_generate_scripts(tmp_path):
     assert Image.open(os.path.join(res, 'run', gifs[0])).n_frames == 12
 
 
+def test_train_and_generate_scripts_with_actions_and_states(tmp_path):
+    """The runners on a dataset that delivers 'actions' and 'states' (use_state=True: softmotion_dataset.py:62-64): scripts/train.py builds the
+    conditioned model from the first batch, trains with the state loss, checkpoints; scripts/generate.py restores and predicts."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    out = str(tmp_path / 'run')
+    cmd = [sys.executable, os.path.join(root, 'scripts', 'train.py'), '--input_dir', 'none', '--dataset', 'synthetic', '--model', 'savp',
+           '--output_dir', out, '--progress_freq', '1', '--summary_freq', '1', '--eval_summary_freq', '0', '--save_freq', '3',
+           '--dataset_hparams', 'sequence_length=8,use_state=True', '--model_hparams', 'batch_size=2,max_steps=3,state_weight=0.0001,clip_length=4']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'progress  global step 3' in r.stdout and os.path.exists(os.path.join(out, 'model-3.index'))
+    rows = [json.loads(l) for l in open(os.path.join(out, 'summaries.jsonl'))]
+    assert any('gen_state_loss' in ' '.join(row) for row in rows), rows[-1]
+    from video_prediction_amd import checkpoint as CK
+    names = set(CK.read_checkpoint(os.path.join(out, 'model-3')))
+    assert 'generator/rnn/savp_cell/state_pred/dense/kernel' in names
+    res = str(tmp_path / 'results')
+    g = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'generate.py'), '--input_dir', 'none', '--dataset', 'synthetic',
+                        '--checkpoint', out, '--results_dir', res, '--batch_size', '2', '--num_samples', '2', '--num_stochastic_samples', '1',
+                        '--dataset_hparams', 'sequence_length=8,use_state=True'], capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout[-2000:] + g.stderr[-2000:]
+    pngs = [f for f in os.listdir(os.path.join(res, 'run')) if f.endswith('.png')]
+    assert len(pngs) == 2 * 1 * 6                                                     # 2 sequences x 1 sample x 6 future frames
+
+
 GRAD_REL_L2 = 0.22      # bf16 datapath, per-variable gradient vs the oracle (measured worst on MI355X: 0.19 at c2; the step is reproducible since round 5)
 
 def _bench_engine(fname, case, lr=None, graph=None):

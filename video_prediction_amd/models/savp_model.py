@@ -239,10 +239,16 @@ class SAVPEngine(object):
         self.dist = dist_module
         self.world = self.replicas.world
         self.dp = self.replicas.active          # the step carries collectives (world > 1, or forced)
-        # Collectives inside the step's hipGraph (one graph launch per step instead of 8 segments + 7 host actions): opt-in, validated at
-        # world size 1 only (tests/test_gpu_dp.py, tests/tools/ab_calls/graph_collectives_probe.py) -- no N > 1 lease exists to show that
-        # every rank's replayed graph issues its RCCL kernels in a compatible order, and a hang there would cost the scaling run.
+        # Collectives inside the step's hipGraph (one graph launch per step instead of 8 segments + 7 host actions): an EXPERIMENT, off unless
+        # SAVP_GRAPH_COLLECTIVES=1 (tests/tools/ab_calls/graph_collectives_probe.py, profiles/r06_graph_collectives_probe.json).  The capture
+        # itself works (one graph, bit-identical variables, -2.5 % per step at forced world size 1), but ProcessGroupNCCL's watchdog thread
+        # can poll a collective's end event that was recorded while capturing -- hipErrorCapturedEvent in that thread aborts the process
+        # (seen in 2 of 7 runs, by box: profiles/r06_graph_collectives_watchdog_abort.log).  Usable only with a communicator the watchdog
+        # does not track (savp_allreduce_bucket with a caller-owned ncclComm_t); not validated with more than one rank.
         self.graph_collectives = self.dp and os.environ.get('SAVP_GRAPH_COLLECTIVES', '0') == '1'
+        if self.graph_collectives:
+            import warnings
+            warnings.warn('SAVP_GRAPH_COLLECTIVES=1: experimental -- the process-group watchdog may abort the process (hipErrorCapturedEvent)')
         self.rank = self.replicas.rank          # independent noise per replica (default_noise)
         self.graph = None                       # a step captured without the collectives is not this engine's step any more
         # Segmented replay pays when the collectives are stream-ordered (RCCL).  Under a backend whose collectives block the host
