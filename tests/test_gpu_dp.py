@@ -266,6 +266,7 @@ def _rccl_world1_worker(port, q, captured=False):
         res['lb'], res['pb'] = lb, b.store.to_numpy()
         # the tuning table broadcast (kernels.sync_tuning_table) and a barrier also run on RCCL here
         dist.barrier()
+        a.replicas.close()
         q.put(res)
     finally:
         dist.destroy_process_group()
@@ -302,6 +303,37 @@ def test_rccl_world_size_one_forced_collectives_and_segmented_replay_equal_the_p
         tot += float(d.sum())
         cnt += d.size
     assert tot / cnt <= 0.2 * hp.lr, tot / cnt           # four Adam steps (each moves a variable by ~lr): a small fraction of one step
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_captured_into_the_steps_one_hipgraph_at_world_size_one():
+    """SAVP_GRAPH_COLLECTIVES=1 (round-5 verdict item 7): the replica group owns an RCCL communicator (ncclGetUniqueId / ncclCommInitRank through
+    ctypes) and issues the step's all-reduces and the u broadcast through the C ABI on the side stream, so they are captured with the kernels: a
+    replica replays ONE hipGraph per step instead of 8 segments with 7 host actions between them.  (Through ProcessGroupNCCL the capture works
+    too, but its watchdog thread polls the captured end events and aborts the process: profiles/r06_graph_collectives_watchdog_abort.log.)
+    Forced collectives at world size 1: four steps must reproduce the plain engine's."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q, True))
+    p.start()
+    r = _get(q, [p], 800)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert r['backend'] == 'nccl' and r['active'] and r['dp'] and r['side_stream'] and r['same']
+    assert r['segments'] == 1 and r['host_ops'] == 0, (r['segments'], r['host_ops'])
+    # host-side counters see the eager step and the capture only (replays issue no host call): 2 x (4 chunks, 1 broadcast)
+    assert r['stats']['chunks'] == 2 * 4 and r['stats']['aux_broadcasts'] == 2, r['stats']
+    hp = _setup(False)[0]
+    for i, ((da, ga), (db, gb)) in enumerate(zip(r['la'], r['lb'])):
+        tol = 2e-5 if i == 0 else 2e-3
+        assert abs(da - db) <= tol * max(abs(db), 1e-3) and abs(ga - gb) <= tol * max(abs(gb), 1e-3), (i, r['la'], r['lb'])
+    tot = cnt = 0.0
+    for name, pb in r['pb'].items():
+        d = np.abs(pb.astype(np.float64) - r['pa'][name])
+        tot += float(d.sum())
+        cnt += d.size
+    assert tot / cnt <= 0.2 * hp.lr, tot / cnt
 
 
 def _bucket_worker(q):

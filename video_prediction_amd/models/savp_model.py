@@ -235,22 +235,19 @@ class SAVPEngine(object):
         from ..parallel import ReplicaGroup
         if force is None:
             force = os.environ.get('SAVP_FORCE_DIST', '0') == '1'
-        self.replicas = ReplicaGroup(self.store, dist_module, overlap=os.environ.get('SAVP_DP_OVERLAP', '1') == '1', force=force)
+        want_graph_coll = os.environ.get('SAVP_GRAPH_COLLECTIVES', '0') == '1'
+        self.replicas = ReplicaGroup(self.store, dist_module, overlap=os.environ.get('SAVP_DP_OVERLAP', '1') == '1', force=force,
+                                     own_comm=want_graph_coll)
         self.dist = dist_module
         self.world = self.replicas.world
         self.dp = self.replicas.active          # the step carries collectives (world > 1, or forced)
-        # Collectives inside the step's hipGraph (one graph launch per step instead of 8 segments + 7 host actions): an EXPERIMENT, off unless
-        # SAVP_GRAPH_COLLECTIVES=1 (tests/tools/ab_calls/graph_collectives_probe.py, profiles/r06_graph_collectives_probe.json).  The capture
-        # itself works (one graph, bit-identical variables, -2.5 % per step at forced world size 1), but ProcessGroupNCCL's watchdog thread
-        # can poll a collective's end event that was recorded while capturing -- hipErrorCapturedEvent in that thread aborts the process
-        # (seen in 2 of 7 runs, by box: profiles/r06_graph_collectives_watchdog_abort.log).  Usable only with a communicator the watchdog
-        # does not track (savp_allreduce_bucket with a caller-owned ncclComm_t); not validated with more than one rank.
-        self.graph_collectives = self.dp and os.environ.get('SAVP_GRAPH_COLLECTIVES', '0') == '1'
-        if self.graph_collectives:
-            import warnings
-            warnings.warn('SAVP_GRAPH_COLLECTIVES=1: experimental -- the process-group watchdog may abort the process (hipErrorCapturedEvent)')
-        self.rank = self.replicas.rank          # independent noise per replica (default_noise)
-        self.graph = None                       # a step captured without the collectives is not this engine's step any more
+        # Collectives inside the step's hipGraph (SAVP_GRAPH_COLLECTIVES=1): one graph launch per step instead of 8 segments + 7 host actions.
+        # The replica group then owns its RCCL communicator and issues ncclAllReduce / ncclBroadcast through the C ABI
+        # (parallel.ReplicaGroup._own_communicator): captured through ProcessGroupNCCL instead, the process-group watchdog thread polls
+        # end events that were recorded while capturing and aborts the process (profiles/r06_graph_collectives_watchdog_abort.log).
+        # Opt-in: validated at world size 1 (tests/test_gpu_dp.py, tests/tools/ab_calls/graph_collectives_probe.py); no N > 1 lease exists
+        # to show every rank's replayed graph issuing its RCCL kernels in a compatible order, and a hang there would cost the scaling run.
+        self.graph_collectives = self.dp and want_graph_coll and self.replicas.comm is not None
         # Segmented replay pays when the collectives are stream-ordered (RCCL).  Under a backend whose collectives block the host
         # on device tensors (gloo) every segment boundary is a full drain; measured with two ranks time-slicing one MI355X:
         # 146 ms/step launch by launch against 213 ms/step replayed in 8 segments (profiles/r04_ab_calls.md, call 13).

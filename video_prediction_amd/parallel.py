@@ -25,7 +25,7 @@ import torch
 
 
 class ReplicaGroup(object):
-    def __init__(self, store, dist_module=None, overlap=True, force=False):
+    def __init__(self, store, dist_module=None, overlap=True, force=False, own_comm=False):
         """force: run every collective even in a group of ONE rank (SAVP_FORCE_DIST=1).  A sum over one replica is the identity,
         so the step's numbers do not change, but process-group creation, the rank-0 broadcast, the side-stream chunked
         all-reduce, the u broadcast and the event chaining all execute on the real transport -- the way to exercise RCCL on a
@@ -42,9 +42,70 @@ class ReplicaGroup(object):
         self.pending = {}          # group -> list of (lo, hi, done event | None)
         self.stats = {'chunks': 0, 'elements': 0, 'aux_broadcasts': 0}
         self.aux_done = None
+        self.comm = None           # own_comm: an ncclComm_t this object owns (see _own_communicator)
+        self._rccl = None
+        if own_comm and self.active and self.on_gpu:
+            self._own_communicator()
         if self.active:
             for g in store.groups.values():            # post_init_ops: every replica starts from rank 0's variables
                 dist_module.broadcast(g.p, src=0)
+
+    # -- a communicator of our own (SAVP_GRAPH_COLLECTIVES=1) ----------------------------------------------------------------------
+    def _own_communicator(self):
+        """RCCL communicator owned by this object: ncclGetUniqueId on rank 0, the id handed round through the existing process group,
+        ncclCommInitRank everywhere.  The step's collectives then go through the C ABI (`savp_allreduce_bucket`: ncclAllReduce on the given
+        stream; the u vectors' broadcast: ncclBroadcast) instead of ProcessGroupNCCL -- the same RCCL kernels, but no Work objects: when the
+        step is CAPTURED with its collectives inside, ProcessGroupNCCL's watchdog thread polls the end event of every collective it issued,
+        and polling an event that was recorded while capturing is an error that aborts the process
+        (profiles/r06_graph_collectives_watchdog_abort.log).  librccl.so is the copy torch already holds."""
+        import ctypes
+
+        class UID(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_char * 128)]
+        rccl = ctypes.CDLL('librccl.so')
+        rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UID)]
+        rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclBroadcast.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        uid = UID()
+        if self.rank == 0 and rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError('ncclGetUniqueId failed')
+        dev = torch.device(self.store.device)
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
+        self.dist.broadcast(t, src=0)
+        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        comm = ctypes.c_void_p()
+        if rccl.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank) != 0 or not comm.value:
+            raise RuntimeError('ncclCommInitRank failed')
+        self.comm, self._rccl = comm, rccl
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            self._rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+    def _all_reduce(self, chunk):
+        """Sum `chunk` (a contiguous fp32 slice of a gradient arena) over the replicas on the CURRENT stream."""
+        if self.comm is None:
+            self.dist.all_reduce(chunk)
+            return
+        import ctypes
+        from . import lib
+        lib.check(lib.get().savp_allreduce_bucket(self.comm, ctypes.c_void_p(torch.cuda.current_stream(chunk.device).cuda_stream),
+                                                  ctypes.c_void_p(chunk.data_ptr()), chunk.numel()), 'savp_allreduce_bucket')
+
+    def _broadcast(self, buf):
+        if self.comm is None:
+            self.dist.broadcast(buf, src=0)
+            return
+        import ctypes
+        NCCL_FLOAT32 = 7
+        assert buf.dtype == torch.float32 and buf.is_contiguous()
+        rc = self._rccl.ncclBroadcast(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(buf.data_ptr()), buf.numel(), NCCL_FLOAT32, 0, self.comm,
+                                      ctypes.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('ncclBroadcast failed with code %d' % rc)
 
     @property
     def grad_scale(self):
@@ -69,11 +130,11 @@ class ReplicaGroup(object):
             ready.record(cur)
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
-                self.dist.all_reduce(chunk)
+                self._all_reduce(chunk)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
         else:
-            self.dist.all_reduce(chunk)
+            self._all_reduce(chunk)
         self.pending.setdefault(group, []).append((lo, hi, done))
         self.stats['chunks'] += 1
         self.stats['elements'] += hi - lo
@@ -120,12 +181,12 @@ class ReplicaGroup(object):
             ready.record(cur)
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
-                self.dist.broadcast(aux.p, src=0)
+                self._broadcast(aux.p)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             self.aux_done = done
         else:
-            self.dist.broadcast(aux.p, src=0)
+            self._broadcast(aux.p)
 
     def wait_aux(self):
         """Order the current stream behind the last sync_aux() broadcast (call before anything reads or writes the 'aux' arena)."""
