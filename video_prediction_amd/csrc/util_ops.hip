@@ -210,7 +210,9 @@ extern "C" int savp_colsum(void* stream, SavpView in, int64_t R, int32_t HW, int
     // gradients too, with ~1024 workgroups: 0.8 ms per step SLOWER than the kernel below -- every workgroup ends in C atomics onto
     // the same one to eight cache lines, and those serialise.)
     const uintptr_t al = (uintptr_t)in.p | (uintptr_t)(in.sn * 4) | (uintptr_t)(in.sp * 4);
-    if (C <= 16 && (C & (C - 1)) == 0 && HW >= 64) {
+    // (C = 32 per row: KTH's 32 tiled-z channels -- eleven launches per step that the 64-lanes-to-channels kernel below ran at half occupancy with
+    //  scalar loads, one pixel per trip: 1.06 ms per step at 1.4 TB/s)
+    if ((C <= 16 || (C == 32 && per_row)) && (C & (C - 1)) == 0 && HW >= 64) {
         const int V = (C >= 4 && (al & 15) == 0) ? 4 : ((C >= 2 && (al & 7) == 0) ? 2 : 1);
         const int per_pass = NT * V / C;
         const long long per_row_wgs = per_row ? 1 : 4;      // per_row: ONE workgroup per row -- a single writer per output, nothing to order

@@ -32,6 +32,13 @@ def ceil4(n):
     return (n + 3) // 4 * 4
 
 
+def ceil8(n):
+    """Channel counts of convolution INPUT buffers are padded to multiples of 8 (zero channels, zero weight rows): the ring / thin kernels of
+    the bf16 datapath take a reduction dimension in whole 8-channel chunks only -- with 4-channel padding KTH's first layer (2 + 32 -> 36
+    channels) and its mask convolution (32 + 7 + 3 -> 44) fell to the general kernel, 35 us instead of 17 us per time step each."""
+    return (n + 7) // 8 * 8
+
+
 class Act(object):
     """Time-major activation buffer with an optional gradient twin."""
 
@@ -169,12 +176,12 @@ class SAVPGenerator(object):
             if i < self.ne:
                 cx = 2 * C if i == 0 else prev_f
                 k = 5 if i == 0 else 3
-                L['in'] = Act((T1, N, h_, w_, ceil4(cx + zc)), dev, grad=g,      # pad channels stay zero
-                              dtype=a16 if (i > 0 and ceil4(cx + zc) % 8 == 0) else torch.float32)     # layer 0 holds the input image: fp32
+                L['in'] = Act((T1, N, h_, w_, ceil8(cx + zc)), dev, grad=g,      # pad channels stay zero
+                              dtype=a16 if i > 0 else torch.float32)     # layer 0 holds the input image: fp32
                 L['zoff_in'] = cx
                 L['conv'] = ConvLayer(store, s + 'conv_pool2d/kernel', s + 'conv_pool2d/bias', 'pool', (k, k), (2, 2),
                                       (same_pad_before(k + 1, 2, h_), same_pad_before(k + 1, 2, w_)),
-                                      cx_pad=ceil4(cx + zc))
+                                      cx_pad=ceil8(cx + zc))
                 h_, w_ = h_ // 2, w_ // 2
             else:
                 j = i - self.ne
@@ -330,7 +337,7 @@ class SAVPGenerator(object):
         if M < 2:
             raise NotImplementedError('a single transformed image (mask == 1 everywhere, savp_model.py:636-637)')
         # maskin = [h_masks (ngf) | nk transformed images | background images | scratch image]   (savp_model.py:632)
-        self.Cmask = Cmask = ceil4(ngf + M * C + ((Cs - C) if self.scratch else 0))     # scratch slot is last: room for its padded write
+        self.Cmask = Cmask = ceil8(ngf + M * C + ((Cs - C) if self.scratch else 0))     # scratch slot is last: room for its padded write
         self.Ml = Ml = ceil4(M)                                    # padded logits row
         self.maskin = Act((T1, N, H, W, Cmask), dev, grad=g)
         self.o_cdna = ngf
