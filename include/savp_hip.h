@@ -159,8 +159,8 @@ int savp_conv(void* stream, const SavpConvArgs* args);
  * channels out (SavpConvArgs.dst_gap):  dz[img, c] = sum_p (F^T dy)[img, p, z0 + c]  computed as
  * sum_{25 regions r} sum_k R[img, r, k] * weff[r, k, c]  with R = region sums of dy (row class x column class, classes
  * {0, 1, middle, n-2, n-1}) -- tests/test_tiled_z_gradient_algebra.py pins the identity against autograd.
- *   savp_tiled_z_weff: weff [25][Cout][8] fp32 from the HWIO kernel w [kh][kw][Cin][Cout] (kh, kw <= 5, pads <= 2, nz <= 8; once per
- *                      step and layer).
+ *   savp_tiled_z_weff: weff [25][Cout][P] fp32 from the HWIO kernel w [kh][kw][Cin][Cout] (kh, kw <= 5, pads <= 2; P = 8 for nz <= 8, 32 for
+ *                      8 < nz <= 32; once per step and layer).
  *   savp_tiled_z_grad: dy [nimg][H][W][C] contiguous (bf16 if dy_bf16, else fp32; 16-byte aligned), one launch for the gate
  *                      gradients of all timesteps; dz [nimg][nz] fp32 is overwritten (beta 0) or accumulated into (beta 1).
  *                      H >= 4, W in {4, 8, 16, 32}, C % 64 == 0; SAVP_EINVAL otherwise.  Two launches (per-chunk partials into ws, then

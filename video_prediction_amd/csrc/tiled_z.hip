@@ -22,7 +22,9 @@
 #include "savp_hip.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? SAVP_OK : SAVP_ELAUNCH)
-#define TZ_NZ 8            // latent channels per launch (padded row of Weff)
+#define TZ_NZ 8            // padded row of Weff / of a partial dz vector for nz <= 8 (BAIR: 8) ...
+#define TZ_NZW 32          // ... and for 8 < nz <= 32 (KTH: 32)
+static inline int tz_pad(int nz) { return nz <= TZ_NZ ? TZ_NZ : TZ_NZW; }
 
 // class of coordinate y in [0, n): 0, 1, 2 = middle, 3 = n-2, 4 = n-1   (n >= 4: the classes are disjoint)
 __device__ __host__ __forceinline__ int tz_class(int y, int n) { return y < 2 ? y : (y >= n - 2 ? y - n + 5 : 2); }
@@ -38,7 +40,7 @@ __device__ __forceinline__ bool tz_tap_valid(int cls, int off) {
 // One thread per (r, c, k): up to 25 independent loads (invalid taps read a valid address and are multiplied by zero, so that all of
 // them are in flight together), coalesced over k.
 __global__ void tiled_z_weff_kernel(const float* __restrict__ w, int kh, int kw, int ph, int pw, int Cin, int Cout, int z0, int nz,
-                                    float* __restrict__ weff) {
+                                    float* __restrict__ weff, int nzp) {
     const int r = blockIdx.y, ry = r / 5, rx = r - ry * 5;
     const int c = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,16 +57,16 @@ __global__ void tiled_z_weff_kernel(const float* __restrict__ w, int kh, int kw,
             }
         }
     }
-    weff[((long long)r * Cout + k) * TZ_NZ + c] = s;
+    weff[((long long)r * Cout + k) * nzp + c] = s;
 }
 
 extern "C" int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t Cin,
                                  int32_t Cout, int32_t z0, int32_t nz, float* weff) {
-    if (!w || !weff || nz < 1 || nz > TZ_NZ || z0 < 0 || z0 + nz > Cin || Cout < 1) return SAVP_EINVAL;
+    if (!w || !weff || nz < 1 || nz > TZ_NZW || z0 < 0 || z0 + nz > Cin || Cout < 1) return SAVP_EINVAL;
     // the class construction needs every tap offset within +-2 of the pixel
     if (kh < 1 || kw < 1 || ph < 0 || pw < 0 || ph > 2 || pw > 2 || kh - 1 - ph > 2 || kw - 1 - pw > 2) return SAVP_EINVAL;
-    dim3 grid((unsigned)((Cout + 63) / 64), 25, TZ_NZ);
-    hipLaunchKernelGGL(tiled_z_weff_kernel, grid, dim3(64), 0, (hipStream_t)stream, w, kh, kw, ph, pw, Cin, Cout, z0, nz, weff);
+    dim3 grid((unsigned)((Cout + 63) / 64), 25, (unsigned)tz_pad(nz));
+    hipLaunchKernelGGL(tiled_z_weff_kernel, grid, dim3(64), 0, (hipStream_t)stream, w, kh, kw, ph, pw, Cin, Cout, z0, nz, weff, tz_pad(nz));
     return LAUNCH_OK();
 }
 
@@ -72,19 +74,19 @@ extern "C" int savp_tiled_z_weff(void* stream, const float* w, int32_t kh, int32
 // column class) is fixed: it keeps one sum per ROW class (5 x 8 channels).
 // (grid.y = the 64-channel chunk: C / 64 times the workgroups of an image-only grid, every one with a quarter to an eighth of the
 // serial walk -- 113 -> measured below; the chunk partials are folded in chunk order by tiled_z_reduce_kernel: deterministic)
-template <bool BF16>
+template <bool BF16, int NZP>
 __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restrict__ dy_, int H, int W, int C, const float* __restrict__ weff,
                                                            int nz, float* __restrict__ part_out) {
     __shared__ float part[32][5][64];          // per pixel slot: row-class sums of the chunk's 64 channels
-    __shared__ float red[4][TZ_NZ];
+    __shared__ float red[4][NZP];
     const long long img = blockIdx.x;
     const int tid = threadIdx.x, lane8 = tid & 7, slot = tid >> 3;
     const int HW = H * W;
     const int wsh = 31 - __builtin_clz((unsigned)W);     // W is a power of two
     const int xcls = tz_class(slot & (W - 1), W);
-    float dzp[TZ_NZ];
+    float dzp[NZP];
 #pragma unroll
-    for (int c = 0; c < TZ_NZ; ++c) dzp[c] = 0.f;
+    for (int c = 0; c < NZP; ++c) dzp[c] = 0.f;
     {
         const int c0 = blockIdx.y * 64;
         float acc[5][8];
@@ -144,40 +146,43 @@ __global__ __launch_bounds__(256) void tiled_z_grad_kernel(const void* __restric
             float R = 0.f;
             for (int s = 0; s < 32; ++s)
                 if (tz_class(s & (W - 1), W) == rx && s < HW) R += part[s][ry][k];
-            const float* wr = weff + ((long long)r * C + c0 + k) * TZ_NZ;
-            const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
-            dzp[0] = fmaf(R, w0.x, dzp[0]); dzp[1] = fmaf(R, w0.y, dzp[1]); dzp[2] = fmaf(R, w0.z, dzp[2]); dzp[3] = fmaf(R, w0.w, dzp[3]);
-            dzp[4] = fmaf(R, w1.x, dzp[4]); dzp[5] = fmaf(R, w1.y, dzp[5]); dzp[6] = fmaf(R, w1.z, dzp[6]); dzp[7] = fmaf(R, w1.w, dzp[7]);
+            const float* wr = weff + ((long long)r * C + c0 + k) * NZP;
+#pragma unroll
+            for (int q4 = 0; q4 < NZP / 4; ++q4) {
+                const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q4);
+                dzp[4 * q4] = fmaf(R, wv.x, dzp[4 * q4]); dzp[4 * q4 + 1] = fmaf(R, wv.y, dzp[4 * q4 + 1]);
+                dzp[4 * q4 + 2] = fmaf(R, wv.z, dzp[4 * q4 + 2]); dzp[4 * q4 + 3] = fmaf(R, wv.w, dzp[4 * q4 + 3]);
+            }
         }
     }
     (void)xcls;
     // fixed-order reduction of the 256 partial dz vectors: butterfly inside the wave, then the four waves in order
 #pragma unroll
-    for (int c = 0; c < TZ_NZ; ++c) {
+    for (int c = 0; c < NZP; ++c) {
         float v = dzp[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if ((tid & 63) == 0) red[tid >> 6][c] = v;
     }
     __syncthreads();
-    if (tid < TZ_NZ) part_out[(img * gridDim.y + blockIdx.y) * TZ_NZ + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < NZP) part_out[(img * gridDim.y + blockIdx.y) * NZP + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-__global__ void tiled_z_reduce_kernel(const float* __restrict__ part, long long nimg, int nchunk, int nz, float* __restrict__ dz, int beta) {
+__global__ void tiled_z_reduce_kernel(const float* __restrict__ part, long long nimg, int nchunk, int nz, float* __restrict__ dz, int beta, int nzp) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= nimg * nz) return;
     const long long img = i / nz;
     const int c = (int)(i - img * nz);
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += part[(img * nchunk + k) * TZ_NZ + c];
+    for (int k = 0; k < nchunk; ++k) s += part[(img * nchunk + k) * nzp + c];
     dz[i] = beta ? dz[i] + s : s;
 }
 
-extern "C" int64_t savp_tiled_z_workspace_bytes(int64_t nimg, int32_t C) { return nimg * (int64_t)((C + 63) / 64) * TZ_NZ * 4; }
+extern "C" int64_t savp_tiled_z_workspace_bytes(int64_t nimg, int32_t C) { return nimg * (int64_t)((C + 63) / 64) * TZ_NZW * 4; }      // (the wider of the two row paddings)
 
 extern "C" int savp_tiled_z_grad(void* stream, const void* dy, int32_t dy_bf16, int64_t nimg, int32_t H, int32_t W, int32_t C,
                                  const float* weff, int32_t nz, float* dz, int32_t beta, void* ws, int64_t ws_bytes) {
-    if (!dy || !weff || !dz || nimg < 0 || nz < 1 || nz > TZ_NZ) return SAVP_EINVAL;
+    if (!dy || !weff || !dz || nimg < 0 || nz < 1 || nz > TZ_NZW) return SAVP_EINVAL;
     if (!ws || ws_bytes < savp_tiled_z_workspace_bytes(nimg, C)) return SAVP_EINVAL;
     // W a power of two dividing 32 (a thread's column is fixed), >= 4 rows and columns (disjoint classes), whole 64-channel chunks
     if (H < 4 || W < 4 || W > 32 || (W & (W - 1)) || (C % 64) || nimg >= (1ll << 31)) return SAVP_EINVAL;
@@ -186,11 +191,16 @@ extern "C" int savp_tiled_z_grad(void* stream, const void* dy, int32_t dy_bf16, 
     const int nchunk = C / 64;
     if (nchunk > 65535) return SAVP_EINVAL;
     const dim3 grid((unsigned)nimg, (unsigned)nchunk);
-    if (dy_bf16)
-        hipLaunchKernelGGL(tiled_z_grad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, (float*)ws);
-    else
-        hipLaunchKernelGGL(tiled_z_grad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, H, W, C, weff, nz, (float*)ws);
-    hipLaunchKernelGGL(tiled_z_reduce_kernel, dim3((unsigned)((nimg * nz + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (long long)nimg,
-                       nchunk, nz, dz, beta);
+    const int nzp = tz_pad(nz);
+    hipStream_t st = (hipStream_t)stream;
+    if (nzp == TZ_NZ) {
+        if (dy_bf16) hipLaunchKernelGGL((tiled_z_grad_kernel<true, TZ_NZ>), grid, dim3(256), 0, st, dy, H, W, C, weff, nz, (float*)ws);
+        else hipLaunchKernelGGL((tiled_z_grad_kernel<false, TZ_NZ>), grid, dim3(256), 0, st, dy, H, W, C, weff, nz, (float*)ws);
+    } else {
+        if (dy_bf16) hipLaunchKernelGGL((tiled_z_grad_kernel<true, TZ_NZW>), grid, dim3(256), 0, st, dy, H, W, C, weff, nz, (float*)ws);
+        else hipLaunchKernelGGL((tiled_z_grad_kernel<false, TZ_NZW>), grid, dim3(256), 0, st, dy, H, W, C, weff, nz, (float*)ws);
+    }
+    hipLaunchKernelGGL(tiled_z_reduce_kernel, dim3((unsigned)((nimg * nz + 255) / 256)), dim3(256), 0, st, (const float*)ws, (long long)nimg,
+                       nchunk, nz, dz, beta, nzp);
     return LAUNCH_OK();
 }

@@ -784,12 +784,17 @@ def tile_channels(z, out, scale=1.0, beta=0):
               'savp_tile_channels')
 
 
+def tiled_z_pad(nz):
+    """Row length of the effective weights / partial sums of csrc/tiled_z.hip for nz latent channels (8 up to nz = 8, 32 up to nz = 32)."""
+    return 8 if nz <= 8 else 32
+
+
 def tiled_z_weff(w_hwio, geom, z0, nz, weff):
-    """Effective weights [25, Cout, 8] of the tiled-z gradient from the master HWIO kernel (csrc/tiled_z.hip)."""
+    """Effective weights [25, Cout, tiled_z_pad(nz)] of the tiled-z gradient from the master HWIO kernel (csrc/tiled_z.hip)."""
     lib.require_device(w_hwio, weff)
     kh, kw, cin, cout = w_hwio.shape[-4:]
-    if not w_hwio.is_contiguous() or weff.numel() < 25 * cout * 8:
-        raise ValueError('tiled_z_weff: contiguous HWIO kernel and a [25, Cout, 8] buffer expected')
+    if not w_hwio.is_contiguous() or weff.numel() < 25 * cout * tiled_z_pad(nz):
+        raise ValueError('tiled_z_weff: contiguous HWIO kernel and a [25, Cout, %d] buffer expected' % tiled_z_pad(nz))
     lib.check(lib.get().savp_tiled_z_weff(lib.stream(), w_hwio.data_ptr(), kh, kw, geom.p[1], geom.p[2], cin, cout, int(z0), int(nz),
                                           weff.data_ptr()), 'savp_tiled_z_weff')
 
@@ -811,7 +816,7 @@ def tiled_z_grad(dy, weff, dz, beta=1):
 def tiled_z_ok(H, W, C, nz, geom):
     """Does csrc/tiled_z.hip cover this plane / kernel (else the data gradient keeps the z channels)?"""
     k, p = geom.k, geom.p
-    return (H >= 4 and 4 <= W <= 32 and (W & (W - 1)) == 0 and C % 64 == 0 and 1 <= nz <= 8 and k[0] == 1 and
+    return (H >= 4 and 4 <= W <= 32 and (W & (W - 1)) == 0 and C % 64 == 0 and 1 <= nz <= 32 and k[0] == 1 and
             p[1] <= 2 and p[2] <= 2 and k[1] - 1 - p[1] <= 2 and k[2] - 1 - p[2] <= 2 and tuple(geom.s) == (1, 1, 1))
 
 

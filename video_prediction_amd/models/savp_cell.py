@@ -253,11 +253,11 @@ class SAVPGenerator(object):
                     L['onorm'] = Norm(store, prefix + 'lstm_h%d/InstanceNorm/' % i, T1, N, f, dev)
                 # The data gradient of the gate convolution leaves the tiled-z channels of [x | z | h] out (their gradient is a per-sample
                 # sum, taken once over all timesteps from region sums of the gate gradient: csrc/tiled_z.hip), which keeps its column count
-                # on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256).  bf16 datapath (the ring kernel owns the column gap).
+                # on a tile boundary (72 / 136 / 264 -> 64 / 128 / 256; KTH's nz = 32: 96 / 160 / 288 -> 64 / 128 / 256).  bf16 datapath (the ring kernel owns the column gap).
                 L['zless'] = bool(g and zr and not cw and L['fused'] and os.environ.get('SAVP_ZLESS_DGRAD', '1') == '1' and
                                   K.tiled_z_ok(h_, w_, 4 * f, zr, L['rconv'].geom))
                 if L['zless']:
-                    L['weff'] = torch.empty(25, 4 * f, 8, device=dev)
+                    L['weff'] = torch.empty(25, 4 * f, K.tiled_z_pad(zr), device=dev)
             else:
                 L['out'] = None
             self.layers.append(L)
