@@ -1002,7 +1002,7 @@ def check_gate_conv_kernel(seed=67):
     rng = np.random.default_rng(seed)
     geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
     for (N, S, Cx, F) in [(4, 32, 72, 32), (6, 16, 136, 64), (8, 8, 264, 128), (3, 32, 96, 32), (5, 16, 160, 64), (32, 16, 136, 64),
-                          (3, 32, 136, 64), (2, 32, 264, 128), (5, 16, 264, 128)]:          # ... and the 128 x 128 model's layers
+                          (3, 32, 136, 64), (2, 32, 264, 128), (5, 16, 264, 128), (4, 32, 64, 32), (4, 16, 128, 64), (4, 8, 256, 128)]:          # ... and the 128 x 128 model's layers
         tag = 'gate_%dx%d_c%d_n%d' % (S, S, Cx, N)
         x = (rnd(rng, N, S, S, Cx)).float().to(torch.bfloat16)
         w = (rnd(rng, 5, 5, Cx, 4 * F) * 0.05).float()
@@ -1068,7 +1068,8 @@ def check_one_launch_cell(seed=71):
     out = []
     rng = np.random.default_rng(seed)
     geom = K.ConvGeom((5, 5), (1, 1), (2, 2))
-    for (N, S, Cx, F, zero_state, nh) in [(3, 16, 136, 64, False, 3), (5, 8, 264, 128, False, 4), (2, 8, 264, 128, True, 1), (2, 16, 160, 64, False, 2)]:
+    for (N, S, Cx, F, zero_state, nh) in [(3, 16, 136, 64, False, 3), (5, 8, 264, 128, False, 4), (2, 8, 264, 128, True, 1), (2, 16, 160, 64, False, 2),
+                                          (4, 16, 128, 64, False, 2), (3, 8, 256, 128, False, 2)]:          # ... and the deterministic (nz = 0) model's layers
         tag = 'cell1_%dx%d_c%d_n%d' % (S, S, Cx, N)
         x = rnd(rng, N, S, S, Cx).float().to(torch.bfloat16)
         w = (rnd(rng, 5, 5, Cx, 4 * F) * 0.05).float()

@@ -714,6 +714,7 @@ static hipError_t launch_gate(const GateP& p, hipStream_t st) {
 #define GATE_SHAPES(X)                                                                                                    \
     X(32, 72, 8, 1, 2, 0) X(16, 136, 4, 1, 1, 0) X(8, 264, 4, 1, 1, 0)     /* BAIR 64 x 64, nz = 8: F = 32 / 64 / 128 */   \
     X(32, 96, 8, 1, 2, 0) X(16, 160, 4, 1, 1, 0)                           /* KTH 64 x 64, nz = 32 (its 8 x 8 layer, 288 channels: the patch of two images exceeds 160 KB) */ \
+    X(32, 64, 8, 1, 2, 0) X(16, 128, 4, 1, 1, 0) X(8, 256, 4, 1, 1, 0)     /* deterministic recipes (nz = 0) at 64 x 64 */ \
     X(32, 136, 8, 1, 2, 0) X(32, 264, 4, 1, 2, 0) X(16, 264, 4, 1, 2, 0)   /* 128 x 128, nz = 8: F = 64 / 128 (its two 520-channel layers do not fit: ring kernel) */ \
     X(32, 72, 4, 1, 2, 1) X(16, 136, 4, 1, 2, 2) X(32, 96, 4, 1, 2, 1) X(16, 160, 4, 1, 2, 2) X(32, 72, 4, 1, 1, 4) X(32, 72, 4, 2, 1, 8)      /* developer A/B (option "gate_alt": bit 0 the 32 x 32 layers, bit 1 the 16 x 16 layers) */
 
@@ -771,7 +772,7 @@ bool conv_gate_try(const SavpConvArgs* a, hipStream_t st, int* rc) {
 // workgroup tile holds whole images -- 16 x 16 (one image per 256-pixel tile) and 8 x 8 (two per 128-pixel tile).  Needs the weights in the
 // INTERLEAVED fragment order (SavpConvArgs.w_frag_il).  false: not this kernel's problem, the caller issues the two launches.
 // ------------------------------------------------------------------------------------------------------------
-#define GATE_CELL_SHAPES(X) X(16, 136, 8) X(8, 264, 4) X(16, 160, 8)
+#define GATE_CELL_SHAPES(X) X(16, 136, 8) X(8, 264, 4) X(16, 160, 8) X(16, 128, 8) X(8, 256, 4)
 
 bool conv_gate_cell_try(const SavpConvLstmCellArgs* c, hipStream_t st, int* rc) {
     const SavpConvArgs* a = &c->conv;
